@@ -1,0 +1,519 @@
+"""CPU oracle for the convasr hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product path (convasr_amd/) never imports it and fails loudly when the
+HIP extension is missing.
+
+What it is: a functional (state-dict in, tensors out) plain-torch fp32 restatement of
+the reference's arithmetic for the one path SURVEY.md section 8 names:
+
+    waveform -> logmel frontend -> masked instance norm -> [conv1d -> batchnorm ->
+    (+residual) -> activation -> dropout(p=0) -> temporal mask] x N -> 1x1 decoder ->
+    log_softmax -> CTC loss / gradient -> training step (clip + SGD), greedy decode.
+
+The reference (vadimkantorov/convasr, /root/reference, read-only) keeps that arithmetic
+inside PyTorch ATen calls; every function below cites the reference file:line it follows.
+
+Pinning: tests/golden/make_golden.py imports the reference itself in the authoring
+container (stubbing its three missing imports) and writes input/output vectors under
+tests/golden/*.npz; tests/test_oracle_golden.py checks every function here against those
+vectors.  The mel filterbank has no in-container pin against real librosa (librosa is not
+installed and the reference does not vendor it): "parity unpinned" for that one matrix --
+it is pinned by its closed-form properties instead and by being committed as a fixture
+that both the reference run and this oracle consumed.
+
+A second, independent restatement of CTC (float64 numpy alpha-beta recursion) lives in
+ctc_loss_numpy() and is checked against torch.nn.functional.ctc_loss on CPU.
+"""
+import math
+import typing
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# mel filterbank: librosa.filters.mel(sr, n_fft, n_mels, fmin=0, fmax=sr/2) as called at
+# models.py:522 (librosa < 0.10 positional signature: Slaney scale, norm='slaney').
+# --------------------------------------------------------------------------------------
+
+
+def _hz_to_mel_slaney(f):
+	f = np.asarray(f, dtype = np.float64)
+	f_sp = 200.0 / 3
+	mels = f / f_sp
+	min_log_hz = 1000.0
+	min_log_mel = min_log_hz / f_sp
+	logstep = np.log(6.4) / 27.0
+	with np.errstate(divide = 'ignore'):
+		log_part = min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep
+	return np.where(f >= min_log_hz, log_part, mels)
+
+
+def _mel_to_hz_slaney(m):
+	m = np.asarray(m, dtype = np.float64)
+	f_sp = 200.0 / 3
+	freqs = f_sp * m
+	min_log_hz = 1000.0
+	min_log_mel = min_log_hz / f_sp
+	logstep = np.log(6.4) / 27.0
+	return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+
+
+def mel_filterbank(sample_rate: int, nfft: int, n_mels: int, fmin: float = 0.0, fmax: typing.Optional[float] = None) -> np.ndarray:
+	"""(n_mels, nfft//2+1) float32 area-normalised triangular filters on the Slaney mel scale."""
+	fmax = float(sample_rate) / 2 if fmax is None else float(fmax)
+	n_bins = 1 + nfft // 2
+	fftfreqs = np.linspace(0, float(sample_rate) / 2, n_bins)
+	mel_pts = np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2)
+	mel_f = _mel_to_hz_slaney(mel_pts)
+	fdiff = np.diff(mel_f)
+	ramps = mel_f[:, None] - fftfreqs[None, :]
+	weights = np.zeros((n_mels, n_bins), dtype = np.float64)
+	for i in range(n_mels):
+		lower = -ramps[i] / fdiff[i]
+		upper = ramps[i + 2] / fdiff[i + 1]
+		weights[i] = np.maximum(0, np.minimum(lower, upper))
+	enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+	weights *= enorm[:, None]
+	return weights.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# lengths / masks: models.py:611-619
+# --------------------------------------------------------------------------------------
+
+
+def compute_output_lengths(time_dim: int, lengths_fraction: typing.Optional[torch.Tensor], batch: int = 1) -> torch.Tensor:
+	"""ceil(frac * T) as int64; full length when frac is None (models.py:611-614)."""
+	if lengths_fraction is None:
+		return torch.full((batch, ), time_dim, dtype = torch.long)
+	return (lengths_fraction * time_dim).ceil().long()
+
+
+def temporal_mask(time_dim: int, lengths: torch.Tensor) -> torch.Tensor:
+	"""bool (B, T): t < length (models.py:617-619, without the view to (B,1,..,T))."""
+	return torch.arange(time_dim, dtype = lengths.dtype).unsqueeze(0) < lengths.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------
+# frontend: models.py:565-597 (+ normalize_signal 684-686)
+# --------------------------------------------------------------------------------------
+
+
+def frontend_config(sample_rate = 16000, window_size = 0.02, window_stride = 0.01):
+	win_length = int(window_size * sample_rate)
+	hop_length = int(window_stride * sample_rate)
+	nfft = 2 ** math.ceil(math.log2(win_length))
+	return dict(win_length = win_length, hop_length = hop_length, nfft = nfft, freq_cutoff = nfft // 2 + 1)
+
+
+def logmel_frontend(
+	signal: torch.Tensor,
+	xlen: typing.Optional[torch.Tensor],
+	window: torch.Tensor,
+	mel_weight: torch.Tensor,
+	mel_bias: torch.Tensor,
+	nfft: int,
+	hop_length: int,
+	preemphasis: float = 0.97,
+	normalize_signal: bool = True,
+	stage: str = 'logmel'
+) -> torch.Tensor:
+	"""(B, T) waveform -> (B, n_mels, F) log-mel features.
+
+	normalize (models.py:684-686), pre-emphasis (572-573), mask (575, mask built at 290),
+	left reflect pad / right zero pad by nfft/2 (577-582), stft center=False (590),
+	power (591-594), mel 1x1 conv with eps bias then log (595).
+	"""
+	assert signal.ndim == 2
+	B, T = signal.shape
+	win_length = window.shape[0]
+	signal = signal if signal.is_floating_point() else signal.to(torch.float32)
+	if normalize_signal and signal.numel() > 0:
+		signal = signal / (signal.abs().max(dim = -1, keepdim = True).values + 1e-5)
+	if preemphasis > 0:
+		signal = torch.cat([signal[..., :1], signal[..., 1:] - preemphasis * signal[..., :-1]], dim = -1)
+	if xlen is not None:
+		mask = temporal_mask(T, compute_output_lengths(T, xlen))
+		signal = signal * mask
+	pad = nfft // 2
+	padded = F.pad(signal.unsqueeze(1), (pad, 0), mode = 'reflect' if pad < T else 'constant').squeeze(1)
+	padded = F.pad(padded, (0, pad), mode = 'constant', value = 0)
+	if stage == 'padded':
+		return padded
+	spec = torch.stft(padded, nfft, hop_length = hop_length, win_length = win_length, window = window, center = False, return_complex = True)
+	spec = torch.view_as_real(spec)
+	power = (spec * spec).sum(dim = -1)
+	if stage == 'power':
+		return power
+	return F.conv1d(power, mel_weight, mel_bias).log()
+
+
+# --------------------------------------------------------------------------------------
+# feature normalisation: models.py:694-719
+# --------------------------------------------------------------------------------------
+
+
+def masked_instance_norm(x: torch.Tensor, mask: typing.Optional[torch.Tensor], eps: float = float(torch.finfo(torch.float16).tiny)) -> torch.Tensor:
+	"""(B, C, T) -> same.  mask: bool (B, T) or None (legacy biased-std branch, 704-710)."""
+	if mask is None:
+		mean = x.mean(dim = -1, keepdim = True)
+		xm = x - mean
+		std = (xm * xm).mean(dim = -1, keepdim = True).add(eps).sqrt()
+		return xm / std
+	mask = mask.unsqueeze(1)
+	n = mask.int().sum(dim = -1, keepdim = True)
+	mean = (x * mask).sum(dim = -1, keepdim = True) / n
+	z = mask * (x - mean)
+	std = ((z * z).sum(dim = -1, keepdim = True) / n).add(eps).sqrt()
+	return z / std
+
+
+# --------------------------------------------------------------------------------------
+# conv block: models.py:47-77 (conv), 111-114 (BN), 127-139 (block), 357-371 (activation)
+# --------------------------------------------------------------------------------------
+
+
+def conv_same_padding(x, weight, bias = None, stride = 1, dilation = 1):
+	"""padding = dilation * kernel_size // 2 (models.py:49) -- grows T by 2 for even d*k."""
+	K = weight.shape[-1]
+	return F.conv1d(x, weight, bias, stride = stride, padding = dilation * K // 2, dilation = dilation)
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum = 0.1, eps = 1e-5):
+	"""nn.BatchNorm1d semantics; updates running stats in place when training."""
+	return F.batch_norm(x, running_mean, running_var, gamma, beta, training, momentum, eps)
+
+
+def activation(y, nonlinearity):
+	"""models.py:368 with dropout p=0: getattr(F, name)(y, *args)."""
+	name = nonlinearity[0]
+	if name == 'relu':
+		return F.relu(y)
+	if name == 'hardtanh':
+		return F.hardtanh(y, nonlinearity[1], nonlinearity[2])
+	if name == 'leaky_relu':
+		return F.leaky_relu(y, nonlinearity[1])
+	raise ValueError(name)
+
+
+def jasper_plan(
+	num_input_features,
+	num_classes,
+	repeat = 3,
+	num_subblocks = 1,
+	dilation = 1,
+	residual = 'dense',
+	kernel_sizes = (11, 13, 17, 21, 25),
+	kernel_size_prologue = 11,
+	kernel_size_epilogue = 29,
+	base_width = 128,
+	out_width_factors = (2, 3, 4, 5, 6),
+	out_width_factors_large = (7, 8),
+	temporal_mask = True,
+	nonlinearity = ('relu', ),
+	stride1 = 2,
+	**unused
+):
+	"""Layer plan of JasperNet.__init__ (models.py:201-264) as a list of dicts."""
+	plan = []
+	in_f = out_width_factors[0]
+	plan.append(dict(cin = num_input_features, cout = in_f * base_width, k = kernel_size_prologue, stride = stride1, dilation = 1, repeat = 1, res = []))
+	res = []
+	for k, out_f in zip(kernel_sizes, out_width_factors):
+		for s in range(num_subblocks):
+			cin = in_f * base_width
+			cout = out_f * base_width if s == num_subblocks - 1 else in_f * base_width
+			if residual == 'dense':
+				res = res + [cin]
+			elif residual == 'flat':
+				res = [None]
+			elif residual:
+				res = [cin]
+			else:
+				res = []
+			plan.append(dict(cin = cin, cout = cout, k = k, stride = 1, dilation = 1, repeat = repeat, res = list(res)))
+		in_f = out_f
+	plan.append(dict(cin = in_f * base_width, cout = out_width_factors_large[0] * base_width, k = kernel_size_epilogue, stride = 1, dilation = dilation, repeat = 1, res = []))
+	plan.append(dict(cin = out_width_factors_large[0] * base_width, cout = out_width_factors_large[1] * base_width, k = 1, stride = 1, dilation = 1, repeat = 1, res = []))
+	return dict(layers = plan, residual = residual, temporal_mask = temporal_mask, nonlinearity = tuple(nonlinearity), num_classes = list(num_classes), c_last = out_width_factors_large[1] * base_width)
+
+
+WAV2LETTER = dict(base_width = 128, kernel_size_prologue = 11, kernel_size_epilogue = 29, kernel_sizes = [11] * 6, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], residual = False, dilation = 2, nonlinearity = ('hardtanh', 0, 20))  # models.py:819-855
+JASPERNET_LARGE = dict(num_subblocks = 2, repeat = 5, temporal_mask = False)  # models.py:1407-1409
+JASPERNET_BIG = dict(num_subblocks = 2, temporal_mask = False)  # models.py:1412-1414
+TINY = dict(base_width = 32, kernel_sizes = [11], out_width_factors = [2], out_width_factors_large = [2, 2], residual = False, repeat = 1)
+
+
+def conv_block(x, sd, prefix, layer, xlen, residual, nonlinearity, use_temporal_mask, training, bn_momentum = 0.1):
+	"""ConvBn1d.forward (models.py:127-139) over state-dict entries '{prefix}.conv.{j}.0.weight' etc."""
+	rep = layer['repeat']
+	for j in range(rep):
+		res_in = []
+		if j == rep - 1:
+			assert len(layer['res']) == len(residual)
+			for r, (cin_r, xr) in enumerate(zip(layer['res'], residual)):
+				if cin_r is None:
+					res_in.append(xr)
+				else:
+					yr = F.conv1d(xr, sd[f'{prefix}.conv_residual.{r}.weight'], sd[f'{prefix}.conv_residual.{r}.bias'])
+					p = f'{prefix}.bn_residual.{r}'
+					res_in.append(batch_norm(yr, sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'], training, bn_momentum))
+		y = conv_same_padding(x, sd[f'{prefix}.conv.{j}.0.weight'], sd.get(f'{prefix}.conv.{j}.0.bias'), stride = layer['stride'], dilation = layer['dilation'])
+		p = f'{prefix}.bn.{j}'
+		if p + '.weight' in sd:
+			y = batch_norm(y, sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'], training, bn_momentum)
+		for r in res_in:
+			y = y + r
+		x = activation(y, nonlinearity)
+		if use_temporal_mask and xlen is not None:
+			lengths = compute_output_lengths(x.shape[-1], xlen)
+			x = x * temporal_mask(x.shape[-1], lengths).unsqueeze(1)
+	return x
+
+
+def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True):
+	"""JasperNet.forward (models.py:282-326).  sd: state dict (tensors, BN buffers are updated in place when
+	training), plan: jasper_plan(...), frontend: dict(window, nfft, hop_length) or None (x is features)."""
+	if frontend is not None:
+		x = logmel_frontend(x, xlen, sd['frontend.window'], sd['frontend.mel.weight'], sd['frontend.mel.bias'], frontend['nfft'], frontend['hop_length'])
+	assert x.ndim == 3
+	if normalize_features:
+		mask = temporal_mask(x.shape[-1], compute_output_lengths(x.shape[-1], xlen)) if xlen is not None else None
+		x = masked_instance_norm(x.float(), mask)
+	residual = []
+	L = len(plan['layers'])
+	for i, layer in enumerate(plan['layers']):
+		x = conv_block(x, sd, f'backbone.{i}', layer, xlen, residual, plan['nonlinearity'], plan['temporal_mask'], training)
+		if i >= L - 2 - 1:
+			residual = []
+		elif plan['residual'] == 'dense':
+			residual = residual + [x]
+		elif plan['residual']:
+			residual = [x]
+		else:
+			residual = []
+	logits = F.conv1d(x, sd['decoder.0.weight'], sd['decoder.0.bias'])
+	log_probs = F.log_softmax(logits, dim = 1).float()
+	olen = compute_output_lengths(logits.shape[-1], xlen.float() if xlen is not None else None, batch = logits.shape[0])
+	out = dict(logits = logits, log_probs = log_probs, olen = olen)
+	if y is not None and ylen is not None:
+		out['loss'] = ctc_loss(log_probs, y[:, 0], olen, ylen[:, 0]) / ylen[:, 0]
+	return out
+
+
+# --------------------------------------------------------------------------------------
+# CTC: call site models.py:323; arithmetic = torch.nn.functional.ctc_loss (ATen, third-party)
+# --------------------------------------------------------------------------------------
+
+
+def ctc_loss(log_probs_bct, targets, olen, ylen, blank = None):
+	"""F.ctc_loss exactly as models.py:323 calls it: (B,C,t) log-probs permuted to (t,B,C), blank = C-1, reduction none."""
+	blank = log_probs_bct.shape[1] - 1 if blank is None else blank
+	return F.ctc_loss(log_probs_bct.permute(2, 0, 1), targets, olen, ylen, blank = blank, reduction = 'none')
+
+
+def ctc_loss_numpy(log_probs_bct: np.ndarray, targets: np.ndarray, olen: np.ndarray, ylen: np.ndarray, blank: typing.Optional[int] = None):
+	"""Independent float64 alpha-beta restatement (Graves 2006 eq. 6-16, the algorithm ATen implements).
+
+	Returns (nll (B,), grad (B,C,t)) where grad is d nll / d log_probs as ATen defines it for log-softmax
+	inputs: exp(lp) - exp(logsum_{s:l'_s=c}(alpha+beta) + nll - lp) for t < olen, 0 for t >= olen.
+	"""
+	lp = np.asarray(log_probs_bct, dtype = np.float64)
+	B, C, T = lp.shape
+	blank = C - 1 if blank is None else blank
+	nll = np.zeros(B)
+	grad = np.zeros_like(lp)
+	NEG = -np.inf
+
+	def lse(*xs):
+		m = max(xs)
+		if m == NEG:
+			return NEG
+		return m + math.log(sum(math.exp(x - m) for x in xs))
+
+	for b in range(B):
+		Tb, S = int(olen[b]), int(ylen[b])
+		ext = [blank] * (2 * S + 1)
+		ext[1::2] = [int(c) for c in targets[b, :S]]
+		L = len(ext)
+		alpha = np.full((Tb, L), NEG)
+		beta = np.full((Tb, L), NEG)
+		if Tb == 0:
+			nll[b] = 0.0 if S == 0 else np.inf
+			continue
+		alpha[0, 0] = lp[b, blank, 0]
+		if L > 1:
+			alpha[0, 1] = lp[b, ext[1], 0]
+		for t in range(1, Tb):
+			for s in range(L):
+				a = [alpha[t - 1, s]]
+				if s >= 1:
+					a.append(alpha[t - 1, s - 1])
+				if s >= 2 and ext[s] != blank and ext[s] != ext[s - 2]:
+					a.append(alpha[t - 1, s - 2])
+				alpha[t, s] = lse(*a) + lp[b, ext[s], t]
+		ll = lse(alpha[Tb - 1, L - 1], alpha[Tb - 1, L - 2]) if L > 1 else alpha[Tb - 1, 0]
+		nll[b] = -ll
+		beta[Tb - 1, L - 1] = lp[b, blank, Tb - 1]
+		if L > 1:
+			beta[Tb - 1, L - 2] = lp[b, ext[L - 2], Tb - 1]
+		for t in range(Tb - 2, -1, -1):
+			for s in range(L):
+				a = [beta[t + 1, s]]
+				if s + 1 < L:
+					a.append(beta[t + 1, s + 1])
+				if s + 2 < L and ext[s] != blank and ext[s] != ext[s + 2]:
+					a.append(beta[t + 1, s + 2])
+				beta[t, s] = lse(*a) + lp[b, ext[s], t]
+		for t in range(Tb):
+			acc = np.full(C, NEG)
+			for s in range(L):
+				acc[ext[s]] = lse(acc[ext[s]], alpha[t, s] + beta[t, s])
+			with np.errstate(invalid = 'ignore'):
+				grad[b, :, t] = np.exp(lp[b, :, t]) - np.exp(acc + nll[b] - lp[b, :, t])
+	return nll, grad
+
+
+# --------------------------------------------------------------------------------------
+# entropy metric: models.py:645-657; greedy decode: transcript_generators.py:27-93
+# --------------------------------------------------------------------------------------
+
+
+def entropy(log_probs_bct, lengths = None, eps = 1e-9):
+	e = -(log_probs_bct.exp() * log_probs_bct).sum(dim = 1)
+	if lengths is None:
+		return e.mean(dim = -1)
+	e = e * temporal_mask(e.shape[-1], lengths)
+	return e.sum(dim = -1) / (eps + lengths.type_as(log_probs_bct))
+
+
+CHAR_LEGACY_ALPHABET = 'абвгдеёжзийклмнопрстуфхцчшщъыьэюя'  # configs/ru_text_config.json:10
+
+
+def char_legacy_vocab(alphabet = CHAR_LEGACY_ALPHABET):
+	"""text_tokenizers.py:8-21: alphabet + ['*', '.', '2', ' ', '|'] -> 38 symbols, space 36, eps/blank 37."""
+	return list(alphabet) + ['*', '.', '2', ' ', '|']
+
+
+def greedy_decode(log_probs_bct, olen = None, vocab = None, blank_amount_to_space = 10):
+	"""GreedyCTCGenerator.generate without timestamps (transcript_generators.py:27-93): returns one string per
+	utterance (with time_stamps None the generator emits a single segment per utterance)."""
+	vocab = vocab or char_legacy_vocab()
+	eps_id, space_id = len(vocab) - 1, len(vocab) - 2
+	idx = log_probs_bct.argmax(dim = 1).tolist()
+	out = []
+	for i, sample in enumerate(idx):
+		n = int(olen[i]) if olen is not None else len(sample)
+		t = 0
+		while t < len(sample) and sample[t] in (eps_id, space_id):
+			t += 1
+		if t >= len(sample):
+			out.append('')
+			continue
+		tokens = [eps_id]
+		allow_repeat = False
+		count_eps = 0
+		for t in range(t, n):
+			c = sample[t]
+			if c == eps_id and tokens[-1] == space_id:
+				continue
+			if c == eps_id:
+				allow_repeat = True
+				count_eps += 1
+				if count_eps >= blank_amount_to_space and tokens[-1] != space_id:
+					tokens.append(space_id)
+				continue
+			elif c == tokens[-1] and not allow_repeat:
+				continue
+			allow_repeat = False
+			tokens.append(c)
+			count_eps = 0
+		out.append(''.join(vocab[c] for c in tokens[1:]))
+	return out
+
+
+# --------------------------------------------------------------------------------------
+# training step: train.py:745-783 with SGD(momentum, weight_decay) (train.py:657-662)
+# --------------------------------------------------------------------------------------
+
+
+def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, max_norm = 100.0, momentum_buffers = None, nesterov = False):
+	"""One iteration of the reference loop with accumulate=1: forward (748), loss = mean(loss * ylen) (755),
+	backward (774), clip_grad_norm_ (777), SGD step (780).  Returns dict(loss, loss_cur, entropy, grad_norm, grads);
+	sd parameters and momentum_buffers are updated in place."""
+	names = [k for k, v in sd.items() if v.is_floating_point() and not k.startswith('frontend.') and 'running_' not in k]
+	for k in names:
+		sd[k].requires_grad_(True)
+		sd[k].grad = None
+	out = jasper_forward(sd, plan, x, xlen, y, ylen, frontend = frontend, training = True)
+	loss_vec = out['loss']
+	loss = (loss_vec * ylen[:, 0]).mean()
+	loss_cur = loss_vec.mean()
+	ent = entropy(out['log_probs'].detach(), out['olen']).mean()
+	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = ent, loss_vec = loss_vec.detach(), log_probs = out['log_probs'].detach(), olen = out['olen'])
+	if not (torch.isinf(loss_cur) or torch.isnan(loss_cur)):
+		loss.backward()
+		params = [sd[k] for k in names]
+		res['grad_norm'] = torch.nn.utils.clip_grad_norm_(params, max_norm).detach()
+		res['grads'] = {k: sd[k].grad.detach().clone() for k in names}
+		with torch.no_grad():
+			for k in names:
+				p = sd[k]
+				g = p.grad
+				if weight_decay != 0:
+					g = g.add(p, alpha = weight_decay)
+				if momentum != 0:
+					if momentum_buffers is not None:
+						buf = momentum_buffers.get(k)
+						if buf is None:
+							buf = momentum_buffers[k] = g.clone()
+						else:
+							buf.mul_(momentum).add_(g)
+						g = g.add(buf, alpha = momentum) if nesterov else buf
+				p.add_(g, alpha = -lr)
+	for k in names:
+		sd[k].requires_grad_(False)
+		sd[k].grad = None
+	return res
+
+
+# --------------------------------------------------------------------------------------
+# fresh parameters with the reference's state-dict layout -- used by bench.py's
+# cpu_baseline leg and by tests that need a full-size model without the reference present.
+# --------------------------------------------------------------------------------------
+
+
+def init_state_dict(plan, seed = 1, frontend = None, num_input_features = 64, sample_rate = 16000):
+	g = torch.Generator().manual_seed(seed)
+	sd = {}
+
+	def conv_w(cout, cin, k):
+		bound = 1.0 / math.sqrt(cin * k)
+		return (torch.rand(cout, cin, k, generator = g) * 2 - 1) * bound
+
+	def bn(prefix, c):
+		sd[prefix + '.weight'] = torch.ones(c)
+		sd[prefix + '.bias'] = torch.zeros(c)
+		sd[prefix + '.running_mean'] = torch.zeros(c)
+		sd[prefix + '.running_var'] = torch.ones(c)
+		sd[prefix + '.num_batches_tracked'] = torch.zeros((), dtype = torch.long)
+
+	for i, layer in enumerate(plan['layers']):
+		for j in range(layer['repeat']):
+			cin = layer['cin'] if j == 0 else layer['cout']
+			sd[f'backbone.{i}.conv.{j}.0.weight'] = conv_w(layer['cout'], cin, layer['k'])
+			bn(f'backbone.{i}.bn.{j}', layer['cout'])
+		for r, cin_r in enumerate(layer['res']):
+			if cin_r is not None:
+				sd[f'backbone.{i}.conv_residual.{r}.weight'] = conv_w(layer['cout'], cin_r, 1)
+				sd[f'backbone.{i}.conv_residual.{r}.bias'] = (torch.rand(layer['cout'], generator = g) * 2 - 1) / math.sqrt(cin_r)
+				bn(f'backbone.{i}.bn_residual.{r}', layer['cout'])
+	sd['decoder.0.weight'] = conv_w(plan['num_classes'][0], plan['c_last'], 1)
+	sd['decoder.0.bias'] = (torch.rand(plan['num_classes'][0], generator = g) * 2 - 1) / math.sqrt(plan['c_last'])
+	if frontend is not None:
+		sd['frontend.window'] = torch.hann_window(frontend['win_length'], periodic = True).float()
+		sd['frontend.mel.weight'] = torch.as_tensor(mel_filterbank(sample_rate, frontend['nfft'], num_input_features)).unsqueeze(-1)
+		sd['frontend.mel.bias'] = torch.full((num_input_features, ), float(torch.finfo(torch.float16).tiny))
+	return sd
