@@ -1,0 +1,97 @@
+"""ctypes binding of libconvasr_hip.so (the C ABI declared in include/convasr_hip.h).
+
+torch is imported first on purpose: it loads its own libamdhip64.so (soname libamdhip64.so.7); our library's DT_NEEDED entry
+of the same soname then resolves to that already-loaded runtime, so torch's streams and device pointers are valid inside
+our kernels.  There is NO fallback: if the shared library is missing the import fails loudly."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libconvasr_hip.so')
+
+F32, BF16, I16 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_HARDTANH, ACT_LEAKY_RELU = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD = 0, 1
+
+c_int, c_i64, c_u64, c_f32, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
+
+_SIGNATURES = dict(
+	convasr_abi_version = (c_int, []),
+	convasr_last_error = (ctypes.c_char_p, []),
+	convasr_convert_layout = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_p]),
+	convasr_signal_absmax = (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
+	convasr_logmel_fwd = (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_conv_cout_pad = (c_int, [c_int]),
+	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p]),
+	convasr_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_bn_finalize = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p, c_p, c_p, c_int, c_p]),
+	convasr_bn_eval_scale_shift = (c_int, [c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_int, c_p]),
+	convasr_bn_act_fwd = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p]),
+	convasr_bn_act_bwd_reduce = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p]),
+	convasr_bn_bwd_apply = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
+	convasr_log_softmax_fwd = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
+	convasr_log_softmax_bwd = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+	convasr_ctc_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
+	convasr_ctc_loss = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_int, c_i64, c_p]),
+	convasr_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
+	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p]),
+	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p]),
+)
+
+_lib = None
+
+
+class ConvasrHipError(RuntimeError):
+	pass
+
+
+def declared_symbols():
+	return sorted(_SIGNATURES)
+
+
+def load():
+	"""Load the shared library (once) and type every entry point.  Raises if it is missing -- no CPU fallback exists."""
+	global _lib
+	if _lib is None:
+		if not os.path.exists(LIB_PATH):
+			raise ConvasrHipError(f'{LIB_PATH} not found: build it with `python -m convasr_amd.build` (hipcc --offload-arch=gfx950)')
+		lib = ctypes.CDLL(LIB_PATH)
+		for name, (res, args) in _SIGNATURES.items():
+			fn = getattr(lib, name)
+			fn.restype, fn.argtypes = res, args
+		if lib.convasr_abi_version() != 1:
+			raise ConvasrHipError('ABI version mismatch')
+		_lib = lib
+	return _lib
+
+
+def call(name, *args):
+	lib = load()
+	rc = getattr(lib, name)(*args)
+	if rc != 0:
+		raise ConvasrHipError(f'{name} failed ({rc}): {lib.convasr_last_error().decode()}')
+
+
+def stream_ptr():
+	return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+	return None if t is None else t.data_ptr()
+
+
+def dtype_code(dtype):
+	return {torch.float32: F32, torch.bfloat16: BF16, torch.int16: I16}[dtype]
+
+
+def require_cuda(*tensors):
+	for t in tensors:
+		if t is not None and not t.is_cuda:
+			raise ConvasrHipError('convasr_amd runs on an MI355X only: tensor on ' + str(t.device) + ' (there is no CPU path; the CPU restatement lives in oracle/ and is test infrastructure)')

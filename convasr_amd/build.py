@@ -1,0 +1,55 @@
+"""Build libconvasr_hip.so (gfx950) in-tree with hipcc.  Usage: python -m convasr_amd.build [--force]"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libconvasr_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-variable']
+
+
+def sources():
+	return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def stale(target, deps):
+	if not os.path.exists(target):
+		return True
+	t = os.path.getmtime(target)
+	return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force = False, verbose = True):
+	srcs = sources()
+	headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'convasr_hip.h')]
+	objdir = os.path.join(HERE, 'build')
+	os.makedirs(objdir, exist_ok = True)
+	jobs = []
+	objs = []
+	for s in srcs:
+		o = os.path.join(objdir, os.path.basename(s)[:-4] + '.o')
+		objs.append(o)
+		if force or stale(o, [s] + headers):
+			jobs.append([HIPCC, *FLAGS, '-c', s, '-o', o])
+
+	def run(cmd):
+		if verbose:
+			print(' '.join(cmd), flush = True)
+		r = subprocess.run(cmd, capture_output = True, text = True)
+		if r.returncode != 0:
+			raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
+		if verbose and r.stderr.strip():
+			print(r.stderr, file = sys.stderr)
+
+	with ThreadPoolExecutor(max_workers = min(6, max(1, len(jobs)))) as ex:
+		list(ex.map(run, jobs))
+	if force or jobs or stale(LIB, objs):
+		run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
+	return LIB
+
+
+if __name__ == '__main__':
+	print(build(force = '--force' in sys.argv))

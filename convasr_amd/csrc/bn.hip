@@ -1,0 +1,340 @@
+// BatchNorm1d (training / eval) + residual sum + activation + dropout + temporal mask, forward and backward, on
+// channels-last (B, T, C) activations.  Reference: nn.BatchNorm1d at models.py:111-114, ConvBn1d.forward 127-139,
+// ResidualActivation.forward 357-371, relu_dropout 436-443.  All HBM-bound: 16 bytes per lane, lanes walk the channel axis.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ statistics -> scale / shift
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const double m = stats[c] / n;
+	double var = stats[C + c] / n - m * m;
+	if (var < 0) var = 0;
+	const float mf = (float)m, vf = (float)var;
+	const float is = 1.0f / sqrtf(vf + eps);
+	const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+	mean[c] = mf;
+	invstd[c] = is;
+	scale[c] = g * is;
+	shift[c] = bt - mf * g * is;
+	if (rmean) {
+		const float unbiased = n > 1 ? (float)(var * n / (n - 1)) : vf;
+		rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+		rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+	}
+}
+
+extern "C" int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, void* stream) {
+	CONVASR_CHECK_ARG(stats && mean && invstd && scale && shift && n > 0 && C > 0, "bn_finalize: bad arguments");
+	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+	CONVASR_CHECK_LAUNCH("bn_finalize");
+	return 0;
+}
+
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean, const float* __restrict__ rvar,
+                               float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const float is = 1.0f / sqrtf(rvar[c] + eps);
+	const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+	scale[c] = g * is;
+	shift[c] = bt - rmean[c] * g * is;
+}
+
+extern "C" int convasr_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                           float* scale, float* shift, int C, void* stream) {
+	CONVASR_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_eval_scale_shift: bad arguments");
+	hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, scale, shift, C);
+	CONVASR_CHECK_LAUNCH("bn_eval_scale_shift");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise forward
+#define MAX_RES 12
+struct ResArgs {
+	const void* res[MAX_RES];
+	const float* rscale[MAX_RES];
+	const float* rshift[MAX_RES];
+	const float* rmean[MAX_RES];
+	const float* rinvstd[MAX_RES];
+	double* rsums[MAX_RES];
+	int n;
+};
+
+struct BnActParams {
+	const void* y;
+	const void* dz;
+	void* out;
+	const float* scale;
+	const float* shift;
+	const float* mean;
+	const float* invstd;
+	const float* xlen;
+	double* sums;
+	int act;
+	float lo, hi, p_drop;
+	uint64_t seed, offset;
+	int B, T, C;
+};
+
+// pre-activation value of 8 consecutive channels at row (b, t): y * scale + shift + sum_r (res_r * rscale_r + rshift_r)
+template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams& p, const ResArgs& ra, int64_t idx, int c, float (&yv)[8], float (&pre)[8]) {
+	load8<T>(reinterpret_cast<const T*>(p.y) + idx, yv);
+	float sc[8], sh[8];
+	if (p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+#pragma unroll
+	for (int i = 0; i < 8; ++i) pre[i] = p.scale ? fmaf(yv[i], sc[i], sh[i]) : yv[i];
+	for (int r = 0; r < ra.n; ++r) {
+		float rv[8];
+		load8<T>(reinterpret_cast<const T*>(ra.res[r]) + idx, rv);
+		if (ra.rscale[r]) {
+			load8<float>(ra.rscale[r] + c, sc);
+			load8<float>(ra.rshift[r] + c, sh);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) pre[i] += fmaf(rv[i], sc[i], sh[i]);
+		} else {
+#pragma unroll
+			for (int i = 0; i < 8; ++i) pre[i] += rv[i];
+		}
+	}
+}
+
+__device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) {
+	// element index -> Philox counter idx/4; idx is a multiple of 8 so two counters cover the 8 lanes' elements
+	const float inv = 1.f / (1.f - p.p_drop);
+	float u[4];
+	philox4(p.seed, p.offset + (uint64_t)(idx >> 2), u);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) keep[i] = u[i] >= p.p_drop ? inv : 0.f;
+	philox4(p.seed, p.offset + (uint64_t)(idx >> 2) + 1, u);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) keep[4 + i] = u[i] >= p.p_drop ? inv : 0.f;
+}
+
+template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra) {
+	const int c8 = p.C >> 3;
+	const int64_t total = (int64_t)p.B * p.T * c8;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+		const int c = (int)(i % c8) << 3;
+		const int64_t row = i / c8;
+		const int t = (int)(row % p.T), b = (int)(row / p.T);
+		const int64_t idx = row * p.C + c;
+		float out[8];
+		if (t >= valid_len(p.xlen, b, p.T)) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) out[k] = 0.f;
+		} else {
+			float yv[8], pre[8];
+			pre_act8<T>(p, ra, idx, c, yv, pre);
+#pragma unroll
+			for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], p.act, p.lo, p.hi);
+			if (p.p_drop > 0.f) {
+				float keep[8];
+				dropout_keep8(p, idx, keep);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) out[k] *= keep[k];
+			}
+		}
+		store8<T>(reinterpret_cast<T*>(p.out) + idx, out);
+	}
+}
+
+static int fill_res(ResArgs& ra, int n_res, const void* const* res, const float* const* rscale, const float* const* rshift, const float* const* rmean,
+                    const float* const* rinvstd, double* const* rsums) {
+	if (n_res < 0 || n_res > MAX_RES) return convasr_fail(CONVASR_EINVAL, "bn_act: n_res %d not in [0, %d]", n_res, MAX_RES);
+	ra.n = n_res;
+	for (int r = 0; r < MAX_RES; ++r) {
+		ra.res[r] = r < n_res ? res[r] : nullptr;
+		ra.rscale[r] = (r < n_res && rscale) ? rscale[r] : nullptr;
+		ra.rshift[r] = (r < n_res && rshift) ? rshift[r] : nullptr;
+		ra.rmean[r] = (r < n_res && rmean) ? rmean[r] : nullptr;
+		ra.rinvstd[r] = (r < n_res && rinvstd) ? rinvstd[r] : nullptr;
+		ra.rsums[r] = (r < n_res && rsums) ? rsums[r] : nullptr;
+	}
+	return 0;
+}
+
+static unsigned ew_grid(int64_t total) {
+	int64_t g = ceil_div64(total, 256);
+	return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
+                                  const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
+                                  uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(y && z && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_fwd: bad arguments (C must be a multiple of 8)");
+	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr) && dropout_p >= 0.f && dropout_p < 1.f, "bn_act_fwd: bad scale/shift/dropout");
+	BnActParams p = {};
+	p.y = y; p.out = z; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p;
+	p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
+	ResArgs ra;
+	if (int rc = fill_res(ra, n_res, res, rscale, rshift, nullptr, nullptr, nullptr)) return rc;
+	const int64_t total = (int64_t)B * T * (C >> 3);
+	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p, ra);
+	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p, ra);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
+	CONVASR_CHECK_LAUNCH("bn_act_fwd");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ backward pass 1: g and channel sums
+// Block = 256 threads = (256 / c8b) row-lanes x c8b channel-groups, where c8b = min(C/8, 256) ... each thread owns 8 channels
+// and strides over rows; per-channel partial sums are combined across the block in LDS and added to the global doubles.
+template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, int rows_per_block) {
+	__shared__ float red[256][17];
+	const int c8 = p.C >> 3;
+	const int cgroups = c8 < 256 ? c8 : 256;   // channel groups handled concurrently by one block
+	const int rlanes = 256 / cgroups;           // threads beyond cgroups * rlanes idle (e.g. C = 384: 48 groups x 5 row-lanes)
+	const int cg = threadIdx.x % cgroups, rl = threadIdx.x / cgroups;
+	const bool lane_on = rl < rlanes;
+	const int64_t rows = (int64_t)p.B * p.T;
+	const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+	for (int cbase = blockIdx.y * cgroups; cbase < c8; cbase += gridDim.y * cgroups) {
+		const int c = (cbase + cg) << 3;
+		const bool cok = lane_on && cbase + cg < c8;
+		float s1[8], s2[8], rs1[2][8], rs2[2][8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { s1[k] = s2[k] = 0.f; rs1[0][k] = rs1[1][k] = rs2[0][k] = rs2[1][k] = 0.f; }
+		float mean[8], istd[8];
+		if (cok && p.mean) { load8<float>(p.mean + c, mean); load8<float>(p.invstd + c, istd); }
+		for (int64_t row = r0 + rl; row < r1 && cok; row += rlanes) {
+			const int t = (int)(row % p.T), b = (int)(row / p.T);
+			const int64_t idx = row * p.C + c;
+			float g[8];
+			if (t >= valid_len(p.xlen, b, p.T)) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) g[k] = 0.f;
+			} else {
+				float yv[8], pre[8], dz[8];
+				pre_act8<T>(p, ra, idx, c, yv, pre);
+				load8<T>(reinterpret_cast<const T*>(p.dz) + idx, dz);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+				if (p.p_drop > 0.f) {
+					float keep[8];
+					dropout_keep8(p, idx, keep);
+#pragma unroll
+					for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+				}
+				if (p.mean) {
+#pragma unroll
+					for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (yv[k] - mean[k]) * istd[k]; }
+				}
+				for (int r = 0; r < ra.n && r < 2; ++r) {
+					if (ra.rsums[r]) {
+						float rv[8], rm[8], ri[8];
+						load8<T>(reinterpret_cast<const T*>(ra.res[r]) + idx, rv);
+						load8<float>(ra.rmean[r] + c, rm);
+						load8<float>(ra.rinvstd[r] + c, ri);
+#pragma unroll
+						for (int k = 0; k < 8; ++k) { rs1[r][k] += g[k]; rs2[r][k] += g[k] * (rv[k] - rm[k]) * ri[k]; }
+					}
+				}
+			}
+			store8<T>(reinterpret_cast<T*>(p.out) + idx, g);
+		}
+		// block reduction over the row-lanes that share a channel group
+		auto reduce_to = [&](float (&a)[8], float (&bq)[8], double* dst) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = a[k]; red[threadIdx.x][8 + k] = bq[k]; }
+			__syncthreads();
+			if (rl == 0 && cok) {
+				for (int k = 0; k < 16; ++k) {
+					float s = 0.f;
+					for (int j = 0; j < rlanes; ++j) s += red[j * cgroups + cg][k];
+					unsafeAtomicAdd(dst + (k < 8 ? c + k : p.C + c + k - 8), (double)s);
+				}
+			}
+			__syncthreads();
+		};
+		if (p.mean && p.sums) reduce_to(s1, s2, p.sums);
+		for (int r = 0; r < ra.n && r < 2; ++r)
+			if (ra.rsums[r]) reduce_to(rs1[r], rs2[r], ra.rsums[r]);
+	}
+}
+
+extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift, const float* mean,
+                                         const float* invstd, int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
+                                         const float* const* rmean, const float* const* rinvstd, double* const* rsums, int act, float act_lo, float act_hi,
+                                         float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(dz && y && g && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
+	CONVASR_CHECK_ARG((mean == nullptr) == (invstd == nullptr) && (mean == nullptr || sums != nullptr), "bn_act_bwd_reduce: mean/invstd/sums go together");
+	BnActParams p = {};
+	p.y = y; p.dz = dz; p.out = g; p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.xlen = xlen; p.sums = sums;
+	p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p; p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
+	ResArgs ra;
+	if (int rc = fill_res(ra, n_res, res, rscale, rshift, rmean, rinvstd, rsums)) return rc;
+	int n_bn_res = 0;
+	for (int r = 0; r < n_res; ++r) if (ra.rsums[r]) { if (r >= 2) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: batch-normed residuals beyond the first two must be reduced by separate calls"); ++n_bn_res; }
+	const int c8 = C >> 3;
+	const int cgroups = c8 < 256 ? c8 : 256;
+	const int64_t rows = (int64_t)B * T;
+	const int rlanes = 256 / cgroups;
+	int rows_per_block = 64 * rlanes;
+	int64_t gx = ceil_div64(rows, rows_per_block);
+	if (gx > 1024) { gx = 1024; rows_per_block = (int)ceil_div64(rows, gx); }
+	const int gy = (c8 + cgroups - 1) / cgroups;
+	dim3 grid((unsigned)ceil_div64(rows, rows_per_block), (unsigned)(gy > 4 ? 4 : gy));
+	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p, ra, rows_per_block);
+	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, p, ra, rows_per_block);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: dtype %d", dtype);
+	CONVASR_CHECK_LAUNCH("bn_act_bwd_reduce");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ backward pass 2
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ dy, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ sums,
+                                                           int64_t rows, int C) {
+	const int c8 = C >> 3;
+	const int64_t total = rows * c8;
+	const float invn = 1.0f / (float)rows;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+		const int c = (int)(i % c8) << 3;
+		const int64_t idx = (i / c8) * C + c;
+		float gv[8], yv[8], m[8], is[8], gm[8], out[8];
+		load8<T>(g + idx, gv);
+		load8<T>(y + idx, yv);
+		load8<float>(mean + c, m);
+		load8<float>(invstd + c, is);
+		if (gamma) load8<float>(gamma + c, gm);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const float sg = (float)sums[c + k] * invn, sgx = (float)sums[C + c + k] * invn;
+			const float xhat = (yv[k] - m[k]) * is[k];
+			out[k] = (gamma ? gm[k] : 1.f) * is[k] * (gv[k] - sg - xhat * sgx);
+		}
+		store8<T>(dy + idx, out);
+	}
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int accumulate) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const float dg = (float)sums[C + c], db = (float)sums[c];
+	if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+	if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+}
+
+extern "C" int convasr_bn_bwd_apply(const void* g, const void* y, void* dy, int dtype, const float* gamma, const float* mean, const float* invstd,
+                                    const double* sums, float* dgamma, float* dbeta, int accumulate, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(g && y && mean && invstd && sums && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_bwd_apply: bad arguments (C must be a multiple of 8)");
+	hipStream_t s = (hipStream_t)stream;
+	const int64_t rows = (int64_t)B * T;
+	if (dy) {
+		const int64_t total = rows * (C >> 3);
+		if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)g, (const float*)y, (float*)dy, gamma, mean, invstd, sums, rows, C);
+		else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)dy, gamma, mean, invstd, sums, rows, C);
+		else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_bwd_apply: dtype %d", dtype);
+		CONVASR_CHECK_LAUNCH("bn_bwd_apply");
+	}
+	if (dgamma || dbeta) {
+		hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, dgamma, dbeta, C, accumulate);
+		CONVASR_CHECK_LAUNCH("bn_param_grad");
+	}
+	return 0;
+}

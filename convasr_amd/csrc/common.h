@@ -1,0 +1,112 @@
+// Shared device/host helpers for libconvasr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/convasr_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+extern thread_local char g_convasr_err[512];
+int convasr_fail(int code, const char* fmt, ...);
+
+#define CONVASR_CHECK_ARG(cond, ...) do { if (!(cond)) return convasr_fail(CONVASR_EINVAL, __VA_ARGS__); } while (0)
+#define CONVASR_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+	__bf16 h = (__bf16)f;
+	return __builtin_bit_cast(unsigned short, h);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+	static constexpr int dtype = CONVASR_F32;
+	__device__ static __forceinline__ float load(const float* p) { return *p; }
+	__device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+	static constexpr int dtype = CONVASR_BF16;
+	__device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+	__device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 8 consecutive elements as fp32 (16 B of bf16 or 32 B of f32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+	float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+	v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+	uint4 a = *reinterpret_cast<const uint4*>(p);
+	unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+	*reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+	*reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+	unsigned w[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+	*reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+	return v;
+}
+
+// valid frames of a T-long axis: ceil(frac * T) computed in fp32 like (lengths_fraction * T).ceil().long() (models.py:614)
+__device__ __forceinline__ int valid_len(const float* xlen, int b, int T) {
+	if (xlen == nullptr) return T;
+	float v = ceilf(xlen[b] * (float)T);
+	return (int)v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float lo, float hi) {
+	switch (act) {
+	case CONVASR_ACT_RELU: return fmaxf(v, 0.f);
+	case CONVASR_ACT_HARDTANH: return fminf(fmaxf(v, lo), hi);
+	case CONVASR_ACT_LEAKY_RELU: return v > 0.f ? v : v * lo;
+	default: return v;
+	}
+}
+// derivative w.r.t. the pre-activation value, matching ATen's backward formulas (hardtanh: strict inequalities)
+__device__ __forceinline__ float act_grad(float pre, int act, float lo, float hi) {
+	switch (act) {
+	case CONVASR_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+	case CONVASR_ACT_HARDTANH: return (pre > lo && pre < hi) ? 1.f : 0.f;
+	case CONVASR_ACT_LEAKY_RELU: return pre > 0.f ? 1.f : lo;
+	default: return 1.f;
+	}
+}
+
+// Philox4x32-10 (Salmon et al. 2011): counter = element index / 4, key = seed; returns 4 uniforms in [0,1)
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, float (&u)[4]) {
+	unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0, c3 = 0;
+	unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+	for (int r = 0; r < 10; ++r) {
+		unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+		unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+		unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+		c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+		k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+	}
+	u[0] = (c0 >> 8) * (1.0f / 16777216.0f); u[1] = (c1 >> 8) * (1.0f / 16777216.0f);
+	u[2] = (c2 >> 8) * (1.0f / 16777216.0f); u[3] = (c3 >> 8) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,624 @@
+// Conv1d as an im2col-free implicit GEMM on the gfx950 matrix cores (reference arithmetic: nn.Conv1d at models.py:53-76).
+//
+//   forward / dgrad :  D[(b,t)][co] = sum_tap sum_ci X[b, t*stride + tap*dil - pad, ci] * Wp[tap][co][ci]
+//   wgrad           :  dW[tap][co][ci] = sum_(b,t) dY[b,t,co] * X[b, t*stride + tap*dil - pad, ci]
+//
+// Activations are channels-last (B, T, C): the GEMM reduction axis (ci) is the unit-stride axis of both operands, so every
+// MFMA fragment is one 16-byte LDS read.  One workgroup owns a 128(t) x 128(co) output tile of ONE utterance; per 128-byte
+// slab of input channels it stages the X rows [t0*stride - pad, ...) ONCE (tile + halo) and re-uses them for all K taps --
+// the tap only shifts the LDS row a fragment is read from.  Weight tiles stream through a 2-deep ring, one per (ci-slab, tap).
+// fp32 runs the same schedule on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), bf16 on v_mfma_f32_32x32x16_bf16.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BM 128
+#define BN 128
+#define NTHREADS 256
+#define ROW_BYTES 128  // one LDS row = 128 B of the reduction axis (64 bf16 or 32 f32)
+
+struct ConvParams {
+	const void* x;
+	const void* w;
+	void* y;
+	const float* bias;
+	double* stats;
+	const float* scale;
+	const float* shift;
+	const float* xlen;
+	int B, Cin, Cout, CoutPad, Tin, Tout, K, stride, dil, pad;
+	int act;
+	float act_lo, act_hi;
+	int m_tiles_per_b, n_tiles, total_tiles;
+	int x_rows;  // LDS rows of one X tile (even)
+};
+
+// Two 128-B rows share one 256-B bank row; 16-B slot = (row parity, chunk ^ row-pair index): 16 consecutive rows at the same
+// chunk land on 16 distinct slots -> ds_read_b128 fragments are bank-conflict free.
+__device__ __forceinline__ int lds_off(int row, int chunk) { return ((row >> 1) << 8) | ((((row & 1) << 3) | (chunk ^ ((row >> 1) & 7))) << 4); }
+
+// XCD-aware bijective remap: consecutive virtual ids (same X tile, neighbouring weight tiles) share one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+	const int q = n >> 3, r = n & 7, xcd = bid & 7, k = bid >> 3;
+	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+	static constexpr int EPC = 8;  // elements per 16-byte chunk
+	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+		c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+	}
+};
+template <> struct Mma<float> {
+	static constexpr int EPC = 4;
+	// lane half h holds k = {4(2j+h) .. +3}; the i-th of four MFMAs pairs element i of both halves: every k is summed once.
+	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+	}
+};
+
+// 16 bytes of a row, zero outside [0, n_valid_elems); scalar path when rows are not 16-byte aligned.
+template <typename T, bool ALIGNED> __device__ __forceinline__ uint4 load_chunk(const T* row, int e0, int n_valid) {
+	constexpr int EPC = 16 / sizeof(T);
+	uint4 v = make_uint4(0, 0, 0, 0);
+	if (ALIGNED) {
+		if (e0 + EPC <= n_valid) v = *reinterpret_cast<const uint4*>(row + e0);
+		else if (e0 < n_valid) {
+			T tmp[EPC];
+#pragma unroll
+			for (int i = 0; i < EPC; ++i) tmp[i] = (e0 + i < n_valid) ? row[e0 + i] : (T)0;
+			v = *reinterpret_cast<uint4*>(tmp);
+		}
+	} else if (e0 < n_valid) {
+		T tmp[EPC];
+#pragma unroll
+		for (int i = 0; i < EPC; ++i) tmp[i] = (e0 + i < n_valid) ? row[e0 + i] : (T)0;
+		v = *reinterpret_cast<uint4*>(tmp);
+	}
+	return v;
+}
+
+template <typename T, typename O, int XI, bool ALIGNED_X>
+__global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	constexpr int EPC = Mma<T>::EPC;
+	constexpr int BK = ROW_BYTES / sizeof(T);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+
+	const int v = xcd_remap(blockIdx.x, p.total_tiles);
+	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
+	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * BM;
+	const int co0 = ntile * BN;
+	const int tin0 = t0 * p.stride - p.pad;
+
+	const int xbytes = p.x_rows * ROW_BYTES;
+	char* const xbuf = smem;
+	char* const wbuf = smem + 2 * xbytes;
+	const T* const xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.Tin * p.Cin;
+	const T* const wp = reinterpret_cast<const T*>(p.w);
+	const int n_cib = (p.Cin + BK - 1) / BK;
+	const int total_x_chunks = p.x_rows * 8;
+
+	uint4 xreg[XI];
+	uint4 wreg[4];
+
+	auto load_x = [&](int cib) {
+		const int ci0 = cib * BK;
+#pragma unroll
+		for (int i = 0; i < XI; ++i) {
+			const int e = tid + NTHREADS * i;
+			const int row = e >> 3, chunk = e & 7;
+			const int tin = tin0 + row;
+			xreg[i] = make_uint4(0, 0, 0, 0);
+			if (e < total_x_chunks && tin >= 0 && tin < p.Tin) xreg[i] = load_chunk<T, ALIGNED_X>(xb + (int64_t)tin * p.Cin, ci0 + chunk * EPC, p.Cin);
+		}
+	};
+	auto store_x = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < XI; ++i) {
+			const int e = tid + NTHREADS * i;
+			if (e < total_x_chunks) *reinterpret_cast<uint4*>(xbuf + buf * xbytes + lds_off(e >> 3, e & 7)) = xreg[i];
+		}
+	};
+	auto load_w = [&](int cib, int tap) {
+		const int ci0 = cib * BK;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int e = tid + NTHREADS * i;
+			const int row = e >> 3, chunk = e & 7;
+			wreg[i] = load_chunk<T, ALIGNED_X>(wp + ((int64_t)tap * p.CoutPad + co0 + row) * p.Cin, ci0 + chunk * EPC, p.Cin);
+		}
+	};
+	auto store_w = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int e = tid + NTHREADS * i;
+			*reinterpret_cast<uint4*>(wbuf + buf * (BN * ROW_BYTES) + lds_off(e >> 3, e & 7)) = wreg[i];
+		}
+	};
+
+	f32x16 acc[2][2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+#pragma unroll
+		for (int j = 0; j < 2; ++j)
+#pragma unroll
+			for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+	load_x(0);
+	load_w(0, 0);
+	store_x(0);
+	store_w(0);
+	__syncthreads();
+
+	const int Q = n_cib * p.K;
+	int cib = 0, tap = 0;
+	const int wrow0 = wn * 64 + r, wrow1 = wrow0 + 32;
+	const int woff0 = (wrow0 >> 1) << 8, wpar0 = (wrow0 & 1) << 3, wsw0 = (wrow0 >> 1) & 7;
+	const int woff1 = (wrow1 >> 1) << 8, wpar1 = (wrow1 & 1) << 3, wsw1 = (wrow1 >> 1) & 7;
+
+	for (int q = 0; q < Q; ++q) {
+		const bool has_next = q + 1 < Q;
+		const bool last_tap = tap == p.K - 1;
+		const bool next_x = has_next && last_tap;
+		if (has_next) load_w(last_tap ? cib + 1 : cib, last_tap ? 0 : tap + 1);
+		if (tap == 0 && cib + 1 < n_cib) load_x(cib + 1);
+
+		const char* xs = xbuf + (cib & 1) * xbytes;
+		const char* ws = wbuf + (q & 1) * (BN * ROW_BYTES);
+		const int xrow0 = (wm * 64 + r) * p.stride + tap * p.dil, xrow1 = xrow0 + 32 * p.stride;
+		const int xoff0 = (xrow0 >> 1) << 8, xpar0 = (xrow0 & 1) << 3, xsw0 = (xrow0 >> 1) & 7;
+		const int xoff1 = (xrow1 >> 1) << 8, xpar1 = (xrow1 & 1) << 3, xsw1 = (xrow1 >> 1) & 7;
+#pragma unroll
+		for (int kk = 0; kk < 4; ++kk) {
+			const int chunk = kk * 2 + h;
+			const uint4 a0 = *reinterpret_cast<const uint4*>(xs + xoff0 + ((xpar0 | (chunk ^ xsw0)) << 4));
+			const uint4 a1 = *reinterpret_cast<const uint4*>(xs + xoff1 + ((xpar1 | (chunk ^ xsw1)) << 4));
+			const uint4 b0 = *reinterpret_cast<const uint4*>(ws + woff0 + ((wpar0 | (chunk ^ wsw0)) << 4));
+			const uint4 b1 = *reinterpret_cast<const uint4*>(ws + woff1 + ((wpar1 | (chunk ^ wsw1)) << 4));
+			Mma<T>::run(a0, b0, acc[0][0]);
+			Mma<T>::run(a0, b1, acc[0][1]);
+			Mma<T>::run(a1, b0, acc[1][0]);
+			Mma<T>::run(a1, b1, acc[1][1]);
+		}
+
+		if (has_next) store_w((q + 1) & 1);
+		if (next_x) store_x((cib + 1) & 1);
+		__syncthreads();
+		if (last_tap) { tap = 0; ++cib; } else ++tap;
+	}
+
+	// ---------------- epilogue: bias, BN statistics, scale/shift, activation, temporal mask, coalesced store through LDS
+	constexpr int OPITCH = BN * sizeof(O) + 16;  // +16 B: rows 4 apart (one lane group's registers) stay off the same banks
+	char* const otile = smem;
+	float* const red = reinterpret_cast<float*>(smem + BM * OPITCH);  // [2 (sum, sumsq)][2 (wm)][BN]
+	const int nvalid = valid_len(p.xlen, b, p.Tout);
+#pragma unroll
+	for (int ni = 0; ni < 2; ++ni) {
+		const int col = wn * 64 + ni * 32 + r, co = co0 + col;
+		const bool cok = co < p.Cout;
+		const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
+		const float sc = (p.scale && cok) ? p.scale[co] : 1.f, sh = (p.scale && cok) ? p.shift[co] : 0.f;
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+			for (int g = 0; g < 16; ++g) {
+				const int row = wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+				const int t = t0 + row;
+				float val = acc[mi][ni][g] + bias;
+				if (t < p.Tout) { s1 += val; s2 += val * val; }
+				val = apply_act(val * sc + sh, p.act, p.act_lo, p.act_hi);
+				if (t >= nvalid) val = 0.f;
+				Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
+			}
+		}
+		if (p.stats) {
+			s1 += __shfl_xor(s1, 32, 64);
+			s2 += __shfl_xor(s2, 32, 64);
+			if (h == 0) { red[(0 * 2 + wm) * BN + col] = s1; red[(1 * 2 + wm) * BN + col] = s2; }
+		}
+	}
+	__syncthreads();
+	if (p.stats && tid < BN && co0 + tid < p.Cout) {
+		unsafeAtomicAdd(p.stats + co0 + tid, (double)red[(0 * 2 + 0) * BN + tid] + (double)red[(0 * 2 + 1) * BN + tid]);
+		unsafeAtomicAdd(p.stats + p.Cout + co0 + tid, (double)red[(1 * 2 + 0) * BN + tid] + (double)red[(1 * 2 + 1) * BN + tid]);
+	}
+	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
+	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN / OEPC;
+	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
+	for (int e = tid; e < BM * OCHUNKS; e += NTHREADS) {
+		const int row = e / OCHUNKS, ch = e % OCHUNKS;
+		const int t = t0 + row, co = co0 + ch * OEPC;
+		if (t >= p.Tout || co >= p.Cout) continue;
+		const O* src = reinterpret_cast<const O*>(otile + row * OPITCH) + ch * OEPC;
+		O* dst = yb + (int64_t)t * p.Cout + co;
+		if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+		else
+			for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = src[i];
+	}
+}
+
+extern "C" int convasr_conv_cout_pad(int cout) { return (cout + BN - 1) / BN * BN; }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int K, int mode, int rows_pad) {
+	// out[k][row][col]; FWD: row = co, col = ci; DGRAD: row = ci, col = co, tap flipped
+	const int rows = mode == CONVASR_PACK_FWD ? Cout : Cin, cols = mode == CONVASR_PACK_FWD ? Cin : Cout;
+	const int64_t total = (int64_t)K * rows_pad * cols;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+		const int col = (int)(i % cols);
+		const int row = (int)((i / cols) % rows_pad);
+		const int k = (int)(i / ((int64_t)cols * rows_pad));
+		float v = 0.f;
+		if (row < rows) {
+			if (mode == CONVASR_PACK_FWD) v = w[((int64_t)row * Cin + col) * K + k];
+			else v = w[((int64_t)col * Cin + row) * K + (K - 1 - k)];
+		}
+		Elem<T>::store(out + i, v);
+	}
+}
+
+extern "C" int convasr_pack_conv_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int K, int mode, void* stream) {
+	CONVASR_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && K > 0 && (mode == CONVASR_PACK_FWD || mode == CONVASR_PACK_DGRAD), "pack_conv_weight: bad arguments");
+	const int rows = mode == CONVASR_PACK_FWD ? Cout : Cin;
+	const int rows_pad = convasr_conv_cout_pad(rows);
+	const int64_t total = (int64_t)K * rows_pad * (mode == CONVASR_PACK_FWD ? Cin : Cout);
+	int64_t blocks = ceil_div64(total, 256);
+	if (blocks > 4096) blocks = 4096;
+	if (dtype == CONVASR_F32) hipLaunchKernelGGL((pack_weight_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, Cout, Cin, K, mode, rows_pad);
+	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, Cout, Cin, K, mode, rows_pad);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
+	CONVASR_CHECK_LAUNCH("pack_conv_weight");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad launcher
+template <typename T, typename O, int XI, bool AL> static int launch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
+	auto kern = conv1d_igemm_kernel<T, O, XI, AL>;
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(NTHREADS), smem, s, p);
+	return 0;
+}
+
+template <typename T, typename O> static int dispatch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
+	const int xi = (p.x_rows * 8 + NTHREADS - 1) / NTHREADS;
+	const bool al = ((p.Cin * sizeof(T)) & 15) == 0;
+	if (!al) {
+		if (xi <= 9) return launch_conv<T, O, 9, false>(p, smem, s);
+		return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
+	}
+	if (xi <= 5) return launch_conv<T, O, 5, true>(p, smem, s);
+	if (xi <= 9) return launch_conv<T, O, 9, true>(p, smem, s);
+	if (xi <= 16) return launch_conv<T, O, 16, true>(p, smem, s);
+	return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
+}
+
+extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
+                                  int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
+                                  float act_lo, float act_hi, const float* xlen, void* stream) {
+	CONVASR_CHECK_ARG(x && wp && y && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_fwd: bad arguments");
+	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd: scale and shift go together");
+	const int64_t expect = ((int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
+	CONVASR_CHECK_ARG(expect == Tout, "conv1d_fwd: Tout %d inconsistent with Tin %d K %d stride %d dil %d pad %d (expect %lld)", Tout, Tin, K, stride, dil, pad, (long long)expect);
+	CONVASR_CHECK_ARG(x_dtype == CONVASR_F32 || x_dtype == CONVASR_BF16, "conv1d_fwd: x dtype %d", x_dtype);
+	ConvParams p;
+	p.x = x; p.w = wp; p.y = y; p.bias = bias; p.stats = stats; p.scale = scale; p.shift = shift; p.xlen = xlen;
+	p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = convasr_conv_cout_pad(Cout); p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
+	p.act = act; p.act_lo = act_lo; p.act_hi = act_hi;
+	p.m_tiles_per_b = (Tout + BM - 1) / BM;
+	p.n_tiles = p.CoutPad / BN;
+	p.total_tiles = B * p.m_tiles_per_b * p.n_tiles;
+	int xr = (BM - 1) * stride + (K - 1) * dil + 1;
+	p.x_rows = (xr + 1) & ~1;
+	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
+	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 2 * BN * ROW_BYTES;
+	const size_t epi = (size_t)BM * (BN * osz + 16) + 4 * BN * sizeof(float);
+	if (epi > smem) smem = epi;
+	CONVASR_CHECK_ARG(smem <= 160 * 1024, "conv1d_fwd: tile needs %zu B of LDS", smem);
+	hipStream_t s = (hipStream_t)stream;
+	int rc;
+	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) rc = dispatch_conv<float, float>(p, smem, s);
+	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_BF16) rc = dispatch_conv<bf16_t, bf16_t>(p, smem, s);
+	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_F32) rc = dispatch_conv<bf16_t, float>(p, smem, s);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd: dtype %d -> %d", x_dtype, y_dtype);
+	if (rc) return rc;
+	CONVASR_CHECK_LAUNCH("conv1d_fwd");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// M = co (A = dY^T), N = ci (B = X), reduction over (b, t).  Both operands are row-major [t][c] tiles in LDS; the MFMA wants
+// 8 consecutive t per lane, i.e. a column read: bf16 uses ds_read_b64_tr_b16 (hardware 4x16 transpose), fp32 plain b32 reads.
+// One workgroup = one (128 co x 128 ci) tile x up to TG taps (the taps share the staged dY rows and the X rows + halo),
+// over one split of the (b, t) axis; partial tiles go to fp32 slabs [split][tap][co][ci], summed (and transposed to the
+// reference's (Cout, Cin, K) parameter layout) by wgrad_reduce_kernel -- deterministic, no float atomics.
+#define WG_TG 4
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+	const void* x;
+	const void* dy;
+	float* slab;
+	int B, Cin, Cout, Tin, Tout, K, stride, dil, pad;
+	int co_tiles, ci_tiles, tap_groups, units, splits;
+	int chunks_per_b, total_chunks, chunks_per_split;
+	int x_rows;
+};
+
+template <typename T> struct WgTile;
+template <> struct WgTile<bf16_t> { static constexpr int BKT = 64, PITCH = 128 * 2 + 64, CPR = 16; };  // rows of 256 B + 64 B pad: tr reads conflict-free
+template <> struct WgTile<float> { static constexpr int BKT = 32, PITCH = 128 * 4 + 16, CPR = 32; };
+
+template <typename T, int XI, bool AL_X, bool AL_Y>
+__global__ __launch_bounds__(NTHREADS, 1) void conv1d_wgrad_kernel(WgradParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	constexpr int EPC = 16 / sizeof(T);
+	constexpr int BKT = WgTile<T>::BKT, PITCH = WgTile<T>::PITCH, CPR = WgTile<T>::CPR;
+	constexpr int YI = BKT * CPR / NTHREADS;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+
+	const int v = xcd_remap(blockIdx.x, p.units * p.splits);
+	const int unit = v % p.units, split = v / p.units;
+	const int tg = unit % p.tap_groups, ci_t = (unit / p.tap_groups) % p.ci_tiles, co_t = unit / (p.tap_groups * p.ci_tiles);
+	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * WG_TG;
+	const int ntaps = min(WG_TG, p.K - tap0);
+	const int c_begin = split * p.chunks_per_split, c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
+
+	const int ybytes = BKT * PITCH, xbytes = p.x_rows * PITCH;
+	char* const ybuf = smem;
+	char* const xbuf = smem + 2 * ybytes;
+	const int total_x_chunks = p.x_rows * CPR;
+
+	uint4 yreg[YI];
+	uint4 xreg[XI];
+	auto load_tiles = [&](int c) {
+		const int b = c / p.chunks_per_b, t0 = (c % p.chunks_per_b) * BKT;
+		const T* yb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.Tout * p.Cout;
+		const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.Tin * p.Cin;
+		const int tin0 = t0 * p.stride - p.pad + tap0 * p.dil;
+#pragma unroll
+		for (int i = 0; i < YI; ++i) {
+			const int e = tid + NTHREADS * i, row = e / CPR, ch = e % CPR, t = t0 + row;
+			yreg[i] = make_uint4(0, 0, 0, 0);
+			if (t < p.Tout) yreg[i] = load_chunk<T, AL_Y>(yb + (int64_t)t * p.Cout, co0 + ch * EPC, p.Cout);
+		}
+#pragma unroll
+		for (int i = 0; i < XI; ++i) {
+			const int e = tid + NTHREADS * i, row = e / CPR, ch = e % CPR, tin = tin0 + row;
+			xreg[i] = make_uint4(0, 0, 0, 0);
+			if (e < total_x_chunks && tin >= 0 && tin < p.Tin) xreg[i] = load_chunk<T, AL_X>(xb + (int64_t)tin * p.Cin, ci0 + ch * EPC, p.Cin);
+		}
+	};
+	auto store_tiles = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < YI; ++i) {
+			const int e = tid + NTHREADS * i;
+			*reinterpret_cast<uint4*>(ybuf + buf * ybytes + (e / CPR) * PITCH + (e % CPR) * 16) = yreg[i];
+		}
+#pragma unroll
+		for (int i = 0; i < XI; ++i) {
+			const int e = tid + NTHREADS * i;
+			if (e < total_x_chunks) *reinterpret_cast<uint4*>(xbuf + buf * xbytes + (e / CPR) * PITCH + (e % CPR) * 16) = xreg[i];
+		}
+	};
+
+	f32x16 acc[WG_TG][2][2];
+#pragma unroll
+	for (int a = 0; a < WG_TG; ++a)
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) acc[a][i][j][k] = 0.f;
+
+	if (c_begin < c_end) {
+		load_tiles(c_begin);
+		store_tiles(0);
+	}
+	__syncthreads();
+
+	for (int c = c_begin; c < c_end; ++c) {
+		const int buf = (c - c_begin) & 1;
+		if (c + 1 < c_end) load_tiles(c + 1);
+		const char* ys = ybuf + buf * ybytes;
+		const char* xs = xbuf + buf * xbytes;
+		if constexpr (sizeof(T) == 2) {
+			// lane -> (16-lane group g4, q = row within the 4-row block, pc = 4-column piece)
+			const int g4 = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+			const int kq = 8 * (g4 >> 1) + q, colb = (g4 & 1) * 16 + 4 * pc;
+#pragma unroll
+			for (int kk = 0; kk < BKT / 16; ++kk) {
+				uint4 a[2];
+#pragma unroll
+				for (int mi = 0; mi < 2; ++mi) {
+					const char* ap = ys + (kk * 16 + kq) * PITCH + (wm * 64 + mi * 32 + colb) * 2;
+					s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap));
+					s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap + 4 * PITCH));
+					a[mi] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+				}
+#pragma unroll
+				for (int tg_i = 0; tg_i < WG_TG; ++tg_i) {
+					if (tg_i < ntaps) {
+						uint4 bb[2];
+#pragma unroll
+						for (int ni = 0; ni < 2; ++ni) {
+							const char* bp = xs + ((kk * 16 + kq) * p.stride + tg_i * p.dil) * PITCH + (wn * 64 + ni * 32 + colb) * 2;
+							s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bp));
+							s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bp + 4 * p.stride * PITCH));
+							bb[ni] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+						}
+#pragma unroll
+						for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+							for (int ni = 0; ni < 2; ++ni) Mma<bf16_t>::run(a[mi], bb[ni], acc[tg_i][mi][ni]);
+					}
+				}
+			}
+		} else {
+			const int r = lane & 31, h = lane >> 5;
+#pragma unroll 4
+			for (int k2 = 0; k2 < BKT / 2; ++k2) {
+				float a[2];
+#pragma unroll
+				for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const float*>(ys + (k2 * 2 + h) * PITCH + (wm * 64 + mi * 32 + r) * 4);
+#pragma unroll
+				for (int tg_i = 0; tg_i < WG_TG; ++tg_i) {
+					if (tg_i < ntaps) {
+						float bb[2];
+#pragma unroll
+						for (int ni = 0; ni < 2; ++ni) bb[ni] = *reinterpret_cast<const float*>(xs + ((k2 * 2 + h) * p.stride + tg_i * p.dil) * PITCH + (wn * 64 + ni * 32 + r) * 4);
+#pragma unroll
+						for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+							for (int ni = 0; ni < 2; ++ni) acc[tg_i][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[tg_i][mi][ni], 0, 0, 0);
+					}
+				}
+			}
+		}
+		if (c + 1 < c_end) store_tiles(buf ^ 1);
+		__syncthreads();
+	}
+
+	const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+	for (int tg_i = 0; tg_i < WG_TG; ++tg_i) {
+		if (tg_i < ntaps) {
+			float* sl = p.slab + ((int64_t)split * p.K + tap0 + tg_i) * p.Cout * p.Cin;
+#pragma unroll
+			for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+				for (int ni = 0; ni < 2; ++ni) {
+					const int ci = ci0 + wn * 64 + ni * 32 + r;
+#pragma unroll
+					for (int g = 0; g < 16; ++g) {
+						const int co = co0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+						if (co < p.Cout && ci < p.Cin) sl[(int64_t)co * p.Cin + ci] = acc[tg_i][mi][ni][g];
+					}
+				}
+		}
+	}
+}
+
+// dw[co][ci][k] (+)= sum_s slab[s][k][co][ci]: coalesced reads along ci, LDS transpose, coalesced writes along (ci, k).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int K, int Cout, int Cin, int accumulate) {
+	extern __shared__ float rbuf[];  // [K][65]
+	const int co = blockIdx.y, ci0 = blockIdx.x * 64;
+	const int c = threadIdx.x & 63;
+	const int64_t plane = (int64_t)Cout * Cin;
+	for (int k = threadIdx.x >> 6; k < K; k += 4) {
+		float a = 0.f;
+		if (ci0 + c < Cin)
+			for (int s = 0; s < S; ++s) a += slab[((int64_t)s * K + k) * plane + (int64_t)co * Cin + ci0 + c];
+		rbuf[k * 65 + c] = a;
+	}
+	__syncthreads();
+	const int ncols = min(64, Cin - ci0);
+	float* out = dw + ((int64_t)co * Cin + ci0) * K;
+	for (int o = threadIdx.x; o < ncols * K; o += 256) {
+		const float val = rbuf[(o % K) * 65 + o / K];
+		out[o] = accumulate ? out[o] + val : val;
+	}
+}
+
+// dbias[c] (+)= sum over rows of a channels-last (rows, C) matrix
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ out, int64_t rows, int C, int accumulate) {
+	__shared__ float red[4][64];
+	const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+	float a = 0.f;
+	if (c < C)
+		for (int64_t rr = w; rr < rows; rr += 4) a += Elem<T>::load(y + rr * C + c);
+	red[w][threadIdx.x & 63] = a;
+	__syncthreads();
+	if (w == 0 && c < C) {
+		const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+		out[c] = accumulate ? out[c] + s : s;
+	}
+}
+
+static void wgrad_plan(WgradParams& p, int bkt) {
+	p.co_tiles = (p.Cout + 127) / 128;
+	p.ci_tiles = (p.Cin + 127) / 128;
+	p.tap_groups = (p.K + WG_TG - 1) / WG_TG;
+	p.units = p.co_tiles * p.ci_tiles * p.tap_groups;
+	p.chunks_per_b = (p.Tout + bkt - 1) / bkt;
+	p.total_chunks = p.B * p.chunks_per_b;
+	int splits = (768 + p.units - 1) / p.units;  // aim at ~3 workgroups per CU
+	if (splits > p.total_chunks / 2) splits = p.total_chunks / 2;
+	if (splits < 1) splits = 1;
+	p.chunks_per_split = (p.total_chunks + splits - 1) / splits;
+	p.splits = (p.total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+	const int taps = p.K < WG_TG ? p.K : WG_TG;
+	p.x_rows = (bkt - 1) * p.stride + (taps - 1) * p.dil + 1;
+}
+
+extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil) {
+	WgradParams p;
+	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil;
+	wgrad_plan(p, 32);  // the fp32 tile (shorter chunks) never needs fewer splits than bf16
+	int64_t s32 = p.splits;
+	wgrad_plan(p, 64);
+	int64_t s = s32 > p.splits ? s32 : p.splits;
+	return s * K * (int64_t)Cout * Cin * 4;
+}
+
+template <typename T, int XI, bool AX, bool AY> static void launch_wgrad(const WgradParams& p, size_t smem, hipStream_t s) {
+	auto kern = conv1d_wgrad_kernel<T, XI, AX, AY>;
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(kern, dim3(p.units * p.splits), dim3(NTHREADS), smem, s, p);
+}
+
+template <typename T> static int dispatch_wgrad(WgradParams& p, hipStream_t s) {
+	wgrad_plan(p, WgTile<T>::BKT);
+	const int xi = (p.x_rows * WgTile<T>::CPR + NTHREADS - 1) / NTHREADS;
+	const size_t smem = 2 * (size_t)(WgTile<T>::BKT + p.x_rows) * WgTile<T>::PITCH;
+	if (smem > 160 * 1024 || xi > 12) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: tile too large (x_rows %d)", p.x_rows);
+	const bool ax = ((p.Cin * sizeof(T)) & 15) == 0, ay = ((p.Cout * sizeof(T)) & 15) == 0;
+	if (ax && ay) { if (xi <= 5) launch_wgrad<T, 5, true, true>(p, smem, s); else launch_wgrad<T, 12, true, true>(p, smem, s); }
+	else if (ax) launch_wgrad<T, 12, true, false>(p, smem, s);
+	else if (ay) launch_wgrad<T, 12, false, true>(p, smem, s);
+	else launch_wgrad<T, 12, false, false>(p, smem, s);
+	return 0;
+}
+
+extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
+                                    int Tout, int K, int stride, int dil, int pad, int accumulate, void* stream) {
+	CONVASR_CHECK_ARG(x && dy && dw && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_wgrad: bad arguments");
+	CONVASR_CHECK_ARG(K <= 64, "conv1d_wgrad: K %d > 64", K);
+	WgradParams p;
+	p.x = x; p.dy = dy; p.slab = (float*)workspace;
+	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
+	hipStream_t s = (hipStream_t)stream;
+	int rc;
+	if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
+	else if (dtype == CONVASR_BF16) rc = dispatch_wgrad<bf16_t>(p, s);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: dtype %d", dtype);
+	if (rc) return rc;
+	CONVASR_CHECK_LAUNCH("conv1d_wgrad");
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cin + 63) / 64, Cout), dim3(256), (size_t)K * 65 * sizeof(float), s, p.slab, dw, p.splits, K, Cout, Cin, accumulate);
+	CONVASR_CHECK_LAUNCH("conv1d_wgrad_reduce");
+	if (dbias) {
+		const int64_t rows = (int64_t)B * Tout;
+		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), dim3((Cout + 63) / 64), dim3(256), 0, s, (const float*)dy, dbias, rows, Cout, accumulate);
+		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3((Cout + 63) / 64), dim3(256), 0, s, (const bf16_t*)dy, dbias, rows, Cout, accumulate);
+		CONVASR_CHECK_LAUNCH("conv1d_dbias");
+	}
+	return 0;
+}

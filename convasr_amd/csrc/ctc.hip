@@ -1,0 +1,208 @@
+// CTC loss and gradient (reference call site: F.ctc_loss at models.py:323, blank = C-1, reduction none, zero_infinity False;
+// arithmetic: the alpha-beta recursion of Graves et al. 2006 as ATen implements it).
+//
+// Kernel 1 -- one workgroup per utterance, wave 0 runs the alpha sweep forward in time while wave 1 runs the beta sweep
+// backward, concurrently.  A lane owns NS consecutive states of the extended target (blank, y1, blank, y2, ...), so the
+// s-1 / s-2 neighbours are registers except for one 2-value shuffle per step; log-sum-exp in fp32; the next frame's
+// log-probs are fetched while the current one is being combined.  The lattices go to an L2/MALL-resident workspace.
+// Kernel 2 -- one wave per frame: posterior[c] = sum_{s: l'_s = c} exp(alpha + beta + nll - lp) accumulated in LDS bins,
+// grad = exp(lp) - posterior for t < olen, 0 beyond.
+#include "common.h"
+
+#define CTC_NEG (-INFINITY)
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+	const float m = fmaxf(a, fmaxf(b, c));
+	if (m == CTC_NEG) return CTC_NEG;
+	return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+template <int NS>
+__global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
+                                                             const int64_t* __restrict__ ylen, float* __restrict__ nll, float* __restrict__ alpha,
+                                                             float* __restrict__ beta, int T, int C, int S_max, int blank) {
+	__shared__ float fin[64 * NS];
+	const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	constexpr int LP = 64 * NS;
+	const int Tb = (int)olen[b], S = (int)ylen[b], L = 2 * S + 1;
+	const float* lpb = lp + (int64_t)b * T * C;
+	const int64_t* tg = targets + (int64_t)b * S_max;
+	float* const lat = (wave == 0 ? alpha : beta) + (int64_t)b * T * LP;
+
+	int cls[NS];
+	bool skip[NS], valid[NS];
+#pragma unroll
+	for (int i = 0; i < NS; ++i) {
+		const int s = lane * NS + i;
+		valid[i] = s < L;
+		const bool nb = (s & 1) && valid[i];
+		cls[i] = nb ? (int)tg[s >> 1] : blank;
+		if (wave == 0) skip[i] = nb && s >= 3 && tg[s >> 1] != tg[(s >> 1) - 1];          // alpha: s-2 allowed
+		else skip[i] = nb && s + 2 < L && tg[s >> 1] != tg[(s >> 1) + 1];                  // beta: s+2 allowed
+	}
+	if (Tb <= 0 || Tb > T) {
+		if (threadIdx.x == 0) nll[b] = (Tb == 0 && S == 0) ? 0.f : INFINITY;
+		return;
+	}
+
+	float a[NS], cur[NS], nxt[NS];
+	if (wave == 0) {
+#pragma unroll
+		for (int i = 0; i < NS; ++i) {
+			const int s = lane * NS + i;
+			a[i] = (s < 2 && valid[i]) ? lpb[cls[i]] : CTC_NEG;
+			lat[s] = a[i];
+		}
+		if (Tb > 1) {
+#pragma unroll
+			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)1 * C + cls[i]];
+		}
+		for (int t = 1; t < Tb; ++t) {
+			if (t + 1 < Tb) {
+#pragma unroll
+				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t + 1) * C + cls[i]];
+			}
+			float p1 = __shfl_up(a[NS - 1], 1, 64), p2 = __shfl_up(NS >= 2 ? a[NS >= 2 ? NS - 2 : 0] : 0.f, 1, 64);
+			if (NS == 1) p2 = __shfl_up(a[0], 2, 64);
+			if (lane == 0) { p1 = CTC_NEG; p2 = CTC_NEG; }
+			if (NS == 1 && lane == 1) p2 = CTC_NEG;
+			float n[NS];
+#pragma unroll
+			for (int i = NS - 1; i >= 0; --i) {
+				const float m1 = i >= 1 ? a[i - 1] : p1;
+				const float m2 = i >= 2 ? a[i - 2] : (i == 1 ? p1 : p2);
+				n[i] = valid[i] ? lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i] : CTC_NEG;
+			}
+#pragma unroll
+			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + lane * NS + i] = n[i]; cur[i] = nxt[i]; }
+		}
+#pragma unroll
+		for (int i = 0; i < NS; ++i) fin[lane * NS + i] = a[i];
+		__builtin_amdgcn_s_waitcnt(0xc07f);
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) {
+			const float l1 = fin[L - 1], l2 = L >= 2 ? fin[L - 2] : CTC_NEG;
+			const float m = fmaxf(l1, l2);
+			nll[b] = m == CTC_NEG ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+		}
+	} else {
+		const float* lrow = lpb + (int64_t)(Tb - 1) * C;
+#pragma unroll
+		for (int i = 0; i < NS; ++i) {
+			const int s = lane * NS + i;
+			a[i] = (valid[i] && s >= L - 2) ? lrow[cls[i]] : CTC_NEG;
+			lat[(int64_t)(Tb - 1) * LP + s] = a[i];
+		}
+		if (Tb > 1) {
+#pragma unroll
+			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)(Tb - 2) * C + cls[i]];
+		}
+		for (int t = Tb - 2; t >= 0; --t) {
+			if (t > 0) {
+#pragma unroll
+				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t - 1) * C + cls[i]];
+			}
+			float p1 = __shfl_down(a[0], 1, 64), p2 = __shfl_down(NS >= 2 ? a[NS >= 2 ? 1 : 0] : 0.f, 1, 64);
+			if (NS == 1) p2 = __shfl_down(a[0], 2, 64);
+			if (lane == 63) { p1 = CTC_NEG; p2 = CTC_NEG; }
+			if (NS == 1 && lane == 62) p2 = CTC_NEG;
+			float n[NS];
+#pragma unroll
+			for (int i = 0; i < NS; ++i) {
+				const float m1 = i + 1 < NS ? a[i + 1 < NS ? i + 1 : 0] : p1;
+				const float m2 = i + 2 < NS ? a[i + 2 < NS ? i + 2 : 0] : (i + 2 == NS ? p1 : p2);
+				n[i] = valid[i] ? lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i] : CTC_NEG;
+			}
+#pragma unroll
+			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + lane * NS + i] = n[i]; cur[i] = nxt[i]; }
+		}
+	}
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
+                                                       const int64_t* __restrict__ ylen, const float* __restrict__ nll, const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta, float* __restrict__ grad, int T, int C, int S_max, int blank, int t_per_block) {
+	extern __shared__ float bins[];  // [4][C]
+	const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	constexpr int LP = 64 * NS;
+	const int Tb = (int)olen[b], S = (int)ylen[b], L = 2 * S + 1;
+	const float nl = nll[b];
+	const bool feasible = nl < INFINITY;
+	const int64_t* tg = targets + (int64_t)b * S_max;
+	int cls[NS];
+#pragma unroll
+	for (int i = 0; i < NS; ++i) {
+		const int s = lane * NS + i;
+		cls[i] = ((s & 1) && s < L) ? (int)tg[s >> 1] : blank;
+	}
+	float* mybins = bins + wave * C;
+	const int t_begin = blockIdx.x * t_per_block, t_end = min(T, t_begin + t_per_block);
+	for (int t = t_begin + wave; t < t_end; t += 4) {
+		const float* row = lp + ((int64_t)b * T + t) * C;
+		float* grow = grad + ((int64_t)b * T + t) * C;
+		if (t >= Tb || !feasible) {
+			for (int c = lane; c < C; c += 64) grow[c] = 0.f;
+			continue;
+		}
+		for (int c = lane; c < C; c += 64) mybins[c] = 0.f;
+		__builtin_amdgcn_s_waitcnt(0xc07f);
+		__builtin_amdgcn_wave_barrier();
+		const float* ar = alpha + ((int64_t)b * T + t) * LP + lane * NS;
+		const float* br = beta + ((int64_t)b * T + t) * LP + lane * NS;
+		float blank_sum = 0.f;
+#pragma unroll
+		for (int i = 0; i < NS; ++i) {
+			const int s = lane * NS + i;
+			if (s < L) {
+				const float v = __expf(ar[i] + br[i] + nl - row[cls[i]]);
+				if (s & 1) atomicAdd(mybins + cls[i], v);
+				else blank_sum += v;
+			}
+		}
+		blank_sum = wave_sum(blank_sum);
+		if (lane == 0) atomicAdd(mybins + blank, blank_sum);
+		__builtin_amdgcn_s_waitcnt(0xc07f);
+		__builtin_amdgcn_wave_barrier();
+		for (int c = lane; c < C; c += 64) grow[c] = __expf(row[c]) - mybins[c];
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+static int ctc_ns(int S_max) {
+	const int L = 2 * S_max + 1;
+	const int need = (L + 63) / 64;
+	const int opts[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
+	for (int o : opts) if (o >= need) return o;
+	return -1;
+}
+
+extern "C" int64_t convasr_ctc_workspace_bytes(int B, int T, int S_max) {
+	const int ns = ctc_ns(S_max);
+	if (ns < 0) return -1;
+	return 2 * (int64_t)B * T * 64 * ns * (int64_t)sizeof(float);
+}
+
+extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, const int64_t* olen, const int64_t* ylen, float* nll, float* grad,
+                                void* workspace, int B, int T, int C, int S_max, int blank, void* stream) {
+	CONVASR_CHECK_ARG(log_probs && targets && olen && ylen && nll && workspace && B > 0 && T > 0 && C > 1 && S_max >= 0 && blank >= 0 && blank < C, "ctc_loss: bad arguments");
+	const int ns = ctc_ns(S_max);
+	if (ns < 0) return convasr_fail(CONVASR_EUNSUPPORTED, "ctc_loss: target length %d > 511", S_max);
+	CONVASR_CHECK_ARG(C <= 8192, "ctc_loss: C %d > 8192", C);
+	hipStream_t s = (hipStream_t)stream;
+	float* alpha = (float*)workspace;
+	float* beta = alpha + (int64_t)B * T * 64 * ns;
+	const int t_per_block = 32;
+	dim3 ggrid((T + t_per_block - 1) / t_per_block, B);
+	const size_t gsmem = 4 * (size_t)C * sizeof(float);
+#define CTC_CASE(NS) case NS: \
+		hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS>), dim3(B), dim3(128), 0, s, log_probs, targets, olen, ylen, nll, alpha, beta, T, C, S_max, blank); \
+		if (grad) hipLaunchKernelGGL((ctc_grad_kernel<NS>), ggrid, dim3(256), gsmem, s, log_probs, targets, olen, ylen, nll, alpha, beta, grad, T, C, S_max, blank, t_per_block); \
+		break;
+	switch (ns) {
+		CTC_CASE(1) CTC_CASE(2) CTC_CASE(3) CTC_CASE(4) CTC_CASE(5) CTC_CASE(6) CTC_CASE(8) CTC_CASE(12) CTC_CASE(16)
+	}
+#undef CTC_CASE
+	CONVASR_CHECK_LAUNCH("ctc_loss");
+	return 0;
+}

@@ -1,0 +1,269 @@
+// HBM-bound plumbing kernels: error state, layout conversion, instance norm, log-softmax, entropy, argmax,
+// gradient-norm and SGD.  gfx950 only.
+#include "common.h"
+
+thread_local char g_convasr_err[512] = {0};
+
+int convasr_fail(int code, const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_convasr_err, sizeof(g_convasr_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+extern "C" int convasr_abi_version(void) { return CONVASR_ABI_VERSION; }
+extern "C" const char* convasr_last_error(void) { return g_convasr_err; }
+
+// ------------------------------------------------------------------------------------------------ convert_layout
+// 64(c) x 64(t) tile through LDS: reads coalesced along the source's unit-stride axis, writes along the destination's.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_layout_kernel(const S* __restrict__ src, int64_t ssb, int64_t ssc, int64_t sst,
+                                                             D* __restrict__ dst, int64_t dsb, int64_t dsc, int64_t dst_st, int C, int T) {
+	__shared__ float tile[64][65];
+	const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const bool src_t_fast = (sst == 1) || (ssc != 1), dst_t_fast = (dst_st == 1) || (dsc != 1);
+#pragma unroll 4
+	for (int i = 0; i < 16; ++i) {
+		int c = src_t_fast ? c0 + ty + 4 * i : c0 + tx, t = src_t_fast ? t0 + tx : t0 + ty + 4 * i;
+		float v = 0.f;
+		if (c < C && t < T) v = Elem<S>::load(src + b * ssb + c * ssc + t * sst);
+		tile[c - c0][t - t0] = v;
+	}
+	__syncthreads();
+#pragma unroll 4
+	for (int i = 0; i < 16; ++i) {
+		int c = dst_t_fast ? c0 + ty + 4 * i : c0 + tx, t = dst_t_fast ? t0 + tx : t0 + ty + 4 * i;
+		if (c < C && t < T) Elem<D>::store(dst + b * dsb + c * dsc + t * dst_st, tile[c - c0][t - t0]);
+	}
+}
+
+extern "C" int convasr_convert_layout(const void* src, int src_dtype, int64_t ssb, int64_t ssc, int64_t sst, void* dst, int dst_dtype,
+                                      int64_t dsb, int64_t dsc, int64_t dst_st, int B, int C, int T, void* stream) {
+	CONVASR_CHECK_ARG(src && dst && B > 0 && C > 0 && T > 0, "convert_layout: bad arguments");
+	dim3 grid((T + 63) / 64, (C + 63) / 64, B);
+	hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(S, D) hipLaunchKernelGGL((convert_layout_kernel<S, D>), grid, dim3(256), 0, s, (const S*)src, ssb, ssc, sst, (D*)dst, dsb, dsc, dst_st, C, T)
+	if (src_dtype == CONVASR_F32 && dst_dtype == CONVASR_F32) LAUNCH(float, float);
+	else if (src_dtype == CONVASR_F32 && dst_dtype == CONVASR_BF16) LAUNCH(float, bf16_t);
+	else if (src_dtype == CONVASR_BF16 && dst_dtype == CONVASR_F32) LAUNCH(bf16_t, float);
+	else if (src_dtype == CONVASR_BF16 && dst_dtype == CONVASR_BF16) LAUNCH(bf16_t, bf16_t);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "convert_layout: dtype %d -> %d", src_dtype, dst_dtype);
+#undef LAUNCH
+	CONVASR_CHECK_LAUNCH("convert_layout");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ instance norm
+// One block per (b, 64-channel group); lane = channel, waves stride over time.  Three passes over an L2-resident slab:
+// masked mean, masked sum of squared deviations (two-pass, like the reference), normalise.
+template <typename S, typename D>
+__global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x, int64_t xsb, int64_t xsc, int64_t xst, D* __restrict__ y,
+                                                        int64_t ysb, int64_t ysc, int64_t yst, const float* __restrict__ xlen, int C, int T, float eps) {
+	__shared__ float red[16][64];
+	__shared__ float bc[64];
+	const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int n = valid_len(xlen, b, T);
+	const bool ok = c < C;
+	const S* xp = x + b * xsb + (ok ? c : 0) * xsc;
+	float acc = 0.f;
+	for (int t = w; t < n; t += 16) acc += ok ? Elem<S>::load(xp + t * xst) : 0.f;
+	red[w][lane] = acc;
+	__syncthreads();
+	if (w == 0) { float s = 0.f; for (int i = 0; i < 16; ++i) s += red[i][lane]; bc[lane] = s / (float)n; }
+	__syncthreads();
+	const float mean = bc[lane];
+	acc = 0.f;
+	for (int t = w; t < n; t += 16) { float d = ok ? Elem<S>::load(xp + t * xst) - mean : 0.f; acc += d * d; }
+	__syncthreads();
+	red[w][lane] = acc;
+	__syncthreads();
+	if (w == 0) { float s = 0.f; for (int i = 0; i < 16; ++i) s += red[i][lane]; bc[lane] = sqrtf(s / (float)n + eps); }
+	__syncthreads();
+	const float stdv = bc[lane];
+	if (!ok) return;
+	D* yp = y + b * ysb + c * ysc;
+	for (int t = w; t < T; t += 16) {
+		float v = t < n ? (Elem<S>::load(xp + t * xst) - mean) / stdv : 0.f;
+		Elem<D>::store(yp + t * yst, v);
+	}
+}
+
+extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb,
+                                    int64_t ysc, int64_t yst, const float* xlen, int B, int C, int T, float eps, void* stream) {
+	CONVASR_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0, "instnorm_fwd: bad arguments");
+	dim3 grid((C + 63) / 64, B);
+	hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(S, D) hipLaunchKernelGGL((instnorm_kernel<S, D>), grid, dim3(1024), 0, s, (const S*)x, xsb, xsc, xst, (D*)y, ysb, ysc, yst, xlen, C, T, eps)
+	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) LAUNCH(float, float);
+	else if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_BF16) LAUNCH(float, bf16_t);
+	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_F32) LAUNCH(bf16_t, float);
+	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_BF16) LAUNCH(bf16_t, bf16_t);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "instnorm_fwd: dtype %d -> %d", x_dtype, y_dtype);
+#undef LAUNCH
+	CONVASR_CHECK_LAUNCH("instnorm_fwd");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ log-softmax over C (rows of a (rows, C) matrix)
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int C) {
+	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (row >= rows) return;
+	const float* xp = x + row * C;
+	float m = -INFINITY;
+	for (int c = lane; c < C; c += 64) m = fmaxf(m, xp[c]);
+	m = wave_max(m);
+	float s = 0.f;
+	for (int c = lane; c < C; c += 64) s += expf(xp[c] - m);
+	s = wave_sum(s);
+	const float lse = m + logf(s);
+	for (int c = lane; c < C; c += 64) y[row * C + c] = xp[c] - lse;
+}
+
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ lp, float* __restrict__ dx, int64_t rows, int C) {
+	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (row >= rows) return;
+	float s = 0.f;
+	for (int c = lane; c < C; c += 64) s += g[row * C + c];
+	s = wave_sum(s);
+	for (int c = lane; c < C; c += 64) dx[row * C + c] = g[row * C + c] - expf(lp[row * C + c]) * s;
+}
+
+extern "C" int convasr_log_softmax_fwd(const float* logits, float* log_probs, int64_t rows, int C, void* stream) {
+	CONVASR_CHECK_ARG(logits && log_probs && rows > 0 && C > 0, "log_softmax_fwd: bad arguments");
+	hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, log_probs, rows, C);
+	CONVASR_CHECK_LAUNCH("log_softmax_fwd");
+	return 0;
+}
+
+extern "C" int convasr_log_softmax_bwd(const float* grad_lp, const float* log_probs, float* dlogits, int64_t rows, int C, void* stream) {
+	CONVASR_CHECK_ARG(grad_lp && log_probs && dlogits && rows > 0 && C > 0, "log_softmax_bwd: bad arguments");
+	hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, grad_lp, log_probs, dlogits, rows, C);
+	CONVASR_CHECK_LAUNCH("log_softmax_bwd");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ entropy / argmax / row scaling
+__global__ __launch_bounds__(256) void entropy_kernel(const float* __restrict__ lp, const int64_t* __restrict__ olen, float* __restrict__ ent, int T, int C, float eps) {
+	__shared__ float red[4];
+	const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int n = olen ? (int)olen[b] : T;
+	float acc = 0.f;
+	for (int t = w; t < n && t < T; t += 4) {
+		const float* p = lp + ((int64_t)b * T + t) * C;
+		for (int c = lane; c < C; c += 64) { float v = p[c]; acc -= expf(v) * v; }
+	}
+	acc = wave_sum(acc);
+	if (lane == 0) red[w] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float s = red[0] + red[1] + red[2] + red[3];
+		ent[b] = olen ? s / (eps + (float)n) : s / (float)T;
+	}
+}
+
+extern "C" int convasr_entropy(const float* log_probs, const int64_t* olen, float* ent, int B, int T, int C, float eps, void* stream) {
+	CONVASR_CHECK_ARG(log_probs && ent && B > 0 && T > 0 && C > 0, "entropy: bad arguments");
+	hipLaunchKernelGGL(entropy_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, log_probs, olen, ent, T, C, eps);
+	CONVASR_CHECK_LAUNCH("entropy");
+	return 0;
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ lp, int64_t* __restrict__ idx, int64_t rows, int C) {
+	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (row >= rows) return;
+	float best = -INFINITY;
+	int bi = 0x7fffffff;
+	for (int c = lane; c < C; c += 64) { float v = lp[row * C + c]; if (v > best || (v != v && best == best)) { best = v; bi = c; } }
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		float ov = __shfl_xor(best, o, 64);
+		int oi = __shfl_xor(bi, o, 64);
+		if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+	}
+	if (lane == 0) idx[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+extern "C" int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, void* stream) {
+	CONVASR_CHECK_ARG(log_probs && idx && rows > 0 && C > 0, "argmax: bad arguments");
+	hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, log_probs, idx, rows, C);
+	CONVASR_CHECK_LAUNCH("argmax");
+	return 0;
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ sc, float* __restrict__ out, int64_t per_b) {
+	const int b = blockIdx.y;
+	const float s = sc[b];
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_b; i += (int64_t)gridDim.x * 256) out[b * per_b + i] = g[b * per_b + i] * s;
+}
+
+extern "C" int convasr_scale_rows(const float* grad, const float* gscale, float* out, int B, int64_t per_b, void* stream) {
+	CONVASR_CHECK_ARG(grad && gscale && out && B > 0 && per_b > 0, "scale_rows: bad arguments");
+	unsigned gx = (unsigned)(ceil_div64(per_b, 256) > 64 ? 64 : ceil_div64(per_b, 256));
+	hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, grad, gscale, out, per_b);
+	CONVASR_CHECK_LAUNCH("scale_rows");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ gradient norm + SGD
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+	__shared__ float red[4];
+	float acc = 0.f;
+	const int64_t n4 = n >> 2;
+	const float4* g4 = reinterpret_cast<const float4*>(g);
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+		float4 v = g4[i];
+		acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[n4 * 4 + threadIdx.x]; acc += v * v; }
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(out, (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
+}
+
+extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream) {
+	CONVASR_CHECK_ARG(g && sumsq && n > 0, "sumsq: bad arguments");
+	CONVASR_CHECK_ARG(((uintptr_t)g & 15) == 0, "sumsq: g must be 16-byte aligned");
+	int64_t blocks = ceil_div64(n, 1024);
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+	CONVASR_CHECK_LAUNCH("sumsq");
+	return 0;
+}
+
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
+                                                       int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first) {
+	float clip = 1.f;
+	if (sumsq) {
+		float total = (float)sqrt(*sumsq);
+		float c = max_norm / (total + 1e-6f);
+		clip = c < 1.f ? c : 1.f;
+	}
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+		float gc = g[i] * clip;
+		if (gout) gout[i] = gc;
+		float pv = p[i];
+		float d = gc + wd * pv;
+		if (mom != 0.f) {
+			float bv = first ? d : mom * buf[i] + d;
+			buf[i] = bv;
+			d = nesterov ? d + mom * bv : bv;
+		}
+		p[i] = pv - lr * d;
+	}
+}
+
+extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm, float lr,
+                                float momentum, float weight_decay, int nesterov, int first, void* stream) {
+	CONVASR_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || buf), "sgd_step: bad arguments");
+	int64_t blocks = ceil_div64(n, 256);
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first);
+	CONVASR_CHECK_LAUNCH("sgd_step");
+	return 0;
+}

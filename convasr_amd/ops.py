@@ -1,0 +1,279 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see functional.py).
+
+Activations travel as torch tensors of LOGICAL shape (B, C, T) -- the reference's convention -- whose memory is
+channels-last: strides (T*C, 1, C).  `empty_cl` allocates one, `as_cl` converts anything else with the HIP layout kernel.
+PyTorch is used for allocation, streams and dtype bookkeeping only; every arithmetic op is a kernel of libconvasr_hip.so.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr, dtype_code, require_cuda
+
+ACT_CODES = dict(none = _lib.ACT_NONE, relu = _lib.ACT_RELU, hardtanh = _lib.ACT_HARDTANH, leaky_relu = _lib.ACT_LEAKY_RELU)
+
+
+def act_args(nonlinearity):
+	"""('relu',) / ('hardtanh', lo, hi) / ('leaky_relu', slope) -> (code, lo, hi) (reference: models.py:368)."""
+	if nonlinearity is None:
+		return _lib.ACT_NONE, 0.0, 0.0
+	name = nonlinearity[0]
+	if name == 'relu':
+		return _lib.ACT_RELU, 0.0, 0.0
+	if name == 'hardtanh':
+		return _lib.ACT_HARDTANH, float(nonlinearity[1]), float(nonlinearity[2])
+	if name == 'leaky_relu':
+		return _lib.ACT_LEAKY_RELU, float(nonlinearity[1]) if len(nonlinearity) > 1 else 0.01, 0.0
+	raise ValueError(f'unsupported nonlinearity {nonlinearity}')
+
+
+def empty_cl(B, C, T, dtype, device):
+	return torch.empty(B, T, C, dtype = dtype, device = device).permute(0, 2, 1)
+
+
+def zeros_cl(B, C, T, dtype, device):
+	return torch.zeros(B, T, C, dtype = dtype, device = device).permute(0, 2, 1)
+
+
+def is_cl(x):
+	B, C, T = x.shape
+	return x.stride(1) == 1 and x.stride(2) == C and (x.stride(0) == T * C or B == 1)
+
+
+def convert(x, dtype, channels_last):
+	"""(B, C, T) tensor of any strides -> new tensor of `dtype`, channels-last or torch-contiguous."""
+	require_cuda(x)
+	B, C, T = x.shape
+	out = empty_cl(B, C, T, dtype, x.device) if channels_last else torch.empty(B, C, T, dtype = dtype, device = x.device)
+	call('convasr_convert_layout', ptr(x), dtype_code(x.dtype), x.stride(0), x.stride(1), x.stride(2), ptr(out), dtype_code(dtype), out.stride(0), out.stride(1), out.stride(2), B, C, T, stream_ptr())
+	return out
+
+
+def as_cl(x, dtype = None):
+	dtype = dtype or x.dtype
+	if x.dtype == dtype and is_cl(x):
+		return x
+	return convert(x, dtype, True)
+
+
+def xlen_f32(xlen, device):
+	if xlen is None:
+		return None
+	return xlen.to(device = device, dtype = torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ frontend / instance norm
+
+def logmel(signal, xlen, window, mel_weight, mel_bias, nfft, hop, preemphasis = 0.97, normalize = True):
+	"""LogFilterBankFrontend.forward (models.py:565-597) -> channels-last (B, nmel, F) fp32."""
+	require_cuda(signal, window, mel_weight, mel_bias)
+	assert signal.ndim == 2
+	if signal.dtype not in (torch.float32, torch.int16):
+		signal = signal.to(torch.float32) if signal.is_floating_point() else signal.to(torch.int16) if signal.dtype in (torch.int8, torch.uint8) else signal.to(torch.float32)
+	signal = signal.contiguous()
+	B, T = signal.shape
+	nmel = mel_weight.shape[0]
+	F = 1 + T // hop
+	absmax = None
+	s = stream_ptr()
+	if normalize:
+		absmax = torch.empty(B, dtype = torch.float32, device = signal.device)
+		call('convasr_signal_absmax', ptr(signal), dtype_code(signal.dtype), B, T, ptr(absmax), s)
+	out = empty_cl(B, nmel, F, torch.float32, signal.device)
+	xl = xlen_f32(xlen, signal.device)
+	call('convasr_logmel_fwd', ptr(signal), dtype_code(signal.dtype), ptr(absmax), ptr(xl), ptr(window), window.shape[0], ptr(mel_weight), ptr(mel_bias), ptr(out), B, T, nfft, hop, nmel, float(preemphasis), s)
+	return out
+
+
+def instnorm(x, xlen, eps, out_dtype = None, channels_last = True):
+	"""MaskedInstanceNorm1d.forward (models.py:694-719); xlen None = legacy unmasked branch."""
+	require_cuda(x)
+	B, C, T = x.shape
+	out_dtype = out_dtype or x.dtype
+	out = empty_cl(B, C, T, out_dtype, x.device) if channels_last else torch.empty(B, C, T, dtype = out_dtype, device = x.device)
+	xl = xlen_f32(xlen, x.device)
+	call('convasr_instnorm_fwd', ptr(x), dtype_code(x.dtype), x.stride(0), x.stride(1), x.stride(2), ptr(out), dtype_code(out_dtype), out.stride(0), out.stride(1), out.stride(2), ptr(xl), B, C, T, float(eps), stream_ptr())
+	return out
+
+
+# ------------------------------------------------------------------------------------------------ conv
+
+def cout_pad(c):
+	return _lib.load().convasr_conv_cout_pad(c)
+
+
+def pack_weight(w, dtype, mode):
+	"""(Cout, Cin, K) fp32 parameter -> packed [K][rows_pad][cols] tensor for the MFMA kernels."""
+	require_cuda(w)
+	w = w.detach()
+	if w.dtype != torch.float32 or not w.is_contiguous():
+		w = w.float().contiguous()
+	Cout, Cin, K = w.shape
+	rows, cols = (Cout, Cin) if mode == _lib.PACK_FWD else (Cin, Cout)
+	out = torch.empty(K, cout_pad(rows), cols, dtype = dtype, device = w.device)
+	call('convasr_pack_conv_weight', ptr(w), ptr(out), dtype_code(dtype), Cout, Cin, K, mode, stream_ptr())
+	return out
+
+
+def conv_out_len(Tin, K, stride, dil, pad):
+	return (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
+
+
+def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None):
+	"""x: channels-last (B, Cin, Tin); wp: packed weights.  Returns channels-last (B, Cout, Tout)."""
+	B, Cin, Tin = x.shape
+	assert is_cl(x), 'conv1d expects a channels-last activation'
+	Tout = conv_out_len(Tin, K, stride, dil, pad)
+	out_dtype = out_dtype or x.dtype
+	y = empty_cl(B, Cout, Tout, out_dtype, x.device)
+	call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), ptr(stats), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), stream_ptr())
+	return y
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag = 'default'):
+	"""Grow-only scratch buffer per (device, tag); kernels that use it are ordered on the current stream."""
+	key = (device, tag)
+	buf = _workspaces.get(key)
+	if buf is None or buf.numel() < nbytes:
+		buf = torch.empty(max(int(nbytes), 1 << 20), dtype = torch.uint8, device = device)
+		_workspaces[key] = buf
+	return buf
+
+
+def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate = False):
+	"""dw (Cout, Cin, K) fp32 (+)= wgrad; x, dy channels-last of the same dtype."""
+	B, Cin, Tin = x.shape
+	Tout = dy.shape[2]
+	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and dw.is_contiguous() and dw.dtype == torch.float32
+	nbytes = _lib.load().convasr_conv1d_wgrad_workspace_bytes(B, Cin, Cout, Tin, Tout, K, stride, dil)
+	ws = workspace(nbytes, x.device, 'wgrad')
+	call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), stream_ptr())
+	return dw
+
+
+# ------------------------------------------------------------------------------------------------ batch norm + activation
+
+def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps):
+	C = stats.numel() // 2
+	dev = stats.device
+	out = torch.empty(4, C, dtype = torch.float32, device = dev)  # mean, invstd, scale, shift
+	call('convasr_bn_finalize', ptr(stats), n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, stream_ptr())
+	return out
+
+
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
+	C = running_mean.numel()
+	out = torch.empty(2, C, dtype = torch.float32, device = running_mean.device)
+	call('convasr_bn_eval_scale_shift', ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), ptr(out[0]), ptr(out[1]), C, stream_ptr())
+	return out
+
+
+def _ptr_array(items):
+	import ctypes
+	arr = (ctypes.c_void_p * max(len(items), 1))()
+	for i, t in enumerate(items):
+		arr[i] = None if t is None else t.data_ptr()
+	return arr
+
+
+def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None):
+	B, C, T = y.shape
+	assert is_cl(y) and all(is_cl(r) and r.dtype == y.dtype for r in res)
+	z = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
+	call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr())
+	return z
+
+
+def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None):
+	B, C, T = y.shape
+	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype
+	g = empty_cl(B, C, T, y.dtype, y.device)
+	call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), B, T, C, stream_ptr())
+	return g
+
+
+def bn_bwd_apply(g, y, gamma, mean, invstd, sums, dgamma = None, dbeta = None, accumulate = False, need_dy = True, inplace = True):
+	B, C, T = y.shape
+	dy = (g if inplace else empty_cl(B, C, T, y.dtype, y.device)) if need_dy else None
+	call('convasr_bn_bwd_apply', ptr(g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(gamma), ptr(mean), ptr(invstd), ptr(sums), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, stream_ptr())
+	return dy
+
+
+# ------------------------------------------------------------------------------------------------ head
+
+def log_softmax(logits):
+	"""channels-last fp32 (B, C, T) -> same."""
+	B, C, T = logits.shape
+	assert is_cl(logits) and logits.dtype == torch.float32
+	out = empty_cl(B, C, T, torch.float32, logits.device)
+	call('convasr_log_softmax_fwd', ptr(logits), ptr(out), B * T, C, stream_ptr())
+	return out
+
+
+def log_softmax_bwd(grad_lp, log_probs):
+	B, C, T = log_probs.shape
+	grad_lp = as_cl(grad_lp, torch.float32)
+	out = empty_cl(B, C, T, torch.float32, log_probs.device)
+	call('convasr_log_softmax_bwd', ptr(grad_lp), ptr(log_probs), ptr(out), B * T, C, stream_ptr())
+	return out
+
+
+def ctc_loss(log_probs, targets, olen, ylen, blank, need_grad = True):
+	"""log_probs channels-last fp32 (B, C, T); returns (nll (B,), grad channels-last (B, C, T) or None)."""
+	B, C, T = log_probs.shape
+	assert is_cl(log_probs) and log_probs.dtype == torch.float32
+	dev = log_probs.device
+	targets = targets.to(device = dev, dtype = torch.int64).contiguous()
+	if targets.ndim == 1:
+		targets = targets.view(B, -1)
+	olen = olen.to(device = dev, dtype = torch.int64).contiguous()
+	ylen = ylen.to(device = dev, dtype = torch.int64).contiguous()
+	S_max = targets.shape[1]
+	nbytes = _lib.load().convasr_ctc_workspace_bytes(B, T, S_max)
+	if nbytes < 0:
+		raise _lib.ConvasrHipError(f'ctc_loss: target length {S_max} unsupported')
+	ws = workspace(nbytes, dev, 'ctc')
+	nll = torch.empty(B, dtype = torch.float32, device = dev)
+	grad = empty_cl(B, C, T, torch.float32, dev) if need_grad else None
+	call('convasr_ctc_loss', ptr(log_probs), ptr(targets), ptr(olen), ptr(ylen), ptr(nll), ptr(grad), ptr(ws), B, T, C, S_max, blank, stream_ptr())
+	return nll, grad
+
+
+def scale_rows(grad, gscale):
+	B = grad.shape[0]
+	out = torch.empty_like(grad)  # preserves strides (channels-last stays channels-last)
+	call('convasr_scale_rows', ptr(grad), ptr(gscale.to(torch.float32).contiguous()), ptr(out), B, grad.numel() // B, stream_ptr())
+	return out
+
+
+def entropy(log_probs, olen = None, eps = 1e-9):
+	B, C, T = log_probs.shape
+	lp = as_cl(log_probs, torch.float32)
+	ent = torch.empty(B, dtype = torch.float32, device = lp.device)
+	ol = None if olen is None else olen.to(device = lp.device, dtype = torch.int64).contiguous()
+	call('convasr_entropy', ptr(lp), ptr(ol), ptr(ent), B, T, C, float(eps), stream_ptr())
+	return ent
+
+
+def argmax(log_probs):
+	B, C, T = log_probs.shape
+	lp = as_cl(log_probs, torch.float32)
+	idx = torch.empty(B, T, dtype = torch.int64, device = lp.device)
+	call('convasr_argmax', ptr(lp), ptr(idx), B * T, C, stream_ptr())
+	return idx
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+
+def sumsq(flat_grad, out = None):
+	out = out if out is not None else torch.zeros(1, dtype = torch.float64, device = flat_grad.device)
+	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), stream_ptr())
+	return out
+
+
+def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None):
+	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), stream_ptr())

@@ -1,0 +1,166 @@
+/* convasr_hip.h -- C ABI of libconvasr_hip.so: the MI355X (gfx950) implementation of convasr's one hot path.
+ *
+ * The reference (vadimkantorov/convasr) has no FFI on this path: its boundary is the Python nn.Module surface of
+ * models.py, whose arithmetic is delegated to torch.nn.functional (ATen/cuDNN/cuFFT).  Each entry point below names
+ * the reference call site(s) (file:line in /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory; nothing here allocates, frees or synchronises;
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns 0, or a negative
+ *     CONVASR_E* code with a message retrievable through convasr_last_error() (thread-local);
+ *   - activations are "channels-last": element (b, c, t) of a logical (B, C, T) tensor lives at
+ *     ((b * T + t) * C + c); dtype is CONVASR_F32 or CONVASR_BF16.  convasr_convert_layout() moves data between
+ *     this layout and arbitrary (B, C, T) strides (e.g. torch-contiguous NCW);
+ *   - conv weights are consumed in a packed layout [tap][cout_pad][cin] produced by convasr_pack_conv_weight()
+ *     from the reference's (Cout, Cin, K) fp32 parameters;
+ *   - lengths are passed the way the reference passes them: `xlen` = fraction of the time axis per utterance
+ *     (float, models.py:611-614); valid frames of a T-long axis are t < ceil(xlen[b] * T).
+ */
+#ifndef CONVASR_HIP_H
+#define CONVASR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONVASR_ABI_VERSION 1
+
+enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2 };
+enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
+enum { CONVASR_OK = 0, CONVASR_EINVAL = -1, CONVASR_ELAUNCH = -2, CONVASR_EUNSUPPORTED = -3 };
+enum { CONVASR_PACK_FWD = 0, CONVASR_PACK_DGRAD = 1 };
+
+int convasr_abi_version(void);
+const char* convasr_last_error(void);
+
+/* ---- layout / dtype plumbing -------------------------------------------------------------------------------- */
+
+/* dst[b,c,t] = (dst_dtype) src[b,c,t] for arbitrary element strides on both sides. */
+int convasr_convert_layout(const void* src, int src_dtype, int64_t src_sb, int64_t src_sc, int64_t src_st,
+                           void* dst, int dst_dtype, int64_t dst_sb, int64_t dst_sc, int64_t dst_st,
+                           int B, int C, int T, void* stream);
+
+/* ---- frontend: models.py:565-597 (LogFilterBankFrontend.forward), models.py:684-686 (normalize_signal) -------- */
+
+/* absmax[b] = max_t |signal[b,t]|  (models.py:685).  signal dtype F32 or I16. */
+int convasr_signal_absmax(const void* signal, int signal_dtype, int B, int T, float* absmax, void* stream);
+
+/* Fused normalise -> pre-emphasis -> mask -> reflect/zero pad -> STFT(nfft, hop, window centred in nfft) -> power ->
+ * mel (nmel x (nfft/2+1), + bias) -> log.  out is channels-last (B, F, nmel) fp32 with F = 1 + T / hop.
+ * absmax may be NULL (normalize_signal=False); xlen may be NULL (no mask).  nfft must be 512, nmel <= 64... see
+ * DESIGN.md for the supported envelope; anything else returns CONVASR_EUNSUPPORTED. */
+int convasr_logmel_fwd(const void* signal, int signal_dtype, const float* absmax, const float* xlen,
+                       const float* window, int win_length, const float* mel_weight, const float* mel_bias,
+                       float* out, int B, int T, int nfft, int hop, int nmel, float preemphasis, void* stream);
+
+/* ---- MaskedInstanceNorm1d.forward: models.py:694-719 ---------------------------------------------------------- */
+
+/* x, y: (B, C, T) with the given element strides.  xlen NULL -> legacy un-masked branch (models.py:704-710). */
+int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc, int64_t x_st,
+                         void* y, int y_dtype, int64_t y_sb, int64_t y_sc, int64_t y_st,
+                         const float* xlen, int B, int C, int T, float eps, void* stream);
+
+/* ---- Conv1d: models.py:47-77 (ConvSamePadding -> nn.Conv1d), models.py:23-44 (Decoder 1x1) --------------------- */
+
+/* cout_pad(cout): rows of the packed weight (multiple of the kernel's N tile). */
+int convasr_conv_cout_pad(int cout);
+
+/* (Cout, Cin, K) fp32 -> packed [K][cout_pad][cin] of `dtype`.  mode FWD: packed[k][co][ci] = w[co][ci][k];
+ * mode DGRAD: packed[k][ci][co] = w[co][ci][K-1-k] (rows padded to convasr_conv_cout_pad(Cin)). */
+int convasr_pack_conv_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int K, int mode, void* stream);
+
+/* y[b,t,co] = epilogue( sum_{k,ci} x[b, t*stride + k*dil - pad, ci] * wp[k][co][ci] ), zero outside [0, Tin).
+ * epilogue: acc -> (+ bias[co] if bias) -> (stats of that value: sum[co] += v, sumsq[co] += v*v over all valid
+ * (b,t) if stats) -> (* scale[co] + shift[co] if scale) -> activation -> (zero frames t >= ceil(xlen[b]*Tout) if xlen)
+ * -> store as y_dtype.  stats points at 2*Cout doubles (sum then sumsq) that the caller zeroed.
+ * Used for forward (mode FWD weights) and for dgrad (mode DGRAD weights, stride must be 1, pad' = dil*(K-1) - pad). */
+int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype,
+                       int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil, int pad,
+                       const float* bias, double* stats, const float* scale, const float* shift,
+                       int act, float act_lo, float act_hi, const float* xlen, void* stream);
+
+/* Bytes of fp32 workspace convasr_conv1d_wgrad needs (split-K partial slabs). */
+int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil);
+
+/* dw[co][ci][k] (+)= sum_{b,t} dy[b,t,co] * x[b, t*stride + k*dil - pad, ci]; dw is the fp32 (Cout, Cin, K) gradient
+ * in the reference's parameter layout.  accumulate != 0 adds to dw.  dbias (Cout fp32, may be NULL) = sum dy. */
+int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype,
+                         int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil, int pad,
+                         int accumulate, void* stream);
+
+/* ---- BatchNorm1d + ResidualActivation + temporal mask: models.py:111-114, 127-139, 357-371, 436-443 ----------- */
+
+/* From the conv epilogue's stats (sum, sumsq over n = B*T values per channel): batch mean / biased var ->
+ * scale = gamma * invstd, shift = beta - mean * scale; mean/invstd saved for backward; running stats updated
+ * with momentum (running_var with the unbiased estimate), exactly nn.BatchNorm1d training semantics. */
+int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+
+/* eval: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale. */
+int convasr_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                float eps, float* scale, float* shift, int C, void* stream);
+
+/* z = mask_t( dropout( act( y * scale[c] + shift[c] + sum_r (res_r * rscale_r[c] + rshift_r[c]) ) ) ).
+ * y, z, res_r channels-last (B, T, C) of `dtype`.  n_res <= 12; rscale_r NULL means the residual is added as is.
+ * dropout_p == 0 disables dropout; otherwise Philox(seed, offset) keyed by element index. */
+int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift,
+                       int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
+                       int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                       const float* xlen, int B, int T, int C, void* stream);
+
+/* Backward of the above, pass 1.  g = dz * mask * dropout * act'(pre), pre recomputed from y (and residuals).
+ * Writes g (same dtype) and accumulates per channel: sums[0..C) += sum g, sums[C..2C) += sum g * xhat with
+ * xhat = (y - mean) * invstd, and for each residual r with BN: rsums_r likewise w.r.t. (res_r, rmean_r, rinvstd_r).
+ * sums are doubles the caller zeroed. */
+int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift,
+                              const float* mean, const float* invstd,
+                              int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
+                              const float* const* rmean, const float* const* rinvstd, double* const* rsums,
+                              int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                              const float* xlen, double* sums, int B, int T, int C, void* stream);
+
+/* Backward pass 2: dy = gamma * invstd * (g - sum_g / n - xhat * sum_gxhat / n)  (batch-norm training backward);
+ * dgamma = sum_gxhat, dbeta = sum_g (written, or added when accumulate).  In place allowed (dy == g). */
+int convasr_bn_bwd_apply(const void* g, const void* y, void* dy, int dtype, const float* gamma, const float* mean,
+                         const float* invstd, const double* sums, float* dgamma, float* dbeta, int accumulate,
+                         int B, int T, int C, void* stream);
+
+/* ---- head: models.py:316 (log_softmax), 323 (F.ctc_loss), 645-657 (entropy), transcript_generators.py:27 (argmax) */
+
+/* logits/log_probs channels-last (B, T, C) fp32. */
+int convasr_log_softmax_fwd(const float* logits, float* log_probs, int64_t rows, int C, void* stream);
+/* dlogits = g - exp(lp) * sum_c g */
+int convasr_log_softmax_bwd(const float* grad_lp, const float* log_probs, float* dlogits, int64_t rows, int C, void* stream);
+
+int64_t convasr_ctc_workspace_bytes(int B, int T, int S_max);
+/* nll[b] = -log p(targets[b,:ylen[b]] | log_probs[b,:olen[b]]) with blank = `blank`, +inf when infeasible
+ * (zero_infinity=False).  grad (B,T,C) = d nll / d log_probs as ATen defines it: exp(lp) - posterior for t < olen,
+ * 0 for t >= olen (may be NULL: forward only).  targets: (B, S_max) int64, olen/ylen int64 (the reference's dtypes). */
+int convasr_ctc_loss(const float* log_probs, const int64_t* targets, const int64_t* olen, const int64_t* ylen,
+                     float* nll, float* grad, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);
+/* out[b,t,c] = grad[b,t,c] * gscale[b]   (chain rule for reduction='none'). */
+int convasr_scale_rows(const float* grad, const float* gscale, float* out, int B, int64_t per_b, void* stream);
+
+/* ent[b] = sum_{t<olen} -sum_c p log p / (eps + olen[b])  (olen NULL: mean over T). */
+int convasr_entropy(const float* log_probs, const int64_t* olen, float* ent, int B, int T, int C, float eps, void* stream);
+/* idx[b,t] = argmax_c log_probs[b,t,c] (first maximum, like torch.argmax on CPU). */
+int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, void* stream);
+
+/* ---- optimizer: train.py:777-782 (clip_grad_norm_, SGD step), optimizers.py:66-90 (NovoGrad) ------------------- */
+
+/* sumsq[0] += sum g^2 over n fp32 values (double accumulator the caller zeroed). */
+int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream);
+/* torch.optim.SGD step with clip folded in: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (c = 1 if sumsq NULL);
+ * g' = c*g + wd*p; buf = first ? g' : mom*buf + g'; p -= lr * (nesterov ? g' + mom*buf : buf).
+ * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad). */
+int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
+                     float lr, float momentum, float weight_decay, int nesterov, int first, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

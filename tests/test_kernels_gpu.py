@@ -1,0 +1,357 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle / golden vectors.  `-m gpu` needs an MI355X."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import convasr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+gpu = pytest.mark.gpu
+T_ = lambda a: torch.as_tensor(np.asarray(a))
+
+
+def dev():
+	return torch.device('cuda:0')
+
+
+def close(a, b, rtol, atol, what = ''):
+	a, b = a.detach().double().cpu(), b.detach().double().cpu()
+	assert a.shape == b.shape, (what, a.shape, b.shape)
+	err = (a - b).abs()
+	tol = atol + rtol * b.abs()
+	assert bool((err <= tol).all()), f'{what}: max abs err {float(err.max()):.3e}, worst excess {float((err - tol).max()):.3e}'
+
+
+# ------------------------------------------------------------------------------------------------ no GPU needed
+
+def test_library_exports_every_declared_symbol():
+	from convasr_amd import _lib
+	header = open(os.path.join(ROOT, 'include', 'convasr_hip.h')).read()
+	declared = set(re.findall(r'\b(convasr_[a-z0-9_]+)\s*\(', header))
+	assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
+	lib = _lib.load()
+	for name in declared:
+		assert hasattr(lib, name), name
+	assert lib.convasr_abi_version() == 1
+	assert lib.convasr_conv_cout_pad(38) == 128 and lib.convasr_conv_cout_pad(256) == 256
+
+
+def test_product_path_refuses_cpu_tensors():
+	from convasr_amd import ops, _lib
+	with pytest.raises(_lib.ConvasrHipError):
+		ops.convert(torch.zeros(1, 8, 8), torch.float32, True)
+
+
+# ------------------------------------------------------------------------------------------------ layout / frontend / instnorm
+
+@gpu
+def test_convert_layout_roundtrip():
+	from convasr_amd import ops
+	x = torch.randn(3, 70, 131)
+	for dt, tol in [(torch.float32, 0), (torch.bfloat16, 1e-2)]:
+		cl = ops.convert(x.to(dev()), dt, True)
+		assert ops.is_cl(cl) and cl.shape == x.shape
+		close(cl.float(), x, tol, tol, 'to channels-last')
+		back = ops.convert(cl, torch.float32, False)
+		assert back.is_contiguous()
+		close(back, x, tol, tol, 'back')
+	sl = x.to(dev())[:, 3:40, 5:100]
+	close(ops.convert(sl, torch.float32, True), x[:, 3:40, 5:100], 0, 0, 'strided source')
+
+
+@gpu
+def test_logmel_frontend_golden():
+	from convasr_amd import ops
+	g = np.load(os.path.join(GOLDEN, 'frontend.npz'))
+	d = dev()
+	win, mw, mb = T_(g['window']).to(d), T_(g['mel_weight'])[:, :, 0].contiguous().to(d), T_(g['mel_bias']).to(d)
+	x, xlen = T_(g['x']).to(d), T_(g['xlen']).to(d)
+	# log-mel of white noise: the reference's own fp32 FFT differs from ours by O(1e-6) relative in power
+	close(ops.logmel(x, xlen, win, mw, mb, 512, 160), T_(g['feat_masked']), 2e-4, 2e-4, 'masked')
+	close(ops.logmel(x, None, win, mw, mb, 512, 160), T_(g['feat_nomask']), 2e-4, 2e-4, 'nomask')
+	close(ops.logmel(T_(g['x16']).to(d), xlen, win, mw, mb, 512, 160), T_(g['feat_int16']), 2e-4, 2e-4, 'int16')
+	close(ops.logmel(T_(g['short']).to(d), None, win, mw, mb, 512, 160), T_(g['feat_short']), 2e-4, 2e-4, 'short (constant pad)')
+
+
+@gpu
+def test_logmel_full_size_against_oracle():
+	from convasr_amd import ops
+	torch.manual_seed(0)
+	d = dev()
+	B, T = 8, 240000
+	x = torch.rand(B, T) * 2 - 1
+	xlen = torch.linspace(0.5, 1, B)
+	win = torch.hann_window(320, periodic = True)
+	mw = torch.as_tensor(O.mel_filterbank(16000, 512, 64))
+	mb = torch.full((64, ), float(torch.finfo(torch.float16).tiny))
+	ref = O.logmel_frontend(x, xlen, win, mw.unsqueeze(-1), mb, 512, 160)
+	out = ops.logmel(x.to(d), xlen.to(d), win.to(d), mw.to(d), mb.to(d), 512, 160)
+	assert out.shape == (B, 64, 1501)
+	close(out, ref, 5e-4, 5e-4, 'logmel 8x15s')
+
+
+@gpu
+def test_instance_norm_golden():
+	from convasr_amd import ops
+	g = np.load(os.path.join(GOLDEN, 'instnorm.npz'))
+	x, xlen = T_(g['x']).to(dev()), T_(g['xlen']).to(dev())
+	close(ops.instnorm(x, xlen, 2.0 ** -14), T_(g['y_masked']), 1e-5, 1e-5, 'masked')
+	close(ops.instnorm(x, None, 2.0 ** -14, channels_last = False), T_(g['y_legacy']), 1e-5, 1e-5, 'legacy')
+	close(ops.instnorm(ops.as_cl(x), xlen, 2.0 ** -14, out_dtype = torch.bfloat16).float(), T_(g['y_masked']), 1e-2, 1e-2, 'bf16 out')
+
+
+# ------------------------------------------------------------------------------------------------ conv
+
+CONV_CASES = [
+	# B, Cin, Cout, T, K, stride, dil
+	(2, 64, 256, 301, 11, 2, 1),
+	(3, 96, 96, 77, 11, 1, 1),
+	(2, 64, 128, 140, 29, 1, 2),
+	(2, 128, 38, 203, 1, 1, 1),
+	(1, 256, 160, 530, 13, 1, 1),
+	(2, 32, 40, 19, 3, 1, 1),
+]
+
+
+def _conv_ref(x, w, bias, stride, dil):
+	return O.conv_same_padding(x, w, bias, stride = stride, dilation = dil)
+
+
+@gpu
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv1d_forward(case, dtype):
+	from convasr_amd import ops, _lib
+	B, Cin, Cout, T, K, stride, dil = case
+	torch.manual_seed(sum(case))
+	dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+	x = torch.randn(B, Cin, T)
+	w = torch.randn(Cout, Cin, K) / (Cin * K) ** 0.5
+	bias = torch.randn(Cout)
+	if dtype == 'bf16':
+		x, w = x.bfloat16().float(), w.bfloat16().float()
+	pad = dil * K // 2
+	ref = _conv_ref(x, w, bias, stride, dil)
+	d = dev()
+	wp = ops.pack_weight(w.to(d), dt, _lib.PACK_FWD)
+	y = ops.conv1d(ops.as_cl(x.to(d), dt), wp, Cout, K, stride, dil, pad, out_dtype = torch.float32 if dtype == 'f32' or Cout == 38 else dt, bias = bias.to(d))
+	assert y.shape == ref.shape and ops.is_cl(y)
+	if dtype == 'f32':
+		close(y, ref, 1e-4, 2e-5, 'conv f32')
+	else:
+		close(y.float(), ref, 2e-2, 2e-2, 'conv bf16')
+
+
+@gpu
+def test_conv1d_epilogue_stats_scale_act_mask():
+	from convasr_amd import ops, _lib
+	torch.manual_seed(3)
+	B, Cin, Cout, T, K = 3, 64, 200, 150, 11
+	x, w = torch.randn(B, Cin, T), torch.randn(Cout, Cin, K) / 26
+	scale, shift = torch.rand(Cout) + 0.5, torch.randn(Cout)
+	xlen = torch.tensor([1.0, 0.61, 0.3])
+	raw = _conv_ref(x, w, None, 1, 1)
+	lengths = O.compute_output_lengths(T, xlen)
+	ref = F.hardtanh(raw * scale[None, :, None] + shift[None, :, None], 0, 20) * O.temporal_mask(T, lengths).unsqueeze(1)
+	d = dev()
+	stats = torch.zeros(2 * Cout, dtype = torch.float64, device = d)
+	y = ops.conv1d(ops.as_cl(x.to(d)), ops.pack_weight(w.to(d), torch.float32, _lib.PACK_FWD), Cout, K, 1, 1, 5, stats = stats, scale = scale.to(d), shift = shift.to(d), act = (_lib.ACT_HARDTANH, 0.0, 20.0), xlen = xlen.to(d))
+	close(y, ref, 1e-4, 2e-5, 'fused epilogue')
+	close(stats[:Cout], raw.double().sum(dim = (0, 2)), 1e-5, 1e-4, 'sum')
+	close(stats[Cout:], (raw.double() ** 2).sum(dim = (0, 2)), 1e-5, 1e-4, 'sumsq')
+
+
+@gpu
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[5] == 1])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv1d_dgrad(case, dtype):
+	from convasr_amd import ops, _lib
+	B, Cin, Cout, T, K, stride, dil = case
+	torch.manual_seed(sum(case) + 1)
+	dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+	w = torch.randn(Cout, Cin, K) / (Cout * K) ** 0.5
+	pad = dil * K // 2
+	Tout = ops.conv_out_len(T, K, 1, dil, pad)
+	dy = torch.randn(B, Cout, Tout)
+	if dtype == 'bf16':
+		dy, w = dy.bfloat16().float(), w.bfloat16().float()
+	x = torch.zeros(B, Cin, T, requires_grad = True)
+	_conv_ref(x, w, None, 1, dil).backward(dy)
+	d = dev()
+	wp = ops.pack_weight(w.to(d), dt, _lib.PACK_DGRAD)
+	dx = ops.conv1d(ops.as_cl(dy.to(d), dt), wp, Cin, K, 1, dil, dil * (K - 1) - pad)
+	assert dx.shape == x.shape
+	if dtype == 'f32':
+		close(dx, x.grad, 1e-4, 2e-5, 'dgrad f32')
+	else:
+		close(dx.float(), x.grad, 2e-2, 2e-2, 'dgrad bf16')
+
+
+@gpu
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv1d_wgrad(case, dtype):
+	from convasr_amd import ops
+	B, Cin, Cout, T, K, stride, dil = case
+	torch.manual_seed(sum(case) + 2)
+	dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+	pad = dil * K // 2
+	Tout = ops.conv_out_len(T, K, stride, dil, pad)
+	x, dy = torch.randn(B, Cin, T), torch.randn(B, Cout, Tout)
+	if dtype == 'bf16':
+		x, dy = x.bfloat16().float(), dy.bfloat16().float()
+	w = torch.zeros(Cout, Cin, K, requires_grad = True)
+	b = torch.zeros(Cout, requires_grad = True)
+	_conv_ref(x, w, b, stride, dil).backward(dy)
+	d = dev()
+	dw = torch.full((Cout, Cin, K), 7.0, device = d)
+	db = torch.full((Cout, ), 7.0, device = d)
+	ops.conv1d_wgrad(ops.as_cl(x.to(d), dt), ops.as_cl(dy.to(d), dt), Cout, K, stride, dil, pad, dw, dbias = db)
+	tol = dict(rtol = 1e-4, atol = 1e-3) if dtype == 'f32' else dict(rtol = 2e-2, atol = 5e-2 * (B * Tout) ** 0.5 / 10)
+	close(dw, w.grad, what = 'wgrad', **tol)
+	close(db, b.grad, what = 'dbias', **tol)
+	ops.conv1d_wgrad(ops.as_cl(x.to(d), dt), ops.as_cl(dy.to(d), dt), Cout, K, stride, dil, pad, dw, dbias = db, accumulate = True)
+	close(dw, 2 * w.grad, what = 'wgrad accumulate', rtol = tol['rtol'], atol = 2 * tol['atol'])
+
+
+# ------------------------------------------------------------------------------------------------ batch norm + activation
+
+@gpu
+@pytest.mark.parametrize('C', [64, 384, 1024, 2560])
+@pytest.mark.parametrize('nonlin', [('hardtanh', 0, 20), ('relu', ), ('leaky_relu', 0.01)])
+def test_bn_act_forward_backward(C, nonlin):
+	from convasr_amd import ops
+	torch.manual_seed(C)
+	B, T = 3, 57
+	y = (torch.randn(B, C, T) * 3 + 1).requires_grad_(True)
+	gamma, beta = (torch.rand(C) + 0.5).requires_grad_(True), torch.randn(C).requires_grad_(True)
+	rm, rv = torch.zeros(C), torch.ones(C)
+	xlen = torch.tensor([1.0, 0.5, 0.77])
+	mask = O.temporal_mask(T, O.compute_output_lengths(T, xlen)).unsqueeze(1)
+	z = O.activation(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5), nonlin) * mask
+	dz = torch.randn_like(z)
+	z.backward(dz)
+	d = dev()
+	ycl = ops.as_cl(y.detach().to(d))
+	stats = torch.stack([y.detach().double().sum(dim = (0, 2)), (y.detach().double() ** 2).sum(dim = (0, 2))]).reshape(-1).to(d)
+	rm_d, rv_d = torch.zeros(C, device = d), torch.ones(C, device = d)
+	mean, invstd, scale, shift = ops.bn_finalize(stats, B * T, gamma.detach().to(d), beta.detach().to(d), rm_d, rv_d, 0.1, 1e-5)
+	close(rm_d, rm, 1e-5, 1e-6, 'running_mean')
+	close(rv_d, rv, 1e-5, 1e-6, 'running_var')
+	act = ops.act_args(nonlin)
+	zz = ops.bn_act(ycl, scale, shift, act, xlen = xlen.to(d))
+	close(zz, z, 1e-4, 1e-4, 'bn_act fwd')
+	sums = torch.zeros(2 * C, dtype = torch.float64, device = d)
+	g = ops.bn_act_bwd_reduce(ops.as_cl(dz.to(d)), ycl, scale, shift, mean, invstd, act, xlen = xlen.to(d), sums = sums)
+	dgamma, dbeta = torch.empty(C, device = d), torch.empty(C, device = d)
+	dy = ops.bn_bwd_apply(g, ycl, gamma.detach().to(d), mean, invstd, sums, dgamma, dbeta)
+	close(dgamma, gamma.grad, 1e-4, 1e-3, 'dgamma')
+	close(dbeta, beta.grad, 1e-4, 1e-3, 'dbeta')
+	close(dy, y.grad, 1e-3, 1e-4, 'dy')
+
+
+@gpu
+def test_bn_act_dropout_statistics_and_backward_consistency():
+	from convasr_amd import ops
+	d = dev()
+	B, C, T = 4, 256, 500
+	y = ops.as_cl(torch.rand(B, C, T, device = d) + 1)
+	act = ops.act_args(('relu', ))
+	z = ops.bn_act(y, None, None, act, dropout_p = 0.2, seed = 1234, offset = 77)
+	keep = (z != 0).float().mean().item()
+	assert abs(keep - 0.8) < 0.01
+	close(z[z != 0], (y / 0.8)[z != 0], 1e-6, 1e-6, 'scaled by 1/(1-p)')
+	z2 = ops.bn_act(y, None, None, act, dropout_p = 0.2, seed = 1234, offset = 77)
+	assert torch.equal(z, z2)
+	g = ops.bn_act_bwd_reduce(torch.ones_like(y), y, None, None, None, None, act, dropout_p = 0.2, seed = 1234, offset = 77)
+	assert torch.equal(g != 0, z != 0)
+
+
+# ------------------------------------------------------------------------------------------------ head
+
+@gpu
+def test_log_softmax_entropy_argmax():
+	from convasr_amd import ops
+	torch.manual_seed(0)
+	B, C, T = 5, 38, 211
+	logits = torch.randn(B, C, T) * 3
+	olen = torch.tensor([211, 100, 1, 57, 210])
+	lp_ref = F.log_softmax(logits, dim = 1)
+	d = dev()
+	lp = ops.log_softmax(ops.as_cl(logits.to(d)))
+	close(lp, lp_ref, 1e-5, 1e-5, 'log_softmax')
+	close(ops.entropy(lp, olen), O.entropy(lp_ref, olen), 1e-4, 1e-5, 'entropy')
+	close(ops.entropy(lp), O.entropy(lp_ref), 1e-4, 1e-5, 'entropy (no lengths)')
+	assert torch.equal(ops.argmax(lp).cpu(), lp_ref.argmax(dim = 1))
+	g = torch.randn(B, C, T)
+	lg = logits.clone().requires_grad_(True)
+	F.log_softmax(lg, dim = 1).backward(g)
+	close(ops.log_softmax_bwd(g.to(d), lp), lg.grad, 1e-4, 1e-5, 'log_softmax bwd')
+
+
+@gpu
+def test_ctc_golden():
+	from convasr_amd import ops
+	g = np.load(os.path.join(GOLDEN, 'ctc.npz'))
+	d = dev()
+	lp = ops.as_cl(T_(g['log_probs']).to(d))
+	nll, grad = ops.ctc_loss(lp, T_(g['targets']), T_(g['olen']), T_(g['ylen']), 37)
+	ref = T_(g['loss'])
+	assert torch.isinf(nll[5]) and nll[5] > 0
+	close(nll[:5], ref[:5], 1e-5, 1e-5, 'nll')
+	w = T_(g['grad_weights'])
+	close(ops.scale_rows(grad, w.to(d))[:5], T_(g['grad'])[:5], 1e-4, 1e-4, 'grad')
+	assert float(grad[1, :, 40:].abs().max()) == 0.0
+	assert torch.isfinite(grad).all()  # infeasible utterance: zeros (ATen leaves NaN; the step is skipped either way)
+
+
+@gpu
+@pytest.mark.parametrize('shape', [(8, 38, 753, 150), (3, 38, 120, 1), (2, 129, 300, 40), (2, 38, 64, 31)])
+def test_ctc_against_oracle(shape):
+	from convasr_amd import ops
+	B, C, T, S = shape
+	torch.manual_seed(T)
+	lp = torch.randn(B, C, T).log_softmax(dim = 1)
+	y = torch.randint(0, C - 1, (B, S))
+	y[0, : S // 2] = y[0, 0]
+	olen = torch.randint(max(T // 2, 2 * S + 1), T + 1, (B, ))
+	olen[0] = T
+	ylen = torch.randint(max(S // 2, 1), S + 1, (B, ))
+	ylen[-1] = S
+	lpr = lp.clone().requires_grad_(True)
+	ref = O.ctc_loss(lpr, y, olen, ylen)
+	ref[torch.isfinite(ref)].sum().backward()
+	nll, grad = ops.ctc_loss(ops.as_cl(lp.to(dev())), y, olen, ylen, C - 1)
+	fin = torch.isfinite(ref)
+	assert torch.equal(torch.isfinite(nll).cpu(), fin)
+	close(nll.cpu()[fin], ref.detach()[fin], 1e-5, 1e-4, 'nll')  # BASELINE bar: 1e-4 relative
+	close(grad.cpu()[fin], lpr.grad[fin], 1e-3, 2e-5, 'grad')
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+
+@gpu
+def test_sumsq_and_sgd_step_match_torch():
+	from convasr_amd import ops
+	torch.manual_seed(0)
+	n = 1_000_003
+	p0, g0 = torch.randn(n), torch.randn(n) * 0.5
+	p = torch.nn.Parameter(p0.clone())
+	opt = torch.optim.SGD([p], lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	d = dev()
+	pd, gd, buf = p0.to(d), g0.to(d), torch.zeros(n, device = d)
+	for it in range(3):
+		p.grad = g0.clone() * (it + 1)
+		norm = torch.nn.utils.clip_grad_norm_([p], 100.0)
+		opt.step()
+		gi = gd * (it + 1)
+		ss = ops.sumsq(gi)
+		close(ss.sqrt().float(), norm, 1e-5, 0, 'grad norm')
+		ops.sgd_step(pd, gi, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, it == 0)
+		close(pd, p.detach(), 1e-5, 1e-6, f'params after step {it}')
