@@ -1,0 +1,294 @@
+"""torch.autograd.Function wrappers: each forward/backward is a fixed sequence of libconvasr_hip.so kernels.
+
+Parameters keep the reference's fp32 (Cout, Cin, K) layout; the packed compute-dtype copies the MFMA kernels consume are
+cached per parameter version.  When a parameter carries `_convasr_grad` (a pre-allocated fp32 gradient view installed by
+`convasr_amd.train.FlatParameters`), backward writes / accumulates into it directly and hands autograd `None` -- no
+extra gradient copies, and the data-parallel engine is told the moment each gradient is final.
+"""
+import torch
+
+from . import ops, _lib
+
+_pack_cache = {}
+
+
+def packed_weight(w, dtype, mode):
+	"""Packed [K][rows_pad][cols] copy of a conv parameter, rebuilt only when the parameter changed."""
+	key = (id(w), dtype, mode)
+	ver = (w._version, w.data_ptr())
+	hit = _pack_cache.get(key)
+	if hit is not None and hit[0] == ver:
+		return hit[1]
+	wp = ops.pack_weight(w, dtype, mode)
+	_pack_cache[key] = (ver, wp, w)  # keep `w` alive so id() stays unique
+	return wp
+
+
+def invalidate_pack_cache():
+	_pack_cache.clear()
+
+
+class _DropoutState:
+	seed = 0x5EEDC0DE
+	offset = 0
+
+	@classmethod
+	def next(cls, numel):
+		off = cls.offset
+		cls.offset += (numel + 3) // 4 + 1
+		return cls.seed, off
+
+
+def manual_seed(seed):
+	_DropoutState.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+	_DropoutState.offset = 0
+
+
+def _deliver(params, compute):
+	"""Gradient hand-off for a group of parameters produced by one kernel sequence.
+
+	compute(outs, accumulate) must fill outs[i] (fp32, parameter-shaped; None for parameters that need no gradient).
+	If every live parameter has a gradient arena the kernels write / accumulate there and autograd gets None;
+	otherwise fresh tensors are returned for autograd to accumulate."""
+	live = [p is not None and p.requires_grad for p in params]
+	if not any(live):
+		return [None] * len(params)
+	arenas = [getattr(p, '_convasr_grad', None) if ok else None for p, ok in zip(params, live)]
+	if all(a is not None for a, ok in zip(arenas, live) if ok):
+		fresh = {bool(getattr(p, '_convasr_fresh', True)) for p, ok in zip(params, live) if ok}
+		if len(fresh) != 1:
+			raise _lib.ConvasrHipError('gradient arenas of one layer are out of step (mixed fresh / accumulated state)')
+		compute(arenas, not fresh.pop())
+		for p, ok in zip(params, live):
+			if ok:
+				p._convasr_fresh = False
+				hook = getattr(p, '_convasr_ready', None)
+				if hook is not None:
+					hook(p)
+		return [None] * len(params)
+	outs = [torch.empty_like(p, dtype = torch.float32, memory_format = torch.contiguous_format) if ok else None for p, ok in zip(params, live)]
+	compute(outs, False)
+	return outs
+
+
+class ConvSpec:
+	"""Static description of one Conv1d (+ optional BatchNorm) as the kernels need it."""
+
+	def __init__(self, K, stride = 1, dilation = 1, padding = 0):
+		self.K, self.stride, self.dilation, self.padding = K, stride, dilation, padding
+
+
+class ConvBnActFunction(torch.autograd.Function):
+	"""One repeat of ConvBn1d (models.py:128-138): conv -> BN(train) -> + sum BN(conv1x1(residual)) -> act -> dropout -> mask.
+
+	apply(cfg, x, weight, gamma, beta, xlen, *flat_residuals) where flat_residuals is, per residual,
+	(res_x, res_weight, res_bias, res_gamma, res_beta) -- the last four None for an identity ('flat') residual.
+	cfg: dict(spec, bn (module holding running stats / momentum / eps), res_bn (list of modules or None), act, dropout_p,
+	temporal_mask, compute_dtype)."""
+
+	@staticmethod
+	def forward(ctx, cfg, x, weight, gamma, beta, xlen, *flat_res):
+		spec, dt = cfg['spec'], cfg['compute_dtype']
+		x = ops.as_cl(x, dt)
+		B, Cin, Tin = x.shape
+		Cout = weight.shape[0]
+		dev = x.device
+		act = cfg['act']
+		xl = ops.xlen_f32(xlen, dev) if (cfg['temporal_mask'] and xlen is not None) else None
+		n_res = len(flat_res) // 5
+
+		stats = torch.zeros(2 * Cout * (1 + n_res), dtype = torch.float64, device = dev)
+		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats[:2 * Cout])
+		Tout = y.shape[2]
+		bn = cfg['bn']
+		bnp = ops.bn_finalize(stats[:2 * Cout], B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps)
+		_tick(bn)
+
+		res_x, res_y, res_bnp = [], [], []
+		for r in range(n_res):
+			rx, rw, rb, rg, rbeta = flat_res[5 * r:5 * r + 5]
+			rx = ops.as_cl(rx, dt)
+			res_x.append(rx)
+			if rw is None:
+				res_y.append(rx)
+				res_bnp.append(None)
+			else:
+				st = stats[2 * Cout * (1 + r):2 * Cout * (2 + r)]
+				ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
+				rbn = cfg['res_bn'][r]
+				res_y.append(ry)
+				res_bnp.append(ops.bn_finalize(st, B * Tout, rg, rbeta, rbn.running_mean, rbn.running_var, _momentum(rbn), rbn.eps))
+				_tick(rbn)
+
+		p_drop = cfg['dropout_p']
+		seed, offset = _DropoutState.next(B * Cout * Tout) if p_drop > 0 else (0, 0)
+		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
+
+		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset)
+		ctx.params = (weight, gamma, beta) + tuple(flat_res[5 * r + k] for r in range(n_res) for k in range(1, 5))
+		ctx.x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
+		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
+		ctx.res_has_bn = [p is not None for p in res_bnp]
+		return z
+
+	@staticmethod
+	def backward(ctx, dz):
+		cfg, n_res = ctx.cfg, ctx.n_res
+		spec, dt, act = cfg['spec'], cfg['compute_dtype'], cfg['act']
+		saved = ctx.saved_tensors
+		x, y, bnp, xl = saved[:4]
+		res_x = list(saved[4:4 + n_res])
+		res_y = list(saved[4 + n_res:4 + 2 * n_res])
+		it = iter(saved[4 + 2 * n_res:])
+		res_bnp = [next(it) if has else None for has in ctx.res_has_bn]
+		weight, gamma, beta = ctx.params[:3]
+		p_drop, seed, offset = ctx.drop
+		B, Cout, Tout = y.shape
+		dev = y.device
+		dz = ops.as_cl(dz, dt)
+
+		bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
+		sums = torch.zeros(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)
+		rsum_of = {r: sums[2 * Cout * (1 + i):2 * Cout * (2 + i)] for i, r in enumerate(bn_idx)}
+		common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
+		# the kernel reduces the main BN plus the first two batch-normed residuals per pass; dense blocks with more take extra passes
+		first = [r for r in bn_idx if r < 2]
+		g = ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, rsums = [rsum_of.get(r) if r in first else None for r in range(n_res)], sums = sums[:2 * Cout], **common)
+		rest = [r for r in bn_idx if r >= 2]
+		while rest:
+			batch, rest = rest[:2], rest[2:]
+			# re-order so the residuals being reduced sit in slots 0/1 of the kernel's argument list
+			order = batch + [r for r in range(n_res) if r not in batch]
+			pick = lambda lst: [lst[r] for r in order]
+			ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], None, None, act, xlen = xl, res = pick(res_y), rscale = pick(common['rscale']), rshift = pick(common['rshift']), rmean = pick(common['rmean']), rinvstd = pick(common['rinvstd']), rsums = [rsum_of[r] if r in batch else None for r in order], dropout_p = p_drop, seed = seed, offset = offset)
+
+		dgamma, dbeta = _deliver([gamma, beta], lambda outs, acc: ops.bn_bwd_apply(g, y, None, bnp[0], bnp[1], sums[:2 * Cout], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
+		dy = ops.bn_bwd_apply(g, y, gamma, bnp[0], bnp[1], sums[:2 * Cout], inplace = n_res == 0)
+
+		dx = None
+		if ctx.x_needs_grad:
+			if spec.stride != 1:
+				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
+			dx = ops.conv1d(dy, packed_weight(weight, dt, _lib.PACK_DGRAD), x.shape[1], spec.K, 1, spec.dilation, spec.dilation * (spec.K - 1) - spec.padding)
+		dw, = _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
+
+		res_grads = []
+		for r in range(n_res):
+			rw, rb, rg, rbeta = ctx.params[3 + 4 * r:3 + 4 * r + 4]
+			rx = res_x[r]
+			need_rx = ctx.needs_input_grad[6 + 5 * r]
+			if res_bnp[r] is None:
+				res_grads += [g if need_rx else None, None, None, None, None]
+				continue
+			p = res_bnp[r]
+			drg, drbeta = _deliver([rg, rbeta], lambda outs, acc, r = r, p = p: ops.bn_bwd_apply(g, res_y[r], None, p[0], p[1], rsum_of[r], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
+			dry = ops.bn_bwd_apply(g, res_y[r], rg, p[0], p[1], rsum_of[r], inplace = False)
+			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), rx.shape[1], 1, 1, 1, 0) if need_rx else None
+			drw, drb = _deliver([rw, rb], lambda outs, acc, rx = rx, dry = dry: ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], dbias = outs[1], accumulate = acc))
+			res_grads += [drx, drw, drb, drg, drbeta]
+		return (None, dx, dw, dgamma, dbeta, None, *res_grads)
+
+
+def _momentum(bn):
+	if bn.momentum is None:  # cumulative moving average (reset_bn_running_stats_, models.py:731)
+		return 1.0 / float(int(bn.num_batches_tracked.item()) + 1)
+	return bn.momentum
+
+
+def _tick(bn):
+	if bn.num_batches_tracked is not None:
+		bn.num_batches_tracked += 1
+
+
+class ConvBiasFunction(torch.autograd.Function):
+	"""Plain Conv1d with optional bias and fp32 output: the decoder head (models.py:26, 40)."""
+
+	@staticmethod
+	def forward(ctx, cfg, x, weight, bias):
+		spec, dt = cfg['spec'], cfg['compute_dtype']
+		x = ops.as_cl(x, dt)
+		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), weight.shape[0], spec.K, spec.stride, spec.dilation, spec.padding, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias)
+		ctx.cfg = cfg
+		ctx.params = (weight, bias)
+		ctx.save_for_backward(x)
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		cfg = ctx.cfg
+		spec, dt = cfg['spec'], cfg['compute_dtype']
+		weight, bias = ctx.params
+		x, = ctx.saved_tensors
+		Cout = weight.shape[0]
+		dy = ops.as_cl(dy, dt)
+		dx = None
+		if ctx.needs_input_grad[1]:
+			if spec.stride != 1:
+				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented')
+			dx = ops.conv1d(dy, packed_weight(weight, dt, _lib.PACK_DGRAD), x.shape[1], spec.K, 1, spec.dilation, spec.dilation * (spec.K - 1) - spec.padding)
+		dw, db = _deliver([weight, bias], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], dbias = outs[1], accumulate = acc))
+		return None, dx, dw, db
+
+
+class ConvBnActEvalFunction:
+	"""Inference path (BN folded into the conv epilogue's scale/shift, or a fused bias after fuse_conv_bn_eval): no graph."""
+
+	@staticmethod
+	def apply(cfg, x, weight, bias, scale_shift, xlen, res_list):
+		spec, dt, act = cfg['spec'], cfg['compute_dtype'], cfg['act']
+		x = ops.as_cl(x, dt)
+		Cout = weight.shape[0]
+		xl = ops.xlen_f32(xlen, x.device) if (cfg['temporal_mask'] and xlen is not None) else None
+		wp = packed_weight(weight, dt, _lib.PACK_FWD)
+		scale, shift = (None, None) if scale_shift is None else (scale_shift[0], scale_shift[1])
+		if not res_list:
+			return ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, scale = scale, shift = shift, act = act, xlen = xl)
+		y = ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias)
+		res_y, rscale, rshift = [], [], []
+		for rx, rw, rb, rss in res_list:
+			rx = ops.as_cl(rx, dt)
+			if rw is None:
+				res_y.append(rx); rscale.append(None); rshift.append(None)
+			else:
+				res_y.append(ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb))
+				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])
+		# rscale None (identity residual, or a residual conv already fused with its BN) means "add as is"
+		return ops.bn_act(y, scale, shift, act, xlen = xl, res = res_y, rscale = rscale, rshift = rshift)
+
+
+class LogSoftmaxFunction(torch.autograd.Function):
+	"""F.log_softmax(logits, dim=1).float() (models.py:316) on channels-last fp32 logits."""
+
+	@staticmethod
+	def forward(ctx, logits):
+		lp = ops.log_softmax(ops.as_cl(logits, torch.float32))
+		ctx.save_for_backward(lp)
+		return lp
+
+	@staticmethod
+	def backward(ctx, g):
+		lp, = ctx.saved_tensors
+		return ops.log_softmax_bwd(g, lp)
+
+
+class CtcLossFunction(torch.autograd.Function):
+	"""F.ctc_loss(lp.permute(2,0,1), y, olen, ylen, blank, reduction='none') (models.py:323): the alpha-beta kernels
+	produce the per-utterance NLL and d nll / d log_probs in one pass; backward is a per-utterance scaling."""
+
+	@staticmethod
+	def forward(ctx, log_probs, targets, olen, ylen, blank):
+		lp = ops.as_cl(log_probs, torch.float32)
+		need = log_probs.requires_grad
+		nll, grad = ops.ctc_loss(lp, targets, olen, ylen, blank, need_grad = need)
+		if need:
+			ctx.save_for_backward(grad)
+		return nll
+
+	@staticmethod
+	def backward(ctx, g):
+		grad, = ctx.saved_tensors
+		return ops.scale_rows(grad, g), None, None, None, None
+
+
+def ctc_loss(log_probs, targets, olen, ylen, blank):
+	return CtcLossFunction.apply(log_probs, targets, olen, ylen, blank)

@@ -1,0 +1,461 @@
+"""MI355X-native mirror of convasr's models.py module surface for the hot path.
+
+Same class names, constructor arguments, forward() signatures, return dictionaries and state-dict keys as the reference
+(/root/reference/models.py: LogFilterBankFrontend 486-603, MaskedInstanceNorm1d 688-719, ConvBn1d 80-151, JasperNet 158-347,
+Decoder 23-44, configs 819-1442), so `getattr(models, args.model)(...)`, `load_state_dict(checkpoint['model_state_dict'])`
+and `model(x, xlen, y = y, ylen = ylen)` work unchanged -- but every arithmetic operation is a hand-written gfx950 kernel
+reached through the C ABI in include/convasr_hip.h.  nn.Conv1d / nn.BatchNorm1d objects are used purely as parameter
+containers (identical names, shapes and initialisation to the reference); their own forward() is never called.
+
+Activations flow between modules as (B, C, T) tensors whose memory is channels-last (strides (T*C, 1, C)); module outputs
+handed back to the caller (logits, log_probs) keep that logical (B, C, T) shape.  There is no CPU implementation here.
+"""
+import math
+import typing
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, _lib
+from . import functional as Fn
+from .functional import ConvSpec
+
+FP16_TINY = float(torch.finfo(torch.float16).tiny)
+
+
+# ------------------------------------------------------------------------------------------------ helpers (models.py:611-733)
+
+def compute_output_lengths(x, lengths_fraction = None):
+	"""models.py:611-614.  Host-side integer bookkeeping on a (B,) vector."""
+	if lengths_fraction is None:
+		return torch.full(x.shape[:1], x.shape[-1], device = x.device, dtype = torch.long)
+	return (lengths_fraction * x.shape[-1]).ceil().long()
+
+
+def temporal_mask(x, lengths):
+	"""models.py:617-619: bool mask broadcastable to x, True for t < length."""
+	return (torch.arange(x.shape[-1], device = x.device, dtype = lengths.dtype).unsqueeze(0) < lengths.unsqueeze(1)).view(x.shape[:1] + (1, ) * (len(x.shape) - 2) + x.shape[-1:])
+
+
+def entropy(log_probs, lengths = None, dim = 1, eps = 1e-9, sum = True, keepdim = False):
+	"""models.py:645-657 (the logged training metric): per-utterance mean entropy over valid frames."""
+	if dim != 1 or not sum or keepdim:
+		raise _lib.ConvasrHipError('entropy: only the dim=1, sum=True form used by train.py:756 / train.py:137 is implemented')
+	return ops.entropy(log_probs, lengths, eps)
+
+
+def unpad(x, lens):
+	return [e[..., :l] for e, l in zip(x, lens)]
+
+
+def compute_capacity(model, scale = 1):
+	return sum(map(torch.numel, model.parameters())) / scale
+
+
+def master_module(model):
+	from .parallel import DataParallelEngine
+	return model.module if isinstance(model, (DataParallelEngine, torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)) else model
+
+
+def reset_bn_running_stats_(model):
+	"""models.py:726-733."""
+	for bn in [m for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]:
+		nn.init.zeros_(bn.running_mean)
+		nn.init.ones_(bn.running_var)
+		nn.init.zeros_(bn.num_batches_tracked)
+		bn.momentum = None
+		bn.train()
+	return model
+
+
+def normalize_signal(signal, dim = -1, eps = 1e-5, denom_multiplier = 1.0):
+	raise _lib.ConvasrHipError('normalize_signal is fused into LogFilterBankFrontend.forward on this backend')
+
+
+# ------------------------------------------------------------------------------------------------ mel filterbank (models.py:522)
+
+def _slaney_hz_to_mel(f):
+	f = np.asarray(f, dtype = np.float64)
+	lin = f * 3.0 / 200.0
+	log_region = 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * (27.0 / np.log(6.4))
+	return np.where(f >= 1000.0, log_region, lin)
+
+
+def _slaney_mel_to_hz(m):
+	m = np.asarray(m, dtype = np.float64)
+	return np.where(m >= 15.0, 1000.0 * np.exp((m - 15.0) * (np.log(6.4) / 27.0)), m * 200.0 / 3.0)
+
+
+def slaney_mel_filterbank(sample_rate, nfft, n_mels, fmin = 0.0, fmax = None):
+	"""What `librosa.filters.mel(sample_rate, nfft, n_mels=..., fmin=0, fmax=sr/2)` (models.py:522; librosa < 0.10 defaults:
+	Slaney scale, area normalisation) evaluates to: (n_mels, nfft//2+1) float32."""
+	fmax = sample_rate / 2.0 if fmax is None else float(fmax)
+	bins = np.linspace(0.0, sample_rate / 2.0, nfft // 2 + 1)
+	edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(fmin), _slaney_hz_to_mel(fmax), n_mels + 2))
+	lo, mid, hi = edges[:-2, None], edges[1:-1, None], edges[2:, None]
+	rising = (bins[None, :] - lo) / (mid - lo)
+	falling = (hi - bins[None, :]) / (hi - mid)
+	tri = np.clip(np.minimum(rising, falling), 0.0, None)
+	return (tri * (2.0 / (hi - lo))).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ frontend
+
+class LogFilterBankFrontend(nn.Module):
+	"""models.py:486-603.  forward(signal (B, T) float or int16, mask = None) -> (B, out_channels, 1 + T // hop) fp32 log-mel."""
+
+	def __init__(self, out_channels, sample_rate, window_size, window_stride, window, dither = 1e-5, dither0 = 0.0, preemphasis = 0.97, eps = FP16_TINY, normalize_signal = True, debug_short_long_records_normalize_signal_multiplier = 1.0, stft_mode = None, window_periodic = True, normalize_features = False, **kwargs):
+		super().__init__()
+		if stft_mode not in (None, ''):
+			raise _lib.ConvasrHipError("stft_mode='conv' is an alternative CPU/ONNX formulation of the same STFT; this backend always runs the fused FFT kernel")
+		if debug_short_long_records_normalize_signal_multiplier != 1.0:
+			raise _lib.ConvasrHipError('debug_short_long_records_normalize_signal_multiplier != 1 is not supported')
+		self.stft_mode, self.dither, self.dither0 = None, dither, dither0
+		self.preemphasis, self.normalize_signal, self.sample_rate = preemphasis, normalize_signal, sample_rate
+		self.win_length = int(window_size * sample_rate)
+		self.hop_length = int(window_stride * sample_rate)
+		self.nfft = 2 ** math.ceil(math.log2(self.win_length))
+		self.freq_cutoff = self.nfft // 2 + 1
+		self.register_buffer('window', getattr(torch, window)(self.win_length, periodic = window_periodic).float())
+		basis = torch.as_tensor(slaney_mel_filterbank(sample_rate, self.nfft, out_channels, 0.0, int(sample_rate / 2)))
+		self.mel = nn.Conv1d(basis.shape[1], basis.shape[0], 1).requires_grad_(False)  # parameter container only
+		with torch.no_grad():
+			self.mel.weight.copy_(basis.unsqueeze(-1))
+			self.mel.bias.fill_(eps)
+		self.stft = None
+
+	def forward(self, signal, mask = None, xlen = None, **kwargs):
+		assert signal.ndim == 2
+		_lib.require_cuda(signal)
+		if xlen is None and mask is not None:
+			# a temporal_mask() prefix mask: recover the lengths exactly ((n - 0.5) / T -> ceil -> n)
+			n = mask.reshape(mask.shape[0], -1).sum(dim = -1).to(torch.float32)
+			xlen = (n - 0.5) / signal.shape[-1]
+		return ops.logmel(signal, xlen, self.window, self.mel.weight.view(self.mel.weight.shape[0], -1), self.mel.bias, self.nfft, self.hop_length, preemphasis = self.preemphasis, normalize = self.normalize_signal)
+
+	@staticmethod
+	def compute_output_shape(time_dim_length, kernel_size, stride, padding, dilation = 1):
+		return int(math.floor((time_dim_length + 2 * padding - dilation * (kernel_size - 1) - 1) / stride + 1))
+
+
+class MaskedInstanceNorm1d(nn.InstanceNorm1d):
+	"""models.py:688-719: per-(utterance, channel) masked mean / biased std over time, no affine, no running stats."""
+
+	def __init__(self, *args, temporal_mask = False, legacy = True, **kwargs):
+		super().__init__(*args, **kwargs)
+		self.temporal_mask, self.legacy = temporal_mask, legacy
+		if self.affine or self.track_running_stats or not legacy:
+			raise _lib.ConvasrHipError('MaskedInstanceNorm1d: only the affine=False, track_running_stats=False, legacy=True form (Wav2Letter / JasperNet* defaults) is implemented')
+
+	def forward(self, x, mask = None, xlen = None, out_dtype = None):
+		_lib.require_cuda(x)
+		if x.requires_grad:
+			raise _lib.ConvasrHipError('MaskedInstanceNorm1d backward is not implemented (features never require grad on this path)')
+		if not self.temporal_mask:
+			xlen, mask = None, None
+		if xlen is None and mask is not None:
+			n = mask.reshape(mask.shape[0], -1).sum(dim = -1).to(torch.float32)
+			xlen = (n - 0.5) / x.shape[-1]
+		return ops.instnorm(x, xlen, self.eps, out_dtype = out_dtype or x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ conv block
+
+class ConvSamePadding(nn.Sequential):
+	"""models.py:47-77: parameter container; padding = dilation * kernel_size // 2."""
+
+	def __init__(self, in_channels, out_channels, kernel_size, stride, dilation, bias, groups, separable):
+		if separable or groups != 1:
+			raise _lib.ConvasrHipError('separable / grouped convolutions (JasperNetSeparable) are outside the hot path implemented here')
+		super().__init__(nn.Conv1d(in_channels, out_channels, kernel_size = kernel_size, stride = stride, padding = dilation * kernel_size // 2, dilation = dilation, groups = groups, bias = bias))
+
+
+def _spec_of(conv):
+	return ConvSpec(conv.kernel_size[0], conv.stride[0], conv.dilation[0], conv.padding[0])
+
+
+class ResidualActivation(nn.Module):
+	"""models.py:350-371: carries the nonlinearity / dropout configuration (the arithmetic is fused into bn_act kernels)."""
+
+	def __init__(self, nonlinearity, dropout = 0, invertible = False):
+		super().__init__()
+		if invertible:
+			raise _lib.ConvasrHipError('in-place invertible activations (the *Inplace configs) are a memory trick of the reference, not needed with 288 GB of HBM')
+		self.nonlinearity, self.dropout, self.invertible = nonlinearity, dropout, invertible
+
+	def extra_repr(self):
+		return f'nonlinearity={self.nonlinearity}, dropout={self.dropout}'
+
+
+class ConvBn1d(nn.Module):
+	"""models.py:80-151."""
+
+	def __init__(self, num_channels, kernel_size, stride = 1, dropout = 0, groups = 1, num_channels_residual: typing.List = [], repeat = 1, dilation = 1, separable = False, temporal_mask = True, nonlinearity = ('relu', ), nonlinearity_reference = True, batch_norm_momentum = 0.1, inplace = False):
+		super().__init__()
+		if inplace:
+			raise _lib.ConvasrHipError('inplace=True (InplaceBatchNorm1d) is a memory trick of the reference and is not implemented')
+		self.conv = nn.ModuleList(ConvSamePadding(num_channels[0] if i == 0 else num_channels[1], num_channels[1], kernel_size = kernel_size, stride = stride, dilation = dilation, separable = separable, bias = False, groups = groups) for i in range(repeat))
+		self.bn = nn.ModuleList(nn.BatchNorm1d(num_channels[1], momentum = batch_norm_momentum) for i in range(repeat))
+		self.conv_residual = nn.ModuleList(nn.Identity() if c is None else nn.Conv1d(c, num_channels[1], kernel_size = 1) for c in num_channels_residual)
+		self.bn_residual = nn.ModuleList(nn.Identity() if c is None else nn.BatchNorm1d(num_channels[1], momentum = batch_norm_momentum) for c in num_channels_residual)
+		self.activation = ResidualActivation(nonlinearity, dropout, invertible = inplace)
+		self.temporal_mask = temporal_mask
+		self.compute_dtype = torch.float32
+
+	def _cfg(self, i, last):
+		conv, bn = self.conv[i][-1], self.bn[i]
+		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype)
+
+	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
+		_lib.require_cuda(x)
+		n = len(self.conv)
+		for i in range(n):
+			last = i == n - 1
+			res = list(residual) if last else []
+			if last:
+				assert len(self.conv_residual) == len(self.bn_residual) == len(residual)
+			cfg = self._cfg(i, last)
+			conv, bn = self.conv[i][-1], self.bn[i]
+			bn_live = isinstance(bn, nn.BatchNorm1d)
+			if bn_live and bn.training:
+				flat = []
+				for rc, rbn, rx in zip(self.conv_residual, self.bn_residual, res):
+					if isinstance(rc, nn.Identity):
+						flat += [rx, None, None, None, None]
+					elif not (isinstance(rbn, nn.BatchNorm1d) and rbn.training):
+						raise _lib.ConvasrHipError('mixed train/eval batch norms inside one ConvBn1d are not supported')
+					else:
+						flat += [rx, rc.weight, rc.bias, rbn.weight, rbn.bias]
+				x = Fn.ConvBnActFunction.apply(cfg, x, conv.weight, bn.weight, bn.bias, lengths_fraction, *flat)
+			else:
+				if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+					raise _lib.ConvasrHipError('backward through eval-mode / fused batch norm is not implemented: call the model under torch.no_grad() for inference')
+				ss = ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps) if bn_live else None
+				res_list = []
+				for rc, rbn, rx in zip(self.conv_residual, self.bn_residual, res):
+					if isinstance(rc, nn.Identity):
+						res_list.append((rx, None, None, None))
+					else:
+						rss = ops.bn_eval_scale_shift(rbn.weight, rbn.bias, rbn.running_mean, rbn.running_var, rbn.eps) if isinstance(rbn, nn.BatchNorm1d) else None
+						res_list.append((rx, rc.weight, rc.bias, rss))
+				x = Fn.ConvBnActEvalFunction.apply(cfg, x, conv.weight, conv.bias, ss, lengths_fraction, res_list)
+		return x
+
+	def fuse_conv_bn_eval(self):
+		"""models.py:141-151: fold BN running statistics into the conv weights / bias (inference)."""
+		for i in range(len(self.conv_residual)):
+			conv, bn = self.conv_residual[i], self.bn_residual[i]
+			if not isinstance(conv, nn.Identity) and not isinstance(bn, nn.Identity):
+				self.conv_residual[i] = nn.utils.fusion.fuse_conv_bn_eval(conv, bn)
+				self.bn_residual[i] = nn.Identity()
+		for i in range(len(self.conv)):
+			self.conv[i][-1] = nn.utils.fusion.fuse_conv_bn_eval(self.conv[i][-1], self.bn[i])
+			self.bn[i] = nn.Identity()
+		Fn.invalidate_pack_cache()
+
+
+class Decoder(nn.Sequential):
+	"""models.py:23-44: 1x1 conv head (with bias) -> tuple of logits; 'bpe' adds a two-block ConvBn1d head."""
+
+	def __init__(self, input_size, num_classes, type = None):
+		if type is None:
+			super().__init__(nn.Conv1d(input_size, num_classes[0], kernel_size = 1))
+		elif type == 'bpe':
+			super().__init__(nn.Conv1d(input_size, num_classes[0], kernel_size = 1), nn.Sequential(ConvBn1d(num_channels = (input_size, input_size), kernel_size = 15), ConvBn1d(num_channels = (input_size, num_classes[1]), kernel_size = 15)))
+		else:
+			raise ValueError(type)
+		self.type = type
+		self.compute_dtype = torch.float32
+
+	def _head(self, x):
+		conv = self[0]
+		cfg = dict(spec = _spec_of(conv), compute_dtype = self.compute_dtype, out_dtype = torch.float32)
+		return Fn.ConvBiasFunction.apply(cfg, x, conv.weight, conv.bias)
+
+	def forward(self, x):
+		if self.type is None:
+			return (self._head(x), )
+		y2 = x
+		for blk in self[1]:
+			y2 = blk(y2)
+		return self._head(x), ops.convert(y2, torch.float32, True) if y2.dtype != torch.float32 else y2
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+
+class JasperNet(nn.Module):
+	"""models.py:158-347."""
+
+	def __init__(self, num_input_features, num_classes, repeat = 3, num_subblocks = 1, dilation = 1, residual = 'dense', kernel_sizes = [11, 13, 17, 21, 25], kernel_size_prologue = 11, kernel_size_epilogue = 29, base_width = 128, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], separable = False, groups = 1, dropout = 0, dropout_prologue = 0.2, dropout_epilogue = 0.4, dropouts = [0.2, 0.2, 0.2, 0.3, 0.3], temporal_mask = True, nonlinearity = ('relu', ), inplace = False, stride1 = 2, stride2 = 1, decoder_type = None, dict = dict, frontend = None, bpe_only = False, normalize_features = True, normalize_features_eps = FP16_TINY, normalize_features_track_running_stats = False, normalize_features_legacy = True, normalize_features_temporal_mask = True, check_time_dim_padded = True, compute_dtype = torch.float32):
+		super().__init__()
+		self.init_params = {name: repr(value) for name, value in locals().items() if name not in ('self', '__class__')}
+		if dropout == 0:
+			dropout_prologue, dropout_epilogue, dropouts = 0, 0, [0] * len(dropouts)
+		common = dict(temporal_mask = temporal_mask, nonlinearity = nonlinearity, inplace = inplace)
+		width = lambda f: f * base_width
+
+		blocks = [ConvBn1d(num_channels = (num_input_features, width(out_width_factors[0])), kernel_size = kernel_size_prologue, dropout = dropout_prologue, stride = stride1, **common)]
+		f_in = out_width_factors[0]
+		res_channels = []
+		for k, p_drop, f_out in zip(kernel_sizes, dropouts, out_width_factors):
+			for s in range(num_subblocks):
+				c_in, c_out = width(f_in), width(f_out if s == num_subblocks - 1 else f_in)
+				if residual == 'dense':
+					res_channels = res_channels + [c_in]
+				elif residual == 'flat':
+					res_channels = [None]
+				elif residual:
+					res_channels = [c_in]
+				else:
+					res_channels = []
+				blocks.append(ConvBn1d(num_channels = (c_in, c_out), kernel_size = k, dropout = p_drop, repeat = repeat, separable = separable, groups = groups, num_channels_residual = list(res_channels), **common))
+			f_in = f_out
+		blocks.append(ConvBn1d(num_channels = (width(f_in), width(out_width_factors_large[0])), kernel_size = kernel_size_epilogue, dropout = dropout_epilogue, dilation = dilation, **common))
+		blocks.append(ConvBn1d(num_channels = (width(out_width_factors_large[0]), width(out_width_factors_large[1])), kernel_size = 1, dropout = dropout_epilogue, **common))
+		self.backbone = nn.ModuleList(blocks)
+		self.num_epilogue_modules = 2
+		self.frontend = frontend
+		self.normalize_features = MaskedInstanceNorm1d(num_input_features, affine = False, eps = normalize_features_eps, track_running_stats = normalize_features_track_running_stats, temporal_mask = normalize_features_temporal_mask, legacy = normalize_features_legacy) if normalize_features else None
+		self.decoder = Decoder(width(out_width_factors_large[1]), num_classes, type = decoder_type)
+		self.residual, self.dict, self.bpe_only, self.check_time_dim_padded = residual, dict, bpe_only, check_time_dim_padded
+		self.set_compute_dtype(compute_dtype)
+
+	def set_compute_dtype(self, dtype):
+		"""fp32 (exact-fp32 MFMA path: parity runs) or bf16 (bf16 MFMA, fp32 accumulate, fp32 master weights: throughput runs)."""
+		assert dtype in (torch.float32, torch.bfloat16)
+		self.compute_dtype = dtype
+		for m in self.modules():
+			if isinstance(m, (ConvBn1d, Decoder)):
+				m.compute_dtype = dtype
+		return self
+
+	def forward(self, x, xlen = None, y = None, ylen = None):
+		_lib.require_cuda(x)
+		if self.frontend is not None:
+			assert (not self.check_time_dim_padded) or (x.shape[-1] % (32 / 2) == 0), 'Shape of input signal is not divisible by 16 '
+			x = x.squeeze(1)
+			x = self.frontend(x, xlen = xlen) if isinstance(self.frontend, LogFilterBankFrontend) else self.frontend(x, mask = temporal_mask(x, compute_output_lengths(x, xlen)) if xlen is not None else None)
+		assert (not self.check_time_dim_padded) or (x.shape[-1] % 32 == 0), 'Shape of features after frontend is not divisible by 32'
+		assert x.ndim == 3
+		if self.normalize_features is not None:
+			x = self.normalize_features(x, xlen = xlen, out_dtype = self.compute_dtype)
+		else:
+			x = ops.as_cl(x, self.compute_dtype)
+
+		residual = []
+		n = len(self.backbone)
+		for i, block in enumerate(self.backbone):
+			x = block(x, residual = residual, lengths_fraction = xlen)
+			if i >= n - self.num_epilogue_modules - 1:
+				residual = []
+			elif self.residual == 'dense':
+				residual = residual + [x]
+			elif self.residual:
+				residual = [x]
+			else:
+				residual = []
+
+		logits = self.decoder(x)
+		log_probs = [Fn.LogSoftmaxFunction.apply(l) for l in logits]
+		olen = [compute_output_lengths(l, xlen.to(torch.float32) if xlen is not None else None) for l in logits]
+		aux = {}
+		if y is not None and ylen is not None:
+			loss = [Fn.ctc_loss(lp, y[:, i], olen[i], ylen[:, i], lp.shape[1] - 1) / ylen[:, 0] for i, lp in enumerate(log_probs)]
+			aux = dict(loss = sum(loss) if not self.bpe_only else sum(loss[1:]))
+		return self.dict(logits = logits, log_probs = log_probs, olen = olen, **aux)
+
+	def freeze(self, backbone = 0, decoder0 = False, frontend = False):
+		"""models.py:328-339."""
+		frozen = (list(self.backbone[:backbone]) if backbone else []) + (list(self.decoder)[:1] if decoder0 else []) + ([self.frontend] if frontend and self.frontend is not None else [])
+		for m in frozen:
+			for module in filter(lambda module: isinstance(module, nn.modules.batchnorm._BatchNorm), m.modules()):
+				module.eval()
+				module.train = lambda training: None
+			for p in m.parameters():
+				p.requires_grad = False
+
+	def fuse_conv_bn_eval(self, K = None):
+		for block in self.backbone[:K]:
+			block.fuse_conv_bn_eval()
+
+	def set_temporal_mask_mode(self, enabled):
+		for module in self.modules():
+			module.temporal_mask = enabled
+
+
+# ------------------------------------------------------------------------------------------------ configs (models.py:819-1442)
+
+class Wav2Letter(JasperNet):
+	"""models.py:819-855: 18 conv layers, hardtanh(0, 20), no residuals, dilated k=29 epilogue."""
+
+	def __init__(self, num_input_features, num_classes, dropout = 0.2, base_width = 128, nonlinearity = ('hardtanh', 0, 20), kernel_size_prologue = 11, kernel_size_epilogue = 29, kernel_sizes = [11, 13, 17, 21, 25], dilation = 2, num_blocks = 6, decoder_type = None, normalize_features = True, frontend = None, **kwargs):
+		super().__init__(num_input_features, num_classes, base_width = base_width, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue, kernel_sizes = [kernel_size_prologue] * num_blocks, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], residual = False, dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend, **kwargs)
+
+
+def _wav2letter_variant(name, doc, **fixed):
+	def __init__(self, num_input_features, num_classes, dropout = 0.2, base_width = 128, nonlinearity = ('hardtanh', 0, 20), kernel_size_prologue = 11, kernel_size_epilogue = 29, kernel_sizes = [11, 13, 17, 21, 25], dilation = 2, num_blocks = 6, decoder_type = None, normalize_features = True, frontend = None, **kwargs):
+		args = dict(base_width = base_width, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue, kernel_sizes = [kernel_size_prologue] * num_blocks, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend)
+		args.update(fixed)
+		args.update(kwargs)
+		JasperNet.__init__(self, num_input_features, num_classes, **args)
+
+	return type(name, (JasperNet, ), dict(__init__ = __init__, __doc__ = doc))
+
+
+Wav2LetterResidual = _wav2letter_variant('Wav2LetterResidual', 'models.py:858-894', residual = True)
+Wav2LetterDense = _wav2letter_variant('Wav2LetterDense', 'models.py:976-1012', residual = 'dense')
+Wav2LetterFlat = _wav2letter_variant('Wav2LetterFlat', 'models.py:1333-1369', residual = 'flat')
+
+
+class JasperNetSmall(JasperNet):
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 1, temporal_mask = False, **kwargs)
+
+
+class JasperNetLarge(JasperNet):
+	"""models.py:1407-1409: 'Jasper 10x5'."""
+
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 2, repeat = 5, temporal_mask = False, **kwargs)
+
+
+class JasperNetBig(JasperNet):
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 2, temporal_mask = False, **kwargs)
+
+
+class JasperNetBigNoStride(JasperNet):
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 2, stride1 = 1, temporal_mask = False, **kwargs)
+
+
+class JasperNetBigBpeOnly(JasperNet):
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 2, temporal_mask = False, bpe_only = True, **kwargs)
+
+
+class JasperNetResidualBig(JasperNet):
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 2, temporal_mask = False, residual = True, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------ wrappers (models.py:736-765)
+
+def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, opt_level = None, **kwargs):
+	"""models.py:736-752.  One process drives one MI355X here, so there is no single-process DataParallel: opt_level selects the
+	compute dtype (None / 'O0' -> fp32; 'O1' / 'O2' / 'O3' -> bf16 MFMA with fp32 master weights, the role apex.amp played)."""
+	master_module(model).set_compute_dtype(torch.float32 if opt_level in (None, '', 'O0') else torch.bfloat16)
+	return model, optimizer
+
+
+def distributed_data_parallel_and_autocast(model, local_rank, optimizer = None, opt_level = None, synchronize_bn = False, **kwargs):
+	"""models.py:755-765: one process per GPU; gradients are all-reduced over RCCL by convasr_amd.parallel.DataParallelEngine."""
+	from .parallel import DataParallelEngine
+	if synchronize_bn:
+		raise _lib.ConvasrHipError('synchronize_bn: the reference trains with per-GPU batch-norm statistics (train.py:704); SyncBatchNorm is not implemented')
+	model, optimizer = data_parallel_and_autocast(model, optimizer, opt_level = opt_level)
+	training = model.training
+	engine = DataParallelEngine(model, device = torch.device('cuda', local_rank))
+	engine.train(training)
+	return engine, optimizer

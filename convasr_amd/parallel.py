@@ -1,0 +1,85 @@
+"""Data-parallel training over the GPUs of one node (reference: DistributedDataParallel at models.py:763, init at train.py:852-874).
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm).  The gradient arena of FlatParameters is
+cut into contiguous buckets; backward kernels report each parameter the moment its gradient is final, and as soon as every
+parameter of a bucket has reported, that bucket's sum-all-reduce is enqueued asynchronously (RCCL runs it on its own HIP
+stream, ordered after the producing kernels by an event) -- so communication overlaps the rest of the backward conv stack.
+xGMI is point-to-point, so a few large buckets (default 32 MiB) beat many small ones.  Batch-norm statistics stay per GPU,
+exactly as in the reference's training path (train.py:704 does not pass synchronize_bn)."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .train import FlatParameters
+
+
+class DataParallelEngine(nn.Module):
+	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None):
+		super().__init__()
+		self.module = module
+		self.group = process_group
+		self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+		self.flat = flat if flat is not None else getattr(module, '_convasr_flat', None) or FlatParameters(module)
+		module._convasr_flat = self.flat
+		self.buckets = self._make_buckets(bucket_bytes)
+		self._pending = []
+		self._remaining = [len(b['params']) for b in self.buckets]
+		for bi, b in enumerate(self.buckets):
+			for p in b['params']:
+				p._convasr_ready = self._make_hook(bi)
+		if self.world_size > 1:
+			dist.broadcast(self.flat.data, src = 0, group = self.group)  # identical initial replicas
+			for buf in module.buffers():
+				dist.broadcast(buf, src = 0, group = self.group)
+
+	def _make_buckets(self, bucket_bytes):
+		flat = self.flat
+		buckets, cur = [], None
+		for p, off in zip(flat.params, flat.offsets):
+			end = off + p.numel()
+			if cur is None or (end - cur['lo']) * 4 > bucket_bytes and cur['params']:
+				cur = dict(lo = off, hi = end, params = [])
+				buckets.append(cur)
+			cur['params'].append(p)
+			cur['hi'] = end
+		return buckets
+
+	def _make_hook(self, bi):
+		def ready(param):
+			self._remaining[bi] -= 1
+			if self._remaining[bi] == 0:
+				self._launch(bi)
+		return ready
+
+	def _launch(self, bi):
+		if self.world_size == 1:
+			return
+		b = self.buckets[bi]
+		view = self.flat.grad[b['lo']:b['hi']]
+		self._pending.append((dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True), view))
+
+	def finish_gradient_sync(self):
+		"""Call after backward, before clip / optimizer: flushes buckets whose parameters got no gradient, waits for the
+		collectives (stream-side) and turns sums into means."""
+		for bi, left in enumerate(self._remaining):
+			if left > 0:
+				for p in self.buckets[bi]['params']:
+					if p._convasr_fresh:
+						p._convasr_grad.zero_()
+						p._convasr_fresh = False
+				self._launch(bi)
+		for work, view in self._pending:
+			work.wait()
+		if self.world_size > 1:
+			self.flat.grad.mul_(1.0 / self.world_size)
+		self._pending = []
+		self._remaining = [len(b['params']) for b in self.buckets]
+
+	def forward(self, *args, **kwargs):
+		return self.module(*args, **kwargs)
+
+	def state_dict(self, *args, **kwargs):
+		return self.module.state_dict(*args, **kwargs)
+
+	def load_state_dict(self, *args, **kwargs):
+		return self.module.load_state_dict(*args, **kwargs)

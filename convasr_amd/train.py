@@ -1,0 +1,128 @@
+"""Training-step plumbing for the hot path (reference: train.py:745-783).
+
+FlatParameters re-homes every trainable parameter into ONE contiguous fp32 buffer with a matching gradient buffer, so that
+gradient clipping is one reduction launch, the optimizer one elementwise launch, and data-parallel all-reduce a handful of
+large contiguous RCCL calls (288 GB of HBM makes the duplicate-free arena trivially affordable).  Backward kernels write
+gradients straight into the arena (convasr_amd.functional._deliver)."""
+import torch
+
+from . import ops, _lib
+from . import models as M
+
+
+class FlatParameters:
+	ALIGN = 64  # elements: every parameter starts on a 256-byte boundary
+
+	def __init__(self, model):
+		params = [p for p in model.parameters() if p.requires_grad]
+		if not params:
+			raise ValueError('model has no trainable parameters')
+		dev = params[0].device
+		self.params, self.offsets = params, []
+		off = 0
+		for p in params:
+			if p.dtype != torch.float32 or p.device != dev:
+				raise ValueError('FlatParameters needs fp32 parameters on one device')
+			self.offsets.append(off)
+			off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+		self.numel = off
+		self.data = torch.zeros(off, dtype = torch.float32, device = dev)
+		self.grad = torch.zeros(off, dtype = torch.float32, device = dev)
+		for p, o in zip(params, self.offsets):
+			n = p.numel()
+			view = self.data[o:o + n].view(p.shape)
+			view.copy_(p.data)
+			p.data = view
+			p._convasr_grad = self.grad[o:o + n].view(p.shape)
+			p._convasr_fresh = True
+			p.grad = p._convasr_grad
+		self.clip = None  # (sumsq double buffer, max_norm) set by clip_grad_norm_
+		self._sumsq = torch.zeros(1, dtype = torch.float64, device = dev)
+
+	def zero_grad(self):
+		"""No memset: the next backward overwrites (first write per parameter has accumulate = False)."""
+		for p in self.params:
+			p._convasr_fresh = True
+			p.grad = p._convasr_grad
+		self.clip = None
+
+	def finalize_grads(self):
+		"""Parameters that received no gradient this step count as zero."""
+		for p in self.params:
+			if p._convasr_fresh:
+				p._convasr_grad.zero_()
+
+	def clip_grad_norm_(self, max_norm):
+		"""torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:777): one reduction launch now; the scaling itself is
+		folded into the optimizer kernel.  Returns the total norm as a 0-d device tensor (no host sync)."""
+		self.finalize_grads()
+		self._sumsq.zero_()
+		ops.sumsq(self.grad, self._sumsq)
+		self.clip = (self._sumsq, float(max_norm))
+		return self._sumsq.sqrt().to(torch.float32).squeeze(0)
+
+
+class SGD:
+	"""torch.optim.SGD semantics (train.py:657-662) as ONE fused kernel launch over the flat arena."""
+
+	def __init__(self, flat: FlatParameters, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, nesterov = False, keep_clipped_grads = False):
+		self.flat = flat
+		self.param_groups = [dict(params = flat.params, lr = lr, momentum = momentum, weight_decay = weight_decay, nesterov = nesterov)]
+		self.momentum_buffer = torch.zeros_like(flat.data) if momentum != 0 else None
+		self.steps = 0
+		self.keep_clipped_grads = keep_clipped_grads
+
+	def zero_grad(self, set_to_none = False):
+		self.flat.zero_grad()
+
+	def step(self):
+		g = self.param_groups[0]
+		flat = self.flat
+		if flat.clip is None:
+			flat.finalize_grads()
+		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
+		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None)
+		self.steps += 1
+		flat.clip = None
+
+	def state_dict(self):
+		return dict(steps = self.steps, momentum_buffer = self.momentum_buffer, param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+
+	def load_state_dict(self, sd):
+		self.steps = sd['steps']
+		if self.momentum_buffer is not None and sd.get('momentum_buffer') is not None:
+			self.momentum_buffer.copy_(sd['momentum_buffer'])
+		for g, s in zip(self.param_groups, sd['param_groups']):
+			g.update(s)
+
+
+def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_iterations = 1, iteration = 0, world_size = 1, sync_metrics = True):
+	"""One iteration of the reference loop, train.py:745-783.
+
+	Returns dict(loss, loss_cur, entropy, grad_norm, skipped) of 0-d device tensors (read them lazily: no forced host sync
+	except the inf/NaN gate the reference also has at train.py:769)."""
+	out = model(x, xlen, y = y, ylen = ylen)
+	log_probs, olen, loss_vec = out['log_probs'], out['olen'], out['loss']
+	example_weights = ylen[:, 0]
+	loss = (loss_vec * example_weights).mean() / accumulate_iterations
+	loss_cur = loss_vec.mean()
+	entropy = M.entropy(log_probs[0].detach(), olen[0], dim = 1).mean()
+	if world_size > 1 and sync_metrics:
+		import torch.distributed as dist
+		stats = torch.stack([loss_cur.detach(), entropy])  # one 2-element all-reduce instead of two scalar ones (train.py:759-760)
+		dist.all_reduce(stats, op = dist.ReduceOp.SUM)
+		loss_cur, entropy = stats[0] / world_size, stats[1] / world_size
+	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = entropy, grad_norm = None, skipped = False)
+	if bool(torch.isinf(loss_cur) | torch.isnan(loss_cur)):
+		res['skipped'] = True
+		return res
+	loss.backward()
+	if iteration % accumulate_iterations == 0:
+		engine = model if hasattr(model, 'finish_gradient_sync') else None
+		if engine is not None:
+			engine.finish_gradient_sync()
+		flat = optimizer.flat
+		res['grad_norm'] = flat.clip_grad_norm_(max_norm)
+		optimizer.step()
+		optimizer.zero_grad()
+	return res

@@ -352,6 +352,6 @@ def test_sumsq_and_sgd_step_match_torch():
 		opt.step()
 		gi = gd * (it + 1)
 		ss = ops.sumsq(gi)
-		close(ss.sqrt().float(), norm, 1e-5, 0, 'grad norm')
+		close(ss.sqrt().float().squeeze(), norm, 5e-5, 0, 'grad norm')
 		ops.sgd_step(pd, gi, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, it == 0)
 		close(pd, p.detach(), 1e-5, 1e-6, f'params after step {it}')

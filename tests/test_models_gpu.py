@@ -1,0 +1,188 @@
+"""Module-level parity on the MI355X: the convasr_amd mirror of models.py against golden vectors produced by the reference
+(tests/golden/make_golden.py) and against the CPU oracle at larger sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import convasr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+pytestmark = pytest.mark.gpu
+T_ = lambda a: torch.as_tensor(np.asarray(a))
+
+
+def close(a, b, rtol, atol, what = ''):
+	a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).detach().double().cpu()
+	assert a.shape == b.shape, (what, a.shape, b.shape)
+	err = (a - b).abs()
+	tol = atol + rtol * b.abs()
+	assert bool((err <= tol).all()), f'{what}: max abs err {float(err.max()):.3e} (max |ref| {float(b.abs().max()):.3e})'
+
+
+def load_sd(module, g, prefix):
+	sd = {k[len(prefix):]: T_(g[k]) for k in g.files if k.startswith(prefix)}
+	missing, unexpected = module.load_state_dict(sd, strict = False)
+	assert not unexpected, unexpected
+	return sd
+
+
+@pytest.mark.parametrize('ci', range(5))
+def test_convbn1d_block_golden(ci):
+	import convasr_amd as ca
+	case = json.load(open(os.path.join(GOLDEN, 'convblock_cases.json')))[ci]
+	g = np.load(os.path.join(GOLDEN, f'convblock{ci}.npz'))
+	d = torch.device('cuda:0')
+	blk = ca.models.ConvBn1d(num_channels = (case['cin'], case['cout']), kernel_size = case['k'], stride = case['stride'], dilation = case['dilation'], repeat = case['repeat'], nonlinearity = tuple(case['nonlinearity']), temporal_mask = case['temporal_mask'], num_channels_residual = [case['cin']] * case['nres'])
+	load_sd(blk, g, f'c{ci}/sd/')
+	blk.to(d).train()
+	need_gx = case['stride'] == 1
+	x = T_(g['x']).to(d).requires_grad_(need_gx)
+	frac = T_(g['frac']).to(d)
+	res = [T_(g[f'res{r}']).to(d) for r in range(case['nres'])]
+	y = blk(x, lengths_fraction = frac, residual = res)
+	close(y, g['y'], 1e-4, 1e-4, 'train forward')
+	y.backward(T_(g['gout']).to(d))
+	if need_gx:
+		close(x.grad, g['gx'], 1e-3, 1e-4, 'dx')
+	for n, p in blk.named_parameters():
+		ref = g[f'c{ci}/grad/{n}']
+		close(p.grad, ref, 2e-3, 2e-4 * max(1.0, float(np.abs(ref).max())), 'grad ' + n)
+	for k in g.files:
+		if k.startswith(f'c{ci}/sd_after/') and 'running' in k:
+			close(dict(blk.named_buffers())[k[len(f'c{ci}/sd_after/'):]], g[k], 1e-4, 1e-5, k)
+	blk.eval()
+	with torch.no_grad():
+		close(blk(T_(g['x']).to(d), lengths_fraction = frac, residual = res), g['y_eval'], 1e-4, 1e-4, 'eval forward')
+		blk.fuse_conv_bn_eval()
+		close(blk(T_(g['x']).to(d), lengths_fraction = frac, residual = res), g['y_eval'], 1e-3, 1e-4, 'fused eval forward')
+
+
+def _tiny(ca, d, compute_dtype = torch.float32):
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	model = ca.models.JasperNet(64, [38], base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.2], out_width_factors_large = [2, 2], residual = False, repeat = 1, frontend = fe, check_time_dim_padded = False, nonlinearity = ('hardtanh', 0, 20), dilation = 2, compute_dtype = compute_dtype)
+	return model
+
+
+def test_tiny_model_end_to_end_training_and_decode_golden():
+	"""BASELINE config 1 on the GPU: forward, CTC loss, gradients, two SGD steps, eval logits and greedy strings vs the reference."""
+	import convasr_amd as ca
+	from convasr_amd.transcript_generators import GreedyCTCGenerator, CharTokenizerLegacy
+	g = np.load(os.path.join(GOLDEN, 'tiny_e2e.npz'))
+	hyp = json.load(open(os.path.join(GOLDEN, 'tiny_e2e_hyp.json')))
+	d = torch.device('cuda:0')
+	model = _tiny(ca, d)
+	sd = load_sd(model, g, 'sd/')
+	assert np.array_equal(model.frontend.mel.weight.numpy(), g['sd/frontend.mel.weight'])  # product mel basis == pinned fixture
+	model.to(d).train()
+	wav, xlen, y, ylen = (T_(g[k]).to(d) for k in ['wav', 'xlen', 'y', 'ylen'])
+	flat = ca.train.FlatParameters(model)
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, keep_clipped_grads = True)
+	gen, tok = GreedyCTCGenerator(), CharTokenizerLegacy(O.CHAR_LEGACY_ALPHABET)
+	first = lambda tt: [t[0][0]['hyp'] if len(t[0]) else '' for t in tt]
+
+	out = model(wav, xlen, y = y, ylen = ylen)
+	close(out['logits'][0], g['step0/logits'], 1e-3, 1e-4, 'logits')  # BASELINE.md fp32 bar: rtol 1e-3 / atol 1e-4
+	close(out['log_probs'][0], g['step0/log_probs'], 1e-3, 1e-4, 'log_probs')
+	assert torch.equal(out['olen'][0].cpu(), T_(g['step0/olen']))
+	close(out['loss'], g['step0/loss_vec'], 1e-4, 0, 'CTC loss (1e-4 relative)')
+	assert first(gen.generate(tok, out['log_probs'][0].detach(), torch.zeros(4), torch.ones(4), output_lengths = out['olen'][0])) == hyp['hyp_step0']
+	ent = ca.models.entropy(out['log_probs'][0].detach(), out['olen'][0], dim = 1).mean()
+	close(ent, g['step0/entropy'], 1e-4, 0, 'entropy')
+	loss = (out['loss'] * ylen[:, 0]).mean()
+	close(loss, g['step0/loss'], 1e-4, 0, 'loss')
+	loss.backward()
+	gn = flat.clip_grad_norm_(100.0)
+	close(gn, g['step0/grad_norm'], 1e-3, 0, 'grad norm')
+	opt.step()
+	for k in ['decoder.0.weight', 'backbone.0.conv.0.0.weight', 'backbone.2.bn.0.weight']:
+		ref = g['step0/grad/' + k]
+		close(dict(model.named_parameters())[k].grad, ref, 5e-3, 1e-3 * float(np.abs(ref).max()), 'clipped grad ' + k)
+	opt.zero_grad()
+
+	res = ca.train.train_step(model, opt, wav, xlen, y, ylen)
+	close(res['loss'], g['step1/loss'], 1e-3, 0, 'step 1 loss')
+	close(res['grad_norm'], g['step1/grad_norm'], 5e-3, 0, 'step 1 grad norm')
+	state = model.state_dict()
+	for k in g.files:
+		if k.startswith('sd_after2/') and 'num_batches' not in k:
+			ref = g[k]
+			close(state[k[len('sd_after2/'):]], ref, 2e-3, 2e-4 * max(float(np.abs(ref).max()), 1e-3), k)
+	assert int(state['backbone.0.bn.0.num_batches_tracked']) == 2
+
+	model.eval()
+	with torch.no_grad():
+		ev = model(wav, xlen)
+	close(ev['logits'][0], g['eval_logits'], 5e-3, 5e-3, 'eval logits after two steps')
+	assert first(gen.generate(tok, ev['log_probs'][0], torch.zeros(4), torch.ones(4), output_lengths = ev['olen'][0])) == hyp['hyp']
+
+
+def test_dense_residual_jaspernet_golden():
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'dense_jasper.npz'))
+	d = torch.device('cuda:0')
+	model = ca.models.JasperNet(64, [38], base_width = 32, kernel_sizes = [11, 13], out_width_factors = [2, 3], dropouts = [0.2, 0.2], out_width_factors_large = [4, 4], residual = 'dense', repeat = 2, num_subblocks = 2, check_time_dim_padded = False, temporal_mask = False)
+	load_sd(model, g, 'sd/')
+	model.to(d).train()
+	out = model(T_(g['x']).to(d), T_(g['xlen']).to(d))
+	close(out['logits'][0], g['logits'], 1e-3, 1e-4, 'dense logits')
+	close(out['log_probs'][0], g['log_probs'], 1e-3, 1e-4, 'dense log_probs')
+	out['logits'][0].square().mean().backward()
+	params = dict(model.named_parameters())
+	for k in ['backbone.1.conv_residual.0.weight', 'backbone.0.conv.0.0.weight']:
+		ref = g['grad/' + k]
+		close(params[k].grad, ref, 5e-3, 5e-3 * float(np.abs(ref).max()), 'grad ' + k)
+
+
+def test_full_wav2letter_forward_fp32_vs_oracle_config2_shape_reduced_batch():
+	"""BASELINE config 2 (full Wav2Letter, fp32, logmel + conv stack + CTC forward) at 4 x 10 s so the CPU oracle finishes in
+	seconds; same tolerances as BASELINE.md: logits rtol 1e-3 / atol 1e-4 scaled to the logit range, CTC 1e-4 relative,
+	greedy strings identical."""
+	import convasr_amd as ca
+	from convasr_amd.transcript_generators import GreedyCTCGenerator, CharTokenizerLegacy
+	torch.manual_seed(1)
+	d = torch.device('cuda:0')
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0, check_time_dim_padded = False)
+	sd = {k: v.clone() for k, v in model.state_dict().items()}
+	B, secs = 4, 10
+	x = torch.rand(B, 16000 * secs) * 2 - 1
+	xlen = torch.linspace(0.5, 1, B)
+	y = torch.randint(0, 37, (B, 1, 10 * secs))
+	ylen = torch.tensor([[50], [60], [80], [100]])
+	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
+	with torch.no_grad():
+		ref = O.jasper_forward(sd, plan, x, xlen, y, ylen, frontend = dict(nfft = 512, hop_length = 160), training = True)
+	model.to(d).train()
+	with torch.no_grad():
+		out = model(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
+	scale = float(ref['logits'].abs().max())
+	close(out['logits'][0], ref['logits'], 1e-3, 1e-4 * max(scale, 1.0), 'logits')
+	close(out['loss'], ref['loss'], 1e-4, 0, 'CTC loss')
+	tok, gen = CharTokenizerLegacy(O.CHAR_LEGACY_ALPHABET), GreedyCTCGenerator()
+	got = [t[0][0]['hyp'] if len(t[0]) else '' for t in gen.generate(tok, out['log_probs'][0], torch.zeros(B), torch.ones(B), output_lengths = out['olen'][0])]
+	assert got == O.greedy_decode(ref['log_probs'], ref['olen'])
+	for k, v in model.state_dict().items():
+		if 'running' in k:
+			close(v, sd[k], 1e-3, 1e-5, k)  # oracle updated its copy of the running stats in place
+
+
+def test_bf16_training_step_tracks_fp32():
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'tiny_e2e.npz'))
+	d = torch.device('cuda:0')
+	losses = {}
+	for dt in (torch.float32, torch.bfloat16):
+		model = _tiny(ca, d, dt)
+		load_sd(model, g, 'sd/')
+		model.to(d).train()
+		flat = ca.train.FlatParameters(model)
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		wav, xlen, y, ylen = (T_(g[k]).to(d) for k in ['wav', 'xlen', 'y', 'ylen'])
+		losses[dt] = [float(ca.train.train_step(model, opt, wav, xlen, y, ylen)['loss']) for _ in range(3)]
+	for a, b in zip(losses[torch.float32], losses[torch.bfloat16]):
+		assert abs(a - b) / abs(a) < 0.03, losses
+	assert losses[torch.bfloat16][2] < losses[torch.bfloat16][0]
