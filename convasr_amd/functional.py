@@ -10,12 +10,17 @@ import torch
 from . import ops, _lib
 
 _pack_cache = {}
+_param_epoch = [0]  # bumped by optimizers that update parameters behind torch's back (convasr_amd.train.SGD)
+
+
+def bump_param_epoch():
+	_param_epoch[0] += 1
 
 
 def packed_weight(w, dtype, mode):
 	"""Packed [K][rows_pad][cols] copy of a conv parameter, rebuilt only when the parameter changed."""
 	key = (id(w), dtype, mode)
-	ver = (w._version, w.data_ptr())
+	ver = (w._version, w.data_ptr(), _param_epoch[0])
 	hit = _pack_cache.get(key)
 	if hit is not None and hit[0] == ver:
 		return hit[1]

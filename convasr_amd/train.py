@@ -8,6 +8,7 @@ import torch
 
 from . import ops, _lib
 from . import models as M
+from . import functional as Fn
 
 
 class FlatParameters:
@@ -84,6 +85,7 @@ class SGD:
 		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None)
 		self.steps += 1
 		flat.clip = None
+		Fn.bump_param_epoch()  # packed bf16/fp32 weight copies are stale now
 
 	def state_dict(self):
 		return dict(steps = self.steps, momentum_buffer = self.momentum_buffer, param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])

@@ -107,16 +107,32 @@ def test_tiny_model_end_to_end_training_and_decode_golden():
 	close(res['loss'], g['step1/loss'], 1e-3, 0, 'step 1 loss')
 	close(res['grad_norm'], g['step1/grad_norm'], 5e-3, 0, 'step 1 grad norm')
 	state = model.state_dict()
+	assert int(state['backbone.0.bn.0.num_batches_tracked']) == 2
+	# (a) against the reference's golden weights.  The reference's own CPU path is only reproducible to ~2e-5 relative in the
+	# gradients across thread counts / hosts (measured: grad norm 164.8170 with 1 thread, 164.8184 with 8), and two SGD steps
+	# amplify that, so the bar is 5 % of the largest update of each tensor ...
 	for k in g.files:
 		if k.startswith('sd_after2/') and 'num_batches' not in k:
-			ref = g[k]
-			close(state[k[len('sd_after2/'):]], ref, 2e-3, 2e-4 * max(float(np.abs(ref).max()), 1e-3), k)
-	assert int(state['backbone.0.bn.0.num_batches_tracked']) == 2
+			name = k[len('sd_after2/'):]
+			ref, before = g[k], g['sd/' + name]
+			close(state[name], ref, 0, 0.05 * float(np.abs(ref - before).max()) + 1e-6, k)
+	# (b) ... and tightly against the oracle taking the same two steps on THIS host's cores.
+	osd = {k[3:]: T_(g[k]).clone() for k in g.files if k.startswith('sd/')}
+	plan = O.jasper_plan(64, [38], nonlinearity = ('hardtanh', 0, 20), dilation = 2, **O.TINY)
+	bufs = {}
+	for _ in range(2):
+		O.train_step(osd, plan, wav.cpu(), xlen.cpu(), y.cpu(), ylen.cpu(), frontend = dict(nfft = 512, hop_length = 160), momentum_buffers = bufs)
+	for name, v in osd.items():
+		if v.is_floating_point() and not name.startswith('frontend.'):
+			close(state[name], v, 1e-4, 2e-5, 'oracle on this host: ' + name)
 
 	model.eval()
 	with torch.no_grad():
 		ev = model(wav, xlen)
-	close(ev['logits'][0], g['eval_logits'], 5e-3, 5e-3, 'eval logits after two steps')
+	close(ev['logits'][0], g['eval_logits'], 0, 3e-2, 'eval logits after two steps (golden; see the reproducibility note above)')
+	with torch.no_grad():
+		oev = O.jasper_forward(osd, plan, wav.cpu(), xlen.cpu(), frontend = dict(nfft = 512, hop_length = 160), training = False)
+	close(ev['logits'][0], oev['logits'], 1e-3, 1e-3, 'eval logits after two steps (oracle on this host)')
 	assert first(gen.generate(tok, ev['log_probs'][0], torch.zeros(4), torch.ones(4), output_lengths = ev['olen'][0])) == hyp['hyp']
 
 
