@@ -1,0 +1,141 @@
+"""bench.py -- BASELINE.json's headline metric on the MI355X-native path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one full training iteration of the hot path on one synthetic batch per GPU (train.py:745-783 of the reference):
+logmel frontend -> instance norm -> Wav2Letter full (18 x Conv1d+BN+hardtanh+dropout+mask, 1x1 decoder) -> log-softmax ->
+CTC loss -> backward (dgrad / wgrad / BN / CTC) -> gradient all-reduce (N > 1) -> clip_grad_norm_ -> SGD.  Workload =
+BASELINE configs[2]/[3]: 64 utterances x 15 s of 16 kHz audio per GPU, bf16 MFMA convolutions with fp32 accumulation and
+fp32 master weights, dropout 0.2.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLE_RATE, SECS, BATCH, TARGET_LEN = 16000, 15, 64, 150
+FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # conv stack, 2*MAC, fwd + dgrad + wgrad
+PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
+	g = torch.Generator().manual_seed(seed)
+	x = torch.rand(batch, SAMPLE_RATE * secs, generator = g) * 2 - 1
+	xlen = torch.ones(batch)
+	y = torch.randint(0, 37, (batch, 1, 10 * secs), generator = g)
+	ylen = torch.full((batch, 1), 10 * secs, dtype = torch.long)
+	return tuple(t.to(device) for t in (x, xlen, y, ylen))
+
+
+def cpu_baseline(secs = SECS, batch = 2, iters = 1):
+	"""The oracle (kind 'port': plain-torch CPU restatement of the reference's path, pinned to the reference by
+	tests/golden) timed on this host's cores on a bounded sample of the same workload: `batch` x 15 s utterances,
+	fwd + CTC + bwd + clip + SGD, 1 warm-up + `iters` timed iterations."""
+	from oracle import convasr_oracle as O
+	cores = min(os.cpu_count() or 1, 16)  # torch's CPU conv/BN kernels stop scaling (and oversubscribe) well before 256 threads
+	torch.set_num_threads(cores)
+	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
+	fe = O.frontend_config()
+	sd = O.init_state_dict(plan, seed = 1, frontend = fe)
+	x, xlen, y, ylen = synthetic_batch('cpu', batch = batch, secs = secs)
+	bufs = {}
+	times = []
+	for it in range(1 + iters):
+		t0 = time.perf_counter()
+		O.train_step(sd, plan, x, xlen, y, ylen, frontend = fe, momentum_buffers = bufs)
+		times.append(time.perf_counter() - t0)
+	best = min(times[1:])
+	return dict(value = round(batch * secs / best, 2), unit = 'audio-seconds/sec', cores = cores, kind = 'port', sample = f'{batch}x{secs}s utterances, Wav2Letter full fp32, fwd+CTC+bwd+clip+SGD, best of {iters} after 1 warm-up ({best:.2f} s/step)')
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument('--gpus', type = int, default = 1)
+	ap.add_argument('--steps', type = int, default = 10)
+	ap.add_argument('--warmup', type = int, default = 3)
+	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f32'])
+	ap.add_argument('--no-cpu-baseline', action = 'store_true')
+	ap.add_argument('--no-kernel-timer', action = 'store_true')
+	args = ap.parse_args()
+
+	world = int(os.environ.get('WORLD_SIZE', '1'))
+	rank = int(os.environ.get('RANK', '0'))
+	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	if args.gpus > 1 and world != args.gpus:
+		raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
+	device = torch.device('cuda', local_rank)
+	torch.cuda.set_device(device)
+	if world > 1:
+		import torch.distributed as dist
+		os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+		dist.init_process_group('nccl', device_id = device)
+
+	import convasr_amd as ca
+	from convasr_amd import _lib
+
+	torch.manual_seed(1)
+	ca.functional.manual_seed(1 + rank)
+	compute = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+	fe = ca.models.LogFilterBankFrontend(64, SAMPLE_RATE, 0.02, 0.01, 'hann_window')
+	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0.2, check_time_dim_padded = False, compute_dtype = compute).to(device).train()
+	flat = ca.train.FlatParameters(model)
+	model._convasr_flat = flat
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	engine = ca.parallel.DataParallelEngine(model, device = device) if world > 1 else model
+	x, xlen, y, ylen = synthetic_batch(device, seed = 1 + rank)
+
+	def step(i):
+		return ca.train.train_step(engine, opt, x, xlen, y, ylen, world_size = world, iteration = i)
+
+	def fence():
+		if world > 1:
+			dist.barrier()
+		torch.cuda.synchronize()
+
+	last = None
+	for i in range(args.warmup):
+		last = step(i)
+	fence()
+	if not args.no_kernel_timer and rank == 0:
+		_lib.timer = _lib.KernelTimer()
+	t0 = time.perf_counter()
+	for i in range(args.steps):
+		last = step(args.warmup + i)
+	fence()
+	elapsed = time.perf_counter() - t0
+	kt = _lib.timer.summary() if _lib.timer is not None else {}
+	_lib.timer = None
+	if world > 1:
+		t = torch.tensor([elapsed], dtype = torch.float64, device = device)
+		dist.all_reduce(t, op = dist.ReduceOp.MAX)
+		elapsed = float(t.item())
+
+	if rank == 0:
+		audio_s = world * BATCH * SECS * args.steps
+		value = audio_s / elapsed
+		roof = None
+		if 'conv1d_igemm' in kt:
+			k = kt['conv1d_igemm']
+			achieved = k['work'] / (k['total_ms'] * 1e-3) / 1e12
+			peak = PEAK_BF16_DENSE / 1e12 if args.dtype == 'bf16' else 157.3
+			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_kernel (forward + dgrad launches)', achieved = round(achieved, 2), peak = peak, unit = 'TFLOP/s', frac = round(achieved / peak, 4), traffic = None, launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			if 'conv1d_wgrad' in kt:
+				w = kt['conv1d_wgrad']
+				roof['wgrad'] = dict(kernel = 'conv1d_wgrad_kernel + wgrad_reduce_kernel', achieved = round(w['work'] / (w['total_ms'] * 1e-3) / 1e12, 2), frac = round(w['work'] / (w['total_ms'] * 1e-3) / 1e12 / peak, 4), avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
+			roof['whole_step_frac'] = round(FLOP_PER_AUDIO_S_FWD_BWD * value / world / (peak * 1e12), 4)
+		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout 0.2', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), roofline = roof)
+		if world == 1 and not args.no_cpu_baseline:
+			line['cpu_baseline'] = cpu_baseline()
+		print(json.dumps(line), flush = True)
+	if world > 1:
+		dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+	main()

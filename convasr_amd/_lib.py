@@ -25,7 +25,7 @@ _SIGNATURES = dict(
 	convasr_logmel_fwd = (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_conv_cout_pad = (c_int, [c_int]),
-	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p]),
 	convasr_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
 	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
@@ -77,6 +77,38 @@ def call(name, *args):
 	rc = getattr(lib, name)(*args)
 	if rc != 0:
 		raise ConvasrHipError(f'{name} failed ({rc}): {lib.convasr_last_error().decode()}')
+
+
+class KernelTimer:
+	"""HIP-event timing of selected launches on the stream they are launched on (bench.py's roofline leg).  Events are
+	recorded around the C-ABI call; elapsed times are read after the caller synchronises."""
+
+	def __init__(self):
+		self.records = {}
+
+	def timed(self, family, work, fn):
+		start, end = torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True)
+		start.record()
+		fn()
+		end.record()
+		self.records.setdefault(family, []).append((start, end, work))
+
+	def summary(self):
+		out = {}
+		for family, recs in self.records.items():
+			ms = [s.elapsed_time(e) for s, e, _ in recs]
+			out[family] = dict(launches = len(recs), total_ms = sum(ms), avg_us = 1e3 * sum(ms) / max(len(ms), 1), work = sum(w for _, _, w in recs))
+		return out
+
+
+timer = None  # set to a KernelTimer by bench.py for the timed region
+
+
+def timed(family, work, fn):
+	if timer is None:
+		fn()
+	else:
+		timer.timed(family, work, fn)
 
 
 def stream_ptr():

@@ -273,9 +273,9 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 	const int cgroups = c8 < 256 ? c8 : 256;
 	const int64_t rows = (int64_t)B * T;
 	const int rlanes = 256 / cgroups;
-	int rows_per_block = 64 * rlanes;
+	int rows_per_block = 16 * rlanes;
 	int64_t gx = ceil_div64(rows, rows_per_block);
-	if (gx > 1024) { gx = 1024; rows_per_block = (int)ceil_div64(rows, gx); }
+	if (gx > 4096) { gx = 4096; rows_per_block = (int)ceil_div64(rows, gx); }
 	const int gy = (c8 + cgroups - 1) / cgroups;
 	dim3 grid((unsigned)ceil_div64(rows, rows_per_block), (unsigned)(gy > 4 ? 4 : gy));
 	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p, ra, rows_per_block);

@@ -248,33 +248,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 extern "C" int convasr_conv_cout_pad(int cout) { return (cout + BN - 1) / BN * BN; }
 
 // ------------------------------------------------------------------------------------------------ weight packing
+// One block = a 32(co) x 32(ci) x K tile of the fp32 parameter: read as 32 contiguous runs of 32*K floats, written as
+// fwd[k][co][ci] (32 contiguous ci per row) and/or dgrad[K-1-k][ci][co] (32 contiguous co per row).
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int K, int mode, int rows_pad) {
-	// out[k][row][col]; FWD: row = co, col = ci; DGRAD: row = ci, col = co, tap flipped
-	const int rows = mode == CONVASR_PACK_FWD ? Cout : Cin, cols = mode == CONVASR_PACK_FWD ? Cin : Cout;
-	const int64_t total = (int64_t)K * rows_pad * cols;
-	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-		const int col = (int)(i % cols);
-		const int row = (int)((i / cols) % rows_pad);
-		const int k = (int)(i / ((int64_t)cols * rows_pad));
-		float v = 0.f;
-		if (row < rows) {
-			if (mode == CONVASR_PACK_FWD) v = w[((int64_t)row * Cin + col) * K + k];
-			else v = w[((int64_t)col * Cin + row) * K + (K - 1 - k)];
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgr, int Cout, int Cin, int K,
+                                                          int co_pad, int ci_pad) {
+	extern __shared__ float tile[];  // [32][32 * K + 1]
+	const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32, pitch = 32 * K + 1;
+	const int ncols = min(32, Cin - ci0) * K;
+	for (int rr = threadIdx.x >> 6; rr < 32; rr += 4) {
+		const int co = co0 + rr;
+		for (int j = threadIdx.x & 63; j < 32 * K; j += 64) tile[rr * pitch + j] = (co < Cout && j < ncols) ? w[((int64_t)co * Cin + ci0) * K + j] : 0.f;
+	}
+	__syncthreads();
+	const int a = threadIdx.x & 31, bq = threadIdx.x >> 5;  // a: fast axis of the write, bq: 8 slow lanes
+	for (int k = 0; k < K; ++k) {
+		if (fwd) {
+			for (int rr = bq; rr < 32; rr += 8) {
+				const int co = co0 + rr, ci = ci0 + a;
+				if (co < co_pad && ci < Cin) Elem<T>::store(fwd + ((int64_t)k * co_pad + co) * Cin + ci, tile[rr * pitch + a * K + k]);
+			}
 		}
-		Elem<T>::store(out + i, v);
+		if (dgr) {
+			for (int cc = bq; cc < 32; cc += 8) {
+				const int ci = ci0 + cc, co = co0 + a;
+				if (ci < ci_pad && co < Cout) Elem<T>::store(dgr + ((int64_t)(K - 1 - k) * ci_pad + ci) * Cout + co, tile[a * pitch + cc * K + k]);
+			}
+		}
 	}
 }
 
-extern "C" int convasr_pack_conv_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int K, int mode, void* stream) {
-	CONVASR_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && K > 0 && (mode == CONVASR_PACK_FWD || mode == CONVASR_PACK_DGRAD), "pack_conv_weight: bad arguments");
-	const int rows = mode == CONVASR_PACK_FWD ? Cout : Cin;
-	const int rows_pad = convasr_conv_cout_pad(rows);
-	const int64_t total = (int64_t)K * rows_pad * (mode == CONVASR_PACK_FWD ? Cin : Cout);
-	int64_t blocks = ceil_div64(total, 256);
-	if (blocks > 4096) blocks = 4096;
-	if (dtype == CONVASR_F32) hipLaunchKernelGGL((pack_weight_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, Cout, Cin, K, mode, rows_pad);
-	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, Cout, Cin, K, mode, rows_pad);
+template <typename T> static void launch_pack(const float* w, void* fwd, void* dgr, int Cout, int Cin, int K, hipStream_t s) {
+	const int co_pad = convasr_conv_cout_pad(Cout), ci_pad = convasr_conv_cout_pad(Cin);
+	// cover the padded rows too so they are zero-filled: grid spans the padded extents of whichever outputs are requested
+	const int gx = ((dgr ? ci_pad : Cin) + 31) / 32, gy = ((fwd ? co_pad : Cout) + 31) / 32;
+	hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(gx, gy), dim3(256), (size_t)32 * (32 * K + 1) * sizeof(float), s, w, (T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
+}
+
+extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream) {
+	CONVASR_CHECK_ARG(w && (packed_fwd || packed_dgrad) && Cout > 0 && Cin > 0 && K > 0 && K <= 64, "pack_conv_weight: bad arguments");
+	if (dtype == CONVASR_F32) launch_pack<float>(w, packed_fwd, packed_dgrad, Cout, Cin, K, (hipStream_t)stream);
+	else if (dtype == CONVASR_BF16) launch_pack<bf16_t>(w, packed_fwd, packed_dgrad, Cout, Cin, K, (hipStream_t)stream);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
 	CONVASR_CHECK_LAUNCH("pack_conv_weight");
 	return 0;
@@ -534,19 +548,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 	}
 }
 
-// dbias[c] (+)= sum over rows of a channels-last (rows, C) matrix
-template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ out, int64_t rows, int C, int accumulate) {
+// dbias[c] (+)= sum over rows of a channels-last (rows, C) matrix: blocks own row chunks, one float atomic per (block, channel)
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ out, int64_t rows, int C, int rows_per_block) {
 	__shared__ float red[4][64];
 	const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+	const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
 	float a = 0.f;
 	if (c < C)
-		for (int64_t rr = w; rr < rows; rr += 4) a += Elem<T>::load(y + rr * C + c);
+		for (int64_t rr = r0 + w; rr < r1; rr += 4) a += Elem<T>::load(y + rr * C + c);
 	red[w][threadIdx.x & 63] = a;
 	__syncthreads();
-	if (w == 0 && c < C) {
-		const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-		out[c] = accumulate ? out[c] + s : s;
-	}
+	if (w == 0 && c < C) unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 static void wgrad_plan(WgradParams& p, int bkt) {
@@ -616,8 +628,11 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 	CONVASR_CHECK_LAUNCH("conv1d_wgrad_reduce");
 	if (dbias) {
 		const int64_t rows = (int64_t)B * Tout;
-		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), dim3((Cout + 63) / 64), dim3(256), 0, s, (const float*)dy, dbias, rows, Cout, accumulate);
-		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3((Cout + 63) / 64), dim3(256), 0, s, (const bf16_t*)dy, dbias, rows, Cout, accumulate);
+		const int rows_per_block = 256;
+		dim3 grid((Cout + 63) / 64, (unsigned)ceil_div64(rows, rows_per_block));
+		if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "conv1d_dbias: memset failed");
+		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, dbias, rows, Cout, rows_per_block);
+		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, dbias, rows, Cout, rows_per_block);
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
 	}
 	return 0;

@@ -18,14 +18,19 @@ def bump_param_epoch():
 
 
 def packed_weight(w, dtype, mode):
-	"""Packed [K][rows_pad][cols] copy of a conv parameter, rebuilt only when the parameter changed."""
-	key = (id(w), dtype, mode)
+	"""Packed [K][rows_pad][cols] copy of a conv parameter, rebuilt only when the parameter changed.  In training both the
+	forward and the dgrad layout are produced by one launch the first time either is asked for."""
 	ver = (w._version, w.data_ptr(), _param_epoch[0])
-	hit = _pack_cache.get(key)
+	hit = _pack_cache.get((id(w), dtype, mode))
 	if hit is not None and hit[0] == ver:
 		return hit[1]
+	if torch.is_grad_enabled() and w.requires_grad:
+		fwd, dgr = ops.pack_weight(w, dtype, None)
+		_pack_cache[(id(w), dtype, _lib.PACK_FWD)] = (ver, fwd, w)  # keep `w` alive so id() stays unique
+		_pack_cache[(id(w), dtype, _lib.PACK_DGRAD)] = (ver, dgr, w)
+		return fwd if mode == _lib.PACK_FWD else dgr
 	wp = ops.pack_weight(w, dtype, mode)
-	_pack_cache[key] = (ver, wp, w)  # keep `w` alive so id() stays unique
+	_pack_cache[(id(w), dtype, mode)] = (ver, wp, w)
 	return wp
 
 

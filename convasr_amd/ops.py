@@ -103,17 +103,18 @@ def cout_pad(c):
 	return _lib.load().convasr_conv_cout_pad(c)
 
 
-def pack_weight(w, dtype, mode):
-	"""(Cout, Cin, K) fp32 parameter -> packed [K][rows_pad][cols] tensor for the MFMA kernels."""
+def pack_weight(w, dtype, mode = None):
+	"""(Cout, Cin, K) fp32 parameter -> packed [K][rows_pad][cols] tensor(s) for the MFMA kernels.
+	mode PACK_FWD / PACK_DGRAD returns that one layout; mode None returns (fwd, dgrad) from a single launch."""
 	require_cuda(w)
 	w = w.detach()
 	if w.dtype != torch.float32 or not w.is_contiguous():
 		w = w.float().contiguous()
 	Cout, Cin, K = w.shape
-	rows, cols = (Cout, Cin) if mode == _lib.PACK_FWD else (Cin, Cout)
-	out = torch.empty(K, cout_pad(rows), cols, dtype = dtype, device = w.device)
-	call('convasr_pack_conv_weight', ptr(w), ptr(out), dtype_code(dtype), Cout, Cin, K, mode, stream_ptr())
-	return out
+	fwd = torch.empty(K, cout_pad(Cout), Cin, dtype = dtype, device = w.device) if mode in (None, _lib.PACK_FWD) else None
+	dgr = torch.empty(K, cout_pad(Cin), Cout, dtype = dtype, device = w.device) if mode in (None, _lib.PACK_DGRAD) else None
+	call('convasr_pack_conv_weight', ptr(w), ptr(fwd), ptr(dgr), dtype_code(dtype), Cout, Cin, K, stream_ptr())
+	return (fwd, dgr) if mode is None else (fwd if mode == _lib.PACK_FWD else dgr)
 
 
 def conv_out_len(Tin, K, stride, dil, pad):
@@ -127,7 +128,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	Tout = conv_out_len(Tin, K, stride, dil, pad)
 	out_dtype = out_dtype or x.dtype
 	y = empty_cl(B, Cout, Tout, out_dtype, x.device)
-	call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), ptr(stats), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), stream_ptr())
+	_lib.timed('conv1d_igemm', 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), ptr(stats), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), stream_ptr()))
 	return y
 
 
@@ -151,7 +152,7 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and dw.is_contiguous() and dw.dtype == torch.float32
 	nbytes = _lib.load().convasr_conv1d_wgrad_workspace_bytes(B, Cin, Cout, Tin, Tout, K, stride, dil)
 	ws = workspace(nbytes, x.device, 'wgrad')
-	call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), stream_ptr())
+	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), stream_ptr()))
 	return dw
 
 

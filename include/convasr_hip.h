@@ -31,7 +31,6 @@ extern "C" {
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
 enum { CONVASR_OK = 0, CONVASR_EINVAL = -1, CONVASR_ELAUNCH = -2, CONVASR_EUNSUPPORTED = -3 };
-enum { CONVASR_PACK_FWD = 0, CONVASR_PACK_DGRAD = 1 };
 
 int convasr_abi_version(void);
 const char* convasr_last_error(void);
@@ -68,9 +67,11 @@ int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc,
 /* cout_pad(cout): rows of the packed weight (multiple of the kernel's N tile). */
 int convasr_conv_cout_pad(int cout);
 
-/* (Cout, Cin, K) fp32 -> packed [K][cout_pad][cin] of `dtype`.  mode FWD: packed[k][co][ci] = w[co][ci][k];
- * mode DGRAD: packed[k][ci][co] = w[co][ci][K-1-k] (rows padded to convasr_conv_cout_pad(Cin)). */
-int convasr_pack_conv_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int K, int mode, void* stream);
+/* (Cout, Cin, K) fp32 parameter -> packed compute-dtype copies, one launch for both (either may be NULL):
+ *   packed_fwd  [K][cout_pad(Cout)][Cin]  : packed_fwd[k][co][ci]   = w[co][ci][k]        (forward and wgrad-free paths)
+ *   packed_dgrad[K][cout_pad(Cin)][Cout]  : packed_dgrad[k][ci][co] = w[co][ci][K-1-k]    (input gradient = conv with flipped taps)
+ * padded rows are zero-filled. */
+int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
 
 /* y[b,t,co] = epilogue( sum_{k,ci} x[b, t*stride + k*dil - pad, ci] * wp[k][co][ci] ), zero outside [0, Tin).
  * epilogue: acc -> (+ bias[co] if bias) -> (stats of that value: sum[co] += v, sumsq[co] += v*v over all valid
