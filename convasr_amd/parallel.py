@@ -24,6 +24,7 @@ class DataParallelEngine(nn.Module):
 		self.buckets = self._make_buckets(bucket_bytes)
 		self._pending = []
 		self._remaining = [len(b['params']) for b in self.buckets]
+		self.sync = True  # False inside no_sync(): gradients accumulate locally, nothing is launched (gradient accumulation)
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
 				p._convasr_ready = self._make_hook(bi)
@@ -46,6 +47,8 @@ class DataParallelEngine(nn.Module):
 
 	def _make_hook(self, bi):
 		def ready(param):
+			if not self.sync:
+				return
 			self._remaining[bi] -= 1
 			if self._remaining[bi] == 0:
 				self._launch(bi)
@@ -57,6 +60,19 @@ class DataParallelEngine(nn.Module):
 		b = self.buckets[bi]
 		view = self.flat.grad[b['lo']:b['hi']]
 		self._pending.append((dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True), view))
+
+	def no_sync(self):
+		"""Context manager for all but the last backward of a gradient-accumulation group (DDP.no_sync semantics)."""
+		import contextlib
+
+		@contextlib.contextmanager
+		def ctx():
+			prev, self.sync = self.sync, False
+			try:
+				yield
+			finally:
+				self.sync = prev
+		return ctx()
 
 	def finish_gradient_sync(self):
 		"""Call after backward, before clip / optimizer: flushes buckets whose parameters got no gradient, waits for the

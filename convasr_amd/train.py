@@ -118,9 +118,14 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	if bool(torch.isinf(loss_cur) | torch.isnan(loss_cur)):
 		res['skipped'] = True
 		return res
-	loss.backward()
-	if iteration % accumulate_iterations == 0:
-		engine = model if hasattr(model, 'finish_gradient_sync') else None
+	engine = model if hasattr(model, 'finish_gradient_sync') else None
+	last_of_group = iteration % accumulate_iterations == 0
+	if engine is not None and not last_of_group:
+		with engine.no_sync():
+			loss.backward()
+	else:
+		loss.backward()
+	if last_of_group:
 		if engine is not None:
 			engine.finish_gradient_sync()
 		flat = optimizer.flat

@@ -1,0 +1,112 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel engine's host logic: flat arenas, bucketing, readiness-ordered launches,
+mean-reduction, broadcast of the initial replica.  The kernels themselves are covered by the -m gpu tests."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	return port
+
+
+class Toy(nn.Module):
+	def __init__(self):
+		super().__init__()
+		self.a = nn.Conv1d(8, 16, 3, bias = False)
+		self.bn = nn.BatchNorm1d(16)
+		self.b = nn.Conv1d(16, 4, 1)
+
+
+def _worker(rank, world, port, out):
+	os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+	dist.init_process_group('gloo', rank = rank, world_size = world)
+	from convasr_amd.parallel import DataParallelEngine
+	from convasr_amd.functional import _deliver
+	torch.manual_seed(100 + rank)  # different initial replicas: rank 0's must win
+	model = Toy()
+	engine = DataParallelEngine(model, bucket_bytes = 1024)
+	flat = engine.flat
+	assert len(engine.buckets) >= 2
+	w0 = flat.data.clone()
+	gathered = [torch.empty_like(w0) for _ in range(world)]
+	dist.all_gather(gathered, w0)
+	assert all(torch.equal(g, gathered[0]) for g in gathered), 'replicas differ after broadcast'
+	assert model.a.weight.data_ptr() == flat.data.data_ptr(), 'parameters must be views of the arena'
+
+	launched = []
+	orig = engine._launch
+	engine._launch = lambda bi: (launched.append(bi), orig(bi))[1]
+	params = list(model.parameters())
+	expect = sum(range(1, world + 1)) / world
+	# step 1 -- "backward": gradients become final in reverse layer order; every rank contributes rank + 1
+	for p in reversed(params):
+		_deliver([p], lambda outs, acc: outs[0].fill_(float(rank + 1)) if not acc else outs[0].add_(float(rank + 1)))
+	assert launched == list(reversed(range(len(engine.buckets)))), ('buckets must launch decoder-side first, as they complete', launched)
+	engine.finish_gradient_sync()
+	for p in params:
+		assert torch.allclose(p.grad, torch.full_like(p, expect)), (rank, p.grad.flatten()[:4])
+	# step 2 -- one parameter gets no gradient: its bucket is flushed (as zeros) by finish_gradient_sync
+	flat.zero_grad()
+	del launched[:]
+	for p in reversed(params):
+		if p is not model.bn.bias:
+			_deliver([p], lambda outs, acc: outs[0].fill_(float(rank + 1)) if not acc else outs[0].add_(float(rank + 1)))
+	engine.finish_gradient_sync()
+	assert sorted(launched) == list(range(len(engine.buckets))), launched
+	for p in params:
+		want = 0.0 if p is model.bn.bias else expect
+		assert torch.allclose(p.grad, torch.full_like(p, want)), (rank, want, p.grad.flatten()[:4])
+
+	# step 3 -- gradient accumulation: the first backward of the group runs under no_sync(), the second launches the buckets
+	flat.zero_grad()
+	del launched[:]
+	with engine.no_sync():
+		for p in reversed(params):
+			_deliver([p], lambda outs, acc: outs[0].fill_(float(rank + 1)) if not acc else outs[0].add_(float(rank + 1)))
+	assert launched == []
+	for p in reversed(params):
+		_deliver([p], lambda outs, acc: outs[0].fill_(float(rank + 1)) if not acc else outs[0].add_(float(rank + 1)))
+	engine.finish_gradient_sync()
+	for p in params:
+		assert torch.allclose(p.grad, torch.full_like(p, 2 * expect)), (rank, p.grad.flatten()[:4])
+	dist.barrier()
+	dist.destroy_process_group()
+	out.put((rank, 'ok'))
+
+
+def test_data_parallel_engine_gloo_world2():
+	ctx = mp.get_context('spawn')
+	out = ctx.Queue()
+	port = _free_port()
+	procs = [ctx.Process(target = _worker, args = (r, 2, port, out)) for r in range(2)]
+	for p in procs:
+		p.start()
+	for p in procs:
+		p.join(120)
+	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+	assert sorted(out.get(timeout = 5)[0] for _ in range(2)) == [0, 1]
+
+
+def test_flat_parameters_views_and_state_dict_roundtrip():
+	from convasr_amd.train import FlatParameters
+	model = Toy()
+	sd = {k: v.clone() for k, v in model.state_dict().items()}
+	flat = FlatParameters(model)
+	for k, v in model.state_dict().items():
+		assert torch.equal(v, sd[k]), k
+	assert flat.numel % FlatParameters.ALIGN == 0
+	with torch.no_grad():
+		flat.data.add_(1.0)
+	assert torch.allclose(model.a.weight, sd['a.weight'] + 1.0)
+	model.load_state_dict(sd)  # load_state_dict copies in place: the views survive
+	assert model.a.weight.data_ptr() == flat.data.data_ptr()
+	assert torch.equal(model.b.bias, sd['b.bias'])
