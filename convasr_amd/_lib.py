@@ -27,6 +27,7 @@ _SIGNATURES = dict(
 	convasr_conv_cout_pad = (c_int, [c_int]),
 	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p]),
+	convasr_debug_set_conv_v2 = (c_int, [c_int]),
 	convasr_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
 	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_bn_finalize = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p, c_p, c_p, c_int, c_p]),

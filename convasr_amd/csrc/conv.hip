@@ -8,59 +8,7 @@
 // slab of input channels it stages the X rows [t0*stride - pad, ...) ONCE (tile + halo) and re-uses them for all K taps --
 // the tap only shifts the LDS row a fragment is read from.  Weight tiles stream through a 2-deep ring, one per (ci-slab, tap).
 // fp32 runs the same schedule on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), bf16 on v_mfma_f32_32x32x16_bf16.
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-#define BM 128
-#define BN 128
-#define NTHREADS 256
-#define ROW_BYTES 128  // one LDS row = 128 B of the reduction axis (64 bf16 or 32 f32)
-
-struct ConvParams {
-	const void* x;
-	const void* w;
-	void* y;
-	const float* bias;
-	double* stats;
-	const float* scale;
-	const float* shift;
-	const float* xlen;
-	int B, Cin, Cout, CoutPad, Tin, Tout, K, stride, dil, pad;
-	int act;
-	float act_lo, act_hi;
-	int m_tiles_per_b, n_tiles, total_tiles;
-	int x_rows;  // LDS rows of one X tile (even)
-};
-
-// Two 128-B rows share one 256-B bank row; 16-B slot = (row parity, chunk ^ row-pair index): 16 consecutive rows at the same
-// chunk land on 16 distinct slots -> ds_read_b128 fragments are bank-conflict free.
-__device__ __forceinline__ int lds_off(int row, int chunk) { return ((row >> 1) << 8) | ((((row & 1) << 3) | (chunk ^ ((row >> 1) & 7))) << 4); }
-
-// XCD-aware bijective remap: consecutive virtual ids (same X tile, neighbouring weight tiles) share one XCD's L2.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-	const int q = n >> 3, r = n & 7, xcd = bid & 7, k = bid >> 3;
-	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-	static constexpr int EPC = 8;  // elements per 16-byte chunk
-	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
-		c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-	}
-};
-template <> struct Mma<float> {
-	static constexpr int EPC = 4;
-	// lane half h holds k = {4(2j+h) .. +3}; the i-th of four MFMAs pairs element i of both halves: every k is summed once.
-	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
-		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-	}
-};
+#include "conv_common.h"
 
 // 16 bytes of a row, zero outside [0, n_valid_elems); scalar path when rows are not 16-byte aligned.
 template <typename T, bool ALIGNED> __device__ __forceinline__ uint4 load_chunk(const T* row, int e0, int n_valid) {
@@ -319,6 +267,11 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 	return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
 }
 
+int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s);  // conv_v2.hip
+static int g_conv_use_v2 = 1;
+// test / A-B hook: 0 forces the register-staged kernel for every dtype
+extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable; return prev; }
+
 extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
                                   int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
                                   float act_lo, float act_hi, const float* xlen, void* stream) {
@@ -342,6 +295,10 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 	if (epi > smem) smem = epi;
 	CONVASR_CHECK_ARG(smem <= 160 * 1024, "conv1d_fwd: tile needs %zu B of LDS", smem);
 	hipStream_t s = (hipStream_t)stream;
+	if (x_dtype == CONVASR_BF16 && g_conv_use_v2 && convasr_conv1d_v2_try(p, y_dtype, s)) {
+		CONVASR_CHECK_LAUNCH("conv1d_fwd (v2)");
+		return 0;
+	}
 	int rc;
 	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) rc = dispatch_conv<float, float>(p, smem, s);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_BF16) rc = dispatch_conv<bf16_t, bf16_t>(p, smem, s);

@@ -1,0 +1,56 @@
+// Shared pieces of the implicit-GEMM conv kernels (conv.hip: register-staged general kernel; conv_v2.hip: LDS-DMA bf16 kernel).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BM 128
+#define BN 128
+#define NTHREADS 256
+#define ROW_BYTES 128  // one LDS row = 128 B of the reduction axis (64 bf16 or 32 f32)
+
+struct ConvParams {
+	const void* x;
+	const void* w;
+	void* y;
+	const float* bias;
+	double* stats;
+	const float* scale;
+	const float* shift;
+	const float* xlen;
+	int B, Cin, Cout, CoutPad, Tin, Tout, K, stride, dil, pad;
+	int act;
+	float act_lo, act_hi;
+	int m_tiles_per_b, n_tiles, total_tiles;
+	int x_rows;  // LDS rows of one X tile (even)
+};
+
+// Two 128-B rows share one 256-B bank row; 16-B slot = (row parity, chunk ^ row-pair index): 16 consecutive rows at the same
+// chunk land on 16 distinct slots -> ds_read_b128 fragments are bank-conflict free.
+__device__ __forceinline__ int lds_off(int row, int chunk) { return ((row >> 1) << 8) | ((((row & 1) << 3) | (chunk ^ ((row >> 1) & 7))) << 4); }
+
+// XCD-aware bijective remap: consecutive virtual ids (same X tile, neighbouring weight tiles) share one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+	const int q = n >> 3, r = n & 7, xcd = bid & 7, k = bid >> 3;
+	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+	static constexpr int EPC = 8;  // elements per 16-byte chunk
+	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+		c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+	}
+};
+template <> struct Mma<float> {
+	static constexpr int EPC = 4;
+	// lane half h holds k = {4(2j+h) .. +3}; the i-th of four MFMAs pairs element i of both halves: every k is summed once.
+	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+	}
+};
+

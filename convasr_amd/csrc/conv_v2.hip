@@ -1,0 +1,222 @@
+// bf16 fast path of the implicit-GEMM conv (forward and dgrad), stride 1, Cin % 64 == 0.
+//
+// Same decomposition as conv.hip (one workgroup = a t x co tile of one utterance; the X rows incl. halo are staged once per
+// 64-channel slab and shared by all K taps) but built around LDS-DMA (`buffer_load_dwordx4 ... lds`):
+//   * 256(t) x 128(co) tile, 8 waves (4 x 2, each 64 x 64): two waves per SIMD cover each other's waits;
+//   * X slabs double-buffered, weight tiles in a 3-deep ring; loads are issued two K-steps ahead and stay in flight across
+//     the raw s_barrier -- the only wait in the loop is a counted `s_waitcnt vmcnt(2)`;
+//   * no staging registers and no ds_write traffic (the v1 kernel spends ~45 % of its LDS cycles on ds_write_b128);
+//   * the conflict-free XOR swizzle is applied on the per-lane SOURCE address (the DMA destination is lane-linear);
+//   * the conv's zero padding is the buffer descriptor's range check: rows before 0 / after Tin read as zeros.
+#include "conv_common.h"
+
+#define V2_BM 256
+#define V2_THREADS 512
+#define V2_WSLOT (BN * ROW_BYTES)  // 16 KiB
+
+// 1 KiB (one wave-instruction) of a swizzled tile: LDS slot p of the tile <- global (row, chunk) with
+// lds_off(row, chunk) == 16 * p.  Returns the byte offset of that lane's 16 bytes relative to the tile's row 0 / chunk 0.
+__device__ __forceinline__ int v2_src_offset(int p, int row_bytes) {
+	const int pair = p >> 4, s = p & 15;
+	const int row = 2 * pair + (s >> 3), chunk = (s & 7) ^ (pair & 7);
+	return row * row_bytes + chunk * 16;
+}
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, range-checked on num_bytes) from wave-uniform pieces
+__device__ __forceinline__ v4i32 make_srd(const void* base, unsigned num_bytes) {
+	const unsigned long long a = (unsigned long long)base;
+	v4i32 d;
+	d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+	d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+	d[2] = __builtin_amdgcn_readfirstlane((int)num_bytes);
+	d[3] = 0x00020000;
+	return d;
+}
+
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at LDS byte address lds_addr), issued from inline asm so that hipcc neither
+// counts it nor drains it with vmcnt(0) before the next ds_read: completion is tracked by the counted waits in the loop.
+__device__ __forceinline__ void dma16(const v4i32& srd, unsigned lds_addr, int voff) {
+	unsigned keep;
+	asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(voff), "s"(srd), "s"(lds_addr)
+	             : "memory");
+}
+
+template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2_kernel(ConvParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+
+	const int v = xcd_remap(blockIdx.x, p.total_tiles);
+	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
+	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * V2_BM;
+	const int co0 = ntile * BN;
+	const int tin0 = t0 - p.pad;  // stride 1
+
+	const int xbytes = p.x_rows * ROW_BYTES;  // x_rows is a multiple of 8: whole 1-KiB DMA pieces
+	char* const xbuf = smem;
+	char* const wbuf = smem + 2 * xbytes;
+	const int row_bytes = p.Cin * 2;
+	const v4i32 xsrc = make_srd(reinterpret_cast<const bf16_t*>(p.x) + (int64_t)b * p.Tin * p.Cin, (unsigned)(p.Tin * row_bytes));
+	const v4i32 wsrc = make_srd(p.w, (unsigned)(p.K * p.CoutPad * row_bytes));
+	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+	const int n_cib = p.Cin >> 6;
+	const int x_units = p.x_rows >> 3;
+
+	// per-lane source offsets of the pieces this wave issues (tile-relative), computed once
+	const int xlane = v2_src_offset(lane, row_bytes);  // piece u adds 8 rows: (u * 8) * row_bytes, and the swizzle term is periodic in 8 pairs = 16 rows
+	auto issue_x = [&](int cib) {
+		const unsigned dst = lds_base + (cib & 1) * xbytes;
+		const int base = tin0 * row_bytes + cib * 128;
+		for (int u = wave; u < x_units; u += 8) {
+			// piece u covers rows 8u .. 8u+7 = pairs 4u .. 4u+3; (pair & 7) depends on u's parity
+			const int off = (u & 1) ? v2_src_offset(64 + lane, row_bytes) - 8 * row_bytes : xlane;
+			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + off);
+		}
+	};
+	const int wl0 = v2_src_offset(wave * 128 + lane, row_bytes), wl1 = v2_src_offset(wave * 128 + 64 + lane, row_bytes);
+	auto issue_w = [&](int q_cib, int q_tap, int slot) {
+		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * xbytes + slot * V2_WSLOT + wave * 2048);
+		const int base = (q_tap * p.CoutPad + co0) * row_bytes + q_cib * 128;
+		dma16(wsrc, dst, base + wl0);
+		dma16(wsrc, dst + 1024, base + wl1);
+	};
+
+	f32x16 acc[2][2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+#pragma unroll
+		for (int j = 0; j < 2; ++j)
+#pragma unroll
+			for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+	const int Q = n_cib * p.K;
+	issue_x(0);
+	issue_w(0, 0, 0);
+	if (Q > 1) issue_w(p.K > 1 ? 0 : 1, p.K > 1 ? 1 : 0, 1);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__builtin_amdgcn_s_barrier();
+
+	const int wrow0 = wn * 64 + r, wrow1 = wrow0 + 32;
+	const int woff0 = (wrow0 >> 1) << 8, wpar0 = (wrow0 & 1) << 3, wsw0 = (wrow0 >> 1) & 7;
+	const int woff1 = (wrow1 >> 1) << 8, wpar1 = (wrow1 & 1) << 3, wsw1 = (wrow1 >> 1) & 7;
+
+	int cib = 0, tap = 0;       // coordinates of step q
+	int cib2 = 0, tap2 = 0;     // coordinates of step q + 2
+	for (int i = 0; i < 2; ++i) { if (++tap2 == p.K) { tap2 = 0; ++cib2; } }
+	int slot = 0;
+	for (int q = 0; q < Q; ++q) {
+		if (tap == 0 && cib + 1 < n_cib) issue_x(cib + 1);
+		const bool more = q + 2 < Q;
+		if (more) issue_w(cib2, tap2, slot >= 1 ? slot - 1 : 2);  // (slot + 2) % 3
+
+		const char* xs = xbuf + (cib & 1) * xbytes;
+		const char* ws = wbuf + slot * V2_WSLOT;
+		const int xrow0 = wm * 64 + r + tap * p.dil, xrow1 = xrow0 + 32;
+		const int xoff0 = (xrow0 >> 1) << 8, xpar0 = (xrow0 & 1) << 3, xsw0 = (xrow0 >> 1) & 7;
+		const int xoff1 = (xrow1 >> 1) << 8, xpar1 = (xrow1 & 1) << 3, xsw1 = (xrow1 >> 1) & 7;
+#pragma unroll
+		for (int kk = 0; kk < 4; ++kk) {
+			const int chunk = kk * 2 + h;
+			const uint4 a0 = *reinterpret_cast<const uint4*>(xs + xoff0 + ((xpar0 | (chunk ^ xsw0)) << 4));
+			const uint4 a1 = *reinterpret_cast<const uint4*>(xs + xoff1 + ((xpar1 | (chunk ^ xsw1)) << 4));
+			const uint4 b0 = *reinterpret_cast<const uint4*>(ws + woff0 + ((wpar0 | (chunk ^ wsw0)) << 4));
+			const uint4 b1 = *reinterpret_cast<const uint4*>(ws + woff1 + ((wpar1 | (chunk ^ wsw1)) << 4));
+			Mma<bf16_t>::run(a0, b0, acc[0][0]);
+			Mma<bf16_t>::run(a0, b1, acc[0][1]);
+			Mma<bf16_t>::run(a1, b0, acc[1][0]);
+			Mma<bf16_t>::run(a1, b1, acc[1][1]);
+		}
+
+		// everything but the two weight pieces issued in this step has landed (X of the next slab is older than them)
+		if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		if (++tap == p.K) { tap = 0; ++cib; }
+		if (++tap2 == p.K) { tap2 = 0; ++cib2; }
+		slot = slot == 2 ? 0 : slot + 1;
+	}
+
+	// ---------------- epilogue (as conv.hip): bias, BN statistics, scale/shift, activation, mask, coalesced store through LDS
+	constexpr int OPITCH = BN * sizeof(O) + 16;
+	char* const otile = smem;
+	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN]
+	const int nvalid = valid_len(p.xlen, b, p.Tout);
+#pragma unroll
+	for (int ni = 0; ni < 2; ++ni) {
+		const int col = wn * 64 + ni * 32 + r, co = co0 + col;
+		const bool cok = co < p.Cout;
+		const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
+		const float sc = (p.scale && cok) ? p.scale[co] : 1.f, sh = (p.scale && cok) ? p.shift[co] : 0.f;
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+			for (int g = 0; g < 16; ++g) {
+				const int row = wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+				const int t = t0 + row;
+				float val = acc[mi][ni][g] + bias;
+				if (t < p.Tout) { s1 += val; s2 += val * val; }
+				val = apply_act(val * sc + sh, p.act, p.act_lo, p.act_hi);
+				if (t >= nvalid) val = 0.f;
+				Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
+			}
+		}
+		if (p.stats) {
+			s1 += __shfl_xor(s1, 32, 64);
+			s2 += __shfl_xor(s2, 32, 64);
+			if (h == 0) { red[(0 * 4 + wm) * BN + col] = s1; red[(1 * 4 + wm) * BN + col] = s2; }
+		}
+	}
+	__syncthreads();
+	if (p.stats && tid < BN && co0 + tid < p.Cout) {
+		double a = 0, q2 = 0;
+#pragma unroll
+		for (int m = 0; m < 4; ++m) { a += (double)red[(0 * 4 + m) * BN + tid]; q2 += (double)red[(1 * 4 + m) * BN + tid]; }
+		unsafeAtomicAdd(p.stats + co0 + tid, a);
+		unsafeAtomicAdd(p.stats + p.Cout + co0 + tid, q2);
+	}
+	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
+	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN / OEPC;
+	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
+	for (int e = tid; e < V2_BM * OCHUNKS; e += V2_THREADS) {
+		const int row = e / OCHUNKS, ch = e % OCHUNKS;
+		const int t = t0 + row, co = co0 + ch * OEPC;
+		if (t >= p.Tout || co >= p.Cout) continue;
+		const O* src = reinterpret_cast<const O*>(otile + row * OPITCH) + ch * OEPC;
+		O* dst = yb + (int64_t)t * p.Cout + co;
+		if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+		else
+			for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = src[i];
+	}
+}
+
+// Returns 1 if the v2 kernel took the launch, 0 if the shape is outside its envelope (caller falls back to conv.hip's kernel).
+int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
+	if (p.stride != 1 || (p.Cin & 63) != 0) return 0;
+	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
+	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
+	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
+	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 3 * V2_WSLOT;
+	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
+	if (epi > smem) smem = epi;
+	if (smem > 160 * 1024) return 0;
+	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
+	p.m_tiles_per_b = (p.Tout + V2_BM - 1) / V2_BM;
+	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
+	static bool set16 = false, set32 = false;
+	if (y_dtype == CONVASR_BF16) {
+		auto kern = conv1d_igemm_v2_kernel<bf16_t>;
+		if (!set16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set16 = true; }
+		hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(V2_THREADS), smem, s, p);
+	} else {
+		auto kern = conv1d_igemm_v2_kernel<float>;
+		if (!set32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set32 = true; }
+		hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(V2_THREADS), smem, s, p);
+	}
+	return 1;
+}

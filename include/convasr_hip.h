@@ -83,6 +83,10 @@ int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int 
                        const float* bias, double* stats, const float* scale, const float* shift,
                        int act, float act_lo, float act_hi, const float* xlen, void* stream);
 
+/* A/B and test hook: 0 routes bf16 launches through the general register-staged kernel instead of the LDS-DMA kernel.
+ * Returns the previous setting. */
+int convasr_debug_set_conv_v2(int enable);
+
 /* Bytes of fp32 workspace convasr_conv1d_wgrad needs (split-K partial slabs). */
 int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil);
 

@@ -116,6 +116,9 @@ CONV_CASES = [
 	(2, 128, 38, 203, 1, 1, 1),
 	(1, 256, 160, 530, 13, 1, 1),
 	(2, 32, 40, 19, 3, 1, 1),
+	(3, 192, 200, 700, 11, 1, 1),   # LDS-DMA kernel: 3 channel slabs, ragged T and Cout
+	(2, 320, 128, 257, 1, 1, 1),    # LDS-DMA kernel: K = 1, one new X slab per step
+	(1, 128, 256, 1003, 29, 1, 2),  # LDS-DMA kernel: dilated, 4 time tiles
 ]
 
 
@@ -146,6 +149,28 @@ def test_conv1d_forward(case, dtype):
 		close(y, ref, 1e-4, 2e-5, 'conv f32')
 	else:
 		close(y.float(), ref, 2e-2, 2e-2, 'conv bf16')
+
+
+@gpu
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[5] == 1 and c[1] % 64 == 0])
+def test_conv1d_lds_dma_kernel_is_bit_identical_to_register_staged_kernel(case):
+	from convasr_amd import ops, _lib
+	B, Cin, Cout, T, K, stride, dil = case
+	torch.manual_seed(sum(case) + 5)
+	d = dev()
+	x = ops.as_cl(torch.randn(B, Cin, T, device = d), torch.bfloat16)
+	w = torch.randn(Cout, Cin, K, device = d) / (Cin * K) ** 0.5
+	wp = ops.pack_weight(w, torch.bfloat16, _lib.PACK_FWD)
+	xlen = torch.linspace(0.4, 1, B, device = d)
+	outs = []
+	for use_v2 in (1, 0):
+		prev = _lib.load().convasr_debug_set_conv_v2(use_v2)
+		stats = torch.zeros(2 * Cout, dtype = torch.float64, device = d)
+		y = ops.conv1d(x, wp, Cout, K, 1, dil, dil * K // 2, stats = stats, act = (_lib.ACT_RELU, 0.0, 0.0), xlen = xlen)
+		_lib.load().convasr_debug_set_conv_v2(prev)
+		outs.append((y, stats))
+	assert torch.equal(outs[0][0], outs[1][0])
+	close(outs[0][1], outs[1][1], 1e-12, 1e-9, 'stats')
 
 
 @gpu
