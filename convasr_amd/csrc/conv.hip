@@ -268,6 +268,7 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 }
 
 int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s);  // conv_v2.hip
+int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s);                 // wgrad_v2.hip
 static int g_conv_use_v2 = 1;
 // test / A-B hook: 0 forces the register-staged kernel for every dtype
 extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable; return prev; }
@@ -315,19 +316,6 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 // One workgroup = one (128 co x 128 ci) tile x up to TG taps (the taps share the staged dY rows and the X rows + halo),
 // over one split of the (b, t) axis; partial tiles go to fp32 slabs [split][tap][co][ci], summed (and transposed to the
 // reference's (Cout, Cin, K) parameter layout) by wgrad_reduce_kernel -- deterministic, no float atomics.
-#define WG_TG 4
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-struct WgradParams {
-	const void* x;
-	const void* dy;
-	float* slab;
-	int B, Cin, Cout, Tin, Tout, K, stride, dil, pad;
-	int co_tiles, ci_tiles, tap_groups, units, splits;
-	int chunks_per_b, total_chunks, chunks_per_split;
-	int x_rows;
-};
-
 template <typename T> struct WgTile;
 template <> struct WgTile<bf16_t> { static constexpr int BKT = 64, PITCH = 128 * 2 + 64, CPR = 16; };  // rows of 256 B + 64 B pad: tr reads conflict-free
 template <> struct WgTile<float> { static constexpr int BKT = 32, PITCH = 128 * 4 + 16, CPR = 32; };
@@ -518,30 +506,11 @@ template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const
 	if (w == 0 && c < C) unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-static void wgrad_plan(WgradParams& p, int bkt) {
-	p.co_tiles = (p.Cout + 127) / 128;
-	p.ci_tiles = (p.Cin + 127) / 128;
-	p.tap_groups = (p.K + WG_TG - 1) / WG_TG;
-	p.units = p.co_tiles * p.ci_tiles * p.tap_groups;
-	p.chunks_per_b = (p.Tout + bkt - 1) / bkt;
-	p.total_chunks = p.B * p.chunks_per_b;
-	int splits = (768 + p.units - 1) / p.units;  // aim at ~3 workgroups per CU
-	if (splits > p.total_chunks / 2) splits = p.total_chunks / 2;
-	if (splits < 1) splits = 1;
-	p.chunks_per_split = (p.total_chunks + splits - 1) / splits;
-	p.splits = (p.total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
-	const int taps = p.K < WG_TG ? p.K : WG_TG;
-	p.x_rows = (bkt - 1) * p.stride + (taps - 1) * p.dil + 1;
-}
-
 extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil) {
 	WgradParams p;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil;
-	wgrad_plan(p, 32);  // the fp32 tile (shorter chunks) never needs fewer splits than bf16
-	int64_t s32 = p.splits;
-	wgrad_plan(p, 64);
-	int64_t s = s32 > p.splits ? s32 : p.splits;
-	return s * K * (int64_t)Cout * Cin * 4;
+	p.pad = 0;
+	return (int64_t)WGRAD_MAX_SPLITS * K * (int64_t)Cout * Cin * 4;
 }
 
 template <typename T, int XI, bool AX, bool AY> static void launch_wgrad(const WgradParams& p, size_t smem, hipStream_t s) {
@@ -555,7 +524,7 @@ template <typename T, int XI, bool AX, bool AY> static void launch_wgrad(const W
 }
 
 template <typename T> static int dispatch_wgrad(WgradParams& p, hipStream_t s) {
-	wgrad_plan(p, WgTile<T>::BKT);
+	wgrad_plan(p, WgTile<T>::BKT, sizeof(T) == 2 ? 2.7 : 11.0);
 	const int xi = (p.x_rows * WgTile<T>::CPR + NTHREADS - 1) / NTHREADS;
 	const size_t smem = 2 * (size_t)(WgTile<T>::BKT + p.x_rows) * WgTile<T>::PITCH;
 	if (smem > 160 * 1024 || xi > 12) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: tile too large (x_rows %d)", p.x_rows);
@@ -576,7 +545,8 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
 	hipStream_t s = (hipStream_t)stream;
 	int rc;
-	if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
+	if (dtype == CONVASR_BF16 && g_conv_use_v2 && convasr_wgrad_v2_try(p, s)) rc = 0;
+	else if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
 	else if (dtype == CONVASR_BF16) rc = dispatch_wgrad<bf16_t>(p, s);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: dtype %d", dtype);
 	if (rc) return rc;

@@ -54,3 +54,46 @@ template <> struct Mma<float> {
 	}
 };
 
+
+// ---------------- wgrad (conv.hip: general kernel; wgrad_v2.hip: LDS-DMA bf16 kernel)
+#define WG_TG 4
+
+struct WgradParams {
+	const void* x;
+	const void* dy;
+	float* slab;
+	int B, Cin, Cout, Tin, Tout, K, stride, dil, pad;
+	int co_tiles, ci_tiles, tap_groups, units, splits;
+	int chunks_per_b, total_chunks, chunks_per_split;
+	int x_rows;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define WGRAD_MAX_SPLITS 32
+
+// Work decomposition of one wgrad call: units = (co tile, ci tile, tap group); the (b, t) reduction axis is cut into `splits`
+// contiguous ranges of chunks.  splits is chosen by a small cost model: rounds of workgroups over the 256 CUs x chunks per
+// workgroup x measured time per chunk, plus the partial-slab traffic (one fp32 slab written and read back per split).
+static inline void wgrad_plan(WgradParams& p, int bkt, double chunk_us) {
+	p.co_tiles = (p.Cout + 127) / 128;
+	p.ci_tiles = (p.Cin + 127) / 128;
+	p.tap_groups = (p.K + WG_TG - 1) / WG_TG;
+	p.units = p.co_tiles * p.ci_tiles * p.tap_groups;
+	p.chunks_per_b = (p.Tout + bkt - 1) / bkt;
+	p.total_chunks = p.B * p.chunks_per_b;
+	const double slab_us = 2.0 * p.K * (double)p.Cout * p.Cin * 4.0 / 4e6;  // bytes / (4 TB/s), write + read
+	double best = 1e30;
+	int best_s = 1;
+	for (int s = 1; s <= WGRAD_MAX_SPLITS && s <= p.total_chunks; ++s) {
+		const int cps = (p.total_chunks + s - 1) / s, s_eff = (p.total_chunks + cps - 1) / cps;
+		const int rounds = (p.units * s_eff + 255) / 256;
+		const double cost = rounds * cps * chunk_us + s_eff * slab_us;
+		if (cost < best) { best = cost; best_s = s_eff; }
+	}
+	p.splits = best_s;
+	p.chunks_per_split = (p.total_chunks + best_s - 1) / best_s;
+	p.splits = (p.total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+	const int taps = p.K < WG_TG ? p.K : WG_TG;
+	p.x_rows = (bkt - 1) * p.stride + (taps - 1) * p.dil + 1;
+}

@@ -119,6 +119,8 @@ CONV_CASES = [
 	(3, 192, 200, 700, 11, 1, 1),   # LDS-DMA kernel: 3 channel slabs, ragged T and Cout
 	(2, 320, 128, 257, 1, 1, 1),    # LDS-DMA kernel: K = 1, one new X slab per step
 	(1, 128, 256, 1003, 29, 1, 2),  # LDS-DMA kernel: dilated, 4 time tiles
+	(5, 256, 128, 333, 11, 1, 1),   # LDS-DMA wgrad kernel: 3 tap groups (4, 4, 3), ragged chunks
+	(2, 128, 384, 100, 2, 1, 1),    # LDS-DMA wgrad kernel: K = 2 (one tap pair idle)
 ]
 
 
