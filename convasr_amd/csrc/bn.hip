@@ -183,7 +183,7 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 // ------------------------------------------------------------------------------------------------ backward pass 1: g and channel sums
 // Block = 256 threads = (256 / c8b) row-lanes x c8b channel-groups, where c8b = min(C/8, 256) ... each thread owns 8 channels
 // and strides over rows; per-channel partial sums are combined across the block in LDS and added to the global doubles.
-template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, int rows_per_block) {
+template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, int rows_per_block, float* __restrict__ ws) {
 	__shared__ float red[256][17];
 	const int c8 = p.C >> 3;
 	const int cgroups = c8 < 256 ? c8 : 256;   // channel groups handled concurrently by one block
@@ -237,29 +237,70 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_k
 			store8<T>(reinterpret_cast<T*>(p.out) + idx, g);
 		}
 		// block reduction over the row-lanes that share a channel group
-		auto reduce_to = [&](float (&a)[8], float (&bq)[8], double* dst) {
+		// per-block partials go to the workspace [set][block][2C] with plain coalesced stores; bn_bwd_finalize_kernel sums them
+		// in fp64 (deterministic, and no contended fp64 atomics: 4096 blocks x 2C atomics per call cost 4x the streaming time)
+		auto reduce_to = [&](float (&a)[8], float (&bq)[8], int set) {
 #pragma unroll
 			for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = a[k]; red[threadIdx.x][8 + k] = bq[k]; }
 			__syncthreads();
 			if (rl == 0 && cok) {
-				for (int k = 0; k < 16; ++k) {
-					float s = 0.f;
-					for (int j = 0; j < rlanes; ++j) s += red[j * cgroups + cg][k];
-					unsafeAtomicAdd(dst + (k < 8 ? c + k : p.C + c + k - 8), (double)s);
+				float* dst = ws + ((int64_t)set * gridDim.x + blockIdx.x) * 2 * p.C;
+				float o1[8], o2[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					float u = 0.f, w2 = 0.f;
+					for (int j = 0; j < rlanes; ++j) { u += red[j * cgroups + cg][k]; w2 += red[j * cgroups + cg][8 + k]; }
+					o1[k] = u; o2[k] = w2;
 				}
+				store8<float>(dst + c, o1);
+				store8<float>(dst + p.C + c, o2);
 			}
 			__syncthreads();
 		};
-		if (p.mean && p.sums) reduce_to(s1, s2, p.sums);
+		if (p.mean && p.sums) reduce_to(s1, s2, 0);
 		for (int r = 0; r < ra.n && r < 2; ++r)
-			if (ra.rsums[r]) reduce_to(rs1[r], rs2[r], ra.rsums[r]);
+			if (ra.rsums[r]) reduce_to(rs1[r], rs2[r], 1 + r);
 	}
+}
+
+// sums[set][ch] = sum over blocks of ws[set][block][ch], accumulated in fp64
+struct BnFinalizeSets { double* dst[3]; };
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C2) {
+	__shared__ double red[4][64];
+	const int set = blockIdx.y;
+	if (sets.dst[set] == nullptr) return;
+	const int ch = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+	double a = 0;
+	if (ch < C2)
+		for (int bq = w; bq < nblocks; bq += 4) a += (double)ws[((int64_t)set * nblocks + bq) * C2 + ch];
+	red[w][threadIdx.x & 63] = a;
+	__syncthreads();
+	if (w == 0 && ch < C2) sets.dst[set][ch] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+static void bn_bwd_grid(int B, int T, int C, int& rows_per_block, int& gx, int& gy) {
+	const int c8 = C >> 3;
+	const int cgroups = c8 < 256 ? c8 : 256;
+	const int rlanes = 256 / cgroups;
+	const int64_t rows = (int64_t)B * T;
+	rows_per_block = 16 * rlanes;
+	int64_t g = ceil_div64(rows, rows_per_block);
+	if (g > 2048) { g = 2048; rows_per_block = (int)ceil_div64(rows, g); }
+	gx = (int)ceil_div64(rows, rows_per_block);
+	gy = (c8 + cgroups - 1) / cgroups;
+	if (gy > 4) gy = 4;
+}
+
+extern "C" int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C) {
+	int rpb, gx, gy;
+	bn_bwd_grid(B, T, C, rpb, gx, gy);
+	return (int64_t)3 * gx * 2 * C * (int64_t)sizeof(float);
 }
 
 extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift, const float* mean,
                                          const float* invstd, int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                                          const float* const* rmean, const float* const* rinvstd, double* const* rsums, int act, float act_lo, float act_hi,
-                                         float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, int B, int T, int C, void* stream) {
+                                         float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, void* workspace, int B, int T, int C, void* stream) {
 	CONVASR_CHECK_ARG(dz && y && g && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG((mean == nullptr) == (invstd == nullptr) && (mean == nullptr || sums != nullptr), "bn_act_bwd_reduce: mean/invstd/sums go together");
 	BnActParams p = {};
@@ -267,20 +308,24 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 	p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p; p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
 	ResArgs ra;
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, rmean, rinvstd, rsums)) return rc;
-	int n_bn_res = 0;
-	for (int r = 0; r < n_res; ++r) if (ra.rsums[r]) { if (r >= 2) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: batch-normed residuals beyond the first two must be reduced by separate calls"); ++n_bn_res; }
-	const int c8 = C >> 3;
-	const int cgroups = c8 < 256 ? c8 : 256;
-	const int64_t rows = (int64_t)B * T;
-	const int rlanes = 256 / cgroups;
-	int rows_per_block = 16 * rlanes;
-	int64_t gx = ceil_div64(rows, rows_per_block);
-	if (gx > 4096) { gx = 4096; rows_per_block = (int)ceil_div64(rows, gx); }
-	const int gy = (c8 + cgroups - 1) / cgroups;
-	dim3 grid((unsigned)ceil_div64(rows, rows_per_block), (unsigned)(gy > 4 ? 4 : gy));
-	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p, ra, rows_per_block);
-	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, p, ra, rows_per_block);
+	for (int r = 2; r < n_res; ++r) if (ra.rsums[r]) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: batch-normed residuals beyond the first two must be reduced by separate calls");
+	int rows_per_block, gx, gy;
+	bn_bwd_grid(B, T, C, rows_per_block, gx, gy);
+	bool any = sums != nullptr;
+	for (int r = 0; r < n_res; ++r) any = any || ra.rsums[r] != nullptr;
+	CONVASR_CHECK_ARG(!any || workspace, "bn_act_bwd_reduce: workspace required when sums are requested");
+	dim3 grid(gx, gy);
+	hipStream_t st = (hipStream_t)stream;
+	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, st, p, ra, rows_per_block, (float*)workspace);
+	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, p, ra, rows_per_block, (float*)workspace);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: dtype %d", dtype);
+	if (any) {
+		BnFinalizeSets sets;
+		sets.dst[0] = (mean && sums) ? sums : nullptr;
+		sets.dst[1] = n_res > 0 ? ra.rsums[0] : nullptr;
+		sets.dst[2] = n_res > 1 ? ra.rsums[1] : nullptr;
+		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((2 * C + 63) / 64, 3), dim3(256), 0, st, (const float*)workspace, sets, gx, 2 * C);
+	}
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_reduce");
 	return 0;
 }

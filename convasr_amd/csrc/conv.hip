@@ -196,45 +196,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 extern "C" int convasr_conv_cout_pad(int cout) { return (cout + BN - 1) / BN * BN; }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// One block = a 32(co) x 32(ci) x K tile of the fp32 parameter: read as 32 contiguous runs of 32*K floats, written as
-// fwd[k][co][ci] (32 contiguous ci per row) and/or dgrad[K-1-k][ci][co] (32 contiguous co per row).
+// fwd[k][co][ci] = w[co][ci][k]: a block takes 256 consecutive (co, ci) pairs = 256 * K contiguous floats, stages them in LDS
+// and writes K contiguous runs of 256 elements (the (co, ci) order is the same on both sides).
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgr, int Cout, int Cin, int K,
-                                                          int co_pad, int ci_pad) {
-	extern __shared__ float tile[];  // [32][32 * K + 1]
-	const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32, pitch = 32 * K + 1;
-	const int ncols = min(32, Cin - ci0) * K;
-	for (int rr = threadIdx.x >> 6; rr < 32; rr += 4) {
-		const int co = co0 + rr;
-		for (int j = threadIdx.x & 63; j < 32 * K; j += 64) tile[rr * pitch + j] = (co < Cout && j < ncols) ? w[((int64_t)co * Cin + ci0) * K + j] : 0.f;
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ fwd, int64_t pairs, int K, int64_t tap_stride) {
+	extern __shared__ float tile[];  // [256 * K]
+	const int64_t lin0 = (int64_t)blockIdx.x * 256;
+	const int n = (int)min((int64_t)256, pairs - lin0);
+	for (int j = threadIdx.x; j < n * K; j += 256) tile[j] = w[lin0 * K + j];
+	__syncthreads();
+	if ((int)threadIdx.x < n)
+		for (int k = 0; k < K; ++k) Elem<T>::store(fwd + k * tap_stride + lin0 + threadIdx.x, tile[threadIdx.x * K + k]);
+}
+
+// dgrad[K-1-k][ci][co] = fwd[k][co][ci]: per-tap 64 x 64 tiled transpose in the compute dtype
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ fwd, T* __restrict__ dgr, int Cout, int Cin, int K, int co_pad, int ci_pad) {
+	__shared__ T tile[64][66];
+	const int k = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const T* src = fwd + (int64_t)k * co_pad * Cin;
+	T* dst = dgr + (int64_t)(K - 1 - k) * ci_pad * Cout;
+#pragma unroll 4
+	for (int i = 0; i < 16; ++i) {
+		const int co = co0 + ty + 4 * i, ci = ci0 + tx;
+		if (co < Cout && ci < Cin) tile[ty + 4 * i][tx] = src[(int64_t)co * Cin + ci];
 	}
 	__syncthreads();
-	const int a = threadIdx.x & 31, bq = threadIdx.x >> 5;  // a: fast axis of the write, bq: 8 slow lanes
-	for (int k = 0; k < K; ++k) {
-		if (fwd) {
-			for (int rr = bq; rr < 32; rr += 8) {
-				const int co = co0 + rr, ci = ci0 + a;
-				if (co < co_pad && ci < Cin) Elem<T>::store(fwd + ((int64_t)k * co_pad + co) * Cin + ci, tile[rr * pitch + a * K + k]);
-			}
-		}
-		if (dgr) {
-			for (int cc = bq; cc < 32; cc += 8) {
-				const int ci = ci0 + cc, co = co0 + a;
-				if (ci < ci_pad && co < Cout) Elem<T>::store(dgr + ((int64_t)(K - 1 - k) * ci_pad + ci) * Cout + co, tile[a * pitch + cc * K + k]);
-			}
-		}
+#pragma unroll 4
+	for (int i = 0; i < 16; ++i) {
+		const int ci = ci0 + ty + 4 * i, co = co0 + tx;
+		if (co < Cout && ci < Cin) dst[(int64_t)ci * Cout + co] = tile[tx][ty + 4 * i];
 	}
 }
 
 template <typename T> static void launch_pack(const float* w, void* fwd, void* dgr, int Cout, int Cin, int K, hipStream_t s) {
 	const int co_pad = convasr_conv_cout_pad(Cout), ci_pad = convasr_conv_cout_pad(Cin);
-	// cover the padded rows too so they are zero-filled: grid spans the padded extents of whichever outputs are requested
-	const int gx = ((dgr ? ci_pad : Cin) + 31) / 32, gy = ((fwd ? co_pad : Cout) + 31) / 32;
-	hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(gx, gy), dim3(256), (size_t)32 * (32 * K + 1) * sizeof(float), s, w, (T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
+	const int64_t pairs = (int64_t)Cout * Cin;
+	hipLaunchKernelGGL((pack_fwd_kernel<T>), dim3((unsigned)ceil_div64(pairs, 256)), dim3(256), (size_t)256 * K * sizeof(float), s, w, (T*)fwd, pairs, K, (int64_t)co_pad * Cin);
+	if (dgr) hipLaunchKernelGGL((pack_dgrad_kernel<T>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
 }
 
 extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream) {
-	CONVASR_CHECK_ARG(w && (packed_fwd || packed_dgrad) && Cout > 0 && Cin > 0 && K > 0 && K <= 64, "pack_conv_weight: bad arguments");
+	CONVASR_CHECK_ARG(w && packed_fwd && Cout > 0 && Cin > 0 && K > 0 && K <= 64, "pack_conv_weight: bad arguments (packed_fwd is required; packed_dgrad is derived from it)");
 	if (dtype == CONVASR_F32) launch_pack<float>(w, packed_fwd, packed_dgrad, Cout, Cin, K, (hipStream_t)stream);
 	else if (dtype == CONVASR_BF16) launch_pack<bf16_t>(w, packed_fwd, packed_dgrad, Cout, Cin, K, (hipStream_t)stream);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);

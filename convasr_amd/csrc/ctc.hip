@@ -17,15 +17,26 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 	return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
-template <int NS>
-__global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
+// LP_LDS: the utterance's whole (T, C) log-prob slab is first copied into LDS (114 KB at T = 753, C = 38) so that the T-step
+// recurrences read their per-frame class scores at LDS latency instead of L2 latency (the sweeps are latency-bound).
+template <int NS, bool LP_LDS>
+__global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
                                                              const int64_t* __restrict__ ylen, float* __restrict__ nll, float* __restrict__ alpha,
                                                              float* __restrict__ beta, int T, int C, int S_max, int blank) {
-	__shared__ float fin[64 * NS];
+	extern __shared__ __attribute__((aligned(16))) float ctc_smem[];
+	float* const fin = ctc_smem;            // [64 * NS]
+	float* const lpl = ctc_smem + 64 * NS;  // [T * C] when LP_LDS
 	const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	constexpr int LP = 64 * NS;
 	const int Tb = (int)olen[b], S = (int)ylen[b], L = 2 * S + 1;
-	const float* lpb = lp + (int64_t)b * T * C;
+	const float* lpg = lp + (int64_t)b * T * C;
+	if (LP_LDS) {
+		const int n = (Tb > 0 && Tb <= T ? Tb : 0) * C;
+		for (int i = threadIdx.x; i < n; i += blockDim.x) lpl[i] = lpg[i];
+		__syncthreads();
+	}
+	if (wave >= 2) return;
+	const float* lpb = LP_LDS ? lpl : lpg;
 	const int64_t* tg = targets + (int64_t)b * S_max;
 	float* const lat = (wave == 0 ? alpha : beta) + (int64_t)b * T * LP;
 
@@ -195,8 +206,15 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
 	const int t_per_block = 32;
 	dim3 ggrid((T + t_per_block - 1) / t_per_block, B);
 	const size_t gsmem = 4 * (size_t)C * sizeof(float);
+	const size_t lds_lp = (size_t)T * C * sizeof(float);
+	const bool in_lds = lds_lp + 64 * 16 * sizeof(float) <= 150 * 1024;
 #define CTC_CASE(NS) case NS: \
-		hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS>), dim3(B), dim3(128), 0, s, log_probs, targets, olen, ylen, nll, alpha, beta, T, C, S_max, blank); \
+		if (in_lds) { \
+			auto kern = ctc_alpha_beta_kernel<NS, true>; \
+			static bool set = false; \
+			if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+			hipLaunchKernelGGL(kern, dim3(B), dim3(256), 64 * NS * sizeof(float) + lds_lp, s, log_probs, targets, olen, ylen, nll, alpha, beta, T, C, S_max, blank); \
+		} else hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS, false>), dim3(B), dim3(128), 64 * NS * sizeof(float), s, log_probs, targets, olen, ylen, nll, alpha, beta, T, C, S_max, blank); \
 		if (grad) hipLaunchKernelGGL((ctc_grad_kernel<NS>), ggrid, dim3(256), gsmem, s, log_probs, targets, olen, ylen, nll, alpha, beta, grad, T, C, S_max, blank, t_per_block); \
 		break;
 	switch (ns) {

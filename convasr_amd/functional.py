@@ -18,20 +18,24 @@ def bump_param_epoch():
 
 
 def packed_weight(w, dtype, mode):
-	"""Packed [K][rows_pad][cols] copy of a conv parameter, rebuilt only when the parameter changed.  In training both the
-	forward and the dgrad layout are produced by one launch the first time either is asked for."""
+	"""Packed [K][rows_pad][cols] copy of a conv parameter, refreshed (in place) only when the parameter changed.  In training
+	the forward and the dgrad layout are produced together the first time either is asked for after an update."""
 	ver = (w._version, w.data_ptr(), _param_epoch[0])
-	hit = _pack_cache.get((id(w), dtype, mode))
-	if hit is not None and hit[0] == ver:
-		return hit[1]
-	if torch.is_grad_enabled() and w.requires_grad:
-		fwd, dgr = ops.pack_weight(w, dtype, None)
-		_pack_cache[(id(w), dtype, _lib.PACK_FWD)] = (ver, fwd, w)  # keep `w` alive so id() stays unique
-		_pack_cache[(id(w), dtype, _lib.PACK_DGRAD)] = (ver, dgr, w)
-		return fwd if mode == _lib.PACK_FWD else dgr
-	wp = ops.pack_weight(w, dtype, mode)
-	_pack_cache[(id(w), dtype, mode)] = (ver, wp, w)
-	return wp
+	ent = _pack_cache.get((id(w), dtype))
+	both = torch.is_grad_enabled() and w.requires_grad
+	if ent is None:
+		ent = _pack_cache[(id(w), dtype)] = dict(w = w, fwd = None, dgr = None, fwd_ver = None, dgr_ver = None)  # holds `w`: id() stays unique
+	if mode == _lib.PACK_FWD and ent['fwd_ver'] == ver:
+		return ent['fwd']
+	if mode == _lib.PACK_DGRAD and ent['dgr_ver'] == ver:
+		return ent['dgr']
+	if both or mode == _lib.PACK_DGRAD:
+		ent['fwd'], ent['dgr'] = ops.pack_weight(w, dtype, None, out = (ent['fwd'], ent['dgr']))
+		ent['fwd_ver'] = ent['dgr_ver'] = ver
+	else:
+		ent['fwd'] = ops.pack_weight(w, dtype, _lib.PACK_FWD, out = (ent['fwd'], None))
+		ent['fwd_ver'] = ver
+	return ent['fwd'] if mode == _lib.PACK_FWD else ent['dgr']
 
 
 def invalidate_pack_cache():
@@ -158,7 +162,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		dz = ops.as_cl(dz, dt)
 
 		bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
-		sums = torch.zeros(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)
+		sums = torch.empty(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)  # written by the reduce kernels
 		rsum_of = {r: sums[2 * Cout * (1 + i):2 * Cout * (2 + i)] for i, r in enumerate(bn_idx)}
 		common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
 		# the kernel reduces the main BN plus the first two batch-normed residuals per pass; dense blocks with more take extra passes

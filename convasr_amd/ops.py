@@ -103,17 +103,21 @@ def cout_pad(c):
 	return _lib.load().convasr_conv_cout_pad(c)
 
 
-def pack_weight(w, dtype, mode = None):
+def pack_weight(w, dtype, mode = None, out = None):
 	"""(Cout, Cin, K) fp32 parameter -> packed [K][rows_pad][cols] tensor(s) for the MFMA kernels.
-	mode PACK_FWD / PACK_DGRAD returns that one layout; mode None returns (fwd, dgrad) from a single launch."""
+	mode PACK_FWD returns the forward layout, PACK_DGRAD the dgrad layout, None both (fwd, dgrad).  `out` = (fwd, dgrad)
+	buffers from an earlier call are refreshed in place (stable addresses, no re-allocation per optimizer step)."""
 	require_cuda(w)
 	w = w.detach()
 	if w.dtype != torch.float32 or not w.is_contiguous():
 		w = w.float().contiguous()
 	Cout, Cin, K = w.shape
-	fwd = torch.empty(K, cout_pad(Cout), Cin, dtype = dtype, device = w.device) if mode in (None, _lib.PACK_FWD) else None
-	dgr = torch.empty(K, cout_pad(Cin), Cout, dtype = dtype, device = w.device) if mode in (None, _lib.PACK_DGRAD) else None
-	call('convasr_pack_conv_weight', ptr(w), ptr(fwd), ptr(dgr), dtype_code(dtype), Cout, Cin, K, stream_ptr())
+	fwd, dgr = out if out is not None else (None, None)
+	if fwd is None:
+		fwd = torch.zeros(K, cout_pad(Cout), Cin, dtype = dtype, device = w.device)
+	if dgr is None and mode in (None, _lib.PACK_DGRAD):
+		dgr = torch.zeros(K, cout_pad(Cin), Cout, dtype = dtype, device = w.device)
+	call('convasr_pack_conv_weight', ptr(w), ptr(fwd), ptr(dgr) if mode in (None, _lib.PACK_DGRAD) else None, dtype_code(dtype), Cout, Cin, K, stream_ptr())
 	return (fwd, dgr) if mode is None else (fwd if mode == _lib.PACK_FWD else dgr)
 
 
@@ -193,7 +197,8 @@ def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res =
 	B, C, T = y.shape
 	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype
 	g = empty_cl(B, C, T, y.dtype, y.device)
-	call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), B, T, C, stream_ptr())
+	ws = workspace(_lib.load().convasr_bn_bwd_workspace_bytes(B, T, C), y.device, 'bn_bwd')
+	call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), B, T, C, stream_ptr())
 	return g
 
 

@@ -67,10 +67,11 @@ int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc,
 /* cout_pad(cout): rows of the packed weight (multiple of the kernel's N tile). */
 int convasr_conv_cout_pad(int cout);
 
-/* (Cout, Cin, K) fp32 parameter -> packed compute-dtype copies, one launch for both (either may be NULL):
- *   packed_fwd  [K][cout_pad(Cout)][Cin]  : packed_fwd[k][co][ci]   = w[co][ci][k]        (forward and wgrad-free paths)
- *   packed_dgrad[K][cout_pad(Cin)][Cout]  : packed_dgrad[k][ci][co] = w[co][ci][K-1-k]    (input gradient = conv with flipped taps)
- * padded rows are zero-filled. */
+/* (Cout, Cin, K) fp32 parameter -> packed compute-dtype copies:
+ *   packed_fwd  [K][cout_pad(Cout)][Cin]  : packed_fwd[k][co][ci]   = w[co][ci][k]        (required)
+ *   packed_dgrad[K][cout_pad(Cin)][Cout]  : packed_dgrad[k][ci][co] = w[co][ci][K-1-k]    (optional; input gradient = conv
+ *                                           with flipped taps; derived from packed_fwd by a tiled transpose)
+ * Only rows < Cout (resp. < Cin) are written: the caller zero-fills the buffers once so the padded rows read as zeros. */
 int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
 
 /* y[b,t,co] = epilogue( sum_{k,ci} x[b, t*stride + k*dil - pad, ci] * wp[k][co][ci] ), zero outside [0, Tin).
@@ -119,14 +120,16 @@ int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, co
 
 /* Backward of the above, pass 1.  g = dz * mask * dropout * act'(pre), pre recomputed from y (and residuals).
  * Writes g (same dtype) and accumulates per channel: sums[0..C) += sum g, sums[C..2C) += sum g * xhat with
- * xhat = (y - mean) * invstd, and for each residual r with BN: rsums_r likewise w.r.t. (res_r, rmean_r, rinvstd_r).
- * sums are doubles the caller zeroed. */
+ * xhat = (y - mean) * invstd, and for each of the first two residuals r with BN: rsums_r likewise w.r.t. (res_r, rmean_r,
+ * rinvstd_r).  sums / rsums_r (2*C doubles each) are WRITTEN (block partials go through `workspace`, then an fp64 sum:
+ * deterministic, no contended atomics).  workspace: convasr_bn_bwd_workspace_bytes(B, T, C) bytes. */
+int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C);
 int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift,
                               const float* mean, const float* invstd,
                               int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                               const float* const* rmean, const float* const* rinvstd, double* const* rsums,
                               int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                              const float* xlen, double* sums, int B, int T, int C, void* stream);
+                              const float* xlen, double* sums, void* workspace, int B, int T, int C, void* stream);
 
 /* Backward pass 2: dy = gamma * invstd * (g - sum_g / n - xhat * sum_gxhat / n)  (batch-norm training backward);
  * dgamma = sum_gxhat, dbeta = sum_g (written, or added when accumulate).  In place allowed (dy == g). */
