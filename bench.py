@@ -62,6 +62,7 @@ def main():
 	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f32'])
 	ap.add_argument('--no-cpu-baseline', action = 'store_true')
 	ap.add_argument('--no-kernel-timer', action = 'store_true')
+	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (+1.5-2 % step rate; off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
 	args = ap.parse_args()
 
 	world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -89,6 +90,8 @@ def main():
 	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
 	engine = ca.parallel.DataParallelEngine(model, device = device) if world > 1 else model
 	x, xlen, y, ylen = synthetic_batch(device, seed = 1 + rank)
+	if args.side_stream:
+		ca.functional.enable_side_stream_wgrad(device)
 
 	def step(i):
 		return ca.train.train_step(engine, opt, x, xlen, y, ylen, world_size = world, iteration = i)

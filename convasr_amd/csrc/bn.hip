@@ -265,17 +265,21 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_k
 
 // sums[set][ch] = sum over blocks of ws[set][block][ch], accumulated in fp64
 struct BnFinalizeSets { double* dst[3]; };
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C2) {
-	__shared__ double red[4][64];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C2) {
+	__shared__ double red[16][64];
 	const int set = blockIdx.y;
 	if (sets.dst[set] == nullptr) return;
 	const int ch = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
 	double a = 0;
 	if (ch < C2)
-		for (int bq = w; bq < nblocks; bq += 4) a += (double)ws[((int64_t)set * nblocks + bq) * C2 + ch];
+		for (int bq = w; bq < nblocks; bq += 16) a += (double)ws[((int64_t)set * nblocks + bq) * C2 + ch];
 	red[w][threadIdx.x & 63] = a;
 	__syncthreads();
-	if (w == 0 && ch < C2) sets.dst[set][ch] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+	if (w == 0 && ch < C2) {
+		double t = 0;
+		for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+		sets.dst[set][ch] = t;
+	}
 }
 
 static void bn_bwd_grid(int B, int T, int C, int& rows_per_block, int& gx, int& gy) {
@@ -285,7 +289,7 @@ static void bn_bwd_grid(int B, int T, int C, int& rows_per_block, int& gx, int& 
 	const int64_t rows = (int64_t)B * T;
 	rows_per_block = 16 * rlanes;
 	int64_t g = ceil_div64(rows, rows_per_block);
-	if (g > 2048) { g = 2048; rows_per_block = (int)ceil_div64(rows, g); }
+	if (g > 768) { g = 768; rows_per_block = (int)ceil_div64(rows, g); }
 	gx = (int)ceil_div64(rows, rows_per_block);
 	gy = (c8 + cgroups - 1) / cgroups;
 	if (gy > 4) gy = 4;
@@ -324,7 +328,7 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 		sets.dst[0] = (mean && sums) ? sums : nullptr;
 		sets.dst[1] = n_res > 0 ? ra.rsums[0] : nullptr;
 		sets.dst[2] = n_res > 1 ? ra.rsums[1] : nullptr;
-		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((2 * C + 63) / 64, 3), dim3(256), 0, st, (const float*)workspace, sets, gx, 2 * C);
+		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((2 * C + 63) / 64, 3), dim3(1024), 0, st, (const float*)workspace, sets, gx, 2 * C);
 	}
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_reduce");
 	return 0;

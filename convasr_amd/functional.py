@@ -22,7 +22,7 @@ def packed_weight(w, dtype, mode):
 	the forward and the dgrad layout are produced together the first time either is asked for after an update."""
 	ver = (w._version, w.data_ptr(), _param_epoch[0])
 	ent = _pack_cache.get((id(w), dtype))
-	both = torch.is_grad_enabled() and w.requires_grad
+	both = w.requires_grad  # (grad mode is off inside autograd.Function.forward, so it cannot be consulted here)
 	if ent is None:
 		ent = _pack_cache[(id(w), dtype)] = dict(w = w, fwd = None, dgr = None, fwd_ver = None, dgr_ver = None)  # holds `w`: id() stays unique
 	if mode == _lib.PACK_FWD and ent['fwd_ver'] == ver:
@@ -83,6 +83,35 @@ def _deliver(params, compute):
 	outs = [torch.empty_like(p, dtype = torch.float32, memory_format = torch.contiguous_format) if ok else None for p, ok in zip(params, live)]
 	compute(outs, False)
 	return outs
+
+
+_side_streams = {}  # device -> torch.cuda.Stream running the weight-gradient kernels (None entry = disabled)
+
+
+def enable_side_stream_wgrad(device, enabled = True):
+	"""Run every wgrad (+ its split-K reduce) on a second HIP stream so its workgroups fill the CUs the concurrent dgrad /
+	BN-backward kernels of the main stream leave idle (partial last rounds, waits).  Only meaningful with gradient arenas
+	(FlatParameters): the consumer of the gradients must call join_side_streams() first (train_step does)."""
+	device = torch.device(device)
+	_side_streams[device] = torch.cuda.Stream(device = device) if enabled else None
+
+
+def join_side_streams():
+	for dev, side in _side_streams.items():
+		if side is not None:
+			torch.cuda.current_stream(dev).wait_stream(side)
+
+
+def _run_wgrad(dev, tensors, fn):
+	side = _side_streams.get(dev)
+	if side is None:
+		return fn()
+	side.wait_stream(torch.cuda.current_stream(dev))
+	with torch.cuda.stream(side):
+		out = fn()
+	for t in tensors:
+		t.record_stream(side)
+	return out
 
 
 class ConvSpec:
@@ -179,12 +208,18 @@ class ConvBnActFunction(torch.autograd.Function):
 		dgamma, dbeta = _deliver([gamma, beta], lambda outs, acc: ops.bn_bwd_apply(g, y, None, bnp[0], bnp[1], sums[:2 * Cout], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
 		dy = ops.bn_bwd_apply(g, y, gamma, bnp[0], bnp[1], sums[:2 * Cout], inplace = n_res == 0)
 
+		arena_mode = getattr(weight, '_convasr_grad', None) is not None
+		wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
+		if arena_mode:
+			# enqueue before dgrad: both only read dy, and the side stream can start while dgrad is still being issued
+			dw, = _run_wgrad(dev, (x, dy), wg)
 		dx = None
 		if ctx.x_needs_grad:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
 			dx = ops.conv1d(dy, packed_weight(weight, dt, _lib.PACK_DGRAD), x.shape[1], spec.K, 1, spec.dilation, spec.dilation * (spec.K - 1) - spec.padding)
-		dw, = _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
+		if not arena_mode:
+			dw, = wg()
 
 		res_grads = []
 		for r in range(n_res):

@@ -125,6 +125,7 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 			loss.backward()
 	else:
 		loss.backward()
+	Fn.join_side_streams()  # weight gradients computed on the side stream are final from here on
 	if last_of_group:
 		if engine is not None:
 			engine.finish_gradient_sync()
