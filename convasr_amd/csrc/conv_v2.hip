@@ -45,7 +45,7 @@ __device__ __forceinline__ void dma16(const v4i32& srd, unsigned lds_addr, int v
 	             : "memory");
 }
 
-template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2_kernel(ConvParams p) {
+template <typename O, bool PIPE> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2_kernel(ConvParams p) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,50 +95,94 @@ template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_ig
 			for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
 	const int Q = n_cib * p.K;
-	issue_x(0);
-	issue_w(0, 0, 0);
-	if (Q > 1) issue_w(p.K > 1 ? 0 : 1, p.K > 1 ? 1 : 0, 1);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__builtin_amdgcn_s_barrier();
-
 	const int wrow0 = wn * 64 + r, wrow1 = wrow0 + 32;
 	const int woff0 = (wrow0 >> 1) << 8, wpar0 = (wrow0 & 1) << 3, wsw0 = (wrow0 >> 1) & 7;
 	const int woff1 = (wrow1 >> 1) << 8, wpar1 = (wrow1 & 1) << 3, wsw1 = (wrow1 >> 1) & 7;
 
-	int cib = 0, tap = 0;       // coordinates of step q
-	int cib2 = 0, tap2 = 0;     // coordinates of step q + 2
-	for (int i = 0; i < 2; ++i) { if (++tap2 == p.K) { tap2 = 0; ++cib2; } }
-	int slot = 0;
-	for (int q = 0; q < Q; ++q) {
-		if (tap == 0 && cib + 1 < n_cib) issue_x(cib + 1);
-		const bool more = q + 2 < Q;
-		if (more) issue_w(cib2, tap2, slot >= 1 ? slot - 1 : 2);  // (slot + 2) % 3
+	struct Frag { uint4 a0, a1, b0, b1; };
+	// the four 16-byte fragments of k-substep kk of the step at (slab buffer xs, weight slot ws, tap)
+	auto load_frag = [&](const char* xs, const char* ws, int tap_, int kk, Frag& f) {
+		const int xrow0 = wm * 64 + r + tap_ * p.dil, xrow1 = xrow0 + 32;
+		const int chunk = kk * 2 + h;
+		f.a0 = *reinterpret_cast<const uint4*>(xs + ((xrow0 >> 1) << 8) + ((((xrow0 & 1) << 3) | (chunk ^ ((xrow0 >> 1) & 7))) << 4));
+		f.a1 = *reinterpret_cast<const uint4*>(xs + ((xrow1 >> 1) << 8) + ((((xrow1 & 1) << 3) | (chunk ^ ((xrow1 >> 1) & 7))) << 4));
+		f.b0 = *reinterpret_cast<const uint4*>(ws + woff0 + ((wpar0 | (chunk ^ wsw0)) << 4));
+		f.b1 = *reinterpret_cast<const uint4*>(ws + woff1 + ((wpar1 | (chunk ^ wsw1)) << 4));
+	};
+	auto mma_frag = [&](const Frag& f) {
+		Mma<bf16_t>::run(f.a0, f.b0, acc[0][0]);
+		Mma<bf16_t>::run(f.a0, f.b1, acc[0][1]);
+		Mma<bf16_t>::run(f.a1, f.b0, acc[1][0]);
+		Mma<bf16_t>::run(f.a1, f.b1, acc[1][1]);
+	};
 
-		const char* xs = xbuf + (cib & 1) * xbytes;
-		const char* ws = wbuf + slot * V2_WSLOT;
-		const int xrow0 = wm * 64 + r + tap * p.dil, xrow1 = xrow0 + 32;
-		const int xoff0 = (xrow0 >> 1) << 8, xpar0 = (xrow0 & 1) << 3, xsw0 = (xrow0 >> 1) & 7;
-		const int xoff1 = (xrow1 >> 1) << 8, xpar1 = (xrow1 & 1) << 3, xsw1 = (xrow1 >> 1) & 7;
-#pragma unroll
-		for (int kk = 0; kk < 4; ++kk) {
-			const int chunk = kk * 2 + h;
-			const uint4 a0 = *reinterpret_cast<const uint4*>(xs + xoff0 + ((xpar0 | (chunk ^ xsw0)) << 4));
-			const uint4 a1 = *reinterpret_cast<const uint4*>(xs + xoff1 + ((xpar1 | (chunk ^ xsw1)) << 4));
-			const uint4 b0 = *reinterpret_cast<const uint4*>(ws + woff0 + ((wpar0 | (chunk ^ wsw0)) << 4));
-			const uint4 b1 = *reinterpret_cast<const uint4*>(ws + woff1 + ((wpar1 | (chunk ^ wsw1)) << 4));
-			Mma<bf16_t>::run(a0, b0, acc[0][0]);
-			Mma<bf16_t>::run(a0, b1, acc[0][1]);
-			Mma<bf16_t>::run(a1, b0, acc[1][0]);
-			Mma<bf16_t>::run(a1, b1, acc[1][1]);
-		}
-
-		// everything but the two weight pieces issued in this step has landed (X of the next slab is older than them)
-		if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if constexpr (PIPE) {
+		// K >= 2.  Weight ring of RING = 4 slots, tiles issued THREE steps ahead: the tile of step q + 1 is already published
+		// (landed + barrier) when step q runs, so the first fragments of step q + 1 are read BEFORE the barrier that ends step q
+		// and each wave has MFMA work queued across the barrier instead of an LDS round trip with an empty matrix pipe.
+		issue_x(0);
+		int ci_ = 0, ti_ = 0;  // coordinates of the next weight tile to issue
+		for (int i = 0; i < 3 && i < Q; ++i) { issue_w(ci_, ti_, i); if (++ti_ == p.K) { ti_ = 0; ++ci_; } }
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
-		if (++tap == p.K) { tap = 0; ++cib; }
-		if (++tap2 == p.K) { tap2 = 0; ++cib2; }
-		slot = slot == 2 ? 0 : slot + 1;
+
+		int cib = 0, tap = 0, slot = 0;
+		Frag cur, nxt;
+		load_frag(xbuf, wbuf, 0, 0, cur);
+		for (int q = 0; q < Q; ++q) {
+			if (tap == 0 && cib + 1 < n_cib) issue_x(cib + 1);
+			const bool more = q + 3 < Q;
+			if (more) { issue_w(ci_, ti_, (slot + 3) & 3); if (++ti_ == p.K) { ti_ = 0; ++ci_; } }
+
+			const char* xs = xbuf + (cib & 1) * xbytes;
+			const char* ws = wbuf + slot * V2_WSLOT;
+			int cib1 = cib, tap1 = tap + 1;
+			if (tap1 == p.K) { tap1 = 0; ++cib1; }
+			const int slot1 = (slot + 1) & 3;
+#pragma unroll
+			for (int kk = 0; kk < 4; ++kk) {
+				if (kk < 3) load_frag(xs, ws, tap, kk + 1, nxt);
+				else if (q + 1 < Q) load_frag(xbuf + (cib1 & 1) * xbytes, wbuf + slot1 * V2_WSLOT, tap1, 0, nxt);
+				mma_frag(cur);
+				cur = nxt;
+			}
+			if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			cib = cib1; tap = tap1; slot = slot1;
+		}
+	} else {
+		issue_x(0);
+		issue_w(0, 0, 0);
+		if (Q > 1) issue_w(p.K > 1 ? 0 : 1, p.K > 1 ? 1 : 0, 1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+
+		int cib = 0, tap = 0;       // coordinates of step q
+		int cib2 = 0, tap2 = 0;     // coordinates of step q + 2
+		for (int i = 0; i < 2; ++i) { if (++tap2 == p.K) { tap2 = 0; ++cib2; } }
+		int slot = 0;
+		for (int q = 0; q < Q; ++q) {
+			if (tap == 0 && cib + 1 < n_cib) issue_x(cib + 1);
+			const bool more = q + 2 < Q;
+			if (more) issue_w(cib2, tap2, slot >= 1 ? slot - 1 : 2);  // (slot + 2) % 3
+
+			const char* xs = xbuf + (cib & 1) * xbytes;
+			const char* ws = wbuf + slot * V2_WSLOT;
+#pragma unroll
+			for (int kk = 0; kk < 4; ++kk) {
+				Frag f;
+				load_frag(xs, ws, tap, kk, f);
+				mma_frag(f);
+			}
+			// everything but the two weight pieces issued in this step has landed (X of the next slab is older than them)
+			if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			if (++tap == p.K) { tap = 0; ++cib; }
+			if (++tap2 == p.K) { tap2 = 0; ++cib2; }
+			slot = slot == 2 ? 0 : slot + 1;
+		}
 	}
 
 	// ---------------- epilogue (as conv.hip): bias, BN statistics, scale/shift, activation, mask, coalesced store through LDS
@@ -201,22 +245,21 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
-	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 3 * V2_WSLOT;
+	const bool pipe = p.K >= 2;
+	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (pipe ? 4 : 3) * V2_WSLOT;
 	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
 	if (epi > smem) smem = epi;
 	if (smem > 160 * 1024) return 0;
 	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
 	p.m_tiles_per_b = (p.Tout + V2_BM - 1) / V2_BM;
 	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
-	static bool set16 = false, set32 = false;
-	if (y_dtype == CONVASR_BF16) {
-		auto kern = conv1d_igemm_v2_kernel<bf16_t>;
-		if (!set16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set16 = true; }
-		hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(V2_THREADS), smem, s, p);
-	} else {
-		auto kern = conv1d_igemm_v2_kernel<float>;
-		if (!set32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set32 = true; }
-		hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(V2_THREADS), smem, s, p);
-	}
+	const void* kern;
+	if (y_dtype == CONVASR_BF16) kern = pipe ? (const void*)conv1d_igemm_v2_kernel<bf16_t, true> : (const void*)conv1d_igemm_v2_kernel<bf16_t, false>;
+	else kern = pipe ? (const void*)conv1d_igemm_v2_kernel<float, true> : (const void*)conv1d_igemm_v2_kernel<float, false>;
+	static bool attr_set[4] = {false, false, false, false};
+	const int ki = (y_dtype == CONVASR_BF16 ? 0 : 2) + (pipe ? 1 : 0);
+	if (!attr_set[ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[ki] = true; }
+	void* args[] = {&p};
+	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;
 	return 1;
 }
