@@ -274,8 +274,9 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s);  // conv_v2.hip
 int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s);                 // wgrad_v2.hip
 static int g_conv_use_v2 = 1;
+static int g_conv_debug = 0;
 // test / A-B hook: 0 forces the register-staged kernel for every dtype
-extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable; return prev; }
+extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable & 1; g_conv_debug = enable >> 8; return prev; }
 
 extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
                                   int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
@@ -288,7 +289,7 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 	ConvParams p;
 	p.x = x; p.w = wp; p.y = y; p.bias = bias; p.stats = stats; p.scale = scale; p.shift = shift; p.xlen = xlen;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = convasr_conv_cout_pad(Cout); p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
-	p.act = act; p.act_lo = act_lo; p.act_hi = act_hi;
+	p.act = act; p.act_lo = act_lo; p.act_hi = act_hi; p.debug = g_conv_debug;
 	p.m_tiles_per_b = (Tout + BM - 1) / BM;
 	p.n_tiles = p.CoutPad / BN;
 	p.total_tiles = B * p.m_tiles_per_b * p.n_tiles;

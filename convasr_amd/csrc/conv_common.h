@@ -24,6 +24,7 @@ struct ConvParams {
 	float act_lo, act_hi;
 	int m_tiles_per_b, n_tiles, total_tiles;
 	int x_rows;  // LDS rows of one X tile (even)
+	int debug;   // experiment flags (scratch/ only): 1 = skip DMA issue in the main loop, 2 = skip MFMAs, 4 = skip epilogue stores
 };
 
 // Two 128-B rows share one 256-B bank row; 16-B slot = (row parity, chunk ^ row-pair index): 16 consecutive rows at the same

@@ -95,31 +95,37 @@ template <typename O, bool PIPE> __global__ __launch_bounds__(V2_THREADS, 2) voi
 			for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
 	const int Q = n_cib * p.K;
-	const int wrow0 = wn * 64 + r, wrow1 = wrow0 + 32;
+	const int wrow0 = wn * 64 + r;
 	const int woff0 = (wrow0 >> 1) << 8, wpar0 = (wrow0 & 1) << 3, wsw0 = (wrow0 >> 1) & 7;
-	const int woff1 = (wrow1 >> 1) << 8, wpar1 = (wrow1 & 1) << 3, wsw1 = (wrow1 >> 1) & 7;
-
-	struct Frag { uint4 a0, a1, b0, b1; };
-	// the four 16-byte fragments of k-substep kk of the step at (slab buffer xs, weight slot ws, tap)
-	auto load_frag = [&](const char* xs, const char* ws, int tap_, int kk, Frag& f) {
-		const int xrow0 = wm * 64 + r + tap_ * p.dil, xrow1 = xrow0 + 32;
-		const int chunk = kk * 2 + h;
-		f.a0 = *reinterpret_cast<const uint4*>(xs + ((xrow0 >> 1) << 8) + ((((xrow0 & 1) << 3) | (chunk ^ ((xrow0 >> 1) & 7))) << 4));
-		f.a1 = *reinterpret_cast<const uint4*>(xs + ((xrow1 >> 1) << 8) + ((((xrow1 & 1) << 3) | (chunk ^ ((xrow1 >> 1) & 7))) << 4));
-		f.b0 = *reinterpret_cast<const uint4*>(ws + woff0 + ((wpar0 | (chunk ^ wsw0)) << 4));
-		f.b1 = *reinterpret_cast<const uint4*>(ws + woff1 + ((wpar1 | (chunk ^ wsw1)) << 4));
+	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+	struct Frag { u32x4 a0, a1, b0, b1; };
+	typedef const __attribute__((address_space(3))) u32x4* lds_u4;
+	// Fragment addressing with a handful of VALU ops per step (the matrix pipe and the address math share the issue port):
+	// lds_off(row, chunk) puts the chunk index in address bits 4..6 XORed with the row-pair index, so stepping the k-substep
+	// (chunk += 2) is `address ^ (kk << 5)`, and rows 32 apart (16 pairs) share the swizzle term: a1 = a0 + 4096, b1 = b0 + 4096.
+	const unsigned w0 = lds_base + 2 * xbytes + woff0 + ((wpar0 | (h ^ wsw0)) << 4);
+	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int kk, Frag& f) {
+		const int xrow0 = wm * 64 + r + tap_ * p.dil;
+		const unsigned xa = (lds_base + xs_off + ((xrow0 >> 1) << 8) + ((((xrow0 & 1) << 3) | (h ^ ((xrow0 >> 1) & 7))) << 4)) ^ (kk << 5);
+		const unsigned wa = (w0 + ws_off) ^ (kk << 5);
+		f.a0 = *(lds_u4)(size_t)(xa);
+		f.a1 = *(lds_u4)(size_t)(xa + 4096);
+		f.b0 = *(lds_u4)(size_t)(wa);
+		f.b1 = *(lds_u4)(size_t)(wa + 4096);
 	};
+	auto mma1 = [](const u32x4& a, const u32x4& bb, f32x16& c) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), c, 0, 0, 0); };
 	auto mma_frag = [&](const Frag& f) {
-		Mma<bf16_t>::run(f.a0, f.b0, acc[0][0]);
-		Mma<bf16_t>::run(f.a0, f.b1, acc[0][1]);
-		Mma<bf16_t>::run(f.a1, f.b0, acc[1][0]);
-		Mma<bf16_t>::run(f.a1, f.b1, acc[1][1]);
+		mma1(f.a0, f.b0, acc[0][0]);
+		mma1(f.a0, f.b1, acc[0][1]);
+		mma1(f.a1, f.b0, acc[1][0]);
+		mma1(f.a1, f.b1, acc[1][1]);
 	};
 
 	if constexpr (PIPE) {
-		// K >= 2.  Weight ring of RING = 4 slots, tiles issued THREE steps ahead: the tile of step q + 1 is already published
-		// (landed + barrier) when step q runs, so the first fragments of step q + 1 are read BEFORE the barrier that ends step q
-		// and each wave has MFMA work queued across the barrier instead of an LDS round trip with an empty matrix pipe.
+		// K >= 2.  Weight ring of 4 slots, tiles issued THREE steps ahead: the tiles of step q + 1 are already published (landed +
+		// barrier) while step q runs, so the fragments of k-substep kk + 1 -- including substep 0 of the NEXT step, across the
+		// barrier -- are read while the MFMAs of kk issue, from two alternating register sets (no copies).  (A deeper pipeline
+		// that pre-reads all 16 fragments of the next step measured 3-4 % slower at 208 VGPRs: LDS latency is not the limiter.)
 		issue_x(0);
 		int ci_ = 0, ti_ = 0;  // coordinates of the next weight tile to issue
 		for (int i = 0; i < 3 && i < Q; ++i) { issue_w(ci_, ti_, i); if (++ti_ == p.K) { ti_ = 0; ++ci_; } }
@@ -127,29 +133,37 @@ template <typename O, bool PIPE> __global__ __launch_bounds__(V2_THREADS, 2) voi
 		__builtin_amdgcn_s_barrier();
 
 		int cib = 0, tap = 0, slot = 0;
-		Frag cur, nxt;
-		load_frag(xbuf, wbuf, 0, 0, cur);
-		for (int q = 0; q < Q; ++q) {
+		const bool late = wave >= 4;  // waves 4-7 issue their DMA pieces mid-step, waves 0-3 up front (no lockstep on a SIMD)
+		auto issue_step = [&](int q) {
 			if (tap == 0 && cib + 1 < n_cib) issue_x(cib + 1);
-			const bool more = q + 3 < Q;
-			if (more) { issue_w(ci_, ti_, (slot + 3) & 3); if (++ti_ == p.K) { ti_ = 0; ++ci_; } }
-
-			const char* xs = xbuf + (cib & 1) * xbytes;
-			const char* ws = wbuf + slot * V2_WSLOT;
-			int cib1 = cib, tap1 = tap + 1;
-			if (tap1 == p.K) { tap1 = 0; ++cib1; }
-			const int slot1 = (slot + 1) & 3;
-#pragma unroll
-			for (int kk = 0; kk < 4; ++kk) {
-				if (kk < 3) load_frag(xs, ws, tap, kk + 1, nxt);
-				else if (q + 1 < Q) load_frag(xbuf + (cib1 & 1) * xbytes, wbuf + slot1 * V2_WSLOT, tap1, 0, nxt);
-				mma_frag(cur);
-				cur = nxt;
-			}
-			if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+			if (q + 3 < Q) { issue_w(ci_, ti_, (slot + 3) & 3); if (++ti_ == p.K) { ti_ = 0; ++ci_; } }
+		};
+		auto end_step = [&](int q) {
+			if (q + 3 < Q) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
-			cib = cib1; tap = tap1; slot = slot1;
+			if (++tap == p.K) { tap = 0; ++cib; }
+			slot = (slot + 1) & 3;
+		};
+		{
+			Frag f0, f1;
+			load_frag(0, 0, 0, 0, f0);
+			for (int q = 0; q < Q; ++q) {
+				if (!late) issue_step(q);
+				const unsigned xs = (cib & 1) * xbytes, ws = slot * V2_WSLOT;
+				int cib1 = cib, tap1 = tap + 1;
+				if (tap1 == p.K) { tap1 = 0; ++cib1; }
+				load_frag(xs, ws, tap, 1, f1);
+				mma_frag(f0);
+				load_frag(xs, ws, tap, 2, f0);
+				mma_frag(f1);
+				if (late) issue_step(q);
+				load_frag(xs, ws, tap, 3, f1);
+				mma_frag(f0);
+				if (q + 1 < Q) load_frag((cib1 & 1) * xbytes, ((slot + 1) & 3) * V2_WSLOT, tap1, 0, f0);
+				mma_frag(f1);
+				end_step(q);
+			}
 		}
 	} else {
 		issue_x(0);
@@ -167,8 +181,7 @@ template <typename O, bool PIPE> __global__ __launch_bounds__(V2_THREADS, 2) voi
 			const bool more = q + 2 < Q;
 			if (more) issue_w(cib2, tap2, slot >= 1 ? slot - 1 : 2);  // (slot + 2) % 3
 
-			const char* xs = xbuf + (cib & 1) * xbytes;
-			const char* ws = wbuf + slot * V2_WSLOT;
+			const unsigned xs = (cib & 1) * xbytes, ws = slot * V2_WSLOT;
 #pragma unroll
 			for (int kk = 0; kk < 4; ++kk) {
 				Frag f;
