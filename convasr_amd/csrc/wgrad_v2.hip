@@ -3,7 +3,7 @@
 //   dW[tap][co][ci] = sum_(b,t) dY[b,t,co] * X[b, t + tap*dil - pad, ci]        M = co, N = ci, reduction over (b, t)
 //
 // One workgroup (8 waves) = one 128(co) x 128(ci) tile x up to 4 taps over one split of the (b, t) axis.  Per 64-frame chunk
-// the dY rows and the X rows (+ tap halo) are brought in by LDS-DMA into a 3-deep ring (issued two chunks ahead, counted
+// the dY rows and the X rows (+ tap halo) are brought in by LDS-DMA into a 4-deep ring (issued three chunks ahead, counted
 // vmcnt, raw s_barrier); both MFMA operands are column reads of row-major [t][c] tiles, served by ds_read_b64_tr_b16, with
 // the 64-byte blocks of each 256-byte row XOR-swizzled by (row & 3) so the four rows a transposed read touches fall on
 // different banks (the swizzle lives in the DMA's per-lane source address).  Waves 0-3 own taps {0,1} of the group, waves 4-7
@@ -90,67 +90,74 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 #pragma unroll
 				for (int k = 0; k < 16; ++k) acc[a][i][j][k] = 0.f;
 
-	if (c_begin < c_end) issue(c_begin, 0);
-	if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
+	// 4-stage ring, chunks issued THREE ahead: chunk c + 1 is already published while chunk c runs, so the first fragments
+	// of the next chunk are read before the barrier that ends this one (same software pipeline as conv_v2.hip).
+	for (int i = 0; i < 3; ++i)
+		if (c_begin + i < c_end) issue(c_begin + i, i);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__builtin_amdgcn_s_barrier();
 
 	// fragment addressing: 16-lane group g4 -> (column block (g4 & 1) * 16, k block 8 * (g4 >> 1)); lane 4q + pc in the group
-	// supplies row q, columns 4 pc .. 4 pc + 3 of the 4 x 16 block (ds_read_b64_tr_b16 contract)
+	// supplies row q, columns 4 pc .. 4 pc + 3 of the 4 x 16 block (ds_read_b64_tr_b16 contract).  Row (r & 3) is q for every
+	// dY row a lane touches and (q + tap offset) & 3 for every X row, so the swizzled byte column is a per-lane constant and
+	// stepping kk / the +4-row half are pure immediates: no address arithmetic inside the loop.
 	const int g4 = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
 	const int krow = 8 * (g4 >> 1) + q;
-	const int colA = (wm * 64 + (g4 & 1) * 16 + 4 * pc) * 2, colB = (wn * 64 + (g4 & 1) * 16 + 4 * pc) * 2;  // byte column of mi/ni = 0 (+64 B for 1)
+	const int colA = (wm * 64 + (g4 & 1) * 16 + 4 * pc) * 2, colB = (wn * 64 + (g4 & 1) * 16 + 4 * pc) * 2;
 	const int offA = (tapA - tap0) * p.dil, offB = (tapB - tap0) * p.dil;
+	auto swz = [](int cb, int r3) { return (((cb >> 6) ^ r3) << 6) | (cb & 63); };
+	const unsigned aoff0 = krow * 256 + swz(colA, q), aoff1 = krow * 256 + swz(colA + 64, q);
+	const unsigned bAoff0 = W2_YBYTES + (krow + offA) * 256 + swz(colB, (q + offA) & 3), bAoff1 = W2_YBYTES + (krow + offA) * 256 + swz(colB + 64, (q + offA) & 3);
+	const unsigned bBoff0 = W2_YBYTES + (krow + offB) * 256 + swz(colB, (q + offB) & 3), bBoff1 = W2_YBYTES + (krow + offB) * 256 + swz(colB + 64, (q + offB) & 3);
+	struct F2 { uint4 u0, u1; };
+	typedef __attribute__((address_space(3))) s16x4* lp;
+	auto tr8 = [](unsigned addr) {
+		const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(size_t)addr);
+		const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(size_t)(addr + 4 * 256));
+		const uint2 l = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+		return make_uint4(l.x, l.y, h2.x, h2.y);
+	};
+	auto load_a = [&](unsigned st, int kk, F2& f) { f.u0 = tr8(st + aoff0 + kk * 4096); f.u1 = tr8(st + aoff1 + kk * 4096); };
+	auto load_bA = [&](unsigned st, int kk, F2& f) { f.u0 = tr8(st + bAoff0 + kk * 4096); f.u1 = tr8(st + bAoff1 + kk * 4096); };
+	auto load_bB = [&](unsigned st, int kk, F2& f) { f.u0 = tr8(st + bBoff0 + kk * 4096); f.u1 = tr8(st + bBoff1 + kk * 4096); };
+	auto mma4 = [&](const F2& a, const F2& bq, f32x16 (&c)[2][2]) {
+		Mma<bf16_t>::run(a.u0, bq.u0, c[0][0]);
+		Mma<bf16_t>::run(a.u0, bq.u1, c[0][1]);
+		Mma<bf16_t>::run(a.u1, bq.u0, c[1][0]);
+		Mma<bf16_t>::run(a.u1, bq.u1, c[1][1]);
+	};
 
+	const bool late = wave >= 4;  // waves 4-7 issue their DMA pieces mid-chunk, waves 0-3 up front
 	int stage = 0;
+	F2 fa0, fa1, fbA, fbB;
+	const unsigned st0 = lds_base;
+	if (c_begin < c_end) { load_a(st0, 0, fa0); if (actA) load_bA(st0, 0, fbA); }
 	for (int c = c_begin; c < c_end; ++c) {
-		const bool more = c + 2 < c_end;
-		if (more) issue(c + 2, stage >= 1 ? stage - 1 : 2);
-		const char* ys = smem + stage * stage_bytes;
-		const char* xs = ys + W2_YBYTES;
-#pragma unroll
-		for (int kk = 0; kk < W2_BKT / 16; ++kk) {
-			const int r0 = kk * 16 + krow;  // (r0 & 3) == q, ((r0 + 4) & 3) == q
-			uint4 a[2];
-#pragma unroll
-			for (int mi = 0; mi < 2; ++mi) {
-				const int cb = colA + mi * 64, sw = (((cb >> 6) ^ q) << 6) | (cb & 63);
-				a[mi] = w2_tr_frag(ys + r0 * 256 + sw, ys + (r0 + 4) * 256 + sw);
-			}
-			if (actA) {
-				const int rx = r0 + offA, s3 = rx & 3;
-				uint4 bb[2];
-#pragma unroll
-				for (int ni = 0; ni < 2; ++ni) {
-					const int cb = colB + ni * 64, sw = (((cb >> 6) ^ s3) << 6) | (cb & 63);
-					bb[ni] = w2_tr_frag(xs + rx * 256 + sw, xs + (rx + 4) * 256 + sw);
-				}
-#pragma unroll
-				for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-					for (int ni = 0; ni < 2; ++ni) Mma<bf16_t>::run(a[mi], bb[ni], acc[0][mi][ni]);
-			}
-			if (actB) {
-				const int rx = r0 + offB, s3 = rx & 3;
-				uint4 bb[2];
-#pragma unroll
-				for (int ni = 0; ni < 2; ++ni) {
-					const int cb = colB + ni * 64, sw = (((cb >> 6) ^ s3) << 6) | (cb & 63);
-					bb[ni] = w2_tr_frag(xs + rx * 256 + sw, xs + (rx + 4) * 256 + sw);
-				}
-#pragma unroll
-				for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-					for (int ni = 0; ni < 2; ++ni) Mma<bf16_t>::run(a[mi], bb[ni], acc[1][mi][ni]);
-			}
-		}
-		// leave only the pieces issued in this iteration (chunk c + 2) in flight
+		const bool more = c + 3 < c_end;
+		if (more && !late) issue(c + 3, (stage + 3) & 3);
+		const unsigned st = lds_base + stage * stage_bytes, stn = lds_base + ((stage + 1) & 3) * stage_bytes;
+		const bool has_next = c + 1 < c_end;
+		// unit (kk, A): MFMAs on (fa, fbA) while the tap-B fragments arrive; unit (kk, B): MFMAs on (fa, fbB) while the next
+		// substep's dY and tap-A fragments arrive.  fa0 / fa1 alternate by kk parity.
+#define W2_SUBSTEP(KK, FA_CUR, FA_NXT)                                                   \
+		if (actB) load_bB(st, KK, fbB);                                                  \
+		if (actA) mma4(FA_CUR, fbA, acc[0]);                                             \
+		if (KK < 3) { load_a(st, KK + 1, FA_NXT); if (actA) load_bA(st, KK + 1, fbA); } \
+		else if (has_next) { load_a(stn, 0, FA_NXT); if (actA) load_bA(stn, 0, fbA); }  \
+		if (actB) mma4(FA_CUR, fbB, acc[1]);
+		W2_SUBSTEP(0, fa0, fa1)
+		W2_SUBSTEP(1, fa1, fa0)
+		if (more && late) issue(c + 3, (stage + 3) & 3);
+		W2_SUBSTEP(2, fa0, fa1)
+		W2_SUBSTEP(3, fa1, fa0)
+#undef W2_SUBSTEP
+		// leave only the pieces issued in this iteration (chunk c + 3) in flight
 		if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
 		else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
-		stage = stage == 2 ? 0 : stage + 1;
+		stage = (stage + 1) & 3;
 	}
 
 	const int r = lane & 31, h = lane >> 5;
@@ -183,7 +190,7 @@ int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s) {
 	q.x_rows = (q.x_rows + 3) & ~3;
 	const int pieces = W2_BKT / 4 + q.x_rows / 4;
 	if (pieces > 40) return 0;  // at most 5 pieces per wave: the counted waits above
-	const size_t smem = 3 * (size_t)(W2_YBYTES + q.x_rows * 256);
+	const size_t smem = 4 * (size_t)(W2_YBYTES + q.x_rows * 256);
 	if (smem > 160 * 1024) return 0;
 	static bool set = false;
 	if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
