@@ -72,9 +72,13 @@ def main():
 		raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
 	device = torch.device('cuda', local_rank)
 	torch.cuda.set_device(device)
-	if world > 1:
+	use_dist = world > 1 or os.environ.get('CONVASR_FORCE_DIST') == '1'  # the latter: single-rank RCCL smoke test of the DP path
+	if use_dist:
 		import torch.distributed as dist
 		os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+		os.environ.setdefault('MASTER_PORT', '29511')
+		os.environ.setdefault('RANK', '0')
+		os.environ.setdefault('WORLD_SIZE', '1')
 		dist.init_process_group('nccl', device_id = device)
 
 	import convasr_amd as ca
@@ -88,16 +92,16 @@ def main():
 	flat = ca.train.FlatParameters(model)
 	model._convasr_flat = flat
 	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
-	engine = ca.parallel.DataParallelEngine(model, device = device) if world > 1 else model
+	engine = ca.parallel.DataParallelEngine(model, device = device, force_collectives = use_dist) if use_dist else model
 	x, xlen, y, ylen = synthetic_batch(device, seed = 1 + rank)
 	if args.side_stream:
 		ca.functional.enable_side_stream_wgrad(device)
 
 	def step(i):
-		return ca.train.train_step(engine, opt, x, xlen, y, ylen, world_size = world, iteration = i)
+		return ca.train.train_step(engine, opt, x, xlen, y, ylen, world_size = world, iteration = i, sync_metrics = use_dist)
 
 	def fence():
-		if world > 1:
+		if use_dist:
 			dist.barrier()
 		torch.cuda.synchronize()
 
@@ -114,7 +118,7 @@ def main():
 	elapsed = time.perf_counter() - t0
 	kt = _lib.timer.summary() if _lib.timer is not None else {}
 	_lib.timer = None
-	if world > 1:
+	if use_dist:
 		t = torch.tensor([elapsed], dtype = torch.float64, device = device)
 		dist.all_reduce(t, op = dist.ReduceOp.MAX)
 		elapsed = float(t.item())
@@ -136,7 +140,7 @@ def main():
 		if world == 1 and not args.no_cpu_baseline:
 			line['cpu_baseline'] = cpu_baseline()
 		print(json.dumps(line), flush = True)
-	if world > 1:
+	if use_dist:
 		dist.destroy_process_group()
 
 

@@ -4,10 +4,11 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ statistics -> scale / shift
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void bn_finalize_kernel(const double* stats, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt, double* __restrict__ rezero) {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c == 0 && nbt) *nbt += 1;
 	if (c >= C) return;
 	const double m = stats[c] / n;
 	double var = stats[C + c] / n - m * m;
@@ -24,12 +25,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, c
 		rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
 		rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
 	}
+	if (rezero) { rezero[c] = 0; rezero[C + c] = 0; }  // the conv epilogue of the next step accumulates into zeros again
 }
 
 extern "C" int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, void* stream) {
+                                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int64_t* num_batches_tracked, int rezero_stats, void* stream) {
 	CONVASR_CHECK_ARG(stats && mean && invstd && scale && shift && n > 0 && C > 0, "bn_finalize: bad arguments");
-	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked, rezero_stats ? const_cast<double*>(stats) : nullptr);
 	CONVASR_CHECK_LAUNCH("bn_finalize");
 	return 0;
 }
@@ -234,7 +236,7 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_k
 					}
 				}
 			}
-			store8<T>(reinterpret_cast<T*>(p.out) + idx, g);
+			if (p.out) store8<T>(reinterpret_cast<T*>(p.out) + idx, g);
 		}
 		// block reduction over the row-lanes that share a channel group
 		// per-block partials go to the workspace [set][block][2C] with plain coalesced stores; bn_bwd_finalize_kernel sums them
@@ -263,22 +265,44 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_k
 	}
 }
 
-// sums[set][ch] = sum over blocks of ws[set][block][ch], accumulated in fp64
-struct BnFinalizeSets { double* dst[3]; };
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C2) {
-	__shared__ double red[16][64];
+// sums[set][.] = sum over blocks of ws[set][block][.], accumulated in fp64; for the main BN (set 0) optionally also the
+// per-channel coefficients of pass 2 (dy = A*g + Bc*y + D) and the parameter gradients dgamma = sum g*xhat, dbeta = sum g.
+struct BnFinalizeSets {
+	double* dst[3];
+	const float* gamma; const float* mean; const float* invstd;
+	float* coef; float* dgamma; float* dbeta;
+	int accumulate; float invn;
+};
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C) {
+	__shared__ double red[2][16][64];
 	const int set = blockIdx.y;
-	if (sets.dst[set] == nullptr) return;
-	const int ch = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-	double a = 0;
-	if (ch < C2)
-		for (int bq = w; bq < nblocks; bq += 16) a += (double)ws[((int64_t)set * nblocks + bq) * C2 + ch];
-	red[w][threadIdx.x & 63] = a;
+	if (sets.dst[set] == nullptr && !(set == 0 && (sets.coef || sets.dgamma || sets.dbeta))) return;
+	const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+	double a = 0, b2 = 0;
+	if (c < C)
+		for (int bq = w; bq < nblocks; bq += 16) {
+			const float* row = ws + ((int64_t)set * nblocks + bq) * 2 * C;
+			a += (double)row[c];
+			b2 += (double)row[C + c];
+		}
+	red[0][w][threadIdx.x & 63] = a;
+	red[1][w][threadIdx.x & 63] = b2;
 	__syncthreads();
-	if (w == 0 && ch < C2) {
-		double t = 0;
-		for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
-		sets.dst[set][ch] = t;
+	if (w == 0 && c < C) {
+		double sg = 0, sgx = 0;
+		for (int i = 0; i < 16; ++i) { sg += red[0][i][threadIdx.x]; sgx += red[1][i][threadIdx.x]; }
+		if (sets.dst[set]) { sets.dst[set][c] = sg; sets.dst[set][C + c] = sgx; }
+		if (set == 0) {
+			if (sets.coef) {
+				const float gm = sets.gamma ? sets.gamma[c] : 1.f, is = sets.invstd[c], m = sets.mean[c];
+				const float msg = (float)sg * sets.invn, msgx = (float)sgx * sets.invn;
+				sets.coef[c] = gm * is;
+				sets.coef[C + c] = -gm * is * is * msgx;
+				sets.coef[2 * C + c] = gm * is * (m * is * msgx - msg);
+			}
+			if (sets.dgamma) sets.dgamma[c] = sets.accumulate ? sets.dgamma[c] + (float)sgx : (float)sgx;
+			if (sets.dbeta) sets.dbeta[c] = sets.accumulate ? sets.dbeta[c] + (float)sg : (float)sg;
+		}
 	}
 }
 
@@ -304,9 +328,10 @@ extern "C" int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C) {
 extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift, const float* mean,
                                          const float* invstd, int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                                          const float* const* rmean, const float* const* rinvstd, double* const* rsums, int act, float act_lo, float act_hi,
-                                         float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, void* workspace, int B, int T, int C, void* stream) {
-	CONVASR_CHECK_ARG(dz && y && g && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
-	CONVASR_CHECK_ARG((mean == nullptr) == (invstd == nullptr) && (mean == nullptr || sums != nullptr), "bn_act_bwd_reduce: mean/invstd/sums go together");
+                                         float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
+                                         int accumulate, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(dz && y && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
+	CONVASR_CHECK_ARG((mean == nullptr) == (invstd == nullptr), "bn_act_bwd_reduce: mean and invstd go together");
 	BnActParams p = {};
 	p.y = y; p.dz = dz; p.out = g; p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.xlen = xlen; p.sums = sums;
 	p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p; p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
@@ -315,8 +340,10 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 	for (int r = 2; r < n_res; ++r) if (ra.rsums[r]) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: batch-normed residuals beyond the first two must be reduced by separate calls");
 	int rows_per_block, gx, gy;
 	bn_bwd_grid(B, T, C, rows_per_block, gx, gy);
-	bool any = sums != nullptr;
+	if (mean && !sums) { p.sums = reinterpret_cast<double*>(workspace); }  // (only a non-null marker: block partials always go to the workspace)
+	bool any = mean != nullptr;
 	for (int r = 0; r < n_res; ++r) any = any || ra.rsums[r] != nullptr;
+	CONVASR_CHECK_ARG(!(coef || dgamma || dbeta) || mean, "bn_act_bwd_reduce: coef / dgamma / dbeta need the main batch norm's mean / invstd");
 	CONVASR_CHECK_ARG(!any || workspace, "bn_act_bwd_reduce: workspace required when sums are requested");
 	dim3 grid(gx, gy);
 	hipStream_t st = (hipStream_t)stream;
@@ -328,7 +355,9 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 		sets.dst[0] = (mean && sums) ? sums : nullptr;
 		sets.dst[1] = n_res > 0 ? ra.rsums[0] : nullptr;
 		sets.dst[2] = n_res > 1 ? ra.rsums[1] : nullptr;
-		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((2 * C + 63) / 64, 3), dim3(1024), 0, st, (const float*)workspace, sets, gx, 2 * C);
+		sets.gamma = gamma; sets.mean = mean; sets.invstd = invstd; sets.coef = coef; sets.dgamma = dgamma; sets.dbeta = dbeta;
+		sets.accumulate = accumulate; sets.invn = 1.0f / (float)((int64_t)B * T);
+		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, 3), dim3(1024), 0, st, (const float*)workspace, sets, gx, C);
 	}
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_reduce");
 	return 0;
@@ -359,6 +388,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 		}
 		store8<T>(dy + idx, out);
 	}
+}
+
+// dy = A[c] * g + Bc[c] * y + D[c] with g either given (FROM_DZ = false) or recomputed from dz: g = dz * act'(pre) * dropout * mask
+template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
+	const int c8 = p.C >> 3;
+	const int64_t total = (int64_t)p.B * p.T * c8;
+	ResArgs none;
+	none.n = 0;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+		const int c = (int)(i % c8) << 3;
+		const int64_t row = i / c8;
+		const int64_t idx = row * p.C + c;
+		float yv[8], pre[8], g[8], A[8], Bc[8], D[8], out[8];
+		load8<float>(coef + c, A);
+		load8<float>(coef + p.C + c, Bc);
+		load8<float>(coef + 2 * p.C + c, D);
+		if (FROM_DZ) {
+			const int t = (int)(row % p.T), b = (int)(row / p.T);
+			pre_act8<T>(p, none, idx, c, yv, pre);
+			if (t >= valid_len(p.xlen, b, p.T)) {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) g[k] = 0.f;
+			} else {
+				float dz[8];
+				load8<T>(reinterpret_cast<const T*>(p.dz) + idx, dz);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+				if (p.p_drop > 0.f) {
+					float keep[8];
+					dropout_keep8(p, idx, keep);
+#pragma unroll
+					for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+				}
+			}
+		} else {
+			load8<T>(reinterpret_cast<const T*>(p.dz) + idx, g);
+			load8<T>(reinterpret_cast<const T*>(p.y) + idx, yv);
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
+		store8<T>(dy + idx, out);
+	}
+}
+
+extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
+                                        const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                        const float* xlen, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(dz_or_g && y && dy && coef && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_apply: bad arguments (C must be a multiple of 8)");
+	BnActParams p = {};
+	p.y = y; p.dz = dz_or_g; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p;
+	p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
+	const int64_t total = (int64_t)B * T * (C >> 3);
+	hipStream_t s = (hipStream_t)stream;
+	if (dtype == CONVASR_F32) {
+		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, true>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (float*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, false>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (float*)dy);
+	} else if (dtype == CONVASR_BF16) {
+		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, true>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (bf16_t*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, false>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (bf16_t*)dy);
+	} else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_apply: dtype %d", dtype);
+	CONVASR_CHECK_LAUNCH("bn_act_bwd_apply");
+	return 0;
 }
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int accumulate) {

@@ -140,12 +140,11 @@ class ConvBnActFunction(torch.autograd.Function):
 		xl = ops.xlen_f32(xlen, dev) if (cfg['temporal_mask'] and xlen is not None) else None
 		n_res = len(flat_res) // 5
 
-		stats = torch.zeros(2 * Cout * (1 + n_res), dtype = torch.float64, device = dev)
-		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats[:2 * Cout])
-		Tout = y.shape[2]
 		bn = cfg['bn']
-		bnp = ops.bn_finalize(stats[:2 * Cout], B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps)
-		_tick(bn)
+		stats = _stats_buffer(bn, Cout, dev)
+		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
+		Tout = y.shape[2]
+		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked, rezero = True)
 
 		res_x, res_y, res_bnp = [], [], []
 		for r in range(n_res):
@@ -156,12 +155,11 @@ class ConvBnActFunction(torch.autograd.Function):
 				res_y.append(rx)
 				res_bnp.append(None)
 			else:
-				st = stats[2 * Cout * (1 + r):2 * Cout * (2 + r)]
-				ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
 				rbn = cfg['res_bn'][r]
+				st = _stats_buffer(rbn, Cout, dev)
+				ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
 				res_y.append(ry)
-				res_bnp.append(ops.bn_finalize(st, B * Tout, rg, rbeta, rbn.running_mean, rbn.running_var, _momentum(rbn), rbn.eps))
-				_tick(rbn)
+				res_bnp.append(ops.bn_finalize(st, B * Tout, rg, rbeta, rbn.running_mean, rbn.running_var, _momentum(rbn), rbn.eps, num_batches_tracked = rbn.num_batches_tracked, rezero = True))
 
 		p_drop = cfg['dropout_p']
 		seed, offset = _DropoutState.next(B * Cout * Tout) if p_drop > 0 else (0, 0)
@@ -190,23 +188,35 @@ class ConvBnActFunction(torch.autograd.Function):
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
 
-		bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
-		sums = torch.empty(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)  # written by the reduce kernels
-		rsum_of = {r: sums[2 * Cout * (1 + i):2 * Cout * (2 + i)] for i, r in enumerate(bn_idx)}
-		common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
-		# the kernel reduces the main BN plus the first two batch-normed residuals per pass; dense blocks with more take extra passes
-		first = [r for r in bn_idx if r < 2]
-		g = ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, rsums = [rsum_of.get(r) if r in first else None for r in range(n_res)], sums = sums[:2 * Cout], **common)
-		rest = [r for r in bn_idx if r >= 2]
-		while rest:
-			batch, rest = rest[:2], rest[2:]
-			# re-order so the residuals being reduced sit in slots 0/1 of the kernel's argument list
-			order = batch + [r for r in range(n_res) if r not in batch]
-			pick = lambda lst: [lst[r] for r in order]
-			ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], None, None, act, xlen = xl, res = pick(res_y), rscale = pick(common['rscale']), rshift = pick(common['rshift']), rmean = pick(common['rmean']), rinvstd = pick(common['rinvstd']), rsums = [rsum_of[r] if r in batch else None for r in order], dropout_p = p_drop, seed = seed, offset = offset)
-
-		dgamma, dbeta = _deliver([gamma, beta], lambda outs, acc: ops.bn_bwd_apply(g, y, None, bnp[0], bnp[1], sums[:2 * Cout], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
-		dy = ops.bn_bwd_apply(g, y, gamma, bnp[0], bnp[1], sums[:2 * Cout], inplace = n_res == 0)
+		if n_res == 0:
+			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
+			# per-channel coefficients, pass 2 recomputes g from dz on the fly: dy = A*g + Bc*y + D
+			coef = torch.empty(3 * Cout, dtype = torch.float32, device = dev)
+			reduce = lambda outs, acc: ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, write_g = False, gamma = gamma, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc)
+			if gamma.requires_grad or beta.requires_grad:
+				dgamma, dbeta = _deliver([gamma, beta], reduce)
+			else:
+				reduce([None, None], False)
+				dgamma = dbeta = None
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset)
+			g = rsum_of = None
+		else:
+			bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
+			sums = torch.empty(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)  # written by the reduce kernels
+			rsum_of = {r: sums[2 * Cout * (1 + i):2 * Cout * (2 + i)] for i, r in enumerate(bn_idx)}
+			common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
+			# the kernel reduces the main BN plus the first two batch-normed residuals per pass; dense blocks with more take extra passes
+			first = [r for r in bn_idx if r < 2]
+			g = ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, rsums = [rsum_of.get(r) if r in first else None for r in range(n_res)], sums = sums[:2 * Cout], **common)
+			rest = [r for r in bn_idx if r >= 2]
+			while rest:
+				batch, rest = rest[:2], rest[2:]
+				# re-order so the residuals being reduced sit in slots 0/1 of the kernel's argument list
+				order = batch + [r for r in range(n_res) if r not in batch]
+				pick = lambda lst: [lst[r] for r in order]
+				ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], None, None, act, xlen = xl, res = pick(res_y), rscale = pick(common['rscale']), rshift = pick(common['rshift']), rmean = pick(common['rmean']), rinvstd = pick(common['rinvstd']), rsums = [rsum_of[r] if r in batch else None for r in order], dropout_p = p_drop, seed = seed, offset = offset)
+			dgamma, dbeta = _deliver([gamma, beta], lambda outs, acc: ops.bn_bwd_apply(g, y, None, bnp[0], bnp[1], sums[:2 * Cout], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
+			dy = ops.bn_bwd_apply(g, y, gamma, bnp[0], bnp[1], sums[:2 * Cout], inplace = False)
 
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
 		wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
@@ -244,9 +254,12 @@ def _momentum(bn):
 	return bn.momentum
 
 
-def _tick(bn):
-	if bn.num_batches_tracked is not None:
-		bn.num_batches_tracked += 1
+def _stats_buffer(bn, C, dev):
+	"""Persistent per-BatchNorm (sum, sumsq) fp64 accumulator: zero between steps (bn_finalize re-zeroes what it consumed)."""
+	buf = getattr(bn, '_convasr_stats', None)
+	if buf is None or buf.device != dev or buf.numel() != 2 * C:
+		buf = bn._convasr_stats = torch.zeros(2 * C, dtype = torch.float64, device = dev)
+	return buf
 
 
 class ConvBiasFunction(torch.autograd.Function):

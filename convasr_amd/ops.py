@@ -162,11 +162,11 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 
 # ------------------------------------------------------------------------------------------------ batch norm + activation
 
-def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps):
+def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked = None, rezero = False):
 	C = stats.numel() // 2
 	dev = stats.device
 	out = torch.empty(4, C, dtype = torch.float32, device = dev)  # mean, invstd, scale, shift
-	call('convasr_bn_finalize', ptr(stats), n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, stream_ptr())
+	call('convasr_bn_finalize', ptr(stats), n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, ptr(num_batches_tracked), int(rezero), stream_ptr())
 	return out
 
 
@@ -193,13 +193,20 @@ def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = ()
 	return z
 
 
-def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None):
+def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None, write_g = True, gamma = None, coef = None, dgamma = None, dbeta = None, accumulate = False):
 	B, C, T = y.shape
 	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype
-	g = empty_cl(B, C, T, y.dtype, y.device)
+	g = empty_cl(B, C, T, y.dtype, y.device) if write_g else None
 	ws = workspace(_lib.load().convasr_bn_bwd_workspace_bytes(B, T, C), y.device, 'bn_bwd')
-	call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), B, T, C, stream_ptr())
+	call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, stream_ptr())
 	return g
+
+
+def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None):
+	B, C, T = y.shape
+	dy = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
+	call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr())
+	return dy
 
 
 def bn_bwd_apply(g, y, gamma, mean, invstd, sums, dgamma = None, dbeta = None, accumulate = False, need_dy = True, inplace = True):

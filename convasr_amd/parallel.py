@@ -14,11 +14,12 @@ from .train import FlatParameters
 
 
 class DataParallelEngine(nn.Module):
-	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None):
+	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None, force_collectives = False):
 		super().__init__()
 		self.module = module
 		self.group = process_group
 		self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+		self.collectives = self.world_size > 1 or (force_collectives and dist.is_initialized())  # world 1 + force: RCCL smoke test
 		self.flat = flat if flat is not None else getattr(module, '_convasr_flat', None) or FlatParameters(module)
 		module._convasr_flat = self.flat
 		self.buckets = self._make_buckets(bucket_bytes)
@@ -28,7 +29,7 @@ class DataParallelEngine(nn.Module):
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
 				p._convasr_ready = self._make_hook(bi)
-		if self.world_size > 1:
+		if self.collectives:
 			dist.broadcast(self.flat.data, src = 0, group = self.group)  # identical initial replicas
 			for buf in module.buffers():
 				dist.broadcast(buf, src = 0, group = self.group)
@@ -55,7 +56,7 @@ class DataParallelEngine(nn.Module):
 		return ready
 
 	def _launch(self, bi):
-		if self.world_size == 1:
+		if not self.collectives:
 			return
 		b = self.buckets[bi]
 		view = self.flat.grad[b['lo']:b['hi']]

@@ -109,7 +109,7 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	loss = (loss_vec * example_weights).mean() / accumulate_iterations
 	loss_cur = loss_vec.mean()
 	entropy = M.entropy(log_probs[0].detach(), olen[0], dim = 1).mean()
-	if world_size > 1 and sync_metrics:
+	if sync_metrics and (world_size > 1 or (sync_metrics is True and __import__('torch').distributed.is_initialized())):
 		import torch.distributed as dist
 		stats = torch.stack([loss_cur.detach(), entropy])  # one 2-element all-reduce instead of two scalar ones (train.py:759-760)
 		dist.all_reduce(stats, op = dist.ReduceOp.SUM)

@@ -101,10 +101,13 @@ int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
 
 /* From the conv epilogue's stats (sum, sumsq over n = B*T values per channel): batch mean / biased var ->
  * scale = gamma * invstd, shift = beta - mean * scale; mean/invstd saved for backward; running stats updated
- * with momentum (running_var with the unbiased estimate), exactly nn.BatchNorm1d training semantics. */
+ * with momentum (running_var with the unbiased estimate), exactly nn.BatchNorm1d training semantics.
+ * num_batches_tracked (may be NULL) is incremented; rezero_stats != 0 zeroes `stats` after reading it so that a persistent
+ * per-layer statistics buffer is ready for the next step's conv epilogue without a separate memset. */
 int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps,
-                        float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+                        float* mean, float* invstd, float* scale, float* shift, int C,
+                        int64_t* num_batches_tracked, int rezero_stats, void* stream);
 
 /* eval: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale. */
 int convasr_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -119,17 +122,26 @@ int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, co
                        const float* xlen, int B, int T, int C, void* stream);
 
 /* Backward of the above, pass 1.  g = dz * mask * dropout * act'(pre), pre recomputed from y (and residuals).
- * Writes g (same dtype) and accumulates per channel: sums[0..C) += sum g, sums[C..2C) += sum g * xhat with
+ * Writes g (same dtype; g may be NULL when pass 2 recomputes it from dz) and reduces per channel: sums[0..C) += sum g, sums[C..2C) += sum g * xhat with
  * xhat = (y - mean) * invstd, and for each of the first two residuals r with BN: rsums_r likewise w.r.t. (res_r, rmean_r,
  * rinvstd_r).  sums / rsums_r (2*C doubles each) are WRITTEN (block partials go through `workspace`, then an fp64 sum:
- * deterministic, no contended atomics).  workspace: convasr_bn_bwd_workspace_bytes(B, T, C) bytes. */
+ * deterministic, no contended atomics).  workspace: convasr_bn_bwd_workspace_bytes(B, T, C) bytes.
+ * Optional outputs for the main BN (need mean / invstd): coef (3*C floats: dy = coef[c]*g + coef[C+c]*y + coef[2C+c], the
+ * batch-norm training backward with `gamma` folded in), dgamma = sum g*xhat, dbeta = sum g (added to when accumulate). */
 int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C);
 int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift,
                               const float* mean, const float* invstd,
                               int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                               const float* const* rmean, const float* const* rinvstd, double* const* rsums,
                               int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                              const float* xlen, double* sums, void* workspace, int B, int T, int C, void* stream);
+                              const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
+                              int accumulate, int B, int T, int C, void* stream);
+
+/* Backward pass 2 in coefficient form: dy = coef[c]*g + coef[C+c]*y + coef[2C+c].  from_dz != 0: g is recomputed on the fly
+ * from dz (activation derivative, dropout, temporal mask; no residuals) so pass 1 need not materialise it. */
+int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz,
+                             const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
+                             uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, void* stream);
 
 /* Backward pass 2: dy = gamma * invstd * (g - sum_g / n - xhat * sum_gxhat / n)  (batch-norm training backward);
  * dgamma = sum_gxhat, dbeta = sum_g (written, or added when accumulate).  In place allowed (dy == g). */

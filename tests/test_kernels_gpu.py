@@ -281,6 +281,14 @@ def test_bn_act_forward_backward(C, nonlin):
 	close(dgamma, gamma.grad, 1e-4, 1e-3, 'dgamma')
 	close(dbeta, beta.grad, 1e-4, 1e-3, 'dbeta')
 	close(dy, y.grad, 1e-3, 1e-4, 'dy')
+	# fused form: pass 1 reduces only (no g), emits coefficients + parameter gradients; pass 2 recomputes g from dz
+	coef = torch.empty(3 * C, device = d)
+	dgamma2, dbeta2 = torch.full((C, ), 5.0, device = d), torch.full((C, ), -5.0, device = d)
+	assert ops.bn_act_bwd_reduce(ops.as_cl(dz.to(d)), ycl, scale, shift, mean, invstd, act, xlen = xlen.to(d), write_g = False, gamma = gamma.detach().to(d), coef = coef, dgamma = dgamma2, dbeta = dbeta2, accumulate = True) is None
+	close(dgamma2 - 5.0, gamma.grad, 1e-4, 1e-3, 'dgamma (fused, accumulate)')
+	close(dbeta2 + 5.0, beta.grad, 1e-4, 1e-3, 'dbeta (fused, accumulate)')
+	dy2 = ops.bn_act_bwd_apply(ops.as_cl(dz.to(d)), ycl, coef, True, scale, shift, act, xlen = xlen.to(d))
+	close(dy2, y.grad, 1e-3, 1e-4, 'dy (fused)')
 
 
 @gpu
