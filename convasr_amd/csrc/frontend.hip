@@ -9,7 +9,8 @@
 
 #define FE_NFFT 512
 #define FE_BINS 257
-#define FE_WAVES 4
+#define FE_WAVES 8
+#define FE_MELP 65  // LDS pitch of the transposed mel matrix: conflict-free for the transposing store and the per-bin read
 
 __global__ __launch_bounds__(256) void absmax_kernel_f32(const float* __restrict__ x, int T, unsigned* __restrict__ out) {
 	const int b = blockIdx.y;
@@ -86,14 +87,14 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
                                                                const float* __restrict__ melb, float* __restrict__ out, int B, int T, int F, int hop, int nmel,
                                                                float preemph, int pairs_per_b, int total_pairs) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float* const melT = reinterpret_cast<float*>(smem);                 // [FE_BINS][64]
-	cpx* const tw = reinterpret_cast<cpx*>(melT + FE_BINS * 64);         // [512] exp(-2 pi i m / 512)
+	float* const melT = reinterpret_cast<float*>(smem);                 // [FE_BINS][FE_MELP]
+	cpx* const tw = reinterpret_cast<cpx*>(melT + FE_BINS * FE_MELP + 1);         // [512] exp(-2 pi i m / 512)
 	float* const win = reinterpret_cast<float*>(tw + FE_NFFT);           // [512] window centred in nfft
 	cpx* const work = reinterpret_cast<cpx*>(win + FE_NFFT);             // [FE_WAVES][512]
 	float* const pw = reinterpret_cast<float*>(work + FE_WAVES * FE_NFFT);  // [FE_WAVES][2][FE_BINS + 7]
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-	for (int i = tid; i < FE_BINS * 64; i += blockDim.x) { const int k = i >> 6, m = i & 63; melT[i] = m < nmel ? melw[m * FE_BINS + k] : 0.f; }
+	for (int i = tid; i < FE_BINS * 64; i += blockDim.x) { const int m = i / FE_BINS, k = i - m * FE_BINS; melT[k * FE_MELP + m] = m < nmel ? melw[i] : 0.f; }  // coalesced read, transposing store
 	for (int i = tid; i < FE_NFFT; i += blockDim.x) {
 		float s, c;
 		sincospif((float)i / 256.0f, &s, &c);
@@ -102,6 +103,16 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		win[i] = (i >= left && i < left + win_length) ? window[i - left] : 0.f;
 	}
 	__syncthreads();
+
+	// support of this lane's mel filter: the filterbank is ~97 % zeros (each triangle spans 3..30 of the 257 bins), so the
+	// dense 257-term dot product is cut to the widest support in the wave; skipping exact zeros changes no result
+	int klo = FE_BINS, khi = 0;
+	for (int k = 0; k < FE_BINS; ++k)
+		if (melT[k * FE_MELP + lane] != 0.f) { klo = min(klo, k); khi = k + 1; }
+	if (khi <= klo) { klo = 0; khi = 0; }
+	int span = khi - klo;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) span = max(span, __shfl_xor(span, o, 64));
 
 	cpx* const buf = work + wave * FE_NFFT;
 	float* const p0 = pw + wave * 2 * (FE_BINS + 7);
@@ -171,9 +182,9 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		__builtin_amdgcn_wave_barrier();
 		// ---- mel + eps bias + log: lane = mel channel
 		float m0 = 0.f, m1 = 0.f;
-#pragma unroll 4
-		for (int k = 0; k < FE_BINS; ++k) {
-			const float w = melT[k * 64 + lane];
+		for (int j = 0; j < span; ++j) {
+			const int k = min(klo + j, FE_BINS - 1);
+			const float w = (klo + j < khi) ? melT[k * FE_MELP + lane] : 0.f;
 			m0 = fmaf(w, p0[k], m0);
 			m1 = fmaf(w, p1[k], m1);
 		}
@@ -193,9 +204,9 @@ extern "C" int convasr_logmel_fwd(const void* signal, int signal_dtype, const fl
 		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft == 512 (window 257..512 samples), nmel <= 64; got nfft %d nmel %d win %d", nfft, nmel, win_length);
 	const int F = 1 + T / hop;  // (T + 2 * pad - nfft) / hop + 1 with pad = nfft / 2
 	const int pairs_per_b = (F + 1) / 2, total_pairs = B * pairs_per_b;
-	const size_t smem = sizeof(float) * (FE_BINS * 64 + 2 * FE_NFFT + FE_NFFT + 2 * FE_WAVES * FE_NFFT + FE_WAVES * 2 * (FE_BINS + 7));
+	const size_t smem = sizeof(float) * (FE_BINS * FE_MELP + 1 + 2 * FE_NFFT + FE_NFFT + 2 * FE_WAVES * FE_NFFT + FE_WAVES * 2 * (FE_BINS + 7));
 	int grid = (total_pairs + FE_WAVES - 1) / FE_WAVES;
-	if (grid > 512) grid = 512;
+	if (grid > 256) grid = 256;  // persistent: one workgroup per CU amortises the table set-up (mel transpose, twiddles) over ~190 frame pairs
 	hipStream_t s = (hipStream_t)stream;
 	if (signal_dtype == CONVASR_F32) {
 		auto kern = logmel_kernel<float>;
