@@ -45,7 +45,8 @@ __device__ __forceinline__ void dma16(const v4i32& srd, unsigned lds_addr, int v
 	             : "memory");
 }
 
-template <typename O, bool PIPE> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2_kernel(ConvParams p) {
+template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2_kernel(ConvParams p) {
+	constexpr bool PIPE = MODE == 1;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,7 +122,57 @@ template <typename O, bool PIPE> __global__ __launch_bounds__(V2_THREADS, 2) voi
 		mma1(f.a1, f.b1, acc[1][1]);
 	};
 
-	if constexpr (PIPE) {
+	if constexpr (MODE == 2) {
+		// K >= 2, TWO taps per barrier interval: the per-step costs (DMA issue, counted wait, barrier skew, post-barrier LDS
+		// round trip) are paid once per 32 MFMAs per wave instead of once per 16.  Weight ring of 4 slots = the current pair +
+		// the next pair (in flight during the whole step, ~2000+ cycles of cover); fragments ping-pong through the 8 substeps.
+		const int npb = (p.K + 1) >> 1, P = n_cib * npb;
+		issue_x(0);
+		issue_w(0, 0, 0);
+		if (p.K > 1) issue_w(0, 1, 1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		const bool late = wave >= 4;
+		int cib = 0, pi = 0;
+		Frag f0, f1;
+		for (int sidx = 0; sidx < P; ++sidx) {
+			const int t0_ = 2 * pi, nt = min(2, p.K - t0_);
+			int cib1 = cib, pi1 = pi + 1;
+			if (pi1 == npb) { pi1 = 0; ++cib1; }
+			const unsigned xs = (cib & 1) * xbytes, ws0 = ((sidx & 1) * 2) * V2_WSLOT, ws1 = ws0 + V2_WSLOT;
+			auto issue_step = [&]() {
+				if (pi == 0 && cib + 1 < n_cib) issue_x(cib + 1);
+				if (sidx + 1 < P) {
+					const int sl = ((sidx + 1) & 1) * 2;
+					issue_w(cib1, 2 * pi1, sl);
+					if (2 * pi1 + 1 < p.K) issue_w(cib1, 2 * pi1 + 1, sl + 1);
+				}
+			};
+			if (!late) issue_step();
+			load_frag(xs, ws0, t0_, 0, f0);
+			load_frag(xs, ws0, t0_, 1, f1);
+			mma_frag(f0);
+			load_frag(xs, ws0, t0_, 2, f0);
+			mma_frag(f1);
+			if (late) issue_step();
+			load_frag(xs, ws0, t0_, 3, f1);
+			mma_frag(f0);
+			if (nt == 2) {
+				load_frag(xs, ws1, t0_ + 1, 0, f0);
+				mma_frag(f1);
+				load_frag(xs, ws1, t0_ + 1, 1, f1);
+				mma_frag(f0);
+				load_frag(xs, ws1, t0_ + 1, 2, f0);
+				mma_frag(f1);
+				load_frag(xs, ws1, t0_ + 1, 3, f1);
+				mma_frag(f0);
+			}
+			mma_frag(f1);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			cib = cib1; pi = pi1;
+		}
+	} else if constexpr (PIPE) {
 		// K >= 2.  Weight ring of 4 slots, tiles issued THREE steps ahead: the tiles of step q + 1 are already published (landed +
 		// barrier) while step q runs, so the fragments of k-substep kk + 1 -- including substep 0 of the NEXT step, across the
 		// barrier -- are read while the MFMAs of kk issue, from two alternating register sets (no copies).  (A deeper pipeline
@@ -258,20 +309,20 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
-	const bool pipe = p.K >= 2;
-	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (pipe ? 4 : 3) * V2_WSLOT;
+	const int mode = p.K < 2 ? 0 : ((p.debug & 64) ? 1 : 2);
+	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (mode == 0 ? 3 : 4) * V2_WSLOT;
 	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
 	if (epi > smem) smem = epi;
 	if (smem > 160 * 1024) return 0;
 	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
 	p.m_tiles_per_b = (p.Tout + V2_BM - 1) / V2_BM;
 	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
-	const void* kern;
-	if (y_dtype == CONVASR_BF16) kern = pipe ? (const void*)conv1d_igemm_v2_kernel<bf16_t, true> : (const void*)conv1d_igemm_v2_kernel<bf16_t, false>;
-	else kern = pipe ? (const void*)conv1d_igemm_v2_kernel<float, true> : (const void*)conv1d_igemm_v2_kernel<float, false>;
-	static bool attr_set[4] = {false, false, false, false};
-	const int ki = (y_dtype == CONVASR_BF16 ? 0 : 2) + (pipe ? 1 : 0);
-	if (!attr_set[ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[ki] = true; }
+	const void* table[2][3] = {{(const void*)conv1d_igemm_v2_kernel<bf16_t, 0>, (const void*)conv1d_igemm_v2_kernel<bf16_t, 1>, (const void*)conv1d_igemm_v2_kernel<bf16_t, 2>},
+	                           {(const void*)conv1d_igemm_v2_kernel<float, 0>, (const void*)conv1d_igemm_v2_kernel<float, 1>, (const void*)conv1d_igemm_v2_kernel<float, 2>}};
+	const int oi = y_dtype == CONVASR_BF16 ? 0 : 1;
+	const void* kern = table[oi][mode];
+	static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+	if (!attr_set[oi][mode]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[oi][mode] = true; }
 	void* args[] = {&p};
 	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;
 	return 1;
