@@ -127,21 +127,35 @@ def main():
 		audio_s = world * BATCH * SECS * args.steps
 		value = audio_s / elapsed
 		roof = None
-		if 'conv1d_igemm' in kt:
-			k = kt['conv1d_igemm']
-			achieved = k['work'] / (k['total_ms'] * 1e-3) / 1e12
+		main = 'conv1d_igemm_v2_kernel<bf16, 2>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
+		if main in kt:
 			peak = PEAK_BF16_DENSE / 1e12 if args.dtype == 'bf16' else 157.3
-			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_kernel (forward + dgrad launches)', achieved = round(achieved, 2), peak = peak, unit = 'TFLOP/s', frac = round(achieved / peak, 4), traffic = None, launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
-			if 'conv1d_wgrad' in kt:
-				w = kt['conv1d_wgrad']
-				roof['wgrad'] = dict(kernel = 'conv1d_wgrad_kernel + wgrad_reduce_kernel', achieved = round(w['work'] / (w['total_ms'] * 1e-3) / 1e12, 2), frac = round(w['work'] / (w['total_ms'] * 1e-3) / 1e12 / peak, 4), avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
+			tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
+			k = kt[main]
+			# HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction)
+			traffic, traffic_src = None, None
+			tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
+			if args.dtype == 'bf16' and os.path.exists(tpath):
+				tj = json.load(open(tpath))
+				hit = [v for name, v in tj.items() if 'conv1d_igemm_v2_kernel<unsigned short, 2>' in name]
+				if hit:
+					traffic, traffic_src = round(hit[0]['hbm_bytes_per_launch'] / 1e6, 1), 'profiles/r01_bench_hbm_traffic.csv (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2_kernel<unsigned short, 2> (forward + dgrad launches of the stride-1 K>=2 layers)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			others = {name: v for name, v in kt.items() if name != main}
+			if 'conv1d_wgrad' in others:
+				w = others['conv1d_wgrad']
+				roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel + wgrad_reduce_kernel (+ general wgrad kernel on 3 small layers)', achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4), launches_per_step = w['launches'] // args.steps, avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
+			allc = [v for v in kt.values()]
+			roof['conv_stack'] = dict(achieved = round(sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12, 2), ms_per_step = round(sum(v['total_ms'] for v in allc) / args.steps, 3))
+			roof['conv_stack']['frac'] = round(roof['conv_stack']['achieved'] / peak, 4)
 			roof['whole_step_frac'] = round(FLOP_PER_AUDIO_S_FWD_BWD * value / world / (peak * 1e12), 4)
 		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout 0.2', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), roofline = roof)
 		if world == 1 and not args.no_cpu_baseline:
 			line['cpu_baseline'] = cpu_baseline()
-		print(json.dumps(line), flush = True)
 	if use_dist:
 		dist.destroy_process_group()
+	if rank == 0:
+		print(json.dumps(line), flush = True)
 
 
 if __name__ == '__main__':

@@ -89,29 +89,29 @@ class KernelTimer:
 	def __init__(self):
 		self.records = {}
 
-	def timed(self, family, work, fn):
+	def timed(self, family, work, fn, nbytes = 0.0):
 		start, end = torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True)
 		start.record()
 		fn()
 		end.record()
-		self.records.setdefault(family, []).append((start, end, work))
+		self.records.setdefault(family, []).append((start, end, work, nbytes))
 
 	def summary(self):
 		out = {}
 		for family, recs in self.records.items():
-			ms = [s.elapsed_time(e) for s, e, _ in recs]
-			out[family] = dict(launches = len(recs), total_ms = sum(ms), avg_us = 1e3 * sum(ms) / max(len(ms), 1), work = sum(w for _, _, w in recs))
+			ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+			out[family] = dict(launches = len(recs), total_ms = sum(ms), avg_us = 1e3 * sum(ms) / max(len(ms), 1), work = sum(r[2] for r in recs), bytes = sum(r[3] for r in recs))
 		return out
 
 
 timer = None  # set to a KernelTimer by bench.py for the timed region
 
 
-def timed(family, work, fn):
+def timed(family, work, fn, nbytes = 0.0):
 	if timer is None:
 		fn()
 	else:
-		timer.timed(family, work, fn)
+		timer.timed(family, work, fn, nbytes)
 
 
 def stream_ptr():
