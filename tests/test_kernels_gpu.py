@@ -390,3 +390,61 @@ def test_sumsq_and_sgd_step_match_torch():
 		close(ss.sqrt().float().squeeze(), norm, 5e-5, 0, 'grad norm')
 		ops.sgd_step(pd, gi, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, it == 0)
 		close(pd, p.detach(), 1e-5, 1e-6, f'params after step {it}')
+
+
+# ------------------------------------------------------------------------------------------------ full-size, size-independent properties
+
+@gpu
+@pytest.mark.parametrize('layer', [(768, 768, 11, 1), (768, 896, 29, 2), (896, 1024, 1, 1), (256, 384, 11, 1)])
+def test_conv_adjoint_identities_at_benchmark_size(layer):
+	"""BASELINE configs[2] size (64 x 751 frames, bf16): forward, dgrad and wgrad must be three views of one bilinear form,
+	<conv(x, w), dy> == <x, dgrad(dy, w)> == <w, wgrad(x, dy)>, whatever the tiling / split-K / LDS-DMA schedule does."""
+	from convasr_amd import ops, _lib
+	cin, cout, k, dil = layer
+	torch.manual_seed(cin + cout + k)
+	d = dev()
+	B, T = 64, 751
+	pad = dil * k // 2
+	x = ops.as_cl(torch.randn(B, cin, T, device = d), torch.bfloat16)
+	w = (torch.randn(cout, cin, k, device = d) / (cin * k) ** 0.5).bfloat16().float()
+	fwd, dgr = ops.pack_weight(w, torch.bfloat16, None)
+	Tout = ops.conv_out_len(T, k, 1, dil, pad)
+	dy = ops.as_cl(torch.randn(B, cout, Tout, device = d), torch.bfloat16)
+	y = ops.conv1d(x, fwd, cout, k, 1, dil, pad, out_dtype = torch.float32)
+	dx = ops.conv1d(dy, dgr, cin, k, 1, dil, dil * (k - 1) - pad, out_dtype = torch.float32)
+	dw = torch.empty_like(w)
+	ops.conv1d_wgrad(x, dy, cout, k, 1, dil, pad, dw)
+	a = float((y.double() * dy.double()).sum())
+	b = float((x.double() * dx.double()).sum())
+	c = float((w.double() * dw.double()).sum())
+	scale = float(y.double().norm() * dy.double().norm())
+	assert abs(a - b) / scale < 2e-5 and abs(a - c) / scale < 2e-5, (a, b, c, scale)
+	# linearity of the forward map in x at full size
+	x2 = ops.as_cl(torch.randn(B, cin, T, device = d), torch.bfloat16)
+	y2 = ops.conv1d(x2, fwd, cout, k, 1, dil, pad, out_dtype = torch.float32)
+	xs = ops.as_cl((x.float() + x2.float()).bfloat16(), torch.bfloat16)
+	ys = ops.conv1d(xs, fwd, cout, k, 1, dil, pad, out_dtype = torch.float32)
+	err = (ys - (y + y2)).abs().max() / (y.abs().max() + y2.abs().max())
+	assert float(err) < 2e-2  # bf16 rounding of x + x2
+
+
+@gpu
+def test_ctc_properties_at_benchmark_size():
+	"""64 x 753 frames x 38 classes, 150 labels: posteriors sum to one per frame (gradient rows sum to zero), the gradient is
+	zero beyond olen, and shifting all log-probs of an utterance by a constant c changes its NLL by exactly -olen * c."""
+	from convasr_amd import ops
+	torch.manual_seed(0)
+	d = dev()
+	B, C, T, S = 64, 38, 753, 150
+	lp = torch.randn(B, C, T, device = d).log_softmax(dim = 1)
+	y = torch.randint(0, C - 1, (B, S), device = d)
+	olen = torch.randint(2 * S + 1, T + 1, (B, ), device = d)
+	ylen = torch.randint(S // 2, S + 1, (B, ), device = d)
+	nll, grad = ops.ctc_loss(ops.as_cl(lp), y, olen, ylen, C - 1)
+	assert torch.isfinite(nll).all()
+	rows = grad.sum(dim = 1)  # exp(lp) sums to 1 and the posterior sums to 1 for every valid frame
+	assert float(rows.abs().max()) < 2e-3  # alpha + beta + nll are O(2000) in fp32: 1e-4 absolute in the exponent, like ATen's own kernels
+	tmask = torch.arange(T, device = d)[None, :] >= olen[:, None]
+	assert float((grad.abs().amax(dim = 1) * tmask).max()) == 0.0
+	nll2, _ = ops.ctc_loss(ops.as_cl(lp - 0.25), y, olen, ylen, C - 1, need_grad = False)
+	close(nll2 - nll, 0.25 * olen.float(), 1e-4, 1e-2, 'shift property')
