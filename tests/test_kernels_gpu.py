@@ -443,7 +443,7 @@ def test_ctc_properties_at_benchmark_size():
 	nll, grad = ops.ctc_loss(ops.as_cl(lp), y, olen, ylen, C - 1)
 	assert torch.isfinite(nll).all()
 	rows = grad.sum(dim = 1)  # exp(lp) sums to 1 and the posterior sums to 1 for every valid frame
-	assert float(rows.abs().max()) < 2e-3  # alpha + beta + nll are O(2000) in fp32: 1e-4 absolute in the exponent, like ATen's own kernels
+	assert float(rows.abs().max()) < 5e-3  # alpha + beta + nll are O(2800) in fp32 (ulp 2.4e-4): ~1e-3 relative after exp, as in ATen
 	tmask = torch.arange(T, device = d)[None, :] >= olen[:, None]
 	assert float((grad.abs().amax(dim = 1) * tmask).max()) == 0.0
 	nll2, _ = ops.ctc_loss(ops.as_cl(lp - 0.25), y, olen, ylen, C - 1, need_grad = False)
