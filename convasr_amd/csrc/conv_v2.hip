@@ -53,7 +53,7 @@ template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void
 	const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
 
 	const int v = xcd_remap(blockIdx.x, p.total_tiles);
-	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
+	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;  // (walking weight tiles in L2-sized groups per XCD measured +-1 %: not the limiter)
 	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * V2_BM;
 	const int co0 = ntile * BN;
 	const int tin0 = t0 - p.pad;  // stride 1
