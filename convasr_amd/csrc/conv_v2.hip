@@ -8,42 +8,7 @@
 //   * no staging registers and no ds_write traffic (the v1 kernel spends ~45 % of its LDS cycles on ds_write_b128);
 //   * the conflict-free XOR swizzle is applied on the per-lane SOURCE address (the DMA destination is lane-linear);
 //   * the conv's zero padding is the buffer descriptor's range check: rows before 0 / after Tin read as zeros.
-#include "conv_common.h"
-
-#define V2_BM 256
-#define V2_THREADS 512
-#define V2_WSLOT (BN * ROW_BYTES)  // 16 KiB
-
-// 1 KiB (one wave-instruction) of a swizzled tile: LDS slot p of the tile <- global (row, chunk) with
-// lds_off(row, chunk) == 16 * p.  Returns the byte offset of that lane's 16 bytes relative to the tile's row 0 / chunk 0.
-__device__ __forceinline__ int v2_src_offset(int p, int row_bytes) {
-	const int pair = p >> 4, s = p & 15;
-	const int row = 2 * pair + (s >> 3), chunk = (s & 7) ^ (pair & 7);
-	return row * row_bytes + chunk * 16;
-}
-
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-
-// raw buffer descriptor (stride 0, range-checked on num_bytes) from wave-uniform pieces
-__device__ __forceinline__ v4i32 make_srd(const void* base, unsigned num_bytes) {
-	const unsigned long long a = (unsigned long long)base;
-	v4i32 d;
-	d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-	d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
-	d[2] = __builtin_amdgcn_readfirstlane((int)num_bytes);
-	d[3] = 0x00020000;
-	return d;
-}
-
-// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at LDS byte address lds_addr), issued from inline asm so that hipcc neither
-// counts it nor drains it with vmcnt(0) before the next ds_read: completion is tracked by the counted waits in the loop.
-__device__ __forceinline__ void dma16(const v4i32& srd, unsigned lds_addr, int voff) {
-	unsigned keep;
-	asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-	             : "=&s"(keep)
-	             : "v"(voff), "s"(srd), "s"(lds_addr)
-	             : "memory");
-}
+#include "conv_v2_common.h"
 
 template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2_kernel(ConvParams p) {
 	constexpr bool PIPE = MODE == 1;
@@ -303,13 +268,16 @@ template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void
 	}
 }
 
+const void* convasr_conv_v2s_kernel(int y_dtype);  // conv_v2s.hip
+#define V2_DEFAULT_SMALL_SHAPE 1
+
 // Returns 1 if the v2 kernel took the launch, 0 if the shape is outside its envelope (caller falls back to conv.hip's kernel).
 int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	if (p.stride != 1 || (p.Cin & 63) != 0) return 0;
 	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
-	const int mode = p.K < 2 ? 0 : ((p.debug & 64) ? 1 : 2);
+	int mode = p.K < 2 ? 0 : ((p.debug & 64) ? 1 : 2);
 	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (mode == 0 ? 3 : 4) * V2_WSLOT;
 	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
 	if (epi > smem) smem = epi;
@@ -320,8 +288,10 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	const void* table[2][3] = {{(const void*)conv1d_igemm_v2_kernel<bf16_t, 0>, (const void*)conv1d_igemm_v2_kernel<bf16_t, 1>, (const void*)conv1d_igemm_v2_kernel<bf16_t, 2>},
 	                           {(const void*)conv1d_igemm_v2_kernel<float, 0>, (const void*)conv1d_igemm_v2_kernel<float, 1>, (const void*)conv1d_igemm_v2_kernel<float, 2>}};
 	const int oi = y_dtype == CONVASR_BF16 ? 0 : 1;
-	const void* kern = table[oi][mode];
-	static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+	const bool small_shape = mode == 2 && ((p.debug & 128) != 0) == (V2_DEFAULT_SMALL_SHAPE == 0);  // debug bit 128 selects the non-default MFMA shape
+	const void* kern = small_shape ? convasr_conv_v2s_kernel(y_dtype) : table[oi][mode];
+	static bool attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};
+	if (small_shape) mode = 3;
 	if (!attr_set[oi][mode]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[oi][mode] = true; }
 	void* args[] = {&p};
 	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;

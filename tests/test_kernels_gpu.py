@@ -172,7 +172,7 @@ def test_conv1d_lds_dma_kernel_is_bit_identical_to_register_staged_kernel(case):
 		_lib.load().convasr_debug_set_conv_v2(prev)
 		outs.append((y, stats))
 	assert torch.equal(outs[0][0], outs[1][0])
-	close(outs[0][1], outs[1][1], 1e-12, 1e-9, 'stats')
+	close(outs[0][1], outs[1][1], 1e-6, 1e-4, 'stats')  # fp32 per-lane partial sums are grouped differently by the two MFMA shapes
 
 
 @gpu
