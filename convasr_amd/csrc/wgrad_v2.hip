@@ -9,6 +9,8 @@
 // different banks (the swizzle lives in the DMA's per-lane source address).  Waves 0-3 own taps {0,1} of the group, waves 4-7
 // taps {2,3}; each wave a 64 x 64 sub-tile x 2 taps = 128 accumulator registers, two waves per SIMD.
 // Zero padding of the conv and ragged chunk ends are the per-utterance buffer descriptors' range checks.
+// (A 16x16x32-MFMA build of this kernel -- 32-byte-unit swizzle, 223 VGPRs -- is bit-identical and measured 3-5 % SLOWER in the
+// same process, the opposite of the forward kernel where that shape wins 3-7 %: kept on 32x32x16.)
 #include "conv_common.h"
 
 #define W2_THREADS 512
