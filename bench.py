@@ -127,7 +127,7 @@ def main():
 		audio_s = world * BATCH * SECS * args.steps
 		value = audio_s / elapsed
 		roof = None
-		main = 'conv1d_igemm_v2_kernel<bf16, 2>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
+		main = 'conv1d_igemm_v2s_kernel<bf16>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
 		if main in kt:
 			peak = PEAK_BF16_DENSE / 1e12 if args.dtype == 'bf16' else 157.3
 			tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
@@ -137,10 +137,10 @@ def main():
 			tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
 			if args.dtype == 'bf16' and os.path.exists(tpath):
 				tj = json.load(open(tpath))
-				hit = [v for name, v in tj.items() if 'conv1d_igemm_v2_kernel<unsigned short, 2>' in name]
+				hit = [v for name, v in tj.items() if 'conv1d_igemm_v2s_kernel<unsigned short>' in name]
 				if hit:
 					traffic, traffic_src = round(hit[0]['hbm_bytes_per_launch'] / 1e6, 1), 'profiles/r01_bench_hbm_traffic.csv (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2_kernel<unsigned short, 2> (forward + dgrad launches of the stride-1 K>=2 layers)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<unsigned short> (forward + dgrad launches of the stride-1 K>=2 layers)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
 			others = {name: v for name, v in kt.items() if name != main}
 			if 'conv1d_wgrad' in others:
 				w = others['conv1d_wgrad']

@@ -23,6 +23,7 @@ struct ConvParams {
 	int act;
 	float act_lo, act_hi;
 	int m_tiles_per_b, n_tiles, total_tiles;
+	int full_tiles;  // conv_v2s only: tiles [0, full_tiles) are 256 x 128; each later one is computed as two 256 x 64 halves by two workgroups
 	int x_rows;  // LDS rows of one X tile (even)
 	int debug;   // experiment flags (scratch/ only): 1 = skip DMA issue in the main loop, 2 = skip MFMAs, 4 = skip epilogue stores
 };

@@ -293,7 +293,16 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	static bool attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};
 	if (small_shape) mode = 3;
 	if (!attr_set[oi][mode]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[oi][mode] = true; }
+	// conv_v2s: a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
+	p.full_tiles = p.total_tiles;
+	if (small_shape && !(p.debug & 32)) {
+		static int n_cu = 0;
+		if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+		const int rest = p.total_tiles % n_cu;
+		if (rest > 0 && 2 * rest <= n_cu && ((p.total_tiles - rest) & 7) == 0) p.full_tiles = p.total_tiles - rest;
+	}
+	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
 	void* args[] = {&p};
-	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;
+	if (hipLaunchKernel(kern, dim3(grid), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;
 	return 1;
 }

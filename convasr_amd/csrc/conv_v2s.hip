@@ -6,16 +6,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2s_kernel(ConvParams p) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+// NB = 16-column blocks per wave: 4 -> the 256 x 128 tile, 2 -> a 256 x 64 half tile (same X tile, half the W rows).  The last
+// partial round of a launch (total_tiles mod 256 workgroups on 256 CUs) is cut into half tiles so that it occupies all CUs for
+// ~0.6 of a round instead of a fraction of them for a whole one; per-element sums are unchanged (same k order).
+template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
+	constexpr int BN_ = 32 * NB;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
 
-	const int v = xcd_remap(blockIdx.x, p.total_tiles);
 	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
 	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * V2_BM;
-	const int co0 = ntile * BN;
+	const int co0 = ntile * BN + half * BN_;
 	const int tin0 = t0 - p.pad;
 
 	const int xbytes = p.x_rows * ROW_BYTES;
@@ -35,39 +37,43 @@ template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_ig
 			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + off);
 		}
 	};
-	const int wl0 = v2_src_offset(wave * 128 + lane, row_bytes), wl1 = v2_src_offset(wave * 128 + 64 + lane, row_bytes);
+	constexpr int WPW = NB / 2;  // 1-KiB pieces of a W slot per wave
+	const int wl0 = v2_src_offset(wave * (64 * WPW) + lane, row_bytes), wl1 = v2_src_offset(wave * (64 * WPW) + 64 + lane, row_bytes);
 	auto issue_w = [&](int q_cib, int q_tap, int slot) {
-		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * xbytes + slot * V2_WSLOT + wave * 2048);
+		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * xbytes + slot * V2_WSLOT + wave * (1024 * WPW));
 		const int base = (q_tap * p.CoutPad + co0) * row_bytes + q_cib * 128;
 		dma16(wsrc, dst, base + wl0);
-		dma16(wsrc, dst + 1024, base + wl1);
+		if (WPW == 2) dma16(wsrc, dst + 1024, base + wl1);
 	};
 
-	f32x4 acc[4][4];
+	f32x4 acc[4][NB];
 #pragma unroll
 	for (int i = 0; i < 4; ++i)
 #pragma unroll
-		for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+		for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 	typedef const __attribute__((address_space(3))) u32x4* lds_u4;
-	struct Frag { u32x4 a[4], b[4]; };
+	struct Frag { u32x4 a[4], b[NB]; };
 	// lane (r16, kb) holds k = 8 kb .. 8 kb + 7 of row r16: 16-byte chunk (ks * 4 + kb) of the 128-byte slab row.  Rows 16 apart
 	// share the swizzle term (+2048 B immediates); the second k32 substep is `address ^ 64`.
-	const int wrow = wn * 64 + r16;
+	const int wrow = wn * (16 * NB) + r16;
 	const unsigned w0 = lds_base + 2 * xbytes + ((wrow >> 1) << 8) + ((((wrow & 1) << 3) | (kb ^ ((wrow >> 1) & 7))) << 4);
 	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int ks, Frag& f) {
 		const int xrow = wm * 64 + r16 + tap_ * p.dil;
 		const unsigned xa = (lds_base + xs_off + ((xrow >> 1) << 8) + ((((xrow & 1) << 3) | (kb ^ ((xrow >> 1) & 7))) << 4)) ^ (ks << 6);
 		const unsigned wa = (w0 + ws_off) ^ (ks << 6);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { f.a[i] = *(lds_u4)(size_t)(xa + i * 2048); f.b[i] = *(lds_u4)(size_t)(wa + i * 2048); }
+		for (int i = 0; i < 4; ++i) {
+			f.a[i] = *(lds_u4)(size_t)(xa + i * 2048);
+			if (i < NB) f.b[i] = *(lds_u4)(size_t)(wa + i * 2048);
+		}
 	};
 	auto mma_frag = [&](const Frag& f) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 #pragma unroll
-			for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+			for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
 	};
 
 	{
@@ -112,13 +118,13 @@ template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_ig
 	}
 
 	// ---------------- epilogue: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg
-	constexpr int OPITCH = BN * sizeof(O) + 16;
+	constexpr int OPITCH = BN_ * sizeof(O) + 16;
 	char* const otile = smem;
-	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN]
+	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN_]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
 #pragma unroll
-	for (int ni = 0; ni < 4; ++ni) {
-		const int col = wn * 64 + ni * 16 + r16, co = co0 + col;
+	for (int ni = 0; ni < NB; ++ni) {
+		const int col = wn * (16 * NB) + ni * 16 + r16, co = co0 + col;
 		const bool cok = co < p.Cout;
 		const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
 		const float sc = (p.scale && cok) ? p.scale[co] : 1.f, sh = (p.scale && cok) ? p.shift[co] : 0.f;
@@ -139,19 +145,19 @@ template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_ig
 		if (p.stats) {
 			s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
 			s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-			if (kb == 0) { red[(0 * 4 + wm) * BN + col] = s1; red[(1 * 4 + wm) * BN + col] = s2; }
+			if (kb == 0) { red[(0 * 4 + wm) * BN_ + col] = s1; red[(1 * 4 + wm) * BN_ + col] = s2; }
 		}
 	}
 	__syncthreads();
-	if (p.stats && tid < BN && co0 + tid < p.Cout) {
+	if (p.stats && tid < BN_ && co0 + tid < p.Cout) {
 		double a = 0, q2 = 0;
 #pragma unroll
-		for (int m = 0; m < 4; ++m) { a += (double)red[(0 * 4 + m) * BN + tid]; q2 += (double)red[(1 * 4 + m) * BN + tid]; }
+		for (int m = 0; m < 4; ++m) { a += (double)red[(0 * 4 + m) * BN_ + tid]; q2 += (double)red[(1 * 4 + m) * BN_ + tid]; }
 		unsafeAtomicAdd(p.stats + co0 + tid, a);
 		unsafeAtomicAdd(p.stats + p.Cout + co0 + tid, q2);
 	}
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
-	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN / OEPC;
+	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN_ / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
 	for (int e = tid; e < V2_BM * OCHUNKS; e += V2_THREADS) {
 		const int row = e / OCHUNKS, ch = e % OCHUNKS;
@@ -162,6 +168,17 @@ template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_ig
 		if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 		else
 			for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = src[i];
+	}
+}
+
+template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2s_kernel(ConvParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int bid = blockIdx.x;
+	if (bid < p.full_tiles) {
+		v2s_tile<O, 4>(p, smem, xcd_remap(bid, p.full_tiles), 0);
+	} else {  // full_tiles is a multiple of 8, so (bid - full_tiles) keeps the workgroup's XCD; the two halves of a tile share an XCD (and its X tile in L2)
+		const int h = xcd_remap(bid - p.full_tiles, 2 * (p.total_tiles - p.full_tiles));
+		v2s_tile<O, 2>(p, smem, p.full_tiles + (h >> 1), h & 1);
 	}
 }
 

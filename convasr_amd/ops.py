@@ -133,7 +133,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	out_dtype = out_dtype or x.dtype
 	y = empty_cl(B, Cout, Tout, out_dtype, x.device)
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
-	family = 'conv1d_igemm_v2_kernel<bf16, 2>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
+	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
 	es, osz = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
 	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), ptr(stats), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
 	return y

@@ -11,7 +11,7 @@ def timeit(fn, iters=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 variants = [tuple(v.split('=')) for v in sys.argv[1:]] or [('base', '0'), ('alt', '64')]
-for (cin, cout, k, dil) in [(768, 768, 11, 1), (512, 640, 11, 1), (768, 896, 29, 2), (256, 256, 11, 1), (1024, 896, 29, 2)]:
+for (cin, cout, k, dil) in [(256, 256, 11, 1), (256, 384, 13, 1), (384, 384, 13, 1), (384, 256, 13, 1), (512, 512, 17, 1), (640, 640, 21, 1), (768, 768, 25, 1), (768, 896, 29, 2), (896, 768, 29, 2)]:
     B, T = 64, 751
     x = ops.as_cl(torch.randn(B, cin, T, device=d), dt)
     w = torch.randn(cout, cin, k, device=d) / (cin*k)**0.5
