@@ -78,25 +78,68 @@ struct BnActParams {
 	double* sums;
 	int act;
 	float lo, hi, p_drop;
+	unsigned drop_thr;  // an element is dropped when its 16 random bits are < drop_thr (= round(p * 65536))
+	float keep_scale;   // 65536 / (65536 - drop_thr): E[keep] = 1 exactly
 	uint64_t seed, offset;
 	int B, T, C;
+	int cgroups, rlanes, rows_per_block;  // thread tid -> channel group tid % cgroups (8 channels), row-lane tid / cgroups
+};
+
+static void set_dropout(BnActParams& p, float dropout_p, uint64_t seed, uint64_t offset) {
+	p.p_drop = dropout_p; p.seed = seed; p.offset = offset;
+	p.drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
+	if (p.drop_thr > 65535u) p.drop_thr = 65535u;
+	p.keep_scale = 65536.f / (float)(65536u - p.drop_thr);
+}
+
+// All three streaming kernels walk the (B*T, C) matrix the same way: a block owns a contiguous range of rows, a thread owns 8
+// consecutive channels (its per-channel constants stay in registers) and every rlanes-th row of the range; (b, t) and the
+// utterance's valid length are carried along instead of divided out per row.  Launch: blockDim = cgroups * rlanes <= 256.
+static void row_walk_config(BnActParams& p, int rows_per_thread, dim3& grid, dim3& block) {
+	const int c8 = p.C >> 3;
+	p.cgroups = c8 < 256 ? c8 : 256;
+	p.rlanes = 256 / p.cgroups;
+	p.rows_per_block = p.rlanes * rows_per_thread;
+	const int64_t rows = (int64_t)p.B * p.T;
+	int gy = (c8 + p.cgroups - 1) / p.cgroups;
+	if (gy > 4) gy = 4;
+	grid = dim3((unsigned)ceil_div64(rows, p.rows_per_block), gy);
+	block = dim3(p.cgroups * p.rlanes);
+}
+
+struct RowWalk {
+	int row, r1, b, t, nv;
+	int64_t idx;
+	__device__ __forceinline__ RowWalk(const BnActParams& p, int rl, int c) {
+		const int rows = p.B * p.T;
+		row = blockIdx.x * p.rows_per_block + rl;
+		r1 = min(rows, (int)(blockIdx.x + 1) * p.rows_per_block);
+		b = row / p.T; t = row - b * p.T;
+		nv = b < p.B ? valid_len(p.xlen, b, p.T) : 0;
+		idx = (int64_t)row * p.C + c;
+	}
+	__device__ __forceinline__ bool live() const { return row < r1; }
+	__device__ __forceinline__ bool masked() const { return t >= nv; }
+	__device__ __forceinline__ void next(const BnActParams& p) {
+		row += p.rlanes; idx += (int64_t)p.rlanes * p.C; t += p.rlanes;
+		while (t >= p.T) { t -= p.T; ++b; nv = b < p.B ? valid_len(p.xlen, b, p.T) : 0; }
+	}
 };
 
 // pre-activation value of 8 consecutive channels at row (b, t): y * scale + shift + sum_r (res_r * rscale_r + rshift_r)
-template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams& p, const ResArgs& ra, int64_t idx, int c, float (&yv)[8], float (&pre)[8]) {
+template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams& p, const ResArgs& ra, int64_t idx, int c, const float (&sc)[8], const float (&sh)[8], float (&yv)[8], float (&pre)[8]) {
 	load8<T>(reinterpret_cast<const T*>(p.y) + idx, yv);
-	float sc[8], sh[8];
-	if (p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
 #pragma unroll
 	for (int i = 0; i < 8; ++i) pre[i] = p.scale ? fmaf(yv[i], sc[i], sh[i]) : yv[i];
 	for (int r = 0; r < ra.n; ++r) {
 		float rv[8];
 		load8<T>(reinterpret_cast<const T*>(ra.res[r]) + idx, rv);
 		if (ra.rscale[r]) {
-			load8<float>(ra.rscale[r] + c, sc);
-			load8<float>(ra.rshift[r] + c, sh);
+			float rsc[8], rsh[8];
+			load8<float>(ra.rscale[r] + c, rsc);
+			load8<float>(ra.rshift[r] + c, rsh);
 #pragma unroll
-			for (int i = 0; i < 8; ++i) pre[i] += fmaf(rv[i], sc[i], sh[i]);
+			for (int i = 0; i < 8; ++i) pre[i] += fmaf(rv[i], rsc[i], rsh[i]);
 		} else {
 #pragma unroll
 			for (int i = 0; i < 8; ++i) pre[i] += rv[i];
@@ -104,43 +147,45 @@ template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams
 	}
 }
 
+// Dropout mask of the 8 elements starting at element index idx (a multiple of 8): one Philox4x32-7 block (the shortest
+// Crush-resistant round count of Salmon et al. 2011) keyed by (seed, offset + idx / 8) gives 8 x 16 random bits.
 __device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) {
-	// element index -> Philox counter idx/4; idx is a multiple of 8 so two counters cover the 8 lanes' elements
-	const float inv = 1.f / (1.f - p.p_drop);
-	float u[4];
-	philox4(p.seed, p.offset + (uint64_t)(idx >> 2), u);
+	unsigned r[4];
+	philox4x32<7>(p.seed, p.offset + (uint64_t)(idx >> 3), r);
 #pragma unroll
-	for (int i = 0; i < 4; ++i) keep[i] = u[i] >= p.p_drop ? inv : 0.f;
-	philox4(p.seed, p.offset + (uint64_t)(idx >> 2) + 1, u);
-#pragma unroll
-	for (int i = 0; i < 4; ++i) keep[4 + i] = u[i] >= p.p_drop ? inv : 0.f;
+	for (int i = 0; i < 4; ++i) {
+		keep[2 * i] = (r[i] & 0xffffu) >= p.drop_thr ? p.keep_scale : 0.f;
+		keep[2 * i + 1] = (r[i] >> 16) >= p.drop_thr ? p.keep_scale : 0.f;
+	}
 }
 
 template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra) {
 	const int c8 = p.C >> 3;
-	const int64_t total = (int64_t)p.B * p.T * c8;
-	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-		const int c = (int)(i % c8) << 3;
-		const int64_t row = i / c8;
-		const int t = (int)(row % p.T), b = (int)(row / p.T);
-		const int64_t idx = row * p.C + c;
-		float out[8];
-		if (t >= valid_len(p.xlen, b, p.T)) {
+	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
+	for (int cbase = blockIdx.y * p.cgroups; cbase < c8; cbase += gridDim.y * p.cgroups) {
+		if (cbase + cg >= c8) continue;
+		const int c = (cbase + cg) << 3;
+		float sc[8], sh[8];
+		if (p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+		for (RowWalk w(p, rl, c); w.live(); w.next(p)) {
+			float out[8];
+			if (w.masked()) {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) out[k] = 0.f;
-		} else {
-			float yv[8], pre[8];
-			pre_act8<T>(p, ra, idx, c, yv, pre);
+				for (int k = 0; k < 8; ++k) out[k] = 0.f;
+			} else {
+				float yv[8], pre[8];
+				pre_act8<T>(p, ra, w.idx, c, sc, sh, yv, pre);
 #pragma unroll
-			for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], p.act, p.lo, p.hi);
-			if (p.p_drop > 0.f) {
-				float keep[8];
-				dropout_keep8(p, idx, keep);
+				for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], p.act, p.lo, p.hi);
+				if (p.drop_thr) {
+					float keep[8];
+					dropout_keep8(p, w.idx, keep);
 #pragma unroll
-				for (int k = 0; k < 8; ++k) out[k] *= keep[k];
+					for (int k = 0; k < 8; ++k) out[k] *= keep[k];
+				}
 			}
+			store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
 		}
-		store8<T>(reinterpret_cast<T*>(p.out) + idx, out);
 	}
 }
 
@@ -164,83 +209,83 @@ static unsigned ew_grid(int64_t total) {
 	return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+#define BN_ROWS_PER_THREAD 8
+
 extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
                                   const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
                                   uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, void* stream) {
 	CONVASR_CHECK_ARG(y && z && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_fwd: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr) && dropout_p >= 0.f && dropout_p < 1.f, "bn_act_fwd: bad scale/shift/dropout");
+	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_fwd: B * T must fit in 31 bits");
 	BnActParams p = {};
-	p.y = y; p.out = z; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p;
-	p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
+	p.y = y; p.out = z; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi;
+	set_dropout(p, dropout_p, seed, offset);
+	p.B = B; p.T = T; p.C = C;
 	ResArgs ra;
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, nullptr, nullptr, nullptr)) return rc;
-	const int64_t total = (int64_t)B * T * (C >> 3);
-	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p, ra);
-	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p, ra);
+	dim3 grid, block;
+	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
+	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, p, ra);
+	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, p, ra);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
 	CONVASR_CHECK_LAUNCH("bn_act_fwd");
 	return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ backward pass 1: g and channel sums
-// Block = 256 threads = (256 / c8b) row-lanes x c8b channel-groups, where c8b = min(C/8, 256) ... each thread owns 8 channels
-// and strides over rows; per-channel partial sums are combined across the block in LDS and added to the global doubles.
-template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, int rows_per_block, float* __restrict__ ws) {
+// Per-channel partial sums are combined across the row-lanes of a block in LDS and stored (plain coalesced stores) to the
+// workspace [set][block][2C]; bn_bwd_finalize_kernel sums the blocks in fp64: deterministic, and no contended fp64 atomics
+// (4096 blocks x 2C atomics per call cost 4x the streaming time).
+template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, float* __restrict__ ws) {
 	__shared__ float red[256][17];
 	const int c8 = p.C >> 3;
-	const int cgroups = c8 < 256 ? c8 : 256;   // channel groups handled concurrently by one block
-	const int rlanes = 256 / cgroups;           // threads beyond cgroups * rlanes idle (e.g. C = 384: 48 groups x 5 row-lanes)
+	const int cgroups = p.cgroups, rlanes = p.rlanes;
 	const int cg = threadIdx.x % cgroups, rl = threadIdx.x / cgroups;
-	const bool lane_on = rl < rlanes;
-	const int64_t rows = (int64_t)p.B * p.T;
-	const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
 	for (int cbase = blockIdx.y * cgroups; cbase < c8; cbase += gridDim.y * cgroups) {
 		const int c = (cbase + cg) << 3;
-		const bool cok = lane_on && cbase + cg < c8;
-		float s1[8], s2[8], rs1[2][8], rs2[2][8];
+		const bool cok = cbase + cg < c8;
+		float s1[8], s2[8], rs1[RES ? 2 : 1][8], rs2[RES ? 2 : 1][8];  // RES: batch-normed residual inputs whose sums are wanted too
 #pragma unroll
-		for (int k = 0; k < 8; ++k) { s1[k] = s2[k] = 0.f; rs1[0][k] = rs1[1][k] = rs2[0][k] = rs2[1][k] = 0.f; }
-		float mean[8], istd[8];
+		for (int k = 0; k < 8; ++k) { s1[k] = s2[k] = 0.f; rs1[0][k] = rs2[0][k] = 0.f; if (RES) rs1[1][k] = rs2[1][k] = 0.f; }
+		float mean[8], istd[8], sc[8], sh[8];
 		if (cok && p.mean) { load8<float>(p.mean + c, mean); load8<float>(p.invstd + c, istd); }
-		for (int64_t row = r0 + rl; row < r1 && cok; row += rlanes) {
-			const int t = (int)(row % p.T), b = (int)(row / p.T);
-			const int64_t idx = row * p.C + c;
-			float g[8];
-			if (t >= valid_len(p.xlen, b, p.T)) {
+		if (cok && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+		if (cok)
+			for (RowWalk w(p, rl, c); w.live(); w.next(p)) {
+				float g[8];
+				if (w.masked()) {
 #pragma unroll
-				for (int k = 0; k < 8; ++k) g[k] = 0.f;
-			} else {
-				float yv[8], pre[8], dz[8];
-				pre_act8<T>(p, ra, idx, c, yv, pre);
-				load8<T>(reinterpret_cast<const T*>(p.dz) + idx, dz);
+					for (int k = 0; k < 8; ++k) g[k] = 0.f;
+				} else {
+					float yv[8], pre[8], dz[8];
+					pre_act8<T>(p, ra, w.idx, c, sc, sh, yv, pre);
+					load8<T>(reinterpret_cast<const T*>(p.dz) + w.idx, dz);
 #pragma unroll
-				for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
-				if (p.p_drop > 0.f) {
-					float keep[8];
-					dropout_keep8(p, idx, keep);
+					for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+					if (p.drop_thr) {
+						float keep[8];
+						dropout_keep8(p, w.idx, keep);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) g[k] *= keep[k];
-				}
-				if (p.mean) {
+						for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+					}
+					if (p.mean) {
 #pragma unroll
-					for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (yv[k] - mean[k]) * istd[k]; }
-				}
-				for (int r = 0; r < ra.n && r < 2; ++r) {
-					if (ra.rsums[r]) {
-						float rv[8], rm[8], ri[8];
-						load8<T>(reinterpret_cast<const T*>(ra.res[r]) + idx, rv);
-						load8<float>(ra.rmean[r] + c, rm);
-						load8<float>(ra.rinvstd[r] + c, ri);
+						for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (yv[k] - mean[k]) * istd[k]; }
+					}
+					for (int r = 0; RES && r < ra.n && r < 2; ++r) {
+						if (ra.rsums[r]) {
+							float rv[8], rm[8], ri[8];
+							load8<T>(reinterpret_cast<const T*>(ra.res[r]) + w.idx, rv);
+							load8<float>(ra.rmean[r] + c, rm);
+							load8<float>(ra.rinvstd[r] + c, ri);
 #pragma unroll
-						for (int k = 0; k < 8; ++k) { rs1[r][k] += g[k]; rs2[r][k] += g[k] * (rv[k] - rm[k]) * ri[k]; }
+							for (int k = 0; k < 8; ++k) { rs1[RES ? r : 0][k] += g[k]; rs2[RES ? r : 0][k] += g[k] * (rv[k] - rm[k]) * ri[k]; }
+						}
 					}
 				}
+				if (p.out) store8<T>(reinterpret_cast<T*>(p.out) + w.idx, g);
 			}
-			if (p.out) store8<T>(reinterpret_cast<T*>(p.out) + idx, g);
-		}
 		// block reduction over the row-lanes that share a channel group
-		// per-block partials go to the workspace [set][block][2C] with plain coalesced stores; bn_bwd_finalize_kernel sums them
-		// in fp64 (deterministic, and no contended fp64 atomics: 4096 blocks x 2C atomics per call cost 4x the streaming time)
 		auto reduce_to = [&](float (&a)[8], float (&bq)[8], int set) {
 #pragma unroll
 			for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = a[k]; red[threadIdx.x][8 + k] = bq[k]; }
@@ -260,37 +305,41 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_k
 			__syncthreads();
 		};
 		if (p.mean && p.sums) reduce_to(s1, s2, 0);
-		for (int r = 0; r < ra.n && r < 2; ++r)
-			if (ra.rsums[r]) reduce_to(rs1[r], rs2[r], 1 + r);
+		for (int r = 0; RES && r < ra.n && r < 2; ++r)
+			if (ra.rsums[r]) reduce_to(rs1[RES ? r : 0], rs2[RES ? r : 0], 1 + r);
 	}
 }
 
 // sums[set][.] = sum over blocks of ws[set][block][.], accumulated in fp64; for the main BN (set 0) optionally also the
 // per-channel coefficients of pass 2 (dy = A*g + Bc*y + D) and the parameter gradients dgamma = sum g*xhat, dbeta = sum g.
+// Block = 32 channels x 16 block-lanes (one 128-byte segment of a partial row per half wave).
 struct BnFinalizeSets {
 	double* dst[3];
 	const float* gamma; const float* mean; const float* invstd;
 	float* coef; float* dgamma; float* dbeta;
 	int accumulate; float invn;
 };
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C) {
-	__shared__ double red[2][16][64];
+__global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C) {
+	__shared__ double red[2][16][32];
 	const int set = blockIdx.y;
 	if (sets.dst[set] == nullptr && !(set == 0 && (sets.coef || sets.dgamma || sets.dbeta))) return;
-	const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+	const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, w = threadIdx.x >> 5;
 	double a = 0, b2 = 0;
-	if (c < C)
+	if (c < C) {
+		const float* base = ws + (int64_t)set * nblocks * 2 * C;
+#pragma unroll 4
 		for (int bq = w; bq < nblocks; bq += 16) {
-			const float* row = ws + ((int64_t)set * nblocks + bq) * 2 * C;
+			const float* row = base + (int64_t)bq * 2 * C;
 			a += (double)row[c];
 			b2 += (double)row[C + c];
 		}
-	red[0][w][threadIdx.x & 63] = a;
-	red[1][w][threadIdx.x & 63] = b2;
+	}
+	red[0][w][cl] = a;
+	red[1][w][cl] = b2;
 	__syncthreads();
 	if (w == 0 && c < C) {
 		double sg = 0, sgx = 0;
-		for (int i = 0; i < 16; ++i) { sg += red[0][i][threadIdx.x]; sgx += red[1][i][threadIdx.x]; }
+		for (int i = 0; i < 16; ++i) { sg += red[0][i][cl]; sgx += red[1][i][cl]; }
 		if (sets.dst[set]) { sets.dst[set][c] = sg; sets.dst[set][C + c] = sgx; }
 		if (set == 0) {
 			if (sets.coef) {
@@ -306,23 +355,24 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 	}
 }
 
-static void bn_bwd_grid(int B, int T, int C, int& rows_per_block, int& gx, int& gy) {
-	const int c8 = C >> 3;
-	const int cgroups = c8 < 256 ? c8 : 256;
-	const int rlanes = 256 / cgroups;
-	const int64_t rows = (int64_t)B * T;
-	rows_per_block = 16 * rlanes;
-	int64_t g = ceil_div64(rows, rows_per_block);
-	if (g > 768) { g = 768; rows_per_block = (int)ceil_div64(rows, g); }
-	gx = (int)ceil_div64(rows, rows_per_block);
-	gy = (c8 + cgroups - 1) / cgroups;
-	if (gy > 4) gy = 4;
+// at most BN_BWD_MAX_BLOCKS blocks (3 per CU): the finalize kernel reads one partial row per block and set
+#define BN_BWD_MAX_BLOCKS 768
+static void bn_bwd_config(BnActParams& p, dim3& grid, dim3& block) {
+	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
+	if (grid.x > BN_BWD_MAX_BLOCKS) {
+		const int64_t rows = (int64_t)p.B * p.T;
+		const int64_t per = ceil_div64(rows, BN_BWD_MAX_BLOCKS);
+		p.rows_per_block = (int)(ceil_div64(per, p.rlanes) * p.rlanes);
+		grid.x = (unsigned)ceil_div64(rows, p.rows_per_block);
+	}
 }
 
 extern "C" int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C) {
-	int rpb, gx, gy;
-	bn_bwd_grid(B, T, C, rpb, gx, gy);
-	return (int64_t)3 * gx * 2 * C * (int64_t)sizeof(float);
+	BnActParams p = {};
+	p.B = B; p.T = T; p.C = C;
+	dim3 grid, block;
+	bn_bwd_config(p, grid, block);
+	return (int64_t)3 * grid.x * 2 * C * (int64_t)sizeof(float);
 }
 
 extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift, const float* mean,
@@ -332,24 +382,31 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
                                          int accumulate, int B, int T, int C, void* stream) {
 	CONVASR_CHECK_ARG(dz && y && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG((mean == nullptr) == (invstd == nullptr), "bn_act_bwd_reduce: mean and invstd go together");
+	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_reduce: B * T must fit in 31 bits");
 	BnActParams p = {};
 	p.y = y; p.dz = dz; p.out = g; p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.xlen = xlen; p.sums = sums;
-	p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p; p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
+	p.act = act; p.lo = act_lo; p.hi = act_hi; p.B = B; p.T = T; p.C = C;
+	set_dropout(p, dropout_p, seed, offset);
 	ResArgs ra;
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, rmean, rinvstd, rsums)) return rc;
 	for (int r = 2; r < n_res; ++r) if (ra.rsums[r]) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: batch-normed residuals beyond the first two must be reduced by separate calls");
-	int rows_per_block, gx, gy;
-	bn_bwd_grid(B, T, C, rows_per_block, gx, gy);
+	dim3 grid, block;
+	bn_bwd_config(p, grid, block);
 	if (mean && !sums) { p.sums = reinterpret_cast<double*>(workspace); }  // (only a non-null marker: block partials always go to the workspace)
 	bool any = mean != nullptr;
 	for (int r = 0; r < n_res; ++r) any = any || ra.rsums[r] != nullptr;
 	CONVASR_CHECK_ARG(!(coef || dgamma || dbeta) || mean, "bn_act_bwd_reduce: coef / dgamma / dbeta need the main batch norm's mean / invstd");
 	CONVASR_CHECK_ARG(!any || workspace, "bn_act_bwd_reduce: workspace required when sums are requested");
-	dim3 grid(gx, gy);
 	hipStream_t st = (hipStream_t)stream;
-	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, st, p, ra, rows_per_block, (float*)workspace);
-	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, p, ra, rows_per_block, (float*)workspace);
-	else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: dtype %d", dtype);
+	bool res_sums = false;
+	for (int r = 0; r < n_res; ++r) res_sums = res_sums || ra.rsums[r] != nullptr;
+	if (dtype == CONVASR_F32) {
+		if (res_sums) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float, true>), grid, block, 0, st, p, ra, (float*)workspace);
+		else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float, false>), grid, block, 0, st, p, ra, (float*)workspace);
+	} else if (dtype == CONVASR_BF16) {
+		if (res_sums) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t, true>), grid, block, 0, st, p, ra, (float*)workspace);
+		else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t, false>), grid, block, 0, st, p, ra, (float*)workspace);
+	} else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: dtype %d", dtype);
 	if (any) {
 		BnFinalizeSets sets;
 		sets.dst[0] = (mean && sums) ? sums : nullptr;
@@ -357,7 +414,7 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 		sets.dst[2] = n_res > 1 ? ra.rsums[1] : nullptr;
 		sets.gamma = gamma; sets.mean = mean; sets.invstd = invstd; sets.coef = coef; sets.dgamma = dgamma; sets.dbeta = dbeta;
 		sets.accumulate = accumulate; sets.invn = 1.0f / (float)((int64_t)B * T);
-		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, 3), dim3(1024), 0, st, (const float*)workspace, sets, gx, C);
+		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32, 3), dim3(512), 0, st, (const float*)workspace, sets, (int)grid.x, C);
 	}
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_reduce");
 	return 0;
@@ -393,42 +450,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // dy = A[c] * g + Bc[c] * y + D[c] with g either given (FROM_DZ = false) or recomputed from dz: g = dz * act'(pre) * dropout * mask
 template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
 	const int c8 = p.C >> 3;
-	const int64_t total = (int64_t)p.B * p.T * c8;
+	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
 	ResArgs none;
 	none.n = 0;
-	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-		const int c = (int)(i % c8) << 3;
-		const int64_t row = i / c8;
-		const int64_t idx = row * p.C + c;
-		float yv[8], pre[8], g[8], A[8], Bc[8], D[8], out[8];
+	for (int cbase = blockIdx.y * p.cgroups; cbase < c8; cbase += gridDim.y * p.cgroups) {
+		if (cbase + cg >= c8) continue;
+		const int c = (cbase + cg) << 3;
+		float A[8], Bc[8], D[8], sc[8], sh[8];
 		load8<float>(coef + c, A);
 		load8<float>(coef + p.C + c, Bc);
 		load8<float>(coef + 2 * p.C + c, D);
-		if (FROM_DZ) {
-			const int t = (int)(row % p.T), b = (int)(row / p.T);
-			pre_act8<T>(p, none, idx, c, yv, pre);
-			if (t >= valid_len(p.xlen, b, p.T)) {
+		if (FROM_DZ && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+		for (RowWalk w(p, rl, c); w.live(); w.next(p)) {
+			float yv[8], pre[8], g[8], out[8];
+			if (FROM_DZ) {
+				pre_act8<T>(p, none, w.idx, c, sc, sh, yv, pre);
+				if (w.masked()) {
 #pragma unroll
-				for (int k = 0; k < 8; ++k) g[k] = 0.f;
-			} else {
-				float dz[8];
-				load8<T>(reinterpret_cast<const T*>(p.dz) + idx, dz);
+					for (int k = 0; k < 8; ++k) g[k] = 0.f;
+				} else {
+					float dz[8];
+					load8<T>(reinterpret_cast<const T*>(p.dz) + w.idx, dz);
 #pragma unroll
-				for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
-				if (p.p_drop > 0.f) {
-					float keep[8];
-					dropout_keep8(p, idx, keep);
+					for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+					if (p.drop_thr) {
+						float keep[8];
+						dropout_keep8(p, w.idx, keep);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+						for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+					}
 				}
+			} else {
+				load8<T>(reinterpret_cast<const T*>(p.dz) + w.idx, g);
+				load8<T>(reinterpret_cast<const T*>(p.y) + w.idx, yv);
 			}
-		} else {
-			load8<T>(reinterpret_cast<const T*>(p.dz) + idx, g);
-			load8<T>(reinterpret_cast<const T*>(p.y) + idx, yv);
-		}
 #pragma unroll
-		for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
-		store8<T>(dy + idx, out);
+			for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
+			store8<T>(dy + w.idx, out);
+		}
 	}
 }
 
@@ -436,17 +495,20 @@ extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void
                                         const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
                                         const float* xlen, int B, int T, int C, void* stream) {
 	CONVASR_CHECK_ARG(dz_or_g && y && dy && coef && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_apply: bad arguments (C must be a multiple of 8)");
+	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_apply: B * T must fit in 31 bits");
 	BnActParams p = {};
-	p.y = y; p.dz = dz_or_g; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.p_drop = dropout_p;
-	p.seed = seed; p.offset = offset; p.B = B; p.T = T; p.C = C;
-	const int64_t total = (int64_t)B * T * (C >> 3);
+	p.y = y; p.dz = dz_or_g; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi;
+	set_dropout(p, dropout_p, seed, offset);
+	p.B = B; p.T = T; p.C = C;
+	dim3 grid, block;
+	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
 	hipStream_t s = (hipStream_t)stream;
 	if (dtype == CONVASR_F32) {
-		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, true>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (float*)dy);
-		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, false>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (float*)dy);
+		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, true>), grid, block, 0, s, p, coef, (float*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, false>), grid, block, 0, s, p, coef, (float*)dy);
 	} else if (dtype == CONVASR_BF16) {
-		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, true>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (bf16_t*)dy);
-		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, false>), dim3(ew_grid(total)), dim3(256), 0, s, p, coef, (bf16_t*)dy);
+		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, true>), grid, block, 0, s, p, coef, (bf16_t*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, false>), grid, block, 0, s, p, coef, (bf16_t*)dy);
 	} else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_apply: dtype %d", dtype);
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_apply");
 	return 0;

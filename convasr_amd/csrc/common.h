@@ -96,17 +96,23 @@ __device__ __forceinline__ float act_grad(float pre, int act, float lo, float hi
 }
 
 // Philox4x32-10 (Salmon et al. 2011): counter = element index / 4, key = seed; returns 4 uniforms in [0,1)
-__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, float (&u)[4]) {
+template <int ROUNDS> __device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr, unsigned (&r)[4]) {
 	unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0, c3 = 0;
 	unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
-	for (int r = 0; r < 10; ++r) {
+	for (int i = 0; i < ROUNDS; ++i) {
 		unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
 		unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
 		unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
 		c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 		k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
 	}
-	u[0] = (c0 >> 8) * (1.0f / 16777216.0f); u[1] = (c1 >> 8) * (1.0f / 16777216.0f);
-	u[2] = (c2 >> 8) * (1.0f / 16777216.0f); u[3] = (c3 >> 8) * (1.0f / 16777216.0f);
+	r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, float (&u)[4]) {
+	unsigned r[4];
+	philox4x32<10>(seed, ctr, r);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) u[i] = (r[i] >> 8) * (1.0f / 16777216.0f);
 }

@@ -301,7 +301,7 @@ def test_bn_act_dropout_statistics_and_backward_consistency():
 	z = ops.bn_act(y, None, None, act, dropout_p = 0.2, seed = 1234, offset = 77)
 	keep = (z != 0).float().mean().item()
 	assert abs(keep - 0.8) < 0.01
-	close(z[z != 0], (y / 0.8)[z != 0], 1e-6, 1e-6, 'scaled by 1/(1-p)')
+	close(z[z != 0], (y / 0.8)[z != 0], 1e-5, 1e-6, 'scaled by 1/(1-p)')  # p is quantised to 16 bits: 13107/65536
 	z2 = ops.bn_act(y, None, None, act, dropout_p = 0.2, seed = 1234, offset = 77)
 	assert torch.equal(z, z2)
 	g = ops.bn_act_bwd_reduce(torch.ones_like(y), y, None, None, None, None, act, dropout_p = 0.2, seed = 1234, offset = 77)
