@@ -3,26 +3,46 @@
 //
 // Kernel 1 -- one workgroup per utterance, wave 0 runs the alpha sweep forward in time while wave 1 runs the beta sweep
 // backward, concurrently.  A lane owns NS consecutive states of the extended target (blank, y1, blank, y2, ...), so the
-// s-1 / s-2 neighbours are registers except for one 2-value shuffle per step; log-sum-exp in fp32; the next frame's
-// log-probs are fetched while the current one is being combined.  The lattices go to an L2/MALL-resident workspace.
-// Kernel 2 -- one wave per frame: posterior[c] = sum_{s: l'_s = c} exp(alpha + beta + nll - lp) accumulated in LDS bins,
+// s-1 / s-2 neighbours are registers except for two DPP wave shifts per step; log-sum-exp in fp32 in BASE 2 (v_exp_f32 and
+// v_log_f32 are base-2 instructions: log-probs are scaled by log2(e) once while they are staged, the lattices hold log2
+// values); the next frame's log-probs are fetched while the current one is being combined.  The lattices go to an L2/MALL-
+// resident workspace laid out [t][i][lane] (state s = lane * NS + i) so that every store / load instruction is one 256-byte row.
+// Every CTC_RENORM steps the sweep subtracts floor(max over states) from its column: an INTEGER in the log2 domain, so the
+// subtraction and the running sum of the offsets (kept per frame beside the lattice) are exact in fp32.  Column values stay
+// O(10) near the likely states instead of growing to ~3 T, and the fp32 lattice keeps ~1e-5 precision in the gradient at
+// T = 753, where an unnormalised fp32 lattice (ATen's CPU/CUDA kernels) is at ~1e-3 (scratch/ctc_prec.py vs float64).
+// Kernel 2 -- one wave per frame: posterior[c] = sum_{s: l'_s = c} exp2(alpha + beta - total - lp) accumulated in LDS bins,
 // grad = exp(lp) - posterior for t < olen, 0 beyond.
 #include "common.h"
 
 #define CTC_NEG (-INFINITY)
+#define CTC_LOG2E 1.4426950408889634f
+#define CTC_LN2 0.6931471805599453
+#define CTC_RENORM 8
 
+// base-2 log-sum-exp of three values that may be -inf
 __device__ __forceinline__ float lse3(float a, float b, float c) {
 	const float m = fmaxf(a, fmaxf(b, c));
-	if (m == CTC_NEG) return CTC_NEG;
-	return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+	const float r = m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m));
+	return m == CTC_NEG ? CTC_NEG : r;
+}
+
+// lane i <- lane i - 1 (lane 0 <- fill) / lane i <- lane i + 1 (lane 63 <- fill): one DPP move, no LDS round trip
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
 // LP_LDS: the utterance's whole (T, C) log-prob slab is first copied into LDS (114 KB at T = 753, C = 38) so that the T-step
 // recurrences read their per-frame class scores at LDS latency instead of L2 latency (the sweeps are latency-bound).
+// offs: [2][B][T] integer-valued offsets (true log2 alpha(t, s) = lattice value + offs[0][b][t]; beta: offs[1]);
+// tot: [B][2] = {integer part, remainder} of the utterance's log2 likelihood.
 template <int NS, bool LP_LDS>
 __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
                                                              const int64_t* __restrict__ ylen, float* __restrict__ nll, float* __restrict__ alpha,
-                                                             float* __restrict__ beta, int T, int C, int S_max, int blank) {
+                                                             float* __restrict__ beta, float* __restrict__ offs, float* __restrict__ tot, int B, int T, int C, int S_max, int blank) {
 	extern __shared__ __attribute__((aligned(16))) float ctc_smem[];
 	float* const fin = ctc_smem;            // [64 * NS]
 	float* const lpl = ctc_smem + 64 * NS;  // [T * C] when LP_LDS
@@ -32,13 +52,15 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 	const float* lpg = lp + (int64_t)b * T * C;
 	if (LP_LDS) {
 		const int n = (Tb > 0 && Tb <= T ? Tb : 0) * C;
-		for (int i = threadIdx.x; i < n; i += blockDim.x) lpl[i] = lpg[i];
+		for (int i = threadIdx.x; i < n; i += blockDim.x) lpl[i] = lpg[i] * CTC_LOG2E;
 		__syncthreads();
 	}
 	if (wave >= 2) return;
 	const float* lpb = LP_LDS ? lpl : lpg;
+	const float lps = LP_LDS ? 1.f : CTC_LOG2E;  // log-probs not staged in LDS are scaled as they are read
 	const int64_t* tg = targets + (int64_t)b * S_max;
 	float* const lat = (wave == 0 ? alpha : beta) + (int64_t)b * T * LP;
+	float* const off = offs + ((int64_t)wave * B + b) * T;
 
 	int cls[NS];
 	bool skip[NS], valid[NS];
@@ -57,26 +79,38 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 	}
 
 	float a[NS], cur[NS], nxt[NS];
+	float cum = 0.f;  // integer-valued: sum of the offsets subtracted so far
+	auto renorm = [&](float (&v)[NS]) {
+		float m = v[0];
+#pragma unroll
+		for (int i = 1; i < NS; ++i) m = fmaxf(m, v[i]);
+		m = wave_max(m);
+		if (m > CTC_NEG) {
+			const float k = floorf(m);
+#pragma unroll
+			for (int i = 0; i < NS; ++i) v[i] -= k;
+			cum += k;
+		}
+	};
 	if (wave == 0) {
 #pragma unroll
 		for (int i = 0; i < NS; ++i) {
 			const int s = lane * NS + i;
-			a[i] = (s < 2 && valid[i]) ? lpb[cls[i]] : CTC_NEG;
-			lat[s] = a[i];
+			a[i] = (s < 2 && valid[i]) ? lpb[cls[i]] * lps : CTC_NEG;
+			lat[i * 64 + lane] = a[i];
 		}
+		if (lane == 0) off[0] = 0.f;
 		if (Tb > 1) {
 #pragma unroll
-			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)1 * C + cls[i]];
+			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)1 * C + cls[i]] * lps;
 		}
 		for (int t = 1; t < Tb; ++t) {
 			if (t + 1 < Tb) {
 #pragma unroll
-				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t + 1) * C + cls[i]];
+				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t + 1) * C + cls[i]] * lps;
 			}
-			float p1 = __shfl_up(a[NS - 1], 1, 64), p2 = __shfl_up(NS >= 2 ? a[NS >= 2 ? NS - 2 : 0] : 0.f, 1, 64);
-			if (NS == 1) p2 = __shfl_up(a[0], 2, 64);
-			if (lane == 0) { p1 = CTC_NEG; p2 = CTC_NEG; }
-			if (NS == 1 && lane == 1) p2 = CTC_NEG;
+			const float p1 = wave_shr1(a[NS - 1], CTC_NEG);
+			const float p2 = NS >= 2 ? wave_shr1(a[NS >= 2 ? NS - 2 : 0], CTC_NEG) : wave_shr1(p1, CTC_NEG);
 			float n[NS];
 #pragma unroll
 			for (int i = NS - 1; i >= 0; --i) {
@@ -84,8 +118,10 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 				const float m2 = i >= 2 ? a[i - 2] : (i == 1 ? p1 : p2);
 				n[i] = valid[i] ? lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i] : CTC_NEG;
 			}
+			if ((t & (CTC_RENORM - 1)) == 0) renorm(n);
 #pragma unroll
-			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + lane * NS + i] = n[i]; cur[i] = nxt[i]; }
+			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + i * 64 + lane] = n[i]; cur[i] = nxt[i]; }
+			if (lane == 0) off[t] = cum;
 		}
 #pragma unroll
 		for (int i = 0; i < NS; ++i) fin[lane * NS + i] = a[i];
@@ -94,29 +130,31 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 		if (lane == 0) {
 			const float l1 = fin[L - 1], l2 = L >= 2 ? fin[L - 2] : CTC_NEG;
 			const float m = fmaxf(l1, l2);
-			nll[b] = m == CTC_NEG ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+			const float rem = m + log2f(exp2f(l1 - m) + exp2f(l2 - m));
+			nll[b] = m == CTC_NEG ? INFINITY : (float)(-CTC_LN2 * ((double)cum + (double)rem));
+			tot[2 * b] = cum;
+			tot[2 * b + 1] = rem;
 		}
 	} else {
 		const float* lrow = lpb + (int64_t)(Tb - 1) * C;
 #pragma unroll
 		for (int i = 0; i < NS; ++i) {
 			const int s = lane * NS + i;
-			a[i] = (valid[i] && s >= L - 2) ? lrow[cls[i]] : CTC_NEG;
-			lat[(int64_t)(Tb - 1) * LP + s] = a[i];
+			a[i] = (valid[i] && s >= L - 2) ? lrow[cls[i]] * lps : CTC_NEG;
+			lat[(int64_t)(Tb - 1) * LP + i * 64 + lane] = a[i];
 		}
+		if (lane == 0) off[Tb - 1] = 0.f;
 		if (Tb > 1) {
 #pragma unroll
-			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)(Tb - 2) * C + cls[i]];
+			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)(Tb - 2) * C + cls[i]] * lps;
 		}
 		for (int t = Tb - 2; t >= 0; --t) {
 			if (t > 0) {
 #pragma unroll
-				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t - 1) * C + cls[i]];
+				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t - 1) * C + cls[i]] * lps;
 			}
-			float p1 = __shfl_down(a[0], 1, 64), p2 = __shfl_down(NS >= 2 ? a[NS >= 2 ? 1 : 0] : 0.f, 1, 64);
-			if (NS == 1) p2 = __shfl_down(a[0], 2, 64);
-			if (lane == 63) { p1 = CTC_NEG; p2 = CTC_NEG; }
-			if (NS == 1 && lane == 62) p2 = CTC_NEG;
+			const float p1 = wave_shl1(a[0], CTC_NEG);
+			const float p2 = NS >= 2 ? wave_shl1(a[NS >= 2 ? 1 : 0], CTC_NEG) : wave_shl1(p1, CTC_NEG);
 			float n[NS];
 #pragma unroll
 			for (int i = 0; i < NS; ++i) {
@@ -124,8 +162,10 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 				const float m2 = i + 2 < NS ? a[i + 2 < NS ? i + 2 : 0] : (i + 2 == NS ? p1 : p2);
 				n[i] = valid[i] ? lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i] : CTC_NEG;
 			}
+			if ((t & (CTC_RENORM - 1)) == 0) renorm(n);
 #pragma unroll
-			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + lane * NS + i] = n[i]; cur[i] = nxt[i]; }
+			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + i * 64 + lane] = n[i]; cur[i] = nxt[i]; }
+			if (lane == 0) off[t] = cum;
 		}
 	}
 }
@@ -133,13 +173,13 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 template <int NS>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
                                                        const int64_t* __restrict__ ylen, const float* __restrict__ nll, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta, float* __restrict__ grad, int T, int C, int S_max, int blank, int t_per_block) {
+                                                       const float* __restrict__ beta, const float* __restrict__ offs, const float* __restrict__ tot, float* __restrict__ grad,
+                                                       int B, int T, int C, int S_max, int blank, int t_per_block) {
 	extern __shared__ float bins[];  // [4][C]
 	const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	constexpr int LP = 64 * NS;
 	const int Tb = (int)olen[b], S = (int)ylen[b], L = 2 * S + 1;
-	const float nl = nll[b];
-	const bool feasible = nl < INFINITY;
+	const bool feasible = nll[b] < INFINITY;
 	const int64_t* tg = targets + (int64_t)b * S_max;
 	int cls[NS];
 #pragma unroll
@@ -159,14 +199,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 		for (int c = lane; c < C; c += 64) mybins[c] = 0.f;
 		__builtin_amdgcn_s_waitcnt(0xc07f);
 		__builtin_amdgcn_wave_barrier();
-		const float* ar = alpha + ((int64_t)b * T + t) * LP + lane * NS;
-		const float* br = beta + ((int64_t)b * T + t) * LP + lane * NS;
+		const float* ar = alpha + ((int64_t)b * T + t) * LP + lane;
+		const float* br = beta + ((int64_t)b * T + t) * LP + lane;
+		// alpha + beta - total = (lattice values - remainder of total) + (offsets - integer part of total): the second group is exact
+		const float shift = (offs[(int64_t)b * T + t] + offs[((int64_t)B + b) * T + t] - tot[2 * b]) - tot[2 * b + 1];
 		float blank_sum = 0.f;
 #pragma unroll
 		for (int i = 0; i < NS; ++i) {
 			const int s = lane * NS + i;
 			if (s < L) {
-				const float v = __expf(ar[i] + br[i] + nl - row[cls[i]]);
+				const float v = __builtin_amdgcn_exp2f((ar[i * 64] + br[i * 64]) + (shift - row[cls[i]] * CTC_LOG2E));
 				if (s & 1) atomicAdd(mybins + cls[i], v);
 				else blank_sum += v;
 			}
@@ -191,7 +233,7 @@ static int ctc_ns(int S_max) {
 extern "C" int64_t convasr_ctc_workspace_bytes(int B, int T, int S_max) {
 	const int ns = ctc_ns(S_max);
 	if (ns < 0) return -1;
-	return 2 * (int64_t)B * T * 64 * ns * (int64_t)sizeof(float);
+	return (2 * (int64_t)B * T * 64 * ns + 2 * (int64_t)B * T + 2 * (int64_t)B) * (int64_t)sizeof(float);  // lattices, offsets, totals
 }
 
 extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, const int64_t* olen, const int64_t* ylen, float* nll, float* grad,
@@ -203,6 +245,8 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
 	hipStream_t s = (hipStream_t)stream;
 	float* alpha = (float*)workspace;
 	float* beta = alpha + (int64_t)B * T * 64 * ns;
+	float* offs = beta + (int64_t)B * T * 64 * ns;
+	float* tot = offs + 2 * (int64_t)B * T;
 	const int t_per_block = 32;
 	dim3 ggrid((T + t_per_block - 1) / t_per_block, B);
 	const size_t gsmem = 4 * (size_t)C * sizeof(float);
@@ -213,9 +257,9 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
 			auto kern = ctc_alpha_beta_kernel<NS, true>; \
 			static bool set = false; \
 			if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-			hipLaunchKernelGGL(kern, dim3(B), dim3(256), 64 * NS * sizeof(float) + lds_lp, s, log_probs, targets, olen, ylen, nll, alpha, beta, T, C, S_max, blank); \
-		} else hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS, false>), dim3(B), dim3(128), 64 * NS * sizeof(float), s, log_probs, targets, olen, ylen, nll, alpha, beta, T, C, S_max, blank); \
-		if (grad) hipLaunchKernelGGL((ctc_grad_kernel<NS>), ggrid, dim3(256), gsmem, s, log_probs, targets, olen, ylen, nll, alpha, beta, grad, T, C, S_max, blank, t_per_block); \
+			hipLaunchKernelGGL(kern, dim3(B), dim3(256), 64 * NS * sizeof(float) + lds_lp, s, log_probs, targets, olen, ylen, nll, alpha, beta, offs, tot, B, T, C, S_max, blank); \
+		} else hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS, false>), dim3(B), dim3(128), 64 * NS * sizeof(float), s, log_probs, targets, olen, ylen, nll, alpha, beta, offs, tot, B, T, C, S_max, blank); \
+		if (grad) hipLaunchKernelGGL((ctc_grad_kernel<NS>), ggrid, dim3(256), gsmem, s, log_probs, targets, olen, ylen, nll, alpha, beta, offs, tot, grad, B, T, C, S_max, blank, t_per_block); \
 		break;
 	switch (ns) {
 		CTC_CASE(1) CTC_CASE(2) CTC_CASE(3) CTC_CASE(4) CTC_CASE(5) CTC_CASE(6) CTC_CASE(8) CTC_CASE(12) CTC_CASE(16)

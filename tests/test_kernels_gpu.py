@@ -359,14 +359,20 @@ def test_ctc_against_oracle(shape):
 	olen[0] = T
 	ylen = torch.randint(max(S // 2, 1), S + 1, (B, ))
 	ylen[-1] = S
-	lpr = lp.clone().requires_grad_(True)
+	# the oracle runs in float64: at T = 753 ATen's own fp32 lattice is only good to ~1.2e-3 in the gradient (measured against
+	# float64, scratch/ctc_prec.py), the renormalised fp32 lattice of the HIP kernel to ~1e-4
+	lpr = lp.double().requires_grad_(True)
 	ref = O.ctc_loss(lpr, y, olen, ylen)
 	ref[torch.isfinite(ref)].sum().backward()
 	nll, grad = ops.ctc_loss(ops.as_cl(lp.to(dev())), y, olen, ylen, C - 1)
 	fin = torch.isfinite(ref)
 	assert torch.equal(torch.isfinite(nll).cpu(), fin)
-	close(nll.cpu()[fin], ref.detach()[fin], 1e-5, 1e-4, 'nll')  # BASELINE bar: 1e-4 relative
-	close(grad.cpu()[fin], lpr.grad[fin], 1e-3, 2e-5, 'grad')
+	close(nll.cpu()[fin], ref.detach().float()[fin], 1e-5, 1e-4, 'nll')  # BASELINE bar: 1e-4 relative
+	close(grad.cpu()[fin], lpr.grad.float()[fin], 1e-4, 2e-4, 'grad vs float64 oracle')
+	lp32 = lp.clone().requires_grad_(True)
+	ref32 = O.ctc_loss(lp32, y, olen, ylen)
+	ref32[torch.isfinite(ref32)].sum().backward()
+	close(grad.cpu()[fin], lp32.grad[fin], 1e-3, 3e-3 if T > 500 else 1e-4, 'grad vs float32 oracle')
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
