@@ -6,12 +6,17 @@
 // the dY rows and the X rows (+ tap halo) are brought in by LDS-DMA into a 4-deep ring (issued three chunks ahead, counted
 // vmcnt, raw s_barrier); both MFMA operands are column reads of row-major [t][c] tiles, served by ds_read_b64_tr_b16, with
 // the 64-byte blocks of each 256-byte row XOR-swizzled by (row & 3) so the four rows a transposed read touches fall on
-// different banks (the swizzle lives in the DMA's per-lane source address).  Waves 0-3 own taps {0,1} of the group, waves 4-7
-// taps {2,3}; each wave a 64 x 64 sub-tile x 2 taps = 128 accumulator registers, two waves per SIMD.
+// different banks (the swizzle lives in the DMA's per-lane source address).  Each wave owns a 64 x 64 sub-tile and two
+// accumulator slots (128 accumulator registers), two waves per SIMD (one of waves 0-3, one of waves 4-7).  A full group gives
+// waves 0-3 taps {0,1} and waves 4-7 taps {2,3}; a ragged last group (K mod 4 taps) is still split evenly: with 3 taps each half
+// takes one whole tap plus half of the third one's frames (k-substeps {0,1} / {2,3} of every chunk), with 2 taps one each, with
+// 1 tap half of its frames each -- the two partial sums of a shared tap meet in LDS in the epilogue.  A group's time is then
+// proportional to its tap count (K = 11: 2.75 group-times instead of 3; K = 29: 7.25 instead of 8).
 // Zero padding of the conv and ragged chunk ends are the per-utterance buffer descriptors' range checks.
 // (A 16x16x32-MFMA build of this kernel -- 32-byte-unit swizzle, 223 VGPRs -- is bit-identical and measured 3-5 % SLOWER in the
 // same process, the opposite of the forward kernel where that shape wins 3-7 %: kept on 32x32x16.)
 #include "conv_common.h"
+#include <type_traits>
 
 #define W2_THREADS 512
 #define W2_BKT 64
@@ -57,8 +62,15 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 	const int tg = unit % p.tap_groups, ci_t = (unit / p.tap_groups) % p.ci_tiles, co_t = unit / (p.tap_groups * p.ci_tiles);
 	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * WG_TG;
 	const int c_begin = split * p.chunks_per_split, c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
-	const int tapA = tap0 + 2 * tp, tapB = tapA + 1;
-	const bool actA = tapA < p.K, actB = tapB < p.K;
+	// slot A / slot B of this wave: tap index, mask of the k-substeps (of 4 per chunk) it covers, shared with the other wave half?
+	const int ntaps = min(WG_TG, p.K - tap0);
+	int tapA, tapB;
+	unsigned mA, mB;
+	bool shA = false, shB = false;
+	if (ntaps == 4) { tapA = tap0 + 2 * tp; tapB = tapA + 1; mA = 15u; mB = 15u; }
+	else if (ntaps == 3) { tapA = tap0 + tp; tapB = tap0 + 2; mA = 15u; mB = tp ? 12u : 3u; shB = true; }
+	else if (ntaps == 2) { tapA = tap0 + tp; tapB = tapA; mA = 15u; mB = 0u; }
+	else { tapA = tap0; tapB = tap0; mA = tp ? 12u : 3u; mB = 0u; shA = true; }
 
 	const int xbytes = p.x_rows * 256;  // x_rows is a multiple of 4: whole 1-KiB pieces
 	const int stage_bytes = W2_YBYTES + xbytes;
@@ -130,56 +142,92 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 	};
 
 	const bool late = wave >= 4;  // waves 4-7 issue their DMA pieces mid-chunk, waves 0-3 up front
-	int stage = 0;
-	F2 fa0, fa1, fbA, fbB;
-	const unsigned st0 = lds_base;
-	if (c_begin < c_end) { load_a(st0, 0, fa0); if (actA) load_bA(st0, 0, fbA); }
-	for (int c = c_begin; c < c_end; ++c) {
-		const bool more = c + 3 < c_end;
-		if (more && !late) issue(c + 3, (stage + 3) & 3);
-		const unsigned st = lds_base + stage * stage_bytes, stn = lds_base + ((stage + 1) & 3) * stage_bytes;
-		const bool has_next = c + 1 < c_end;
-		// unit (kk, A): MFMAs on (fa, fbA) while the tap-B fragments arrive; unit (kk, B): MFMAs on (fa, fbB) while the next
-		// substep's dY and tap-A fragments arrive.  fa0 / fa1 alternate by kk parity.
-#define W2_SUBSTEP(KK, FA_CUR, FA_NXT)                                                   \
-		if (actB) load_bB(st, KK, fbB);                                                  \
-		if (actA) mma4(FA_CUR, fbA, acc[0]);                                             \
-		if (KK < 3) { load_a(st, KK + 1, FA_NXT); if (actA) load_bA(st, KK + 1, fbA); } \
-		else if (has_next) { load_a(stn, 0, FA_NXT); if (actA) load_bA(stn, 0, fbA); }  \
-		if (actB) mma4(FA_CUR, fbB, acc[1]);
-		W2_SUBSTEP(0, fa0, fa1)
-		W2_SUBSTEP(1, fa1, fa0)
-		if (more && late) issue(c + 3, (stage + 3) & 3);
-		W2_SUBSTEP(2, fa0, fa1)
-		W2_SUBSTEP(3, fa1, fa0)
+	// The chunk loop is instantiated per (slot A mask, slot B mask) so that every fragment load and MFMA group is unconditional
+	// inside it (runtime masks cost 5-14 %: waits at every branch join).
+	auto chunk_loop = [&](auto MA_, auto MB_) {
+		constexpr unsigned MA = decltype(MA_)::value, MB = decltype(MB_)::value, MAB = MA | MB;
+		int stage = 0;
+		F2 fa0, fa1, fbA, fbB;
+		const unsigned st0 = lds_base;
+		if (c_begin < c_end) { if (MAB & 1u) load_a(st0, 0, fa0); if (MA & 1u) load_bA(st0, 0, fbA); }
+		for (int c = c_begin; c < c_end; ++c) {
+			const bool more = c + 3 < c_end;
+			if (more && !late) issue(c + 3, (stage + 3) & 3);
+			const unsigned st = lds_base + stage * stage_bytes, stn = lds_base + ((stage + 1) & 3) * stage_bytes;
+			const bool has_next = c + 1 < c_end;
+			// unit (kk, A): MFMAs on (fa, fbA) while the slot-B fragments arrive; unit (kk, B): MFMAs on (fa, fbB) while the next
+			// substep's dY and slot-A fragments arrive.  fa0 / fa1 alternate by kk parity.
+#define W2_SUBSTEP(KK, FA_CUR, FA_NXT)                                                                                              \
+			if ((MB >> KK) & 1u) load_bB(st, KK, fbB);                                                                                  \
+			if ((MA >> KK) & 1u) mma4(FA_CUR, fbA, acc[0]);                                                                             \
+			if (KK < 3) { if ((MAB >> ((KK + 1) & 3)) & 1u) load_a(st, KK + 1, FA_NXT); if ((MA >> ((KK + 1) & 3)) & 1u) load_bA(st, KK + 1, fbA); } \
+			else if (has_next) { if (MAB & 1u) load_a(stn, 0, FA_NXT); if (MA & 1u) load_bA(stn, 0, fbA); }                             \
+			if ((MB >> KK) & 1u) mma4(FA_CUR, fbB, acc[1]);
+			W2_SUBSTEP(0, fa0, fa1)
+			W2_SUBSTEP(1, fa1, fa0)
+			if (more && late) issue(c + 3, (stage + 3) & 3);
+			W2_SUBSTEP(2, fa0, fa1)
+			W2_SUBSTEP(3, fa1, fa0)
 #undef W2_SUBSTEP
-		// leave only the pieces issued in this iteration (chunk c + 3) in flight
-		if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-		else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__builtin_amdgcn_s_barrier();
-		stage = (stage + 1) & 3;
-	}
+			// leave only the pieces issued in this iteration (chunk c + 3) in flight
+			if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+			else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			stage = (stage + 1) & 3;
+		}
+	};
+	typedef std::integral_constant<unsigned, 15u> M15;
+	typedef std::integral_constant<unsigned, 12u> M12;
+	typedef std::integral_constant<unsigned, 3u> M3;
+	typedef std::integral_constant<unsigned, 0u> M0;
+	if (ntaps == 4) chunk_loop(M15(), M15());
+	else if (ntaps == 3) { if (tp) chunk_loop(M15(), M12()); else chunk_loop(M15(), M3()); }
+	else if (ntaps == 2) chunk_loop(M15(), M0());
+	else { if (tp) chunk_loop(M12(), M0()); else chunk_loop(M3(), M0()); }
 
+	// epilogue: a tap shared by the two wave halves is summed through LDS (the ring is dead after the last barrier), the lower
+	// half stores it; [wave & 3][register][lane] floats = 64 KiB
 	const int r = lane & 31, h = lane >> 5;
+	float* const red = reinterpret_cast<float*>(smem) + (wave & 3) * 64 * 64 + lane;
 #pragma unroll
 	for (int a = 0; a < 2; ++a) {
-		const int tap = tapA + a;
-		if (tap < p.K) {
-			float* sl = p.slab + ((int64_t)split * p.K + tap) * p.Cout * p.Cin;
+		const bool shared = a == 0 ? shA : shB;   // workgroup-uniform
+		const unsigned m = a == 0 ? mA : mB;
+		if (shared) {
+			if (tp == 1) {
 #pragma unroll
-			for (int mi = 0; mi < 2; ++mi)
+				for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-				for (int ni = 0; ni < 2; ++ni) {
-					const int ci = ci0 + wn * 64 + ni * 32 + r;
+					for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-					for (int g = 0; g < 16; ++g) {
-						const int co = co0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-						sl[(int64_t)co * p.Cin + ci] = acc[a][mi][ni][g];
-					}
-				}
+						for (int g = 0; g < 16; ++g) red[((mi * 2 + ni) * 16 + g) * 64] = acc[a][mi][ni][g];
+			}
+			__syncthreads();
+			if (tp == 0) {
+#pragma unroll
+				for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+					for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+						for (int g = 0; g < 16; ++g) acc[a][mi][ni][g] += red[((mi * 2 + ni) * 16 + g) * 64];
+			}
 		}
+		if (m == 0u || (shared && tp == 1)) continue;
+		const int tap = a == 0 ? tapA : tapB;
+		float* sl = p.slab + ((int64_t)split * p.K + tap) * p.Cout * p.Cin;
+#pragma unroll
+		for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+			for (int ni = 0; ni < 2; ++ni) {
+				const int ci = ci0 + wn * 64 + ni * 32 + r;
+#pragma unroll
+				for (int g = 0; g < 16; ++g) {
+					const int co = co0 + wm * 64 + mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+					sl[(int64_t)co * p.Cin + ci] = acc[a][mi][ni][g];
+				}
+			}
 	}
 }
 
