@@ -1,4 +1,4 @@
-// bf16 fast path of the weight gradient (stride 1, Cin % 128 == 0, Cout % 128 == 0, K >= 2).
+// bf16 fast path of the weight gradient (stride 1, Cin % 128 == 0, Cout % 128 == 0).
 //
 //   dW[tap][co][ci] = sum_(b,t) dY[b,t,co] * X[b, t + tap*dil - pad, ci]        M = co, N = ci, reduction over (b, t)
 //
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 
 // Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
 int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s) {
-	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0 || p.K < 2) return 0;
+	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0) return 0;
 	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.Tout * p.Cout * 2 >= (1ll << 31)) return 0;
 	WgradParams q = p;
 	wgrad_plan(q, W2_BKT, 1.6);
