@@ -147,27 +147,31 @@ extern "C" int convasr_log_softmax_bwd(const float* grad_lp, const float* log_pr
 }
 
 // ------------------------------------------------------------------------------------------------ entropy / argmax / row scaling
-__global__ __launch_bounds__(256) void entropy_kernel(const float* __restrict__ lp, const int64_t* __restrict__ olen, float* __restrict__ ent, int T, int C, float eps) {
-	__shared__ float red[4];
+// one workgroup per utterance walks its n x C valid log-probs as one flat coalesced array (C = 38 would leave 40 % of a
+// frame-per-wave mapping idle); fixed summation order: deterministic
+__global__ __launch_bounds__(1024) void entropy_kernel(const float* __restrict__ lp, const int64_t* __restrict__ olen, float* __restrict__ ent, int T, int C, float eps) {
+	__shared__ float red[16];
 	const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int n = olen ? (int)olen[b] : T;
-	float acc = 0.f;
-	for (int t = w; t < n && t < T; t += 4) {
-		const float* p = lp + ((int64_t)b * T + t) * C;
-		for (int c = lane; c < C; c += 64) { float v = p[c]; acc -= expf(v) * v; }
-	}
-	acc = wave_sum(acc);
+	const int total = min(n, T) * C;
+	const float* p = lp + (int64_t)b * T * C;
+	float a0 = 0.f, a1 = 0.f;
+	int i = threadIdx.x;
+	for (; i + 1024 < total; i += 2048) { const float v0 = p[i], v1 = p[i + 1024]; a0 -= expf(v0) * v0; a1 -= expf(v1) * v1; }
+	if (i < total) { const float v = p[i]; a0 -= expf(v) * v; }
+	float acc = wave_sum(a0 + a1);
 	if (lane == 0) red[w] = acc;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		float s = red[0] + red[1] + red[2] + red[3];
+		float s = 0.f;
+		for (int k = 0; k < 16; ++k) s += red[k];
 		ent[b] = olen ? s / (eps + (float)n) : s / (float)T;
 	}
 }
 
 extern "C" int convasr_entropy(const float* log_probs, const int64_t* olen, float* ent, int B, int T, int C, float eps, void* stream) {
 	CONVASR_CHECK_ARG(log_probs && ent && B > 0 && T > 0 && C > 0, "entropy: bad arguments");
-	hipLaunchKernelGGL(entropy_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, log_probs, olen, ent, T, C, eps);
+	hipLaunchKernelGGL(entropy_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, log_probs, olen, ent, T, C, eps);
 	CONVASR_CHECK_LAUNCH("entropy");
 	return 0;
 }
