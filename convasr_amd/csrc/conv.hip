@@ -515,7 +515,16 @@ extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout
 	WgradParams p;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil;
 	p.pad = 0;
-	return (int64_t)WGRAD_MAX_SPLITS * K * (int64_t)Cout * Cin * 4;
+	// the largest split count any of the kernels' plans would pick for this shape (bf16 LDS-DMA kernel, bf16 / fp32 general kernel)
+	int splits = 1;
+	const int bkt[3] = {64, WgTile<bf16_t>::BKT, WgTile<float>::BKT};
+	const double us[3] = {1.6, 2.7, 11.0};
+	for (int i = 0; i < 3; ++i) {
+		WgradParams q = p;
+		wgrad_plan(q, bkt[i], us[i]);
+		if (q.splits > splits) splits = q.splits;
+	}
+	return (int64_t)splits * K * (int64_t)Cout * Cin * 4;
 }
 
 template <typename T, int XI, bool AX, bool AY> static void launch_wgrad(const WgradParams& p, size_t smem, hipStream_t s) {

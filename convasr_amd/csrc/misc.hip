@@ -241,7 +241,12 @@ extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* str
 }
 
 __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
-                                                       int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first) {
+                                                       int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first,
+                                                       const float* __restrict__ loss_gate) {
+	if (loss_gate) {
+		const float l = *loss_gate;
+		if (!(fabsf(l) < INFINITY)) return;  // inf or NaN loss: the step is skipped (train.py:769-772)
+	}
 	float clip = 1.f;
 	if (sumsq) {
 		float total = (float)sqrt(*sumsq);
@@ -263,11 +268,11 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
 }
 
 extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm, float lr,
-                                float momentum, float weight_decay, int nesterov, int first, void* stream) {
+                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, void* stream) {
 	CONVASR_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || buf), "sgd_step: bad arguments");
 	int64_t blocks = ceil_div64(n, 256);
 	if (blocks > 4096) blocks = 4096;
-	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first);
+	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate);
 	CONVASR_CHECK_LAUNCH("sgd_step");
 	return 0;
 }

@@ -76,13 +76,14 @@ class SGD:
 	def zero_grad(self, set_to_none = False):
 		self.flat.zero_grad()
 
-	def step(self):
+	def step(self, loss_gate = None):
+		"""loss_gate: optional 1-element fp32 device tensor; a non-finite value turns the launch into a no-op (device-side skip)."""
 		g = self.param_groups[0]
 		flat = self.flat
 		if flat.clip is None:
 			flat.finalize_grads()
 		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
-		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None)
+		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate)
 		self.steps += 1
 		flat.clip = None
 		Fn.bump_param_epoch()  # packed bf16/fp32 weight copies are stale now
@@ -98,11 +99,15 @@ class SGD:
 			g.update(s)
 
 
-def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_iterations = 1, iteration = 0, world_size = 1, sync_metrics = True):
+def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_iterations = 1, iteration = 0, world_size = 1, sync_metrics = True, device_gate = True):
 	"""One iteration of the reference loop, train.py:745-783.
 
-	Returns dict(loss, loss_cur, entropy, grad_norm, skipped) of 0-d device tensors (read them lazily: no forced host sync
-	except the inf/NaN gate the reference also has at train.py:769)."""
+	Returns dict(loss, loss_cur, entropy, grad_norm, skipped) of 0-d device tensors (read them lazily: no forced host sync).
+	The reference's inf/NaN gate (train.py:769: skip backward and the optimizer step) is applied on the device when
+	device_gate is set and there is no gradient accumulation: backward still runs, but the fused optimizer kernel reads the
+	(all-reduced) loss and leaves parameters and momentum untouched when it is not finite -- the same parameters as the
+	reference after the iteration, without draining the GPU in the middle of every step.  With accumulation (or
+	device_gate = False) the gate is the reference's host-side check."""
 	out = model(x, xlen, y = y, ylen = ylen)
 	log_probs, olen, loss_vec = out['log_probs'], out['olen'], out['loss']
 	example_weights = ylen[:, 0]
@@ -115,7 +120,11 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 		dist.all_reduce(stats, op = dist.ReduceOp.SUM)
 		loss_cur, entropy = stats[0] / world_size, stats[1] / world_size
 	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = entropy, grad_norm = None, skipped = False)
-	if bool(torch.isinf(loss_cur) | torch.isnan(loss_cur)):
+	gate = None
+	if device_gate and accumulate_iterations == 1 and hasattr(optimizer, 'flat'):
+		gate = loss_cur.detach().to(torch.float32).reshape(1)
+		res['skipped'] = ~torch.isfinite(gate[0])
+	elif bool(torch.isinf(loss_cur) | torch.isnan(loss_cur)):
 		res['skipped'] = True
 		return res
 	engine = model if hasattr(model, 'finish_gradient_sync') else None
@@ -131,6 +140,9 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 			engine.finish_gradient_sync()
 		flat = optimizer.flat
 		res['grad_norm'] = flat.clip_grad_norm_(max_norm)
-		optimizer.step()
+		if gate is not None:
+			optimizer.step(loss_gate = gate)
+		else:
+			optimizer.step()
 		optimizer.zero_grad()
 	return res

@@ -176,9 +176,11 @@ int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, vo
 int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream);
 /* torch.optim.SGD step with clip folded in: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (c = 1 if sumsq NULL);
  * g' = c*g + wd*p; buf = first ? g' : mom*buf + g'; p -= lr * (nesterov ? g' + mom*buf : buf).
- * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad). */
+ * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad).
+ * If loss_gate != NULL and *loss_gate (a device float, the all-reduced loss) is inf or NaN the launch changes nothing: the
+ * reference's "skip the step on a non-finite loss" (train.py:769-772) without a host round trip in the middle of the step. */
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
-                     float lr, float momentum, float weight_decay, int nesterov, int first, void* stream);
+                     float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, void* stream);
 
 #ifdef __cplusplus
 }

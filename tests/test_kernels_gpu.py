@@ -396,6 +396,36 @@ def test_sumsq_and_sgd_step_match_torch():
 		close(ss.sqrt().float().squeeze(), norm, 5e-5, 0, 'grad norm')
 		ops.sgd_step(pd, gi, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, it == 0)
 		close(pd, p.detach(), 1e-5, 1e-6, f'params after step {it}')
+	# device-side loss gate (train.py:769-772 without the host round trip): a non-finite loss leaves parameters and momentum alone
+	before, mom = pd.clone(), buf.clone()
+	for bad in (float('inf'), float('nan'), -float('inf')):
+		ops.sgd_step(pd, gd, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, False, loss_gate = torch.tensor([bad], device = d))
+		assert torch.equal(pd, before) and torch.equal(buf, mom)
+	ops.sgd_step(pd, gd, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, False, loss_gate = torch.tensor([3.5], device = d))
+	assert not torch.equal(pd, before)
+
+
+@gpu
+def test_train_step_device_gate_skips_on_infeasible_target():
+	"""An utterance whose target cannot be aligned (more labels than frames) gives an inf CTC loss: the reference skips the
+	iteration; here backward runs but the optimizer kernel must leave every parameter untouched, on the device-gated path and
+	on the host-gated one alike."""
+	import convasr_amd as ca
+	d = dev()
+	for device_gate in (True, False):
+		torch.manual_seed(0)
+		model = ca.models.JasperNet(64, [38], base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.0], out_width_factors_large = [2, 2], residual = False, repeat = 1, check_time_dim_padded = False, temporal_mask = False).to(d).train()
+		flat = ca.train.FlatParameters(model)
+		model._convasr_flat = flat
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		x, xlen = torch.randn(2, 64, 40, device = d), torch.ones(2, device = d)
+		y = torch.randint(0, 37, (2, 1, 30), device = d)
+		ok_len, bad_len = torch.tensor([[5], [4]], device = d), torch.tensor([[5], [30]], device = d)  # 30 labels in 20 output frames
+		before = flat.data.clone()
+		res = ca.train.train_step(model, opt, x, xlen, y, bad_len, device_gate = device_gate)
+		assert bool(res['skipped']) and torch.equal(flat.data, before)
+		res = ca.train.train_step(model, opt, x, xlen, y, ok_len, device_gate = device_gate)
+		assert not bool(res['skipped']) and not torch.equal(flat.data, before) and torch.isfinite(flat.data).all()
 
 
 # ------------------------------------------------------------------------------------------------ full-size, size-independent properties
