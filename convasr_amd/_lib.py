@@ -46,6 +46,9 @@ _SIGNATURES = dict(
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p]),
 	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p]),
+	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_p]),
+	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),
+	convasr_ctc_alignment = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 )
 
 _lib = None

@@ -1,0 +1,216 @@
+// SURVEY section 8(f) "next" rows that share the hot path's data:
+//   f2  NovoGrad (optimizers.py:66-90) with clip_grad_norm_ (train.py:777) folded in, over the flat parameter arena
+//   f3  ctc.alignment (ctc.py:7-75): forced alignment with 2-bit back-pointers, one wave per utterance
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ NovoGrad
+// The arena is a concatenation of segments (one per parameter tensor, offsets[n_seg + 1]); NovoGrad's second moment is one
+// scalar per segment: the EMA of the squared gradient norm of that tensor.  Two launches over the arena: per-segment sums of
+// squares (fp64), then the fused update.  A workgroup owns NG_CHUNK consecutive arena elements; almost every workgroup lies
+// inside one segment (one table lookup, one atomic); the few that straddle a boundary look the segment up per element.
+#define NG_CHUNK 8192
+
+__device__ __forceinline__ int ng_segment(const int64_t* __restrict__ offsets, int n_seg, int64_t i) {
+	int lo = 0, hi = n_seg - 1;  // largest s with offsets[s] <= i
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (offsets[mid] <= i) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+__global__ __launch_bounds__(256) void ng_sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ offsets, int n_seg, int64_t n, double* __restrict__ g2) {
+	__shared__ double red[4];
+	const int64_t i0 = (int64_t)blockIdx.x * NG_CHUNK, i1 = min(n, i0 + NG_CHUNK);
+	const int s0 = ng_segment(offsets, n_seg, i0), s1 = ng_segment(offsets, n_seg, i1 - 1);
+	if (s0 == s1) {
+		double acc = 0;
+		float a = 0.f;
+		for (int64_t i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+			if (i + 4 <= i1) { const float4 v = *reinterpret_cast<const float4*>(g + i); a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+			else for (int64_t j = i; j < i1; ++j) a += g[j] * g[j];
+		}
+		acc = (double)a;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+		__syncthreads();
+		if (threadIdx.x == 0) unsafeAtomicAdd(g2 + s0, red[0] + red[1] + red[2] + red[3]);
+	} else {
+		for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+			const float v = g[i];
+			if (v != 0.f) unsafeAtomicAdd(g2 + ng_segment(offsets, n_seg, i), (double)v * (double)v);
+		}
+	}
+}
+
+struct NgParams {
+	float* p; const float* g; float* mom; const float* ema_in; float* ema_out; const double* g2; const int64_t* offsets;
+	int n_seg; int64_t n;
+	float max_norm, lr, b1, b2, eps, wd;
+	int dampening, first;
+	const float* loss_gate; float* norm_out;
+};
+
+__global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
+	__shared__ double red[4];
+	__shared__ float s_clip;
+	if (q.loss_gate) {
+		const float l = *q.loss_gate;
+		if (!(fabsf(l) < INFINITY)) {  // skipped step: nothing changes; the caller still swaps its two EMA buffers, so carry the EMAs over
+			if (blockIdx.x == 0)
+				for (int s = threadIdx.x; s < q.n_seg; s += 256) q.ema_out[s] = q.ema_in[s];
+			return;
+		}
+	}
+	double tot = 0;
+	for (int s = threadIdx.x; s < q.n_seg; s += 256) tot += q.g2[s];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const float total = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+		float c = 1.f;
+		if (q.max_norm > 0.f) { c = q.max_norm / (total + 1e-6f); c = c < 1.f ? c : 1.f; }
+		s_clip = c;
+		if (blockIdx.x == 0 && q.norm_out) *q.norm_out = total;
+	}
+	__syncthreads();
+	const float clip = s_clip;
+	const int64_t i0 = (int64_t)blockIdx.x * NG_CHUNK, i1 = min(q.n, i0 + NG_CHUNK);
+	const int s0 = ng_segment(q.offsets, q.n_seg, i0), s1 = ng_segment(q.offsets, q.n_seg, i1 - 1);
+	auto seg_ema = [&](int s) {
+		const float g2c = (float)(q.g2[s] * (double)clip * (double)clip);  // sum of squares of the CLIPPED gradient (clip_grad_norm_ scales .grad in place)
+		return q.first ? g2c : q.ema_in[s] * q.b2 + g2c * (1.f - q.b2);
+	};
+	// the workgroup that holds a segment's first element publishes its new EMA (ema_in / ema_out are distinct buffers)
+	for (int s = s0 + threadIdx.x; s <= s1; s += 256)
+		if (q.offsets[s] >= i0) q.ema_out[s] = seg_ema(s);
+	auto update = [&](int64_t i, float inv_denom) {
+		const float pv = q.p[i];
+		float d = q.g[i] * clip * inv_denom;
+		if (q.wd > 0.f) d += q.wd * pv;
+		if (q.dampening) d *= 1.f - q.b1;
+		const float m = q.first ? d : q.mom[i] * q.b1 + d;
+		q.mom[i] = m;
+		q.p[i] = pv - q.lr * m;
+	};
+	if (s0 == s1) {
+		const float inv = 1.f / sqrtf(seg_ema(s0) + q.eps);
+		for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) update(i, inv);
+	} else {
+		for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) update(i, 1.f / sqrtf(seg_ema(ng_segment(q.offsets, q.n_seg, i)) + q.eps));
+	}
+}
+
+extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets, int n_seg,
+                                     int64_t n, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
+                                     const float* loss_gate, float* total_norm, void* stream) {
+	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && n_seg > 0 && n > 0, "novograd_step: bad arguments");
+	hipStream_t s = (hipStream_t)stream;
+	if (hipMemsetAsync(g2, 0, sizeof(double) * n_seg, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "novograd_step: memset failed");
+	const unsigned blocks = (unsigned)ceil_div64(n, NG_CHUNK);
+	hipLaunchKernelGGL(ng_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, offsets, n_seg, n, g2);
+	NgParams q;
+	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
+	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
+	q.loss_gate = loss_gate; q.norm_out = total_norm;
+	hipLaunchKernelGGL(ng_step_kernel, dim3(blocks), dim3(256), 0, s, q);
+	CONVASR_CHECK_LAUNCH("novograd_step");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forced alignment
+// One wave per utterance; lane l owns states l*NS .. l*NS+NS-1 of the extended target.  The forward variable is the reference's
+// SUM recursion in natural log (expf / logf, the precision class of torch.logsumexp) with finfo.min as "log zero"; the
+// back-pointer of a state is the first maximum of (stay, s-1, s-2 if allowed), 2 bits per state, one packed dword per lane and
+// frame in a global workspace [B][T][64].  Lane 0 then walks the path back from frame input_length-1 (the end state is chosen
+// from the column at T-1, as ctc.py:53-58 does) and records for every label the last frame spent in its state.
+#define AL_ZERO (-3.4028234663852886e38f)
+
+template <int NS>
+__global__ __launch_bounds__(64) void ctc_alignment_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len,
+                                                           const int64_t* __restrict__ tgt_len, int64_t* __restrict__ out, unsigned* __restrict__ bp, int T, int C,
+                                                           int S_max, int blank) {
+	__shared__ float fin[64 * NS];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	const int S = (int)tgt_len[b], Tb = (int)in_len[b], L = 2 * S + 1;
+	const int64_t* tg = targets + (int64_t)b * S_max;
+	int64_t* ob = out + (int64_t)b * S_max;
+	for (int j = lane; j < S_max; j += 64) ob[j] = 0;
+	if (S <= 0 || Tb <= 0 || Tb > T) return;
+	const float* lpb = lp + (int64_t)b * T * C;
+	unsigned* bpb = bp + (int64_t)b * T * 64;
+
+	int cls[NS];
+	bool allow2[NS], valid[NS];
+	float a[NS];
+#pragma unroll
+	for (int i = 0; i < NS; ++i) {
+		const int s = lane * NS + i;
+		valid[i] = s < L;
+		const bool lab = (s & 1) && valid[i];
+		cls[i] = lab ? (int)tg[s >> 1] : blank;
+		allow2[i] = lab && s >= 3 && tg[s >> 1] != tg[(s >> 1) - 1];  // blanks never take the s-2 move (equal to the blank two states back)
+		a[i] = (valid[i] && s < 2) ? lpb[cls[i]] : AL_ZERO;
+	}
+	for (int t = 1; t < T; ++t) {
+		const float* row = lpb + (int64_t)t * C;
+		float p1 = __shfl_up(a[NS - 1], 1, 64), p2 = NS >= 2 ? __shfl_up(a[NS >= 2 ? NS - 2 : 0], 1, 64) : __shfl_up(a[0], 2, 64);
+		if (lane == 0) { p1 = AL_ZERO; p2 = AL_ZERO; }
+		if (NS == 1 && lane == 1) p2 = AL_ZERO;
+		float n[NS];
+		unsigned word = 0;
+#pragma unroll
+		for (int i = NS - 1; i >= 0; --i) {
+			const float stay = a[i];
+			const float one = i >= 1 ? a[i - 1] : p1;
+			const float two = allow2[i] ? (i >= 2 ? a[i - 2] : (i == 1 ? p1 : p2)) : AL_ZERO;
+			unsigned k = 0;
+			float best = stay;
+			if (one > best) { k = 1; best = one; }
+			if (two > best) { k = 2; best = two; }
+			word |= k << (2 * i);
+			n[i] = valid[i] ? row[cls[i]] + (best + logf(expf(stay - best) + expf(one - best) + expf(two - best))) : AL_ZERO;
+		}
+		bpb[(int64_t)t * 64 + lane] = word;
+#pragma unroll
+		for (int i = 0; i < NS; ++i) a[i] = n[i];
+	}
+#pragma unroll
+	for (int i = 0; i < NS; ++i) fin[lane * NS + i] = a[i];
+	__threadfence_block();
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		int s = 2 * S - 1 + (fin[2 * S] > fin[2 * S - 1] ? 1 : 0);
+		int seen = -1;
+		for (int t = Tb - 1; t >= 0; --t) {
+			if (s != seen) { if (s & 1) ob[s >> 1] = t; seen = s; }
+			if (t > 0) s -= (int)((bpb[(int64_t)t * 64 + s / NS] >> (2 * (s % NS))) & 3u);
+		}
+	}
+}
+
+static int al_ns(int S_max) {
+	const int need = (2 * S_max + 1 + 63) / 64;
+	const int opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
+	for (int o : opts) if (o >= need) return o;
+	return -1;
+}
+
+extern "C" int64_t convasr_ctc_alignment_workspace_bytes(int B, int T) { return (int64_t)B * T * 64 * (int64_t)sizeof(unsigned); }
+
+extern "C" int convasr_ctc_alignment(const float* log_probs, const int64_t* targets, const int64_t* input_lengths, const int64_t* target_lengths, int64_t* alignment,
+                                     void* workspace, int B, int T, int C, int S_max, int blank, void* stream) {
+	CONVASR_CHECK_ARG(log_probs && targets && input_lengths && target_lengths && alignment && workspace && B > 0 && T > 0 && C > 1 && S_max > 0 && blank >= 0 && blank < C, "ctc_alignment: bad arguments");
+	const int ns = al_ns(S_max);
+	if (ns < 0) return convasr_fail(CONVASR_EUNSUPPORTED, "ctc_alignment: target length %d > 511", S_max);
+	hipStream_t s = (hipStream_t)stream;
+#define AL_CASE(NS) case NS: hipLaunchKernelGGL((ctc_alignment_kernel<NS>), dim3(B), dim3(64), 0, s, log_probs, targets, input_lengths, target_lengths, alignment, (unsigned*)workspace, T, C, S_max, blank); break;
+	switch (ns) { AL_CASE(1) AL_CASE(2) AL_CASE(3) AL_CASE(4) AL_CASE(6) AL_CASE(8) AL_CASE(12) AL_CASE(16) }
+#undef AL_CASE
+	CONVASR_CHECK_LAUNCH("ctc_alignment");
+	return 0;
+}

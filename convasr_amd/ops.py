@@ -294,3 +294,26 @@ def sumsq(flat_grad, out = None):
 def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None):
 	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
 	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
+
+def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None):
+	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]."""
+	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), offsets.numel() - 1, n, float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), stream_ptr())
+
+
+def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):
+	"""log_probs_btc: contiguous (B, T, C) fp32 on the GPU.  Returns (B, S_max) int64 (see include/convasr_hip.h)."""
+	B, T, C = log_probs_btc.shape
+	dev = log_probs_btc.device
+	assert log_probs_btc.is_contiguous() and log_probs_btc.dtype == torch.float32
+	targets = targets.to(device = dev, dtype = torch.int64).contiguous()
+	il = input_lengths.to(device = dev, dtype = torch.int64).contiguous()
+	tl = target_lengths.to(device = dev, dtype = torch.int64).contiguous()
+	S_max = targets.shape[1]
+	out = torch.empty(B, S_max, dtype = torch.int64, device = dev)
+	ws = workspace(_lib.load().convasr_ctc_alignment_workspace_bytes(B, T), dev, 'ctc_alignment')
+	call('convasr_ctc_alignment', ptr(log_probs_btc), ptr(targets), ptr(il), ptr(tl), ptr(out), ptr(ws), B, T, C, S_max, int(blank), stream_ptr())
+	return out

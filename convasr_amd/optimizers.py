@@ -1,0 +1,104 @@
+"""Host mirror of the reference's optimizers.py for the flat-arena training step.
+
+NovoGrad (optimizers.py:66-90) is ONE fused launch pair over FlatParameters (per-tensor squared gradient norms, then the
+update with torch.nn.utils.clip_grad_norm_ of train.py:777 folded in) instead of ~8 elementwise launches per parameter
+tensor; it replaces both the reference's Python loop and apex's FusedNovoGrad (train.py:674).  The learning-rate schedules
+are host arithmetic and keep the reference's class names and arguments."""
+import torch
+
+from . import ops
+from . import functional as Fn
+
+
+class NovoGrad:
+	def __init__(self, flat, lr = 1.0, betas = (0.95, 0.98), eps = 1e-8, weight_decay = 0.0, dampening = False):
+		self.flat = flat
+		self.defaults = dict(lr = lr, betas = betas, eps = eps, weight_decay = weight_decay, dampening = dampening)
+		self.param_groups = [dict(params = flat.params, **self.defaults)]
+		dev = flat.data.device
+		n_seg = len(flat.params)
+		self.offsets = torch.tensor(list(flat.offsets) + [flat.numel], dtype = torch.int64, device = dev)
+		self.momentum_buffer = torch.zeros_like(flat.data)
+		self.grads_ema = torch.zeros(2, n_seg, dtype = torch.float32, device = dev)  # [steps & 1] is current
+		self._g2 = torch.zeros(n_seg, dtype = torch.float64, device = dev)
+		self.total_norm = torch.zeros(1, dtype = torch.float32, device = dev)
+		self.steps = 0
+
+	def zero_grad(self, set_to_none = False):
+		self.flat.zero_grad()
+
+	def step(self, loss_gate = None):
+		g = self.param_groups[0]
+		flat = self.flat
+		if flat.clip is None:
+			flat.finalize_grads()
+		max_norm = flat.clip[1] if flat.clip is not None else 0.0
+		cur = self.steps & 1
+		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], self.steps == 0, loss_gate = loss_gate, total_norm = self.total_norm)
+		self.steps += 1
+		flat.clip = None
+		Fn.bump_param_epoch()
+
+	@property
+	def state(self):
+		"""Per-parameter view in the reference's vocabulary: {'_grads_ema': 0-d tensor, 'momentum_buffer': tensor}."""
+		ema = self.grads_ema[self.steps & 1]
+		return {p: dict(_grads_ema = ema[i], momentum_buffer = self.momentum_buffer[o:o + p.numel()].view(p.shape)) for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets))}
+
+	def state_dict(self):
+		return dict(steps = self.steps, momentum_buffer = self.momentum_buffer, grads_ema = self.grads_ema[self.steps & 1].clone(), param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+
+	def load_state_dict(self, sd):
+		self.steps = sd['steps']
+		self.momentum_buffer.copy_(sd['momentum_buffer'])
+		self.grads_ema[self.steps & 1].copy_(sd['grads_ema'])
+		for g, s in zip(self.param_groups, sd['param_groups']):
+			g.update(s)
+
+
+def reset_options(optimizer):
+	for group in optimizer.param_groups:
+		group.update(optimizer.defaults)
+
+
+class LRScheduler:
+	def __init__(self, optimizer):
+		self.optimizer = optimizer
+
+	def step(self, step):
+		for group, lr in zip(self.optimizer.param_groups, self.get_lr(step)):
+			group['lr'] = lr
+
+
+class NoopLR(LRScheduler):
+	def get_lr(self, step):
+		return [group['lr'] for group in self.optimizer.param_groups]
+
+
+class MultiStepLR(LRScheduler):
+	def __init__(self, optimizer, gamma, milestones):
+		self.init_lr = [group['lr'] for group in optimizer.param_groups]
+		self.gamma, self.milestones = gamma, milestones
+		super().__init__(optimizer)
+
+	def get_lr(self, step):
+		hit = [i + 1 for i, m in enumerate(self.milestones) if step >= m]  # the last milestone reached, in list order (optimizers.py:31)
+		power = hit[-1] if hit else 0
+		return [lr0 * self.gamma ** power for lr0 in self.init_lr]
+
+
+class PolynomialDecayLR(LRScheduler):
+	"""Linear warm-up to the initial rate, then polynomial decay to end_lr over decay_steps (optimizers.py:36-63; the
+	reference's decay branch reads an undefined name and cannot run, this is the schedule its arguments describe)."""
+
+	def __init__(self, optimizer, decay_steps, power = 1.0, begin_decay_at = 0, end_lr = 0.0, warmup_steps = 0):
+		self.decay_steps, self.power, self.begin_decay_at, self.end_lr, self.warmup_steps = decay_steps, power, begin_decay_at, end_lr, warmup_steps
+		self.init_lr = [group['lr'] for group in optimizer.param_groups]
+		super().__init__(optimizer)
+
+	def get_lr(self, step):
+		lrs = [lr0 * step / self.warmup_steps if self.warmup_steps > 0 and step < self.warmup_steps else lr0 for lr0 in self.init_lr]
+		if step >= self.begin_decay_at:
+			k = min(step - self.begin_decay_at, self.decay_steps)
+			lrs = [self.end_lr + (lr0 - self.end_lr) * ((self.decay_steps - k) / self.decay_steps) ** self.power if k < self.decay_steps else self.end_lr for lr0 in self.init_lr]
+		return lrs

@@ -182,6 +182,28 @@ int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream);
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, void* stream);
 
+/* ---- SURVEY 8(f) "next" rows ------------------------------------------------------------------------------------ */
+
+/* NovoGrad.step (optimizers.py:66-90) with torch.nn.utils.clip_grad_norm_ (train.py:777) folded in, over a flat arena of n
+ * fp32 values cut into n_seg tensors by offsets[n_seg + 1] (device int64; a tensor's padding belongs to it and must hold
+ * zero gradients).  Per tensor s: g2 = sum (c*g)^2 with c = min(1, max_norm / (||g||_all + 1e-6)) (c = 1 if max_norm <= 0);
+ * ema_out[s] = first ? g2 : ema_in[s]*beta2 + g2*(1-beta2); d = c*g / sqrt(ema_out[s] + eps) (+ wd*p) (* (1-beta1) if
+ * dampening); mom = first ? d : mom*beta1 + d; p -= lr*mom.  ema_in / ema_out must be different buffers (the caller swaps
+ * them every call); g2 is n_seg doubles of scratch; total_norm (may be NULL) receives ||g||_all; loss_gate as in
+ * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else). */
+int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets,
+                          int n_seg, int64_t n, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int dampening, int first, const float* loss_gate, float* total_norm, void* stream);
+
+int64_t convasr_ctc_alignment_workspace_bytes(int B, int T);
+/* ctc.alignment (ctc.py:7-75): forced alignment of targets[b, :target_lengths[b]] to log_probs[b, :input_lengths[b]]
+ * (log_probs batch-major (B, T, C) fp32; the reference's (T, B, C) tensor permuted).  alignment (B, S_max) int64: the last
+ * frame the best path spends in each label's state, 0 for padded labels.  Forward variable = the reference's sum recursion
+ * with finfo.min as log-zero over all T frames, back-pointer = first maximum of (stay, s-1, s-2), end state chosen from the
+ * column at T-1, walk started at input_lengths[b]-1. */
+int convasr_ctc_alignment(const float* log_probs, const int64_t* targets, const int64_t* input_lengths, const int64_t* target_lengths,
+                          int64_t* alignment, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

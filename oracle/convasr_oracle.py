@@ -439,6 +439,78 @@ def greedy_decode(log_probs_bct, olen = None, vocab = None, blank_amount_to_spac
 # --------------------------------------------------------------------------------------
 
 
+def ctc_alignment(log_probs_tbc: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor, target_lengths: torch.Tensor, blank: int = 0) -> torch.Tensor:
+	"""Forced alignment as ctc.py:7-75 defines it, restated one utterance at a time.
+
+	The forward variable is the SUM recursion (logsumexp over stay / s-1 / s-2, forbidden moves and unreachable states held
+	at finfo.min, not -inf: ctc.py:27-30,45-46); the back-pointer of (t, s) is the argmax over those three predecessors
+	(first maximum: 0 = stay, 1 = s-1, 2 = s-2, ctc.py:47).  The sweep runs over ALL T frames of the padded batch and the end
+	state (last label vs trailing blank) is picked from the column at T-1 (ctc.py:53-58), the walk starts at frame
+	input_lengths-1 (ctc.py:58).  Result (B, S_max) int64: for label j the LAST frame the path spends in its state (the
+	reference scatters t in increasing order, ctc.py:72-75); 0 for padded labels."""
+	T, B, C = log_probs_tbc.shape
+	S_max = targets.shape[1]
+	zero = torch.tensor(torch.finfo(torch.float16).min if log_probs_tbc.dtype is torch.float16 else torch.finfo(torch.float32).min, dtype = log_probs_tbc.dtype)
+	out = torch.zeros(B, S_max, dtype = torch.long)
+	for b in range(B):
+		S, Tb = int(target_lengths[b]), int(input_lengths[b])
+		ext = torch.full((2 * S + 1, ), blank, dtype = torch.long)
+		ext[1::2] = targets[b, :S]
+		L = len(ext)
+		allow2 = torch.zeros(L, dtype = torch.bool)
+		allow2[2:] = ext[2:] != ext[:-2]
+		alpha = torch.full((L, ), float(zero), dtype = log_probs_tbc.dtype)
+		alpha[0] = log_probs_tbc[0, b, blank]
+		if L > 1:
+			alpha[1] = log_probs_tbc[0, b, ext[1]]
+		back = torch.zeros(T, L, dtype = torch.long)
+		for t in range(1, T):
+			stay = alpha
+			one = torch.cat([zero.reshape(1), alpha[:-1]])
+			two = torch.where(allow2, torch.cat([zero.reshape(1).expand(2), alpha[:-2]]), zero)
+			prev = torch.stack([stay, one, two])
+			back[t] = prev.argmax(dim = 0)
+			alpha = log_probs_tbc[t, b, ext] + prev.logsumexp(dim = 0)
+		if S == 0:
+			continue
+		s = 2 * S - 1 + int(alpha[2 * S] > alpha[2 * S - 1])  # argmax of (last label, trailing blank): first maximum
+		last = {}
+		for t in range(Tb - 1, -1, -1):
+			last.setdefault(s, t)
+			if t > 0:
+				s -= int(back[t, s])
+		for j in range(S):
+			out[b, j] = last.get(2 * j + 1, 0)
+	return out
+
+
+def novograd_step(params, grads, state, lr = 1.0, betas = (0.95, 0.98), eps = 1e-8, weight_decay = 0.0, dampening = False, max_norm = None):
+	"""torch.nn.utils.clip_grad_norm_ (train.py:777) followed by NovoGrad.step (optimizers.py:66-90), functional.
+
+	params / grads: lists of tensors (params updated in place, grads left untouched); state: dict that carries 'ema' (one 0-d
+	tensor per parameter: the EMA of the squared gradient NORM of that tensor) and 'mom' between calls.  Returns the total
+	gradient norm before clipping."""
+	total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+	coef = 1.0
+	if max_norm is not None:
+		coef = float(torch.clamp(max_norm / (total + 1e-6), max = 1.0))
+	first = 'ema' not in state
+	if first:
+		state['ema'], state['mom'] = [None] * len(params), [None] * len(params)
+	for i, (p, g) in enumerate(zip(params, grads)):
+		g = g * coef
+		g2 = (g ** 2).sum()
+		state['ema'][i] = g2 if first else state['ema'][i] * betas[1] + g2 * (1.0 - betas[1])
+		d = g / (state['ema'][i] + eps).sqrt()
+		if weight_decay > 0:
+			d = d + weight_decay * p
+		if dampening:
+			d = d * (1 - betas[0])
+		state['mom'][i] = d if first else state['mom'][i] * betas[0] + d
+		p.sub_(lr * state['mom'][i])
+	return total
+
+
 def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, max_norm = 100.0, momentum_buffers = None, nesterov = False):
 	"""One iteration of the reference loop with accumulate=1: forward (748), loss = mean(loss * ylen) (755),
 	backward (774), clip_grad_norm_ (777), SGD step (780).  Returns dict(loss, loss_cur, entropy, grad_norm, grads);

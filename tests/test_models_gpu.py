@@ -202,3 +202,94 @@ def test_bf16_training_step_tracks_fp32():
 	for a, b in zip(losses[torch.float32], losses[torch.bfloat16]):
 		assert abs(a - b) / abs(a) < 0.03, losses
 	assert losses[torch.bfloat16][2] < losses[torch.bfloat16][0]
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
+
+def test_novograd_matches_reference_golden():
+	"""optimizers.NovoGrad after clip_grad_norm_ (tests/golden/make_golden_next.py), 4 steps, two hyper-parameter sets; the
+	fused kernel works on the flat arena, so the tensors go through FlatParameters like a model's would."""
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'novograd.npz'))
+	d = torch.device('cuda:0')
+	for case in (0, 1):
+		lr, b1, b2, eps, wd, damp, max_norm = [float(v) for v in g[f'c{case}/hyper']]
+		n = len([k for k in g.files if k.startswith(f'c{case}/p0/')])
+		holder = torch.nn.Module()
+		holder.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(g[f'c{case}/p0/{i}']).to(d)) for i in range(n)])
+		flat = ca.train.FlatParameters(holder)
+		opt = ca.optimizers.NovoGrad(flat, lr = lr, betas = (b1, b2), eps = eps, weight_decay = wd, dampening = bool(damp))
+		for step in range(4):
+			for i, p in enumerate(flat.params):
+				p._convasr_grad.copy_(torch.from_numpy(g[f'c{case}/g{step}/{i}']).to(d))
+				p._convasr_fresh = False
+			norm = flat.clip_grad_norm_(max_norm)
+			opt.step()
+			opt.zero_grad()
+			close(norm.cpu(), torch.from_numpy(g[f'c{case}/norm{step}']), 1e-5, 0, 'grad norm')
+			close(opt.total_norm.cpu().squeeze(), torch.from_numpy(g[f'c{case}/norm{step}']), 1e-5, 0, 'grad norm (fused)')
+			st = opt.state
+			for i, p in enumerate(flat.params):
+				close(p.detach().cpu(), torch.from_numpy(g[f'c{case}/p{step + 1}/{i}']), 2e-5, 2e-6, f'case {case} step {step} param {i}')
+				close(st[p]['_grads_ema'].cpu(), torch.from_numpy(g[f'c{case}/ema{step + 1}/{i}']), 2e-5, 0, f'case {case} step {step} ema {i}')
+		# a gated (non-finite loss) step changes nothing, including the EMAs
+		before, ema = flat.data.clone(), opt.state[flat.params[0]]['_grads_ema'].clone()
+		for p in flat.params:
+			p._convasr_fresh = False
+		flat.clip_grad_norm_(max_norm)
+		opt.step(loss_gate = torch.tensor([float('nan')], device = d))
+		assert torch.equal(flat.data, before) and torch.equal(opt.state[flat.params[0]]['_grads_ema'], ema)
+
+
+def test_novograd_train_step_on_tiny_model_tracks_oracle():
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	torch.manual_seed(0)
+	model = ca.models.JasperNet(64, [38], base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.0], out_width_factors_large = [2, 2], residual = False, repeat = 1, check_time_dim_padded = False, temporal_mask = False).to(d).train()
+	flat = ca.train.FlatParameters(model)
+	model._convasr_flat = flat
+	opt = ca.optimizers.NovoGrad(flat, lr = 1e-3, betas = (0.95, 0.98), weight_decay = 1e-3)
+	ref_params = [p.detach().cpu().clone() for p in flat.params]
+	state = {}
+	x, xlen = torch.randn(2, 64, 40, device = d), torch.ones(2, device = d)
+	y, ylen = torch.randint(0, 37, (2, 1, 6), device = d), torch.tensor([[5], [4]], device = d)
+	for it in range(3):
+		grads_before = None
+		res = ca.train.train_step(model, opt, x, xlen, y, ylen, max_norm = 1.0)
+		assert not bool(res['skipped'])
+		# replay the same update with the oracle's NovoGrad on the gradients the device produced
+		grads = [p._convasr_grad.detach().cpu().clone() for p in flat.params]
+		O.novograd_step(ref_params, grads, state, lr = 1e-3, betas = (0.95, 0.98), eps = 1e-8, weight_decay = 1e-3, dampening = False, max_norm = 1.0)
+		for p, r in zip(flat.params, ref_params):
+			close(p.detach().cpu(), r, 1e-4, 1e-6, f'iteration {it}')
+
+
+def test_ctc_alignment_matches_reference_golden():
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'alignment.npz'))
+	d = torch.device('cuda:0')
+	for case in (0, 1, 2):
+		T_ = lambda k: torch.from_numpy(g[f'c{case}/{k}'])
+		al = ca.ctc.alignment(T_('log_probs').to(d), T_('targets'), T_('input_lengths'), T_('target_lengths'), blank = int(g[f'c{case}/blank']))
+		assert torch.equal(al.cpu(), T_('alignment')), (case, (al.cpu() != T_('alignment')).sum())
+
+
+def test_ctc_alignment_properties_at_benchmark_size():
+	"""64 x 753 frames x 150 labels: the alignment of every utterance is strictly increasing over its labels, inside
+	[0, input_length), padded labels are 0, and it equals the oracle's on a sample of utterances."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	B, C, T, S = 64, 38, 753, 150
+	gen = torch.Generator().manual_seed(5)
+	lp = torch.randn(T, B, C, generator = gen).log_softmax(dim = -1)
+	tg = torch.randint(0, C - 1, (B, S), generator = gen)
+	il = torch.randint(2 * S + 1, T + 1, (B, ), generator = gen)
+	tl = torch.randint(S // 2, S + 1, (B, ), generator = gen)
+	al = ca.ctc.alignment(lp.to(d), tg, il, tl, blank = C - 1).cpu()
+	for b in range(B):
+		a = al[b, :tl[b]]
+		assert bool((a[1:] > a[:-1]).all()) and int(a[0]) >= 0 and int(a[-1]) < int(il[b])
+		assert int(al[b, tl[b]:].abs().sum()) == 0
+	sample = [0, 17, 63]
+	ref = O.ctc_alignment(lp[:, sample], tg[sample], il[sample], tl[sample], blank = C - 1)
+	assert torch.equal(al[sample], ref)

@@ -168,3 +168,29 @@ def test_wav2letter_layout_matches_reference():
 	assert {k: list(v.shape) for k, v in sd.items()} == ref
 	n = sum(v.numel() for k, v in sd.items() if v.is_floating_point() and 'running' not in k)
 	assert n == layout['num_params']
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
+
+def test_oracle_novograd_matches_reference():
+	g = np.load(os.path.join(GOLDEN, 'novograd.npz'))
+	for case in (0, 1):
+		lr, b1, b2, eps, wd, damp, max_norm = [float(v) for v in g[f'c{case}/hyper']]
+		n = len([k for k in g.files if k.startswith(f'c{case}/p0/')])
+		params = [torch.from_numpy(g[f'c{case}/p0/{i}']).clone() for i in range(n)]
+		state = {}
+		for step in range(4):
+			grads = [torch.from_numpy(g[f'c{case}/g{step}/{i}']) for i in range(n)]
+			norm = O.novograd_step(params, grads, state, lr = lr, betas = (b1, b2), eps = eps, weight_decay = wd, dampening = bool(damp), max_norm = max_norm)
+			assert abs(float(norm) - float(g[f'c{case}/norm{step}'])) <= 1e-5 * float(norm)
+			for i in range(n):
+				np.testing.assert_allclose(params[i].numpy(), g[f'c{case}/p{step + 1}/{i}'], rtol = 2e-5, atol = 2e-6)
+				np.testing.assert_allclose(float(state['ema'][i]), float(g[f'c{case}/ema{step + 1}/{i}']), rtol = 2e-5)
+
+
+def test_oracle_alignment_matches_reference():
+	g = np.load(os.path.join(GOLDEN, 'alignment.npz'))
+	for case in (0, 1, 2):
+		T_ = lambda k: torch.from_numpy(g[f'c{case}/{k}'])
+		al = O.ctc_alignment(T_('log_probs'), T_('targets'), T_('input_lengths'), T_('target_lengths'), blank = int(g[f'c{case}/blank']))
+		assert torch.equal(al, T_('alignment')), case

@@ -110,3 +110,37 @@ def test_flat_parameters_views_and_state_dict_roundtrip():
 	model.load_state_dict(sd)  # load_state_dict copies in place: the views survive
 	assert model.a.weight.data_ptr() == flat.data.data_ptr()
 	assert torch.equal(model.b.bias, sd['b.bias'])
+
+
+def test_lr_schedules_host_arithmetic():
+	"""optimizers.py:9-63 mirrors: schedules only touch param_groups[...]['lr'] (no device work: importable without a GPU)."""
+	import importlib.util, sys, types
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	# load convasr_amd/optimizers.py without importing the package (the package refuses to import without its HIP library)
+	pkg = types.ModuleType('_cv_stub'); pkg.__path__ = [os.path.join(root, 'convasr_amd')]
+	sys.modules['_cv_stub'] = pkg
+	for name in ('ops', 'functional'):
+		sys.modules[f'_cv_stub.{name}'] = types.ModuleType(f'_cv_stub.{name}')
+	spec = importlib.util.spec_from_file_location('_cv_stub.optimizers', os.path.join(root, 'convasr_amd', 'optimizers.py'))
+	opt_mod = importlib.util.module_from_spec(spec)
+	spec.loader.exec_module(opt_mod)
+
+	class FakeOpt:
+		def __init__(self):
+			self.defaults = dict(lr = 0.1)
+			self.param_groups = [dict(lr = 0.1), dict(lr = 0.2)]
+	o = FakeOpt()
+	s = opt_mod.MultiStepLR(o, gamma = 0.5, milestones = [10, 20])
+	for step, want in [(0, 0.1), (9, 0.1), (10, 0.05), (19, 0.05), (20, 0.025), (1000, 0.025)]:
+		s.step(step)
+		assert abs(o.param_groups[0]['lr'] - want) < 1e-12 and abs(o.param_groups[1]['lr'] - 2 * want) < 1e-12
+	o = FakeOpt()
+	s = opt_mod.PolynomialDecayLR(o, decay_steps = 100, power = 2.0, begin_decay_at = 50, end_lr = 0.01, warmup_steps = 10)
+	s.step(5); assert abs(o.param_groups[0]['lr'] - 0.05) < 1e-12
+	s.step(20); assert abs(o.param_groups[0]['lr'] - 0.1) < 1e-12
+	s.step(100); assert abs(o.param_groups[0]['lr'] - (0.01 + 0.09 * 0.25)) < 1e-12
+	s.step(500); assert abs(o.param_groups[0]['lr'] - 0.01) < 1e-12
+	o = FakeOpt()
+	opt_mod.NoopLR(o).step(7); assert o.param_groups[0]['lr'] == 0.1
+	o.param_groups[0]['lr'] = 3.0
+	opt_mod.reset_options(o); assert o.param_groups[0]['lr'] == 0.1
