@@ -292,7 +292,7 @@ class JasperNet(nn.Module):
 		self.init_params = {name: repr(value) for name, value in locals().items() if name not in ('self', '__class__')}
 		if dropout == 0:
 			dropout_prologue, dropout_epilogue, dropouts = 0, 0, [0] * len(dropouts)
-		common = dict(temporal_mask = temporal_mask, nonlinearity = nonlinearity, inplace = inplace)
+		common = {'temporal_mask': temporal_mask, 'nonlinearity': nonlinearity, 'inplace': inplace}  # (the reference's constructor argument named dict shadows the builtin here)
 		width = lambda f: f * base_width
 
 		blocks = [ConvBn1d(num_channels = (num_input_features, width(out_width_factors[0])), kernel_size = kernel_size_prologue, dropout = dropout_prologue, stride = stride1, **common)]

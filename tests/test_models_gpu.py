@@ -293,3 +293,34 @@ def test_ctc_alignment_properties_at_benchmark_size():
 	sample = [0, 17, 63]
 	ref = O.ctc_alignment(lp[:, sample], tg[sample], il[sample], tl[sample], blank = C - 1)
 	assert torch.equal(al[sample], ref)
+
+
+def test_fused_eval_forward_under_hip_graph_replay_is_bit_identical():
+	"""f1: the fused eval forward (frontend -> instance norm -> BN-folded conv stack -> decoder -> log-softmax) captured into a
+	HIP graph replays to the same bits as the eager launches, for new input written into the static buffer."""
+	import bench_infer
+	d = torch.device('cuda:0')
+	torch.manual_seed(3)
+	model = bench_infer.build_model('Wav2Letter', d, torch.bfloat16)
+	xlen = torch.ones(1, device = d)
+	static_in = torch.empty(1, 48000, device = d)
+	with torch.no_grad():
+		static_in.copy_(torch.rand(1, 48000) * 2 - 1)
+		side = torch.cuda.Stream()
+		side.wait_stream(torch.cuda.current_stream())
+		with torch.cuda.stream(side):
+			for _ in range(2):
+				model(static_in, xlen)
+		torch.cuda.current_stream().wait_stream(side)
+		torch.cuda.synchronize()
+		graph = torch.cuda.CUDAGraph()
+		with torch.cuda.graph(graph):
+			out = model(static_in, xlen)
+		for seed in (10, 11):
+			x = torch.rand(1, 48000, generator = torch.Generator().manual_seed(seed)) * 2 - 1
+			static_in.copy_(x)
+			graph.replay()
+			torch.cuda.synchronize()
+			replayed = out.clone()
+			eager = model(x.to(d), xlen)
+			assert torch.isfinite(eager).all() and torch.equal(replayed, eager)
