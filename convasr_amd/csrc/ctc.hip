@@ -251,7 +251,7 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
 	dim3 ggrid((T + t_per_block - 1) / t_per_block, B);
 	const size_t gsmem = 4 * (size_t)C * sizeof(float);
 	const size_t lds_lp = (size_t)T * C * sizeof(float);
-	const bool in_lds = lds_lp + 64 * 16 * sizeof(float) <= 150 * 1024;
+	const bool in_lds = lds_lp + 64 * 16 * sizeof(float) <= 159 * 1024;  // T = 1001 (20 s) x C = 38 still fits the 160 KiB of a CU
 #define CTC_CASE(NS) case NS: \
 		if (in_lds) { \
 			auto kern = ctc_alpha_beta_kernel<NS, true>; \

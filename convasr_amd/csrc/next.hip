@@ -9,8 +9,16 @@
 // squares (fp64), then the fused update.  A workgroup owns NG_CHUNK consecutive arena elements; almost every workgroup lies
 // inside one segment (one table lookup, one atomic); the few that straddle a boundary look the segment up per element.
 #define NG_CHUNK 8192
+#define NG_TABLE 2048  // segment offsets are searched in LDS (a dependent chain of global loads per lookup made the launches latency-bound)
 
-__device__ __forceinline__ int ng_segment(const int64_t* __restrict__ offsets, int n_seg, int64_t i) {
+__device__ __forceinline__ const int64_t* ng_stage_offsets(const int64_t* __restrict__ offsets, int n_seg, int64_t* tab) {
+	if (n_seg + 1 > NG_TABLE) return offsets;
+	for (int s = threadIdx.x; s <= n_seg; s += blockDim.x) tab[s] = offsets[s];
+	__syncthreads();
+	return tab;
+}
+
+__device__ __forceinline__ int ng_segment(const int64_t* offsets, int n_seg, int64_t i) {
 	int lo = 0, hi = n_seg - 1;  // largest s with offsets[s] <= i
 	while (lo < hi) {
 		const int mid = (lo + hi + 1) >> 1;
@@ -19,29 +27,59 @@ __device__ __forceinline__ int ng_segment(const int64_t* __restrict__ offsets, i
 	return lo;
 }
 
-__global__ __launch_bounds__(256) void ng_sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ offsets, int n_seg, int64_t n, double* __restrict__ g2) {
+// A workgroup walks a CONTIGUOUS run of chunks and keeps one running sum for the segment it is in: one fp64 atomic per
+// (workgroup, segment) -- ~1000 + n_seg in all.  (One atomic per chunk put 1300 same-address fp64 atomics on every large
+// weight tensor and ran at a tenth of the streaming rate.)
+__global__ __launch_bounds__(256) void ng_sumsq_kernel(const float* __restrict__ g, const int64_t* offsets, int n_seg, int64_t n, int chunks_per_block, double* __restrict__ g2) {
 	__shared__ double red[4];
-	const int64_t i0 = (int64_t)blockIdx.x * NG_CHUNK, i1 = min(n, i0 + NG_CHUNK);
-	const int s0 = ng_segment(offsets, n_seg, i0), s1 = ng_segment(offsets, n_seg, i1 - 1);
-	if (s0 == s1) {
-		double acc = 0;
-		float a = 0.f;
-		for (int64_t i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
-			if (i + 4 <= i1) { const float4 v = *reinterpret_cast<const float4*>(g + i); a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
-			else for (int64_t j = i; j < i1; ++j) a += g[j] * g[j];
-		}
-		acc = (double)a;
+	__shared__ int64_t tab[NG_TABLE];
+	offsets = ng_stage_offsets(offsets, n_seg, tab);
+	const int64_t n_chunks = (n + NG_CHUNK - 1) / NG_CHUNK;
+	const int64_t c0 = (int64_t)blockIdx.x * chunks_per_block, c1 = min(n_chunks, c0 + chunks_per_block);
+	int cur = -1;
+	double acc = 0;
+	auto flush = [&]() {  // workgroup-uniform
+		double v = acc;
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
 		__syncthreads();
-		if (threadIdx.x == 0) unsafeAtomicAdd(g2 + s0, red[0] + red[1] + red[2] + red[3]);
-	} else {
-		for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-			const float v = g[i];
-			if (v != 0.f) unsafeAtomicAdd(g2 + ng_segment(offsets, n_seg, i), (double)v * (double)v);
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+		__syncthreads();
+		if (threadIdx.x == 0 && cur >= 0) unsafeAtomicAdd(g2 + cur, red[0] + red[1] + red[2] + red[3]);
+		acc = 0;
+	};
+	for (int64_t c = c0; c < c1; ++c) {
+		const int64_t i0 = c * NG_CHUNK, i1 = min(n, i0 + NG_CHUNK);
+		// still inside the current segment?  (one LDS compare instead of two searches per chunk)
+		const bool inside = cur >= 0 && i0 >= offsets[cur] && i1 <= offsets[cur + 1];
+		const int s0 = inside ? cur : ng_segment(offsets, n_seg, i0), s1 = inside ? cur : ng_segment(offsets, n_seg, i1 - 1);
+		if (s0 == s1) {
+			if (s0 != cur) { flush(); cur = s0; }
+			float a = 0.f;
+			if (i1 - i0 == NG_CHUNK) {  // 8 independent 16-byte loads per thread in flight
+				float4 v[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(g + i0 + k * 1024 + threadIdx.x * 4);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) a += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+			} else {
+				for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) a += g[i] * g[i];
+			}
+			acc += (double)a;
+		} else {  // a chunk that straddles segment boundaries: one workgroup reduction (and one atomic) per segment piece
+			flush();
+			for (int sg = s0; sg <= s1; ++sg) {
+				const int64_t lo = max(i0, offsets[sg]), hi = min(i1, offsets[sg + 1]);
+				float a = 0.f;
+				for (int64_t i = lo + threadIdx.x; i < hi; i += 256) a += g[i] * g[i];
+				acc = (double)a;
+				cur = sg;
+				flush();
+			}
+			cur = -1;
 		}
 	}
+	flush();
 }
 
 struct NgParams {
@@ -55,6 +93,7 @@ struct NgParams {
 __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 	__shared__ double red[4];
 	__shared__ float s_clip;
+	__shared__ int64_t tab[NG_TABLE];
 	if (q.loss_gate) {
 		const float l = *q.loss_gate;
 		if (!(fabsf(l) < INFINITY)) {  // skipped step: nothing changes; the caller still swaps its two EMA buffers, so carry the EMAs over
@@ -63,6 +102,7 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 			return;
 		}
 	}
+	q.offsets = ng_stage_offsets(q.offsets, q.n_seg, tab);
 	double tot = 0;
 	for (int s = threadIdx.x; s < q.n_seg; s += 256) tot += q.g2[s];
 #pragma unroll
@@ -111,7 +151,8 @@ extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const
 	hipStream_t s = (hipStream_t)stream;
 	if (hipMemsetAsync(g2, 0, sizeof(double) * n_seg, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "novograd_step: memset failed");
 	const unsigned blocks = (unsigned)ceil_div64(n, NG_CHUNK);
-	hipLaunchKernelGGL(ng_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, offsets, n_seg, n, g2);
+	const int chunks_per_block = (int)ceil_div64(blocks, 1024);
+	hipLaunchKernelGGL(ng_sumsq_kernel, dim3((unsigned)ceil_div64(blocks, chunks_per_block)), dim3(256), 0, s, g, offsets, n_seg, n, chunks_per_block, g2);
 	NgParams q;
 	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
 	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
