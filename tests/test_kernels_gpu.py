@@ -347,7 +347,7 @@ def test_ctc_golden():
 
 
 @gpu
-@pytest.mark.parametrize('shape', [(8, 38, 753, 150), (3, 38, 120, 1), (2, 129, 300, 40), (2, 38, 64, 31)])
+@pytest.mark.parametrize('shape', [(8, 38, 753, 150), (3, 38, 120, 1), (2, 129, 300, 40), (2, 38, 64, 31), (2, 38, 1001, 100), (2, 38, 1200, 100)])
 def test_ctc_against_oracle(shape):
 	from convasr_amd import ops
 	B, C, T, S = shape
