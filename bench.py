@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 SAMPLE_RATE, SECS, BATCH, TARGET_LEN = 16000, 15, 64, 150
 FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # conv stack, 2*MAC, fwd + dgrad + wgrad
 PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
@@ -60,6 +61,7 @@ def main():
 	ap.add_argument('--steps', type = int, default = 10)
 	ap.add_argument('--warmup', type = int, default = 3)
 	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f32'])
+	ap.add_argument('--dropout', type = float, default = 0.2, help = 'the reference Wav2Letter default is 0.2; other values are for experiments only')
 	ap.add_argument('--no-cpu-baseline', action = 'store_true')
 	ap.add_argument('--no-kernel-timer', action = 'store_true')
 	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (+1.5-2 % step rate; off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
@@ -88,7 +90,7 @@ def main():
 	ca.functional.manual_seed(1 + rank)
 	compute = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 	fe = ca.models.LogFilterBankFrontend(64, SAMPLE_RATE, 0.02, 0.01, 'hann_window')
-	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0.2, check_time_dim_padded = False, compute_dtype = compute).to(device).train()
+	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = args.dropout, check_time_dim_padded = False, compute_dtype = compute).to(device).train()
 	flat = ca.train.FlatParameters(model)
 	model._convasr_flat = flat
 	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
@@ -141,6 +143,8 @@ def main():
 				if hit:
 					traffic, traffic_src = round(hit[0]['hbm_bytes_per_launch'] / 1e6, 1), 'profiles/r01_bench_hbm_traffic.csv (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
 			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<unsigned short> (forward + dgrad launches of the stride-1 K>=2 layers)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
+			kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
 			others = {name: v for name, v in kt.items() if name != main}
 			if 'conv1d_wgrad' in others:
 				w = others['conv1d_wgrad']
@@ -149,7 +153,9 @@ def main():
 			roof['conv_stack'] = dict(achieved = round(sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12, 2), ms_per_step = round(sum(v['total_ms'] for v in allc) / args.steps, 3))
 			roof['conv_stack']['frac'] = round(roof['conv_stack']['achieved'] / peak, 4)
 			roof['whole_step_frac'] = round(FLOP_PER_AUDIO_S_FWD_BWD * value / world / (peak * 1e12), 4)
-		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout 0.2', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), roofline = roof)
+			# the HBM-bound kernels of the path (frontend, BN + activation passes): algorithmic bytes / HIP-event time against 8 TB/s
+			roof['hbm_kernels'] = {name: dict(achieved = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1), peak = PEAK_HBM_GBS, unit = 'GB/s', frac = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), launches_per_step = v['launches'] // args.steps, ms_per_step = round(v['total_ms'] / args.steps, 3)) for name, v in hbm.items()}
+		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout {args.dropout:g}', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), roofline = roof)
 		if world == 1 and not args.no_cpu_baseline:
 			line['cpu_baseline'] = cpu_baseline()
 	if use_dist:

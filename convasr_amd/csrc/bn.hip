@@ -126,9 +126,25 @@ struct RowWalk {
 	}
 };
 
+// 8 consecutive elements as loaded (16 B of bf16 / 32 B of f32): kept raw so that the loads of two rows can be issued back to
+// back before either is unpacked -- the kernels below are latency-bound on bytes in flight, not on arithmetic
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { uint4 v; };
+template <> struct Raw8<float> { float4 a, b; };
+__device__ __forceinline__ Raw8<bf16_t> raw_load8(const bf16_t* p) { Raw8<bf16_t> r; r.v = *reinterpret_cast<const uint4*>(p); return r; }
+__device__ __forceinline__ Raw8<float> raw_load8(const float* p) { Raw8<float> r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r; }
+__device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) {
+	const unsigned w[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&v)[8]) {
+	v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+
 // pre-activation value of 8 consecutive channels at row (b, t): y * scale + shift + sum_r (res_r * rscale_r + rshift_r)
-template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams& p, const ResArgs& ra, int64_t idx, int c, const float (&sc)[8], const float (&sh)[8], float (&yv)[8], float (&pre)[8]) {
-	load8<T>(reinterpret_cast<const T*>(p.y) + idx, yv);
+template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams& p, const ResArgs& ra, int64_t idx, int c, const float (&sc)[8], const float (&sh)[8], const Raw8<T>& yraw, float (&yv)[8], float (&pre)[8]) {
+	unpack8(yraw, yv);
 #pragma unroll
 	for (int i = 0; i < 8; ++i) pre[i] = p.scale ? fmaf(yv[i], sc[i], sh[i]) : yv[i];
 	for (int r = 0; r < ra.n; ++r) {
@@ -144,6 +160,20 @@ template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams
 #pragma unroll
 			for (int i = 0; i < 8; ++i) pre[i] += rv[i];
 		}
+	}
+}
+
+// Two rows per trip: both rows' loads are issued (through `load`) before the first is consumed (by `use`).
+template <typename L, typename U> __device__ __forceinline__ void walk_rows2(const BnActParams& p, int rl, int c, L load, U use) {
+	for (RowWalk w(p, rl, c); w.live();) {
+		RowWalk w2 = w;
+		w2.next(p);
+		const bool two = w2.live();
+		auto r1 = load(w);
+		auto r2 = two ? load(w2) : r1;
+		use(w, r1);
+		if (two) { use(w2, r2); w2.next(p); }
+		w = w2;
 	}
 }
 
@@ -167,25 +197,28 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(B
 		const int c = (cbase + cg) << 3;
 		float sc[8], sh[8];
 		if (p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
-		for (RowWalk w(p, rl, c); w.live(); w.next(p)) {
-			float out[8];
-			if (w.masked()) {
+		const T* const py = reinterpret_cast<const T*>(p.y);
+		walk_rows2(p, rl, c,
+			[&](const RowWalk& w) { return raw_load8(py + w.idx); },  // unconditional (a masked row is still inside the tensor): no branch between the two rows' loads
+			[&](const RowWalk& w, const Raw8<T>& yraw) {
+				float out[8];
+				if (w.masked()) {
 #pragma unroll
-				for (int k = 0; k < 8; ++k) out[k] = 0.f;
-			} else {
-				float yv[8], pre[8];
-				pre_act8<T>(p, ra, w.idx, c, sc, sh, yv, pre);
+					for (int k = 0; k < 8; ++k) out[k] = 0.f;
+				} else {
+					float yv[8], pre[8];
+					pre_act8<T>(p, ra, w.idx, c, sc, sh, yraw, yv, pre);
 #pragma unroll
-				for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], p.act, p.lo, p.hi);
-				if (p.drop_thr) {
-					float keep[8];
-					dropout_keep8(p, w.idx, keep);
+					for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], p.act, p.lo, p.hi);
+					if (p.drop_thr) {
+						float keep[8];
+						dropout_keep8(p, w.idx, keep);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) out[k] *= keep[k];
+						for (int k = 0; k < 8; ++k) out[k] *= keep[k];
+					}
 				}
-			}
-			store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
-		}
+				store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
+			});
 	}
 }
 
@@ -250,41 +283,46 @@ template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bw
 		float mean[8], istd[8], sc[8], sh[8];
 		if (cok && p.mean) { load8<float>(p.mean + c, mean); load8<float>(p.invstd + c, istd); }
 		if (cok && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+		struct Pair { Raw8<T> y, dz; };
+		const T* const py = reinterpret_cast<const T*>(p.y);
+		const T* const pdz = reinterpret_cast<const T*>(p.dz);
 		if (cok)
-			for (RowWalk w(p, rl, c); w.live(); w.next(p)) {
-				float g[8];
-				if (w.masked()) {
+			walk_rows2(p, rl, c,
+				[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); return q; },
+				[&](const RowWalk& w, const Pair& q) {
+					float g[8];
+					if (w.masked()) {
 #pragma unroll
-					for (int k = 0; k < 8; ++k) g[k] = 0.f;
-				} else {
-					float yv[8], pre[8], dz[8];
-					pre_act8<T>(p, ra, w.idx, c, sc, sh, yv, pre);
-					load8<T>(reinterpret_cast<const T*>(p.dz) + w.idx, dz);
+						for (int k = 0; k < 8; ++k) g[k] = 0.f;
+					} else {
+						float yv[8], pre[8], dz[8];
+						pre_act8<T>(p, ra, w.idx, c, sc, sh, q.y, yv, pre);
+						unpack8(q.dz, dz);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
-					if (p.drop_thr) {
-						float keep[8];
-						dropout_keep8(p, w.idx, keep);
+						for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+						if (p.drop_thr) {
+							float keep[8];
+							dropout_keep8(p, w.idx, keep);
 #pragma unroll
-						for (int k = 0; k < 8; ++k) g[k] *= keep[k];
-					}
-					if (p.mean) {
+							for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+						}
+						if (p.mean) {
 #pragma unroll
-						for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (yv[k] - mean[k]) * istd[k]; }
-					}
-					for (int r = 0; RES && r < ra.n && r < 2; ++r) {
-						if (ra.rsums[r]) {
-							float rv[8], rm[8], ri[8];
-							load8<T>(reinterpret_cast<const T*>(ra.res[r]) + w.idx, rv);
-							load8<float>(ra.rmean[r] + c, rm);
-							load8<float>(ra.rinvstd[r] + c, ri);
+							for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (yv[k] - mean[k]) * istd[k]; }
+						}
+						for (int r = 0; RES && r < ra.n && r < 2; ++r) {
+							if (ra.rsums[r]) {
+								float rv[8], rm[8], ri[8];
+								load8<T>(reinterpret_cast<const T*>(ra.res[r]) + w.idx, rv);
+								load8<float>(ra.rmean[r] + c, rm);
+								load8<float>(ra.rinvstd[r] + c, ri);
 #pragma unroll
-							for (int k = 0; k < 8; ++k) { rs1[RES ? r : 0][k] += g[k]; rs2[RES ? r : 0][k] += g[k] * (rv[k] - rm[k]) * ri[k]; }
+								for (int k = 0; k < 8; ++k) { rs1[RES ? r : 0][k] += g[k]; rs2[RES ? r : 0][k] += g[k] * (rv[k] - rm[k]) * ri[k]; }
+							}
 						}
 					}
-				}
-				if (p.out) store8<T>(reinterpret_cast<T*>(p.out) + w.idx, g);
-			}
+					if (p.out) store8<T>(reinterpret_cast<T*>(p.out) + w.idx, g);
+				});
 		// block reduction over the row-lanes that share a channel group
 		auto reduce_to = [&](float (&a)[8], float (&bq)[8], int set) {
 #pragma unroll
@@ -461,33 +499,38 @@ template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_ac
 		load8<float>(coef + p.C + c, Bc);
 		load8<float>(coef + 2 * p.C + c, D);
 		if (FROM_DZ && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
-		for (RowWalk w(p, rl, c); w.live(); w.next(p)) {
-			float yv[8], pre[8], g[8], out[8];
-			if (FROM_DZ) {
-				pre_act8<T>(p, none, w.idx, c, sc, sh, yv, pre);
-				if (w.masked()) {
+		struct Pair { Raw8<T> y, dz; };
+		const T* const py = reinterpret_cast<const T*>(p.y);
+		const T* const pdz = reinterpret_cast<const T*>(p.dz);
+		walk_rows2(p, rl, c,
+			[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); return q; },
+			[&](const RowWalk& w, const Pair& q) {
+				float yv[8], pre[8], g[8], out[8];
+				if (FROM_DZ) {
+					pre_act8<T>(p, none, w.idx, c, sc, sh, q.y, yv, pre);
+					if (w.masked()) {
 #pragma unroll
-					for (int k = 0; k < 8; ++k) g[k] = 0.f;
-				} else {
-					float dz[8];
-					load8<T>(reinterpret_cast<const T*>(p.dz) + w.idx, dz);
+						for (int k = 0; k < 8; ++k) g[k] = 0.f;
+					} else {
+						float dz[8];
+						unpack8(q.dz, dz);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
-					if (p.drop_thr) {
-						float keep[8];
-						dropout_keep8(p, w.idx, keep);
+						for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+						if (p.drop_thr) {
+							float keep[8];
+							dropout_keep8(p, w.idx, keep);
 #pragma unroll
-						for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+							for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+						}
 					}
+				} else {
+					unpack8(q.dz, g);
+					unpack8(q.y, yv);
 				}
-			} else {
-				load8<T>(reinterpret_cast<const T*>(p.dz) + w.idx, g);
-				load8<T>(reinterpret_cast<const T*>(p.y) + w.idx, yv);
-			}
 #pragma unroll
-			for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
-			store8<T>(dy + w.idx, out);
-		}
+				for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
+				store8<T>(dy + w.idx, out);
+			});
 	}
 }
 

@@ -82,7 +82,7 @@ def logmel(signal, xlen, window, mel_weight, mel_bias, nfft, hop, preemphasis = 
 		call('convasr_signal_absmax', ptr(signal), dtype_code(signal.dtype), B, T, ptr(absmax), s)
 	out = empty_cl(B, nmel, F, torch.float32, signal.device)
 	xl = xlen_f32(xlen, signal.device)
-	call('convasr_logmel_fwd', ptr(signal), dtype_code(signal.dtype), ptr(absmax), ptr(xl), ptr(window), window.shape[0], ptr(mel_weight), ptr(mel_bias), ptr(out), B, T, nfft, hop, nmel, float(preemphasis), s)
+	_lib.timed('hbm:logmel_kernel', 0.0, lambda: call('convasr_logmel_fwd', ptr(signal), dtype_code(signal.dtype), ptr(absmax), ptr(xl), ptr(window), window.shape[0], ptr(mel_weight), ptr(mel_bias), ptr(out), B, T, nfft, hop, nmel, float(preemphasis), s), nbytes = float(B * T * signal.element_size() + B * F * nmel * 4))
 	return out
 
 
@@ -192,7 +192,7 @@ def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = ()
 	B, C, T = y.shape
 	assert is_cl(y) and all(is_cl(r) and r.dtype == y.dtype for r in res)
 	z = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
-	call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr())
+	_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res))))
 	return z
 
 
@@ -201,14 +201,14 @@ def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res =
 	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype
 	g = empty_cl(B, C, T, y.dtype, y.device) if write_g else None
 	ws = workspace(_lib.load().convasr_bn_bwd_workspace_bytes(B, T, C), y.device, 'bn_bwd')
-	call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, stream_ptr())
+	_lib.timed('hbm:bn_act_bwd_reduce_kernel', 0.0, lambda: call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res) + (1 if write_g else 0))))
 	return g
 
 
 def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None):
 	B, C, T = y.shape
 	dy = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
-	call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr())
+	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr()), nbytes = float(B * T * C * y.element_size() * 3))
 	return dy
 
 
