@@ -11,6 +11,7 @@ ap.add_argument('--B', type = int, default = 64)
 ap.add_argument('--T', type = int, default = 751)
 ap.add_argument('--what', default = 'fwd,dgrad,wgrad')
 ap.add_argument('--dtype', default = 'bf16')
+ap.add_argument('--nostats', action = 'store_true')
 a = ap.parse_args()
 d = torch.device('cuda:0')
 dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
@@ -35,7 +36,7 @@ for spec in a.layers.split(';'):
     stats = torch.zeros(2 * cout, dtype = torch.float64, device = d)
     res = []
     if 'fwd' in a.what:
-        ms = timeit(lambda: ops.conv1d(x, fwd, cout, k, stride, dil, pad, stats = stats), a.iters); res.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s')
+        ms = timeit(lambda: ops.conv1d(x, fwd, cout, k, stride, dil, pad, stats = None if a.nostats else stats), a.iters); res.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s')
     if 'dgrad' in a.what and stride == 1:
         ms = timeit(lambda: ops.conv1d(dy, dgr, cin, k, 1, dil, dil * (k - 1) - pad), a.iters); res.append(f'dgrad {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s')
     if 'wgrad' in a.what:
