@@ -230,9 +230,55 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ f
 	}
 }
 
+// bf16 builds of the two packers with 4-byte accesses on the 2-byte side (two neighbouring elements per lane): half the wave
+// instructions of the scalar versions above, which remain for fp32 and for odd channel counts.
+__global__ __launch_bounds__(256) void pack_fwd_bf16x2_kernel(const float* __restrict__ w, bf16_t* __restrict__ fwd, int64_t pairs, int K, int64_t tap_stride) {
+	extern __shared__ float tile[];  // [512 * K]
+	const int64_t lin0 = (int64_t)blockIdx.x * 512;
+	const int n = (int)min((int64_t)512, pairs - lin0);  // even: pairs = Cout * Cin with Cin even
+	for (int j = threadIdx.x; j < n * K; j += 256) tile[j] = w[lin0 * K + j];
+	__syncthreads();
+	const int t2 = threadIdx.x * 2;
+	if (t2 < n)
+		for (int k = 0; k < K; ++k) {
+			const unsigned v = (unsigned)f32_to_bf16(tile[t2 * K + k]) | ((unsigned)f32_to_bf16(tile[(t2 + 1) * K + k]) << 16);
+			*reinterpret_cast<unsigned*>(fwd + k * tap_stride + lin0 + t2) = v;
+		}
+}
+
+__global__ __launch_bounds__(256) void pack_dgrad_bf16x2_kernel(const bf16_t* __restrict__ fwd, bf16_t* __restrict__ dgr, int Cout, int Cin, int K, int co_pad, int ci_pad) {
+	__shared__ bf16_t tile[64][66];
+	const int k = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 element pairs x 8 rows per pass
+	const bf16_t* src = fwd + (int64_t)k * co_pad * Cin;
+	bf16_t* dst = dgr + (int64_t)(K - 1 - k) * ci_pad * Cout;
+#pragma unroll 4
+	for (int i = 0; i < 8; ++i) {
+		const int co = co0 + ty + 8 * i, ci = ci0 + 2 * tx;
+		if (co < Cout && ci < Cin) {
+			const unsigned v = *reinterpret_cast<const unsigned*>(src + (int64_t)co * Cin + ci);
+			tile[ty + 8 * i][2 * tx] = (bf16_t)(v & 0xffffu);
+			tile[ty + 8 * i][2 * tx + 1] = (bf16_t)(v >> 16);
+		}
+	}
+	__syncthreads();
+#pragma unroll 4
+	for (int i = 0; i < 8; ++i) {
+		const int ci = ci0 + ty + 8 * i, co = co0 + 2 * tx;
+		if (co < Cout && ci < Cin)
+			*reinterpret_cast<unsigned*>(dst + (int64_t)ci * Cout + co) = (unsigned)tile[2 * tx][ty + 8 * i] | ((unsigned)tile[2 * tx + 1][ty + 8 * i] << 16);
+	}
+}
+
 template <typename T> static void launch_pack(const float* w, void* fwd, void* dgr, int Cout, int Cin, int K, hipStream_t s) {
 	const int co_pad = convasr_conv_cout_pad(Cout), ci_pad = convasr_conv_cout_pad(Cin);
 	const int64_t pairs = (int64_t)Cout * Cin;
+	const bool x2 = sizeof(T) == 2 && (Cin & 1) == 0 && (Cout & 1) == 0 && (size_t)512 * K * sizeof(float) <= 64 * 1024;
+	if (x2) {
+		hipLaunchKernelGGL(pack_fwd_bf16x2_kernel, dim3((unsigned)ceil_div64(pairs, 512)), dim3(256), (size_t)512 * K * sizeof(float), s, w, (bf16_t*)fwd, pairs, K, (int64_t)co_pad * Cin);
+		if (dgr) hipLaunchKernelGGL(pack_dgrad_bf16x2_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const bf16_t*)fwd, (bf16_t*)dgr, Cout, Cin, K, co_pad, ci_pad);
+		return;
+	}
 	hipLaunchKernelGGL((pack_fwd_kernel<T>), dim3((unsigned)ceil_div64(pairs, 256)), dim3(256), (size_t)256 * K * sizeof(float), s, w, (T*)fwd, pairs, K, (int64_t)co_pad * Cin);
 	if (dgr) hipLaunchKernelGGL((pack_dgrad_kernel<T>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
 }
