@@ -1,0 +1,99 @@
+"""Two data-parallel ranks running the REAL kernels (both on cuda:0, collectives over gloo, which stages CUDA tensors through
+the host): the bucketed all-reduce hooks of DataParallelEngine inside a real backward, replicas staying identical, and the
+averaged update equal to a single process that computes the two ranks' gradients one after the other.  (RCCL itself needs one
+GPU per rank: the driver's multi-GPU bench is the first place it runs with world > 1; bench.py's CONVASR_FORCE_DIST=1 mode
+covers it with world = 1.)"""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	return port
+
+
+def _make(ca, d):
+	torch.manual_seed(0)
+	return ca.models.JasperNet(64, [38], base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.0], out_width_factors_large = [2, 2], residual = False, repeat = 1, check_time_dim_padded = False, temporal_mask = True).to(d).train()
+
+
+def _batch(rank, d):
+	g = torch.Generator().manual_seed(50 + rank)
+	x = torch.randn(3, 64, 48, generator = g).to(d)
+	xlen = torch.tensor([1.0, 0.8, 0.6]).to(d)
+	y = torch.randint(0, 37, (3, 1, 5), generator = g).to(d)
+	ylen = torch.tensor([[5], [4], [3]]).to(d)
+	return x, xlen, y, ylen
+
+
+def _worker(rank, world, port, out_dir):
+	os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+	dist.init_process_group('gloo', rank = rank, world_size = world)
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	torch.cuda.set_device(d)
+	model = _make(ca, d)
+	flat = ca.train.FlatParameters(model)
+	model._convasr_flat = flat
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	engine = ca.parallel.DataParallelEngine(model, device = d, bucket_bytes = 64 << 10)
+	assert len(engine.buckets) >= 2
+	batch = _batch(rank, d)
+	losses = []
+	for it in range(2):
+		res = ca.train.train_step(engine, opt, *batch, world_size = world, iteration = it, sync_metrics = True)
+		assert not bool(res['skipped'])
+		losses.append(float(res['loss_cur']))
+	torch.cuda.synchronize()
+	torch.save(dict(params = flat.data.cpu(), losses = losses), os.path.join(out_dir, f'rank{rank}.pt'))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+def test_two_ranks_real_kernels_match_sequential_average():
+	import convasr_amd as ca
+	world = 2
+	with tempfile.TemporaryDirectory() as out_dir:
+		mp.spawn(_worker, args = (world, _free_port(), out_dir), nprocs = world, join = True)
+		got = [torch.load(os.path.join(out_dir, f'rank{r}.pt')) for r in range(world)]
+	assert torch.equal(got[0]['params'], got[1]['params']), 'replicas diverged'
+	assert got[0]['losses'] == got[1]['losses'], 'the all-reduced metric must be the same number on every rank'
+
+	# single process: per-rank replicas of the batch-norm buffers, shared parameters, gradients averaged by hand
+	d = torch.device('cuda:0')
+	models = [_make(ca, d) for _ in range(world)]
+	flats = [ca.train.FlatParameters(m) for m in models]
+	for m, f in zip(models, flats):
+		m._convasr_flat = f
+	opt = ca.train.SGD(flats[0], lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	for it in range(2):
+		grads = []
+		for r in range(world):
+			flats[r].data.copy_(flats[0].data)
+			ca.functional.bump_param_epoch()
+			x, xlen, y, ylen = _batch(r, d)
+			out = models[r](x, xlen, y = y, ylen = ylen)
+			((out['loss'] * ylen[:, 0]).mean()).backward()
+			flats[r].finalize_grads()
+			grads.append(flats[r].grad.clone())
+			flats[r].zero_grad()
+		flats[0].grad.copy_(sum(grads) / world)
+		for p in flats[0].params:
+			p._convasr_fresh = False
+		flats[0].clip_grad_norm_(100.0)
+		opt.step()
+		opt.zero_grad()
+	ref = flats[0].data.cpu()
+	err = (got[0]['params'] - ref).abs().max().item()
+	assert err <= 2e-6 + 1e-5 * ref.abs().max().item(), err
