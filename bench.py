@@ -72,7 +72,8 @@ def main():
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 	if args.gpus > 1 and world != args.gpus:
 		raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
-	device = torch.device('cuda', local_rank)
+	# (test hooks for a 1-GPU box: CONVASR_SHARE_GPU=1 puts every rank on cuda:0, CONVASR_DIST_BACKEND=gloo replaces RCCL, which needs one GPU per rank)
+	device = torch.device('cuda', 0 if os.environ.get('CONVASR_SHARE_GPU') == '1' else local_rank)
 	torch.cuda.set_device(device)
 	use_dist = world > 1 or os.environ.get('CONVASR_FORCE_DIST') == '1'  # the latter: single-rank RCCL smoke test of the DP path
 	if use_dist:
@@ -81,7 +82,11 @@ def main():
 		os.environ.setdefault('MASTER_PORT', '29511')
 		os.environ.setdefault('RANK', '0')
 		os.environ.setdefault('WORLD_SIZE', '1')
-		dist.init_process_group('nccl', device_id = device)
+		backend = os.environ.get('CONVASR_DIST_BACKEND', 'nccl')
+		if backend == 'nccl':
+			dist.init_process_group('nccl', device_id = device)
+		else:
+			dist.init_process_group(backend)
 
 	import convasr_amd as ca
 	from convasr_amd import _lib
