@@ -46,6 +46,8 @@ _SIGNATURES = dict(
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p]),
 	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p]),
+	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p]),
+	convasr_bn_bwd_finalize = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_int, c_p]),
 	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),
 	convasr_ctc_alignment = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
@@ -83,6 +85,15 @@ def call(name, *args):
 	rc = getattr(lib, name)(*args)
 	if rc != 0:
 		raise ConvasrHipError(f'{name} failed ({rc}): {lib.convasr_last_error().decode()}')
+
+
+def call_rc(name, *args):
+	"""For entry points whose positive return codes are answers, not errors (negative codes still raise)."""
+	lib = load()
+	rc = getattr(lib, name)(*args)
+	if rc < 0:
+		raise ConvasrHipError(f'{name} failed ({rc}): {lib.convasr_last_error().decode()}')
+	return rc
 
 
 class KernelTimer:

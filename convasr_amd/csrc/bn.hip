@@ -177,17 +177,7 @@ template <typename L, typename U> __device__ __forceinline__ void walk_rows2(con
 	}
 }
 
-// Dropout mask of the 8 elements starting at element index idx (a multiple of 8): one Philox4x32-7 block (the shortest
-// Crush-resistant round count of Salmon et al. 2011) keyed by (seed, offset + idx / 8) gives 8 x 16 random bits.
-__device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) {
-	unsigned r[4];
-	philox4x32<7>(p.seed, p.offset + (uint64_t)(idx >> 3), r);
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		keep[2 * i] = (r[i] & 0xffffu) >= p.drop_thr ? p.keep_scale : 0.f;
-		keep[2 * i + 1] = (r[i] >> 16) >= p.drop_thr ? p.keep_scale : 0.f;
-	}
-}
+__device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) { dropout_mask8(p.seed, p.offset, p.drop_thr, p.keep_scale, idx, keep); }
 
 template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra) {
 	const int c8 = p.C >> 3;
@@ -391,6 +381,35 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __res
 			if (sets.dbeta) sets.dbeta[c] = sets.accumulate ? sets.dbeta[c] + (float)sg : (float)sg;
 		}
 	}
+}
+
+// The same finalize for sums that were accumulated directly (fp64 atomics) by the fused dgrad epilogue of conv_v2s.hip:
+// emits coef / dgamma / dbeta and zeroes the accumulators for the next step.
+__global__ void bn_bwd_finalize_sums_kernel(double* __restrict__ sums, BnFinalizeSets sets, int C, int rezero) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	const double sg = sums[c], sgx = sums[C + c];
+	if (sets.coef) {
+		const float gm = sets.gamma ? sets.gamma[c] : 1.f, is = sets.invstd[c], m = sets.mean[c];
+		const float msg = (float)sg * sets.invn, msgx = (float)sgx * sets.invn;
+		sets.coef[c] = gm * is;
+		sets.coef[C + c] = -gm * is * is * msgx;
+		sets.coef[2 * C + c] = gm * is * (m * is * msgx - msg);
+	}
+	if (sets.dgamma) sets.dgamma[c] = sets.accumulate ? sets.dgamma[c] + (float)sgx : (float)sgx;
+	if (sets.dbeta) sets.dbeta[c] = sets.accumulate ? sets.dbeta[c] + (float)sg : (float)sg;
+	if (rezero) { sums[c] = 0; sums[C + c] = 0; }
+}
+
+extern "C" int convasr_bn_bwd_finalize(double* sums, const float* gamma, const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                                       int accumulate, int64_t n, int C, int rezero_sums, void* stream) {
+	CONVASR_CHECK_ARG(sums && mean && invstd && n > 0 && C > 0, "bn_bwd_finalize: bad arguments");
+	BnFinalizeSets sets = {};
+	sets.gamma = gamma; sets.mean = mean; sets.invstd = invstd; sets.coef = coef; sets.dgamma = dgamma; sets.dbeta = dbeta;
+	sets.accumulate = accumulate; sets.invn = 1.0f / (float)n;
+	hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, sets, C, rezero_sums);
+	CONVASR_CHECK_LAUNCH("bn_bwd_finalize");
+	return 0;
 }
 
 // at most BN_BWD_MAX_BLOCKS blocks (3 per CU): the finalize kernel reads one partial row per block and set

@@ -110,6 +110,19 @@ template <int ROUNDS> __device__ __forceinline__ void philox4x32(uint64_t seed, 
 	r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
+// Dropout mask of the 8 elements starting at element index idx (a multiple of 8): one Philox4x32-7 block (the shortest
+// Crush-resistant round count of Salmon et al. 2011) keyed by (seed, offset + idx / 8) gives 8 x 16 random bits; an element is
+// dropped when its bits are < thr (= round(p * 65536)), kept ones are scaled by `scale` (= 65536 / (65536 - thr)).
+__device__ __forceinline__ void dropout_mask8(uint64_t seed, uint64_t offset, unsigned thr, float scale, int64_t idx, float (&keep)[8]) {
+	unsigned r[4];
+	philox4x32<7>(seed, offset + (uint64_t)(idx >> 3), r);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		keep[2 * i] = (r[i] & 0xffffu) >= thr ? scale : 0.f;
+		keep[2 * i + 1] = (r[i] >> 16) >= thr ? scale : 0.f;
+	}
+}
+
 __device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, float (&u)[4]) {
 	unsigned r[4];
 	philox4x32<10>(seed, ctr, r);

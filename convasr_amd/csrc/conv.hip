@@ -324,15 +324,16 @@ static int g_conv_debug = 0;
 // test / A-B hook: 0 forces the register-staged kernel for every dtype
 extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable & 1; g_conv_debug = enable >> 8; return prev; }
 
-extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
-                                  int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
-                                  float act_lo, float act_hi, const float* xlen, void* stream) {
+static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
+                      int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
+                      float act_lo, float act_hi, const float* xlen, const ConvParams* bn_fusion, void* stream) {
 	CONVASR_CHECK_ARG(x && wp && y && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_fwd: bad arguments");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd: scale and shift go together");
 	const int64_t expect = ((int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
 	CONVASR_CHECK_ARG(expect == Tout, "conv1d_fwd: Tout %d inconsistent with Tin %d K %d stride %d dil %d pad %d (expect %lld)", Tout, Tin, K, stride, dil, pad, (long long)expect);
 	CONVASR_CHECK_ARG(x_dtype == CONVASR_F32 || x_dtype == CONVASR_BF16, "conv1d_fwd: x dtype %d", x_dtype);
-	ConvParams p;
+	ConvParams p = {};
+	if (bn_fusion) p = *bn_fusion;  // only the bn_* fields are set in it
 	p.x = x; p.w = wp; p.y = y; p.bias = bias; p.stats = stats; p.scale = scale; p.shift = shift; p.xlen = xlen;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = convasr_conv_cout_pad(Cout); p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
 	p.act = act; p.act_lo = act_lo; p.act_hi = act_hi; p.debug = g_conv_debug;
@@ -351,6 +352,7 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 		CONVASR_CHECK_LAUNCH("conv1d_fwd (v2)");
 		return 0;
 	}
+	if (p.bn_y) return 1;  // the fused epilogue lives in the LDS-DMA kernel only: nothing was launched, the caller runs the two steps apart
 	int rc;
 	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) rc = dispatch_conv<float, float>(p, smem, s);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_BF16) rc = dispatch_conv<bf16_t, bf16_t>(p, smem, s);
@@ -359,6 +361,27 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("conv1d_fwd");
 	return 0;
+}
+
+extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
+                                  int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
+                                  float act_lo, float act_hi, const float* xlen, void* stream) {
+	return conv1d_run(x, wp, y, x_dtype, y_dtype, B, Cin, Cout, Tin, Tout, K, stride, dil, pad, bias, stats, scale, shift, act, act_lo, act_hi, xlen, nullptr, stream);
+}
+
+extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad,
+                                              const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                                              int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                              const float* bn_xlen, double* bn_sums, void* stream) {
+	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0, "conv1d_dgrad_bn_reduce: bad arguments");
+	ConvParams f = {};
+	f.bn_y = bn_y; f.bn_scale = bn_scale; f.bn_shift = bn_shift; f.bn_mean = bn_mean; f.bn_invstd = bn_invstd; f.bn_xlen = bn_xlen; f.bn_sums = bn_sums;
+	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = seed; f.bn_offset = offset;
+	f.bn_drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
+	if (f.bn_drop_thr > 65535u) f.bn_drop_thr = 65535u;
+	f.bn_keep_scale = 65536.f / (float)(65536u - f.bn_drop_thr);
+	// dgrad = the forward kernel on (dy, flipped packed weights): channels in = Cout, channels out = Cin, stride 1
+	return conv1d_run(dy, packed_dgrad, dx, CONVASR_BF16, CONVASR_BF16, B, Cout, Cin, T_dy, T_dx, K, 1, dil, pad, nullptr, nullptr, nullptr, nullptr, CONVASR_ACT_NONE, 0.f, 0.f, nullptr, &f, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad

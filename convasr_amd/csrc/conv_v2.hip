@@ -289,6 +289,7 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	                           {(const void*)conv1d_igemm_v2_kernel<float, 0>, (const void*)conv1d_igemm_v2_kernel<float, 1>, (const void*)conv1d_igemm_v2_kernel<float, 2>}};
 	const int oi = y_dtype == CONVASR_BF16 ? 0 : 1;
 	const bool small_shape = mode == 2 && ((p.debug & 128) != 0) == (V2_DEFAULT_SMALL_SHAPE == 0);  // debug bit 128 selects the non-default MFMA shape
+	if (p.bn_y && !(small_shape && y_dtype == CONVASR_BF16)) return 0;  // the fused BN-backward epilogue exists in conv_v2s.hip only
 	const void* kern = small_shape ? convasr_conv_v2s_kernel(y_dtype) : table[oi][mode];
 	static bool attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};
 	if (small_shape) mode = 3;

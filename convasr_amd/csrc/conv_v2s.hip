@@ -122,6 +122,19 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 	char* const otile = smem;
 	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN_]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
+	// fused BN-backward epilogue (see below): the consumer layer's y tile is fetched now, 16 B per lane and store-loop trip, so
+	// that its latency hides under the accumulator staging (loading it inside the store loop cost ~8 serial L2/HBM round trips per tile)
+	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
+	const bool bnf = sizeof(O) == 2 && p.bn_y != nullptr;
+	uint4 ypre[TRIPS];
+	if (bnf) {
+#pragma unroll
+		for (int i = 0; i < TRIPS; ++i) {
+			const int e = tid + i * V2_THREADS, row = e / OCH_, t = t0 + row, co = co0 + (e % OCH_) * OEPC_;
+			ypre[i] = make_uint4(0, 0, 0, 0);
+			if (t < p.Tout && co < p.Cout) ypre[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + ((int64_t)b * p.Tout + t) * p.Cout + co);
+		}
+	}
 #pragma unroll
 	for (int ni = 0; ni < NB; ++ni) {
 		const int col = wn * (16 * NB) + ni * 16 + r16, co = co0 + col;
@@ -159,7 +172,22 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN_ / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
-	for (int e = tid; e < V2_BM * OCHUNKS; e += V2_THREADS) {
+	// Fused pass 1 of the consumer layer's batch-norm backward (bf16 only): this tile IS dz of that layer; with its conv output y
+	// (same coordinates) g = dz * act'(y * scale + shift) * dropout * mask, and the tile's per-channel sums of g and g * xhat go to
+	// fp64 accumulators -- the separate reduce pass (2 reads of B*T*C) and its launch disappear.  A thread keeps one 8-channel
+	// chunk for all its rows (V2_THREADS % OCHUNKS == 0), reads dz back from the LDS tile exactly as it is stored (bf16-rounded).
+	float bs1[8], bs2[8], bsc[8], bsh[8], bmean[8], bistd[8];
+	const int bco = co0 + (tid % OCHUNKS) * OEPC;
+	int bnv = 0;
+	if (bnf) {
+#pragma unroll
+		for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+		if (bco < p.Cout) { load8<float>(p.bn_scale + bco, bsc); load8<float>(p.bn_shift + bco, bsh); load8<float>(p.bn_mean + bco, bmean); load8<float>(p.bn_invstd + bco, bistd); }
+		bnv = valid_len(p.bn_xlen, b, p.Tout);
+	}
+#pragma unroll
+	for (int it = 0; it < TRIPS; ++it) {
+		const int e = tid + it * V2_THREADS;
 		const int row = e / OCHUNKS, ch = e % OCHUNKS;
 		const int t = t0 + row, co = co0 + ch * OEPC;
 		if (t >= p.Tout || co >= p.Cout) continue;
@@ -168,6 +196,39 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 		if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 		else
 			for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = src[i];
+		if (bnf && t < bnv) {
+			const int64_t idx = ((int64_t)b * p.Tout + t) * p.Cout + co;
+			float dz[8], yv[8], g[8];
+			load8<bf16_t>(reinterpret_cast<const bf16_t*>(src), dz);
+			{
+				const unsigned w[4] = {ypre[it].x, ypre[it].y, ypre[it].z, ypre[it].w};
+#pragma unroll
+				for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(w[k] << 16); yv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+			}
+#pragma unroll
+			for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(fmaf(yv[k], bsc[k], bsh[k]), p.bn_act, p.bn_lo, p.bn_hi);
+			if (p.bn_drop_thr) {
+				float keep[8];
+				dropout_mask8(p.bn_seed, p.bn_offset, p.bn_drop_thr, p.bn_keep_scale, idx, keep);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+			}
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { bs1[k] += g[k]; bs2[k] = fmaf(g[k], yv[k], bs2[k]); }  // sum g*y; centred and scaled once per tile below
+		}
+	}
+	if (bnf) {
+		float* const bnred = reinterpret_cast<float*>(smem + V2_BM * OPITCH + 8 * BN * sizeof(float));  // [V2_THREADS][17], past the output tile and `red`
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { bnred[tid * 17 + k] = bs1[k]; bnred[tid * 17 + 8 + k] = (bs2[k] - bmean[k] * bs1[k]) * bistd[k]; }  // sum g * xhat of this thread's rows
+		__syncthreads();
+		if (tid < BN_ && co0 + tid < p.Cout) {
+			const int chunk = tid >> 3, k = tid & 7;
+			double a = 0, q2 = 0;
+			for (int j = chunk; j < V2_THREADS; j += OCHUNKS) { a += (double)bnred[j * 17 + k]; q2 += (double)bnred[j * 17 + 8 + k]; }
+			unsafeAtomicAdd(p.bn_sums + co0 + tid, a);
+			unsafeAtomicAdd(p.bn_sums + p.Cout + co0 + tid, q2);
+		}
 	}
 }
 

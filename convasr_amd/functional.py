@@ -5,6 +5,8 @@ cached per parameter version.  When a parameter carries `_convasr_grad` (a pre-a
 `convasr_amd.train.FlatParameters`), backward writes / accumulates into it directly and hands autograd `None` -- no
 extra gradient copies, and the data-parallel engine is told the moment each gradient is final.
 """
+import os
+
 import torch
 
 from . import ops, _lib
@@ -121,6 +123,42 @@ class ConvSpec:
 		self.K, self.stride, self.dilation, self.padding = K, stride, dilation, padding
 
 
+# Cross-layer backward fusion (bf16 training): pass 1 of a layer's batch-norm backward (per-channel sums of g and g * xhat) runs
+# in the epilogue of the dgrad launch that PRODUCES that layer's dz, i.e. in the backward of the layer's consumer.  The producer
+# registers what the epilogue needs under its output's address at forward time; the consumer's backward looks its input up, and
+# tags the dz it returns so that the producer's backward skips its own reduce pass.  Only outputs with exactly one consumer are
+# registered (a gradient that autograd accumulates from several consumers is not the tile the epilogue saw).
+_PRODUCERS = {}
+_FUSED = {}
+FUSE_BWD = os.environ.get('CONVASR_NO_BWD_FUSION') != '1'  # tests / A-B runs flip this to compare against the separate reduce pass
+
+
+def clear_fusion_state():
+	_PRODUCERS.clear()
+	_FUSED.clear()
+
+
+def _bwd_sums_buffer(bn, C, dev):
+	buf = getattr(bn, '_convasr_bwd_sums', None)
+	if buf is None or buf.numel() != 2 * C or buf.device != dev:
+		buf = bn._convasr_bwd_sums = torch.zeros(2 * C, dtype = torch.float64, device = dev)
+	return buf
+
+
+def _dgrad(x, dy, weight, spec, dt):
+	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer registered for it."""
+	Cin = x.shape[1]
+	pad = spec.dilation * (spec.K - 1) - spec.padding
+	wd = packed_weight(weight, dt, _lib.PACK_DGRAD)
+	info = _PRODUCERS.pop(x.data_ptr(), None)
+	if info is not None and dt == torch.bfloat16 and spec.stride == 1:
+		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, info['y'], info['bnp'][2], info['bnp'][3], info['bnp'][0], info['bnp'][1], info['act'], info['drop'][0], info['drop'][1], info['drop'][2], info['xl'], info['sums'])
+		if dx is not None:
+			_FUSED[dx.data_ptr()] = info['sums']
+			return dx
+	return ops.conv1d(dy, wd, Cin, spec.K, 1, spec.dilation, pad)
+
+
 class ConvBnActFunction(torch.autograd.Function):
 	"""One repeat of ConvBn1d (models.py:128-138): conv -> BN(train) -> + sum BN(conv1x1(residual)) -> act -> dropout -> mask.
 
@@ -170,6 +208,8 @@ class ConvBnActFunction(torch.autograd.Function):
 		ctx.x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
+		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt == torch.bfloat16 and Cout % 8 == 0:
+			_PRODUCERS[z.data_ptr()] = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev))
 		return z
 
 	@staticmethod
@@ -187,8 +227,20 @@ class ConvBnActFunction(torch.autograd.Function):
 		B, Cout, Tout = y.shape
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
+		fused_sums = _FUSED.pop(dz.data_ptr(), None)
 
-		if n_res == 0:
+		if n_res == 0 and fused_sums is not None:
+			# pass 1 already ran inside the dgrad launch that produced dz: only the per-channel finalize is left
+			coef = torch.empty(3 * Cout, dtype = torch.float32, device = dev)
+			finalize = lambda outs, acc: ops.bn_bwd_finalize(fused_sums, gamma, bnp[0], bnp[1], B * Tout, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc)
+			if gamma.requires_grad or beta.requires_grad:
+				dgamma, dbeta = _deliver([gamma, beta], finalize)
+			else:
+				finalize([None, None], False)
+				dgamma = dbeta = None
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset)
+			g = rsum_of = None
+		elif n_res == 0:
 			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
 			# per-channel coefficients, pass 2 recomputes g from dz on the fly: dy = A*g + Bc*y + D
 			coef = torch.empty(3 * Cout, dtype = torch.float32, device = dev)
@@ -227,7 +279,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		if ctx.x_needs_grad:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
-			dx = ops.conv1d(dy, packed_weight(weight, dt, _lib.PACK_DGRAD), x.shape[1], spec.K, 1, spec.dilation, spec.dilation * (spec.K - 1) - spec.padding)
+			dx = _dgrad(x, dy, weight, spec, dt)
 		if not arena_mode:
 			dw, = wg()
 
@@ -287,7 +339,7 @@ class ConvBiasFunction(torch.autograd.Function):
 		if ctx.needs_input_grad[1]:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented')
-			dx = ops.conv1d(dy, packed_weight(weight, dt, _lib.PACK_DGRAD), x.shape[1], spec.K, 1, spec.dilation, spec.dilation * (spec.K - 1) - spec.padding)
+			dx = _dgrad(x, dy, weight, spec, dt)
 		dw, db = _deliver([weight, bias], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], dbias = outs[1], accumulate = acc))
 		return None, dx, dw, db
 

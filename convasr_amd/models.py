@@ -202,10 +202,11 @@ class ConvBn1d(nn.Module):
 		self.activation = ResidualActivation(nonlinearity, dropout, invertible = inplace)
 		self.temporal_mask = temporal_mask
 		self.compute_dtype = torch.float32
+		self.single_consumer_output = False  # set by the network when this block's output feeds exactly one conv (no residual taps): enables cross-layer backward fusion
 
 	def _cfg(self, i, last):
 		conv, bn = self.conv[i][-1], self.bn[i]
-		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype)
+		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output))
 
 	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
 		_lib.require_cuda(x)
@@ -319,6 +320,10 @@ class JasperNet(nn.Module):
 		self.normalize_features = MaskedInstanceNorm1d(num_input_features, affine = False, eps = normalize_features_eps, track_running_stats = normalize_features_track_running_stats, temporal_mask = normalize_features_temporal_mask, legacy = normalize_features_legacy) if normalize_features else None
 		self.decoder = Decoder(width(out_width_factors_large[1]), num_classes, type = decoder_type)
 		self.residual, self.dict, self.bpe_only, self.check_time_dim_padded = residual, dict, bpe_only, check_time_dim_padded
+		# a block output that is not tapped as a residual and feeds one conv only (the next block, or a single decoder head)
+		for i, blk in enumerate(self.backbone):
+			tapped = bool(residual) and i < len(self.backbone) - self.num_epilogue_modules - 1
+			blk.single_consumer_output = (not tapped) and (i < len(self.backbone) - 1 or len(num_classes) == 1)
 		self.set_compute_dtype(compute_dtype)
 
 	def set_compute_dtype(self, dtype):
@@ -332,6 +337,7 @@ class JasperNet(nn.Module):
 
 	def forward(self, x, xlen = None, y = None, ylen = None):
 		_lib.require_cuda(x)
+		Fn.clear_fusion_state()  # registrations of a forward whose backward never ran
 		if self.frontend is not None:
 			assert (not self.check_time_dim_padded) or (x.shape[-1] % (32 / 2) == 0), 'Shape of input signal is not divisible by 16 '
 			x = x.squeeze(1)

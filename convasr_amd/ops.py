@@ -296,6 +296,26 @@ def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nest
 	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), stream_ptr())
 
 
+def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums):
+	"""dx = dgrad(dy) with pass 1 of the consumer layer's batch-norm backward fused into the epilogue (bn_sums += per-channel sums).
+	Returns dx, or None when the shape is outside the fused kernel's envelope (nothing was launched)."""
+	B, Cout, Tdy = dy.shape
+	T = conv_out_len(Tdy, K, 1, dil, pad)
+	assert is_cl(dy) and dy.dtype == torch.bfloat16 and is_cl(bn_y) and bn_y.dtype == torch.bfloat16 and tuple(bn_y.shape) == (B, Cin, T) and bn_sums.dtype == torch.float64, (dy.shape, bn_y.shape, Cin, T)
+	dx = empty_cl(B, Cin, T, torch.bfloat16, dy.device)
+	rc = [0]
+	def run():
+		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums), stream_ptr())
+	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if (Cout % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
+	_lib.timed(family, 2.0 * B * T * Cout * Cin * K, run, nbytes = float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2))
+	return dx if rc[0] == 0 else None
+
+
+def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, dbeta = None, accumulate = False, rezero = True):
+	C = mean.numel()
+	call('convasr_bn_bwd_finalize', ptr(sums), ptr(gamma), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), int(n), C, int(rezero), stream_ptr())
+
+
 # ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
 
 def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None):

@@ -182,6 +182,21 @@ int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream);
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, void* stream);
 
+/* Fused backward step (bf16, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
+ * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:
+ * g = dx * act'(bn_y*bn_scale+bn_shift) * dropout * mask(bn_xlen); bn_sums[c] += sum g, bn_sums[C+c] += sum g*(bn_y-mean)*invstd
+ * (C = Cin of this conv; fp64 accumulators the caller keeps zeroed: convasr_bn_bwd_finalize re-zeroes them).  It replaces
+ * convasr_conv1d_fwd(dy, packed_dgrad) + convasr_bn_act_bwd_reduce(write_g = 0) (models.py:111-139 backward) when dx has this
+ * single consumer.  dy is (B, T_dy, Cout), dx and bn_y are (B, T_dx, Cin); pad = dil*(K-1) - padding of the forward conv.  Returns 1 (nothing launched) when the shape is outside the
+ * LDS-DMA kernel's envelope (Cout % 64 != 0 or K < 2): run the two calls separately. */
+int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
+                                   int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                   const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
+                                   uint64_t offset, const float* bn_xlen, double* bn_sums, void* stream);
+/* coef / dgamma / dbeta from directly accumulated sums (the second half of convasr_bn_act_bwd_reduce); n = B*T. */
+int convasr_bn_bwd_finalize(double* sums, const float* gamma, const float* mean, const float* invstd, float* coef, float* dgamma,
+                            float* dbeta, int accumulate, int64_t n, int C, int rezero_sums, void* stream);
+
 /* ---- SURVEY 8(f) "next" rows ------------------------------------------------------------------------------------ */
 
 /* NovoGrad.step (optimizers.py:66-90) with torch.nn.utils.clip_grad_norm_ (train.py:777) folded in, over a flat arena of n
