@@ -14,6 +14,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL / cross-process GPU buffers need it on this driver (already exported on the pool)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
