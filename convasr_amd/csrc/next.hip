@@ -1,6 +1,7 @@
 // SURVEY section 8(f) "next" rows that share the hot path's data:
 //   f2  NovoGrad (optimizers.py:66-90) with clip_grad_norm_ (train.py:777) folded in, over the flat parameter arena
 //   f3  ctc.alignment (ctc.py:7-75): forced alignment with 2-bit back-pointers, one wave per utterance
+//   f4  the padding half of AudioTextDataset.collate_fn (datasets.py:305-332) on the GPU: ragged samples -> zero-padded batch
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ NovoGrad
@@ -253,5 +254,34 @@ extern "C" int convasr_ctc_alignment(const float* log_probs, const int64_t* targ
 	switch (ns) { AL_CASE(1) AL_CASE(2) AL_CASE(3) AL_CASE(4) AL_CASE(6) AL_CASE(8) AL_CASE(12) AL_CASE(16) }
 #undef AL_CASE
 	CONVASR_CHECK_LAUNCH("ctc_alignment");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ GPU-side collate
+// out[b][c][t] = t < len[b] ? packed[off[b] + c * len[b] + t] : 0 for a batch whose samples arrived as ONE packed buffer
+// (one host-to-device copy per batch instead of one per utterance); `elem` = bytes per element (2: int16 / bf16, 4: fp32, 8: int64).
+template <typename E>
+__global__ __launch_bounds__(256) void collate_pad_kernel(const E* __restrict__ packed, const int64_t* __restrict__ off, const int64_t* __restrict__ len, E* __restrict__ out,
+                                                           int rows, int64_t Tpad) {
+	const int b = blockIdx.z, c = blockIdx.y;
+	const int64_t n = len[b];
+	const E* src = packed + off[b] + (int64_t)c * n;
+	E* dst = out + ((int64_t)b * rows + c) * Tpad;
+	for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < Tpad; t += (int64_t)gridDim.x * 256) dst[t] = t < n ? src[t] : E(0);
+}
+
+extern "C" int convasr_collate_pad(const void* packed, const int64_t* offsets, const int64_t* lengths, void* out, int elem_bytes, int B, int rows, int64_t Tpad,
+                                   void* stream) {
+	CONVASR_CHECK_ARG(packed && offsets && lengths && out && B > 0 && rows > 0 && Tpad > 0, "collate_pad: bad arguments");
+	unsigned gx = (unsigned)ceil_div64(Tpad, 256 * 8);
+	if (gx < 1) gx = 1;
+	if (gx > 256) gx = 256;
+	dim3 grid(gx, rows, B);
+	hipStream_t s = (hipStream_t)stream;
+	if (elem_bytes == 2) hipLaunchKernelGGL((collate_pad_kernel<short>), grid, dim3(256), 0, s, (const short*)packed, offsets, lengths, (short*)out, rows, Tpad);
+	else if (elem_bytes == 4) hipLaunchKernelGGL((collate_pad_kernel<int>), grid, dim3(256), 0, s, (const int*)packed, offsets, lengths, (int*)out, rows, Tpad);
+	else if (elem_bytes == 8) hipLaunchKernelGGL((collate_pad_kernel<int64_t>), grid, dim3(256), 0, s, (const int64_t*)packed, offsets, lengths, (int64_t*)out, rows, Tpad);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "collate_pad: element size %d", elem_bytes);
+	CONVASR_CHECK_LAUNCH("collate_pad");
 	return 0;
 }

@@ -219,6 +219,12 @@ int64_t convasr_ctc_alignment_workspace_bytes(int B, int T);
 int convasr_ctc_alignment(const float* log_probs, const int64_t* targets, const int64_t* input_lengths, const int64_t* target_lengths,
                           int64_t* alignment, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);
 
+/* The padding half of AudioTextDataset.collate_fn (datasets.py:320-330) on the device: B ragged samples of `rows` rows each,
+ * delivered as one packed buffer (sample b starts at element offsets[b], its rows are lengths[b] long and contiguous), become the
+ * zero-padded batch out (B, rows, Tpad).  elem_bytes: 2 (int16 / bf16), 4 (fp32 / int32) or 8 (int64 targets). */
+int convasr_collate_pad(const void* packed, const int64_t* offsets, const int64_t* lengths, void* out, int elem_bytes, int B, int rows,
+                        int64_t Tpad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

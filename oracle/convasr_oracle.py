@@ -484,6 +484,51 @@ def ctc_alignment(log_probs_tbc: torch.Tensor, targets: torch.Tensor, input_leng
 	return out
 
 
+def bucketing_schedule(bucket: torch.Tensor, batch_size: int, world_size: int, epoch: int) -> torch.Tensor:
+	"""BucketingBatchSampler.set_epoch (datasets.py:370-393): (num_batches, batch_size) example indices for one epoch.
+
+	Per bucket (ascending id): pad the bucket with randomly repeated members up to a multiple of batch_size * world_size, shuffle,
+	cut into batches; then shuffle GROUPS of world_size consecutive batches (so the world_size ranks of one iteration draw from one
+	bucket).  All randomness comes from one torch.Generator seeded with the epoch, consumed in exactly this order."""
+	rng = torch.Generator()
+	rng.manual_seed(epoch)
+	unit = batch_size * world_size
+	per_bucket = []
+	for k in bucket.unique():
+		members = (bucket == k).nonzero(as_tuple = True)[0]
+		need = int(math.ceil(len(members) / unit)) * unit
+		repeats = torch.randint(0, len(members), size = (need - len(members), ), generator = rng)
+		padded = torch.cat([members, members[repeats]])
+		per_bucket.append(padded[torch.randperm(len(padded), generator = rng)].reshape(-1, batch_size))
+	batches = torch.cat(per_bucket)
+	group_order = torch.randperm(len(batches) // world_size, generator = rng)
+	order = torch.arange(len(batches)).view(-1, world_size)[group_order].flatten()
+	return batches[order]
+
+
+def collate(samples, time_padding_multiple: int = 128, speaker_missing: int = 0):
+	"""AudioTextDataset.collate_fn (datasets.py:305-332) for samples (speaker (S,), x (C, T), *targets (L,)):
+	returns (s (B, Smax), x (B, C, Tpad), xlen (B,) fractions of Tpad, y (B, n_targets, Lpad), ylen (B, n_targets));
+	T and L are padded up to multiples of time_padding_multiple, S to the batch maximum."""
+	up = lambda n, m: int(math.ceil(n / m)) * m
+	B, n_t = len(samples), len(samples[0]) - 2
+	Smax = max(b[0].shape[-1] for b in samples)
+	Tpad = up(max(b[1].shape[-1] for b in samples), time_padding_multiple)
+	Lpad = max(up(max(b[2 + j].shape[-1] for b in samples), time_padding_multiple) for j in range(n_t)) if n_t else 0
+	s = torch.full((B, Smax), speaker_missing, dtype = torch.int64)
+	x = torch.zeros(B, len(samples[0][1]), Tpad, dtype = samples[0][1].dtype)
+	y = torch.zeros(B, n_t, Lpad, dtype = torch.int64)
+	xlen, ylen = torch.zeros(B, dtype = torch.float32), torch.zeros(B, n_t, dtype = torch.int64)
+	for k, (sp, sx, *sy) in enumerate(samples):
+		xlen[k] = sx.shape[-1] / Tpad if Tpad > 0 else 1.0
+		x[k, ..., :sx.shape[-1]] = sx
+		s[k, :sp.shape[-1]] = sp
+		for j, t in enumerate(sy):
+			y[k, j, :t.shape[-1]] = t
+			ylen[k, j] = len(t)
+	return s, x, xlen, y, ylen
+
+
 def novograd_step(params, grads, state, lr = 1.0, betas = (0.95, 0.98), eps = 1e-8, weight_decay = 0.0, dampening = False, max_norm = None):
 	"""torch.nn.utils.clip_grad_norm_ (train.py:777) followed by NovoGrad.step (optimizers.py:66-90), functional.
 

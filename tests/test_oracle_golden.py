@@ -194,3 +194,19 @@ def test_oracle_alignment_matches_reference():
 		T_ = lambda k: torch.from_numpy(g[f'c{case}/{k}'])
 		al = O.ctc_alignment(T_('log_probs'), T_('targets'), T_('input_lengths'), T_('target_lengths'), blank = int(g[f'c{case}/blank']))
 		assert torch.equal(al, T_('alignment')), case
+
+
+def _collate_inputs(g):
+	return [(torch.from_numpy(g[f'collate/in/s{k}']), torch.from_numpy(g[f'collate/in/x{k}']), torch.from_numpy(g[f'collate/in/y0_{k}']), torch.from_numpy(g[f'collate/in/y1_{k}'])) for k in range(5)]
+
+
+def test_oracle_bucketing_and_collate_match_reference():
+	g = np.load(os.path.join(GOLDEN, 'bucketing.npz'))
+	bucket = torch.from_numpy(g['bucket'])
+	for world in (1, 2):
+		for epoch in (0, 1, 5):
+			got = O.bucketing_schedule(bucket, 8, world, epoch)
+			assert torch.equal(got, torch.from_numpy(g[f'w{world}/e{epoch}'])), (world, epoch)
+	s, x, xlen, y, ylen = O.collate(_collate_inputs(g), 128, int(g['collate/speaker_missing']))
+	for name, t in dict(s = s, x = x, xlen = xlen, y = y, ylen = ylen).items():
+		assert torch.equal(t, torch.from_numpy(g[f'collate/{name}'])), name
