@@ -24,6 +24,10 @@ that both the reference run and this oracle consumed.
 
 A second, independent restatement of CTC (float64 numpy alpha-beta recursion) lives in
 ctc_loss_numpy() and is checked against torch.nn.functional.ctc_loss on CPU.
+
+"Next" rows restated here as well, each pinned by vectors tests/golden/make_golden_next.py generates by importing
+the reference: novograd_step (optimizers.py:66-90 + train.py:777), ctc_alignment (ctc.py:7-75), bucketing_schedule and collate
+(datasets.py:357-401, 305-332).
 """
 import math
 import typing
