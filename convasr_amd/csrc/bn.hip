@@ -6,7 +6,7 @@
 // ------------------------------------------------------------------------------------------------ statistics -> scale / shift
 __global__ void bn_finalize_kernel(const double* stats, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt, double* __restrict__ rezero) {
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt, double* __restrict__ rezero, int rezero_blocks) {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c == 0 && nbt) *nbt += 1;
 	if (c >= C) return;
@@ -25,13 +25,14 @@ __global__ void bn_finalize_kernel(const double* stats, double n, const float* _
 		rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
 		rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
 	}
-	if (rezero) { rezero[c] = 0; rezero[C + c] = 0; }  // the conv epilogue of the next step accumulates into zeros again
+	if (rezero)  // the conv epilogue of the next step accumulates into zeros again (block 0); further [2C] blocks of the same buffer
+		for (int k = 0; k < 2 * rezero_blocks; ++k) rezero[k * C + c] = 0;  // are accumulators of other passes (the fused BN-backward sums)
 }
 
 extern "C" int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int64_t* num_batches_tracked, int rezero_stats, void* stream) {
 	CONVASR_CHECK_ARG(stats && mean && invstd && scale && shift && n > 0 && C > 0, "bn_finalize: bad arguments");
-	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked, rezero_stats ? const_cast<double*>(stats) : nullptr);
+	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked, rezero_stats ? const_cast<double*>(stats) : nullptr, rezero_stats);
 	CONVASR_CHECK_LAUNCH("bn_finalize");
 	return 0;
 }

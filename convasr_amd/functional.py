@@ -139,10 +139,7 @@ def clear_fusion_state():
 
 
 def _bwd_sums_buffer(bn, C, dev):
-	buf = getattr(bn, '_convasr_bwd_sums', None)
-	if buf is None or buf.numel() != 2 * C or buf.device != dev:
-		buf = bn._convasr_bwd_sums = torch.zeros(2 * C, dtype = torch.float64, device = dev)
-	return buf
+	return _stats_buffer(bn, C, dev)[2 * C:]
 
 
 def _dgrad(x, dy, weight, spec, dt):
@@ -307,10 +304,12 @@ def _momentum(bn):
 
 
 def _stats_buffer(bn, C, dev):
-	"""Persistent per-BatchNorm (sum, sumsq) fp64 accumulator: zero between steps (bn_finalize re-zeroes what it consumed)."""
+	"""Persistent per-BatchNorm fp64 accumulators, [4C]: (sum, sumsq) of the forward conv epilogue, then (sum g, sum g*xhat) of the
+	fused backward epilogue.  Zero between steps: the forward's bn_finalize re-zeroes BOTH halves (so a backward that died half
+	way cannot leak into the next step), the backward's finalize re-zeroes its half."""
 	buf = getattr(bn, '_convasr_stats', None)
-	if buf is None or buf.device != dev or buf.numel() != 2 * C:
-		buf = bn._convasr_stats = torch.zeros(2 * C, dtype = torch.float64, device = dev)
+	if buf is None or buf.device != dev or buf.numel() != 4 * C:
+		buf = bn._convasr_stats = torch.zeros(4 * C, dtype = torch.float64, device = dev)
 	return buf
 
 

@@ -166,10 +166,12 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 # ------------------------------------------------------------------------------------------------ batch norm + activation
 
 def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked = None, rezero = False):
-	C = stats.numel() // 2
+	"""stats: [2C] (sum, sumsq) or [4C] (+ the fused backward sums, see functional._stats_buffer); rezero zeroes all of it."""
+	C = running_mean.numel() if running_mean is not None else (gamma.numel() if gamma is not None else stats.numel() // 2)
+	blocks = stats.numel() // (2 * C)
 	dev = stats.device
 	out = torch.empty(4, C, dtype = torch.float32, device = dev)  # mean, invstd, scale, shift
-	call('convasr_bn_finalize', ptr(stats), n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, ptr(num_batches_tracked), int(rezero), stream_ptr())
+	call('convasr_bn_finalize', ptr(stats), n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, ptr(num_batches_tracked), blocks if rezero else 0, stream_ptr())
 	return out
 
 

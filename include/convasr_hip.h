@@ -102,7 +102,8 @@ int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
 /* From the conv epilogue's stats (sum, sumsq over n = B*T values per channel): batch mean / biased var ->
  * scale = gamma * invstd, shift = beta - mean * scale; mean/invstd saved for backward; running stats updated
  * with momentum (running_var with the unbiased estimate), exactly nn.BatchNorm1d training semantics.
- * num_batches_tracked (may be NULL) is incremented; rezero_stats != 0 zeroes `stats` after reading it so that a persistent
+ * num_batches_tracked (may be NULL) is incremented; rezero_stats = r > 0 zeroes the first r blocks of 2C doubles of `stats` after
+ * reading block 0 (r = 2: a 4C buffer whose second half holds the fused BN-backward sums) so that a persistent
  * per-layer statistics buffer is ready for the next step's conv epilogue without a separate memset. */
 int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps,
