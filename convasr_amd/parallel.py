@@ -4,7 +4,8 @@ One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm
 cut into contiguous buckets; backward kernels report each parameter the moment its gradient is final, and as soon as every
 parameter of a bucket has reported, that bucket's sum-all-reduce is enqueued asynchronously (RCCL runs it on its own HIP
 stream, ordered after the producing kernels by an event) -- so communication overlaps the rest of the backward conv stack.
-xGMI is point-to-point, so a few large buckets (default 32 MiB) beat many small ones.  Batch-norm statistics stay per GPU,
+xGMI is point-to-point, so a few large buckets (default 32 MiB) beat many small ones; only the bucket that completes last (the
+first layers, nothing left to overlap it with) is kept small.  Batch-norm statistics stay per GPU,
 exactly as in the reference's training path (train.py:704 does not pass synchronize_bn)."""
 import torch
 import torch.distributed as dist
@@ -14,7 +15,7 @@ from .train import FlatParameters
 
 
 class DataParallelEngine(nn.Module):
-	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None, force_collectives = False):
+	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20):
 		super().__init__()
 		self.module = module
 		self.group = process_group
@@ -22,7 +23,7 @@ class DataParallelEngine(nn.Module):
 		self.collectives = self.world_size > 1 or (force_collectives and dist.is_initialized())  # world 1 + force: RCCL smoke test
 		self.flat = flat if flat is not None else getattr(module, '_convasr_flat', None) or FlatParameters(module)
 		module._convasr_flat = self.flat
-		self.buckets = self._make_buckets(bucket_bytes)
+		self.buckets = self._make_buckets(bucket_bytes, min(first_bucket_bytes, bucket_bytes))
 		self._pending = []
 		self._remaining = [len(b['params']) for b in self.buckets]
 		self.sync = True  # False inside no_sync(): gradients accumulate locally, nothing is launched (gradient accumulation)
@@ -34,12 +35,15 @@ class DataParallelEngine(nn.Module):
 			for buf in module.buffers():
 				dist.broadcast(buf, src = 0, group = self.group)
 
-	def _make_buckets(self, bucket_bytes):
+	def _make_buckets(self, bucket_bytes, first_bucket_bytes):
+		"""Contiguous arena ranges.  Backward completes them from the END of the arena towards its start, so the bucket at the start
+		(the prologue layers) is the one whose all-reduce nothing overlaps: it is kept small (first_bucket_bytes)."""
 		flat = self.flat
 		buckets, cur = [], None
 		for p, off in zip(flat.params, flat.offsets):
 			end = off + p.numel()
-			if cur is None or (end - cur['lo']) * 4 > bucket_bytes and cur['params']:
+			limit = first_bucket_bytes if len(buckets) <= 1 else bucket_bytes
+			if cur is None or (end - cur['lo']) * 4 > limit and cur['params']:
 				cur = dict(lo = off, hi = end, params = [])
 				buckets.append(cur)
 			cur['params'].append(p)
