@@ -242,17 +242,18 @@ extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* str
 
 __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
                                                        int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first,
-                                                       const float* __restrict__ loss_gate) {
+                                                       const float* __restrict__ loss_gate, float grad_scale) {
 	if (loss_gate) {
 		const float l = *loss_gate;
 		if (!(fabsf(l) < INFINITY)) return;  // inf or NaN loss: the step is skipped (train.py:769-772)
 	}
 	float clip = 1.f;
 	if (sumsq) {
-		float total = (float)sqrt(*sumsq);
+		float total = (float)sqrt(*sumsq) * grad_scale;  // norm of the scaled gradient (grad_scale = 1 / world size on summed gradients)
 		float c = max_norm / (total + 1e-6f);
 		clip = c < 1.f ? c : 1.f;
 	}
+	clip *= grad_scale;
 	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
 		float gc = g[i] * clip;
 		if (gout) gout[i] = gc;
@@ -268,11 +269,11 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
 }
 
 extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm, float lr,
-                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, void* stream) {
+                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale, void* stream) {
 	CONVASR_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || buf), "sgd_step: bad arguments");
 	int64_t blocks = ceil_div64(n, 256);
 	if (blocks > 4096) blocks = 4096;
-	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate);
+	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale);
 	CONVASR_CHECK_LAUNCH("sgd_step");
 	return 0;
 }

@@ -88,7 +88,7 @@ struct NgParams {
 	int n_seg; int64_t n;
 	float max_norm, lr, b1, b2, eps, wd;
 	int dampening, first;
-	const float* loss_gate; float* norm_out;
+	const float* loss_gate; float* norm_out; float grad_scale;
 };
 
 __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		const float total = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+		const float total = (float)sqrt(red[0] + red[1] + red[2] + red[3]) * q.grad_scale;  // norm of the scaled (e.g. rank-averaged) gradient
 		float c = 1.f;
 		if (q.max_norm > 0.f) { c = q.max_norm / (total + 1e-6f); c = c < 1.f ? c : 1.f; }
-		s_clip = c;
+		s_clip = c * q.grad_scale;
 		if (blockIdx.x == 0 && q.norm_out) *q.norm_out = total;
 	}
 	__syncthreads();
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 
 extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets, int n_seg,
                                      int64_t n, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
-                                     const float* loss_gate, float* total_norm, void* stream) {
+                                     const float* loss_gate, float* total_norm, float grad_scale, void* stream) {
 	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && n_seg > 0 && n > 0, "novograd_step: bad arguments");
 	hipStream_t s = (hipStream_t)stream;
 	if (hipMemsetAsync(g2, 0, sizeof(double) * n_seg, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "novograd_step: memset failed");
@@ -157,7 +157,7 @@ extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const
 	NgParams q;
 	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
 	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
-	q.loss_gate = loss_gate; q.norm_out = total_norm;
+	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale;
 	hipLaunchKernelGGL(ng_step_kernel, dim3(blocks), dim3(256), 0, s, q);
 	CONVASR_CHECK_LAUNCH("novograd_step");
 	return 0;

@@ -293,9 +293,9 @@ def sumsq(flat_grad, out = None):
 	return out
 
 
-def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None):
+def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0):
 	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
-	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), stream_ptr())
+	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), stream_ptr())
 
 
 def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums):
@@ -320,10 +320,10 @@ def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, db
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
 
-def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None):
+def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0):
 	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]."""
 	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
-	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), offsets.numel() - 1, n, float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), stream_ptr())
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), offsets.numel() - 1, n, float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), stream_ptr())
 
 
 def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):

@@ -34,9 +34,9 @@ class NovoGrad:
 			flat.finalize_grads()
 		max_norm = flat.clip[1] if flat.clip is not None else 0.0
 		cur = self.steps & 1
-		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], self.steps == 0, loss_gate = loss_gate, total_norm = self.total_norm)
+		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], self.steps == 0, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = flat.grad_scale)
 		self.steps += 1
-		flat.clip = None
+		flat.clip, flat.grad_scale = None, 1.0
 		Fn.bump_param_epoch()
 
 	@property

@@ -15,7 +15,7 @@ from .train import FlatParameters
 
 
 class DataParallelEngine(nn.Module):
-	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20):
+	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True):
 		super().__init__()
 		self.module = module
 		self.group = process_group
@@ -26,6 +26,7 @@ class DataParallelEngine(nn.Module):
 		self.buckets = self._make_buckets(bucket_bytes, min(first_bucket_bytes, bucket_bytes))
 		self._pending = []
 		self._remaining = [len(b['params']) for b in self.buckets]
+		self.fold_mean = fold_mean  # True: the 1 / world_size of the gradient mean rides in the optimizer kernel (flat.grad_scale) instead of a pass over the arena
 		self.sync = True  # False inside no_sync(): gradients accumulate locally, nothing is launched (gradient accumulation)
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
@@ -81,7 +82,8 @@ class DataParallelEngine(nn.Module):
 
 	def finish_gradient_sync(self):
 		"""Call after backward, before clip / optimizer: flushes buckets whose parameters got no gradient, waits for the
-		collectives (stream-side) and turns sums into means."""
+		collectives (stream-side) and turns sums into means (by default lazily: flat.grad_scale = 1 / world_size, which
+		clip_grad_norm_ and the fused optimizer kernels apply)."""
 		for bi, left in enumerate(self._remaining):
 			if left > 0:
 				for p in self.buckets[bi]['params']:
@@ -92,7 +94,10 @@ class DataParallelEngine(nn.Module):
 		for work, view in self._pending:
 			work.wait()
 		if self.world_size > 1:
-			self.flat.grad.mul_(1.0 / self.world_size)
+			if self.fold_mean:
+				self.flat.grad_scale = 1.0 / self.world_size  # flat.grad holds the SUM over ranks until the optimizer consumes it
+			else:
+				self.flat.grad.mul_(1.0 / self.world_size)
 		self._pending = []
 		self._remaining = [len(b['params']) for b in self.buckets]
 

@@ -38,6 +38,7 @@ class FlatParameters:
 			p._convasr_fresh = True
 			p.grad = p._convasr_grad
 		self.clip = None  # (sumsq double buffer, max_norm) set by clip_grad_norm_
+		self.grad_scale = 1.0  # pending scale of .grad (the data-parallel engine's 1 / world_size), consumed by the next optimizer step
 		self._sumsq = torch.zeros(1, dtype = torch.float64, device = dev)
 
 	def zero_grad(self):
@@ -60,7 +61,7 @@ class FlatParameters:
 		self._sumsq.zero_()
 		ops.sumsq(self.grad, self._sumsq)
 		self.clip = (self._sumsq, float(max_norm))
-		return self._sumsq.sqrt().to(torch.float32).squeeze(0)
+		return (self._sumsq.sqrt() * self.grad_scale).to(torch.float32).squeeze(0)
 
 
 class SGD:
@@ -83,9 +84,9 @@ class SGD:
 		if flat.clip is None:
 			flat.finalize_grads()
 		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
-		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate)
+		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = flat.grad_scale)
 		self.steps += 1
-		flat.clip = None
+		flat.clip, flat.grad_scale = None, 1.0
 		Fn.bump_param_epoch()  # packed bf16/fp32 weight copies are stale now
 
 	def state_dict(self):

@@ -178,10 +178,13 @@ int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream);
 /* torch.optim.SGD step with clip folded in: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (c = 1 if sumsq NULL);
  * g' = c*g + wd*p; buf = first ? g' : mom*buf + g'; p -= lr * (nesterov ? g' + mom*buf : buf).
  * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad).
+ * grad_scale multiplies g before everything else (1 / world size when g holds rank-SUMMED gradients: the mean is never
+ * materialised; sumsq is then the sum of squares of the summed gradient).
  * If loss_gate != NULL and *loss_gate (a device float, the all-reduced loss) is inf or NaN the launch changes nothing: the
  * reference's "skip the step on a non-finite loss" (train.py:769-772) without a host round trip in the middle of the step. */
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
-                     float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, void* stream);
+                     float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale,
+                     void* stream);
 
 /* Fused backward step (bf16, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
  * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:
@@ -205,11 +208,11 @@ int convasr_bn_bwd_finalize(double* sums, const float* gamma, const float* mean,
  * zero gradients).  Per tensor s: g2 = sum (c*g)^2 with c = min(1, max_norm / (||g||_all + 1e-6)) (c = 1 if max_norm <= 0);
  * ema_out[s] = first ? g2 : ema_in[s]*beta2 + g2*(1-beta2); d = c*g / sqrt(ema_out[s] + eps) (+ wd*p) (* (1-beta1) if
  * dampening); mom = first ? d : mom*beta1 + d; p -= lr*mom.  ema_in / ema_out must be different buffers (the caller swaps
- * them every call); g2 is n_seg doubles of scratch; total_norm (may be NULL) receives ||g||_all; loss_gate as in
+ * them every call); g2 is n_seg doubles of scratch; total_norm (may be NULL) receives ||g||_all; loss_gate and grad_scale as in
  * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else). */
 int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets,
                           int n_seg, int64_t n, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                          int dampening, int first, const float* loss_gate, float* total_norm, void* stream);
+                          int dampening, int first, const float* loss_gate, float* total_norm, float grad_scale, void* stream);
 
 int64_t convasr_ctc_alignment_workspace_bytes(int B, int T);
 /* ctc.alignment (ctc.py:7-75): forced alignment of targets[b, :target_lengths[b]] to log_probs[b, :input_lengths[b]]

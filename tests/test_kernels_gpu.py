@@ -403,6 +403,14 @@ def test_sumsq_and_sgd_step_match_torch():
 		assert torch.equal(pd, before) and torch.equal(buf, mom)
 	ops.sgd_step(pd, gd, buf, n, ss, 100.0, 1e-2, 0.9, 1e-3, False, False, loss_gate = torch.tensor([3.5], device = d))
 	assert not torch.equal(pd, before)
+	# grad_scale: rank-summed gradients with 1 / world folded into the kernel == the averaged gradient fed plainly (clip included)
+	pa, pb, ba, bb = p0.to(d), p0.to(d), torch.zeros(n, device = d), torch.zeros(n, device = d)
+	gsum = gd * 400.0  # large enough for max_norm = 100 to clip after the 1/4 scaling
+	ops.sgd_step(pa, gsum, ba, n, ops.sumsq(gsum), 100.0, 1e-2, 0.9, 1e-3, False, True, grad_scale = 0.25)
+	gavg = gsum * 0.25
+	ops.sgd_step(pb, gavg, bb, n, ops.sumsq(gavg), 100.0, 1e-2, 0.9, 1e-3, False, True)
+	close(pa, pb, 1e-6, 1e-7, 'grad_scale')
+	close(ba, bb, 1e-5, 1e-6, 'grad_scale momentum')
 
 
 @gpu

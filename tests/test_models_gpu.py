@@ -232,6 +232,22 @@ def test_novograd_matches_reference_golden():
 			for i, p in enumerate(flat.params):
 				close(p.detach().cpu(), torch.from_numpy(g[f'c{case}/p{step + 1}/{i}']), 2e-5, 2e-6, f'case {case} step {step} param {i}')
 				close(st[p]['_grads_ema'].cpu(), torch.from_numpy(g[f'c{case}/ema{step + 1}/{i}']), 2e-5, 0, f'case {case} step {step} ema {i}')
+		# the same steps fed with 4x the gradients and grad_scale = 1/4 (rank-summed gradients, mean folded into the kernel)
+		holder2 = torch.nn.Module()
+		holder2.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(g[f'c{case}/p0/{i}']).to(d)) for i in range(n)])
+		flat2 = ca.train.FlatParameters(holder2)
+		opt2 = ca.optimizers.NovoGrad(flat2, lr = lr, betas = (b1, b2), eps = eps, weight_decay = wd, dampening = bool(damp))
+		for step in range(4):
+			for i, p in enumerate(flat2.params):
+				p._convasr_grad.copy_(4 * torch.from_numpy(g[f'c{case}/g{step}/{i}']).to(d))
+				p._convasr_fresh = False
+			flat2.grad_scale = 0.25
+			norm = flat2.clip_grad_norm_(max_norm)
+			opt2.step()
+			opt2.zero_grad()
+			close(norm.cpu(), torch.from_numpy(g[f'c{case}/norm{step}']), 1e-5, 0, 'grad norm (scaled)')
+		for i, p in enumerate(flat2.params):
+			close(p.detach().cpu(), torch.from_numpy(g[f'c{case}/p4/{i}']), 2e-5, 2e-6, f'case {case} grad_scale param {i}')
 		# a gated (non-finite loss) step changes nothing, including the EMAs
 		before, ema = flat.data.clone(), opt.state[flat.params[0]]['_grads_ema'].clone()
 		for p in flat.params:

@@ -33,7 +33,7 @@ def _worker(rank, world, port, out):
 	from convasr_amd.functional import _deliver
 	torch.manual_seed(100 + rank)  # different initial replicas: rank 0's must win
 	model = Toy()
-	engine = DataParallelEngine(model, bucket_bytes = 1024)
+	engine = DataParallelEngine(model, bucket_bytes = 1024, fold_mean = False)  # eager mean: the assertions below read p.grad directly
 	flat = engine.flat
 	assert len(engine.buckets) >= 2
 	w0 = flat.data.clone()
