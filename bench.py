@@ -69,6 +69,12 @@ def main():
 	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (+1.5-2 % step rate; off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
 	args = ap.parse_args()
 
+	# stdout carries exactly one line, the JSON result of rank 0: native libraries (RCCL prints a version banner through C stdio,
+	# flushed at exit, i.e. AFTER a Python print) are pointed at stderr for the duration of the run
+	sys.stdout.flush()
+	real_stdout = os.dup(1)
+	os.dup2(2, 1)
+
 	world = int(os.environ.get('WORLD_SIZE', '1'))
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -177,6 +183,10 @@ def main():
 	if use_dist:
 		dist.destroy_process_group()
 	if rank == 0:
+		import ctypes
+		ctypes.CDLL(None).fflush(None)
+		sys.stdout.flush()
+		os.dup2(real_stdout, 1)
 		print(json.dumps(line), flush = True)
 
 
