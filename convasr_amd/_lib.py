@@ -26,11 +26,13 @@ _SIGNATURES = dict(
 	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_conv_cout_pad = (c_int, [c_int]),
 	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
-	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p]),
+	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p, c_p]),
+	convasr_conv_stats_max_rows = (c_int, [c_int, c_int]),
+	convasr_reduce_rows = (c_int, [c_p, c_int, c_int, c_p, c_p]),
 	convasr_debug_set_conv_v2 = (c_int, [c_int]),
 	convasr_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
 	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
-	convasr_bn_finalize = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p, c_p, c_p, c_int, c_p, c_int, c_p]),
+	convasr_bn_finalize = (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p, c_p, c_p, c_int, c_p, c_p]),
 	convasr_bn_eval_scale_shift = (c_int, [c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_int, c_p]),
 	convasr_bn_act_fwd = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p]),
 	convasr_bn_bwd_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
@@ -44,10 +46,11 @@ _SIGNATURES = dict(
 	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_int, c_i64, c_p]),
 	convasr_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
-	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p]),
+	convasr_sumsq_workspace_bytes = (c_i64, []),
+	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p]),
 	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p]),
-	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p]),
-	convasr_bn_bwd_finalize = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_int, c_p]),
+	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p]),
+	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
 	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p]),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),

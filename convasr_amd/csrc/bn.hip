@@ -4,14 +4,26 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ statistics -> scale / shift
-__global__ void bn_finalize_kernel(const double* stats, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt, double* __restrict__ rezero, int rezero_blocks) {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c == 0 && nbt) *nbt += 1;
-	if (c >= C) return;
-	const double m = stats[c] / n;
-	double var = stats[C + c] / n - m * m;
+// stats: [rows][2][C] fp64 partial sums, one row per m-tile of the conv launch that produced them (rows = 1: plain totals).
+// Block = 64 channels x 16 row-lanes; a lane adds rows w, w + 16, ... in order and the 16 lanes are combined in order: the
+// result does not depend on which workgroup of the conv finished first (the conv epilogue uses no atomics).
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ stats, int rows, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt) {
+	__shared__ double red[2][16][64];
+	const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, w = threadIdx.x >> 6;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+	double a = 0, q2 = 0;
+	if (c < C)
+		for (int r = w; r < rows; r += 16) { a += stats[((int64_t)r * 2) * C + c]; q2 += stats[((int64_t)r * 2 + 1) * C + c]; }
+	red[0][w][cl] = a;
+	red[1][w][cl] = q2;
+	__syncthreads();
+	if (w != 0 || c >= C) return;
+	double s1 = 0, s2 = 0;
+	for (int i = 0; i < 16; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }
+	const double m = s1 / n;
+	double var = s2 / n - m * m;
 	if (var < 0) var = 0;
 	const float mf = (float)m, vf = (float)var;
 	const float is = 1.0f / sqrtf(vf + eps);
@@ -25,15 +37,32 @@ __global__ void bn_finalize_kernel(const double* stats, double n, const float* _
 		rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
 		rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
 	}
-	if (rezero)  // the conv epilogue of the next step accumulates into zeros again (block 0); further [2C] blocks of the same buffer
-		for (int k = 0; k < 2 * rezero_blocks; ++k) rezero[k * C + c] = 0;  // are accumulators of other passes (the fused BN-backward sums)
 }
 
-extern "C" int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int64_t* num_batches_tracked, int rezero_stats, void* stream) {
-	CONVASR_CHECK_ARG(stats && mean && invstd && scale && shift && n > 0 && C > 0, "bn_finalize: bad arguments");
-	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked, rezero_stats ? const_cast<double*>(stats) : nullptr, rezero_stats);
+extern "C" int convasr_bn_finalize(const double* stats, int stats_rows, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int64_t* num_batches_tracked, void* stream) {
+	CONVASR_CHECK_ARG(stats && stats_rows > 0 && mean && invstd && scale && shift && n > 0 && C > 0, "bn_finalize: bad arguments");
+	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked);
 	CONVASR_CHECK_LAUNCH("bn_finalize");
+	return 0;
+}
+
+// totals of a [rows][width] fp64 partial buffer, same fixed order (tests / tools that want the plain sums)
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restrict__ part, int rows, int width, double* __restrict__ out) {
+	__shared__ double red[16][64];
+	const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, w = threadIdx.x >> 6;
+	double a = 0;
+	if (c < width)
+		for (int r = w; r < rows; r += 16) a += part[(int64_t)r * width + c];
+	red[w][cl] = a;
+	__syncthreads();
+	if (w == 0 && c < width) { double s = 0; for (int i = 0; i < 16; ++i) s += red[i][cl]; out[c] = s; }
+}
+
+extern "C" int convasr_reduce_rows(const double* part, int rows, int width, double* out, void* stream) {
+	CONVASR_CHECK_ARG(part && out && rows > 0 && width > 0, "reduce_rows: bad arguments");
+	hipLaunchKernelGGL(reduce_rows_kernel, dim3((width + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, rows, width, out);
+	CONVASR_CHECK_LAUNCH("reduce_rows");
 	return 0;
 }
 
@@ -384,12 +413,20 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __res
 	}
 }
 
-// The same finalize for sums that were accumulated directly (fp64 atomics) by the fused dgrad epilogue of conv_v2s.hip:
-// emits coef / dgamma / dbeta and zeroes the accumulators for the next step.
-__global__ void bn_bwd_finalize_sums_kernel(double* __restrict__ sums, BnFinalizeSets sets, int C, int rezero) {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C) return;
-	const double sg = sums[c], sgx = sums[C + c];
+// The same finalize for the per-tile partial rows [rows][2][C] written by the fused dgrad epilogue of conv_v2s.hip: sums them in a
+// fixed order (64 channels x 16 row-lanes per block) and emits coef / dgamma / dbeta.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_sums_kernel(const double* __restrict__ sums, int rows, BnFinalizeSets sets, int C) {
+	__shared__ double red[2][16][64];
+	const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, w = threadIdx.x >> 6;
+	double a = 0, b2 = 0;
+	if (c < C)
+		for (int r = w; r < rows; r += 16) { a += sums[((int64_t)r * 2) * C + c]; b2 += sums[((int64_t)r * 2 + 1) * C + c]; }
+	red[0][w][cl] = a;
+	red[1][w][cl] = b2;
+	__syncthreads();
+	if (w != 0 || c >= C) return;
+	double sg = 0, sgx = 0;
+	for (int i = 0; i < 16; ++i) { sg += red[0][i][cl]; sgx += red[1][i][cl]; }
 	if (sets.coef) {
 		const float gm = sets.gamma ? sets.gamma[c] : 1.f, is = sets.invstd[c], m = sets.mean[c];
 		const float msg = (float)sg * sets.invn, msgx = (float)sgx * sets.invn;
@@ -399,16 +436,15 @@ __global__ void bn_bwd_finalize_sums_kernel(double* __restrict__ sums, BnFinaliz
 	}
 	if (sets.dgamma) sets.dgamma[c] = sets.accumulate ? sets.dgamma[c] + (float)sgx : (float)sgx;
 	if (sets.dbeta) sets.dbeta[c] = sets.accumulate ? sets.dbeta[c] + (float)sg : (float)sg;
-	if (rezero) { sums[c] = 0; sums[C + c] = 0; }
 }
 
-extern "C" int convasr_bn_bwd_finalize(double* sums, const float* gamma, const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
-                                       int accumulate, int64_t n, int C, int rezero_sums, void* stream) {
-	CONVASR_CHECK_ARG(sums && mean && invstd && n > 0 && C > 0, "bn_bwd_finalize: bad arguments");
+extern "C" int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamma, const float* mean, const float* invstd, float* coef, float* dgamma,
+                                       float* dbeta, int accumulate, int64_t n, int C, void* stream) {
+	CONVASR_CHECK_ARG(sums && sums_rows > 0 && mean && invstd && n > 0 && C > 0, "bn_bwd_finalize: bad arguments");
 	BnFinalizeSets sets = {};
 	sets.gamma = gamma; sets.mean = mean; sets.invstd = invstd; sets.coef = coef; sets.dgamma = dgamma; sets.dbeta = dbeta;
 	sets.accumulate = accumulate; sets.invn = 1.0f / (float)n;
-	hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, sets, C, rezero_sums);
+	hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, sums, sums_rows, sets, C);
 	CONVASR_CHECK_LAUNCH("bn_bwd_finalize");
 	return 0;
 }

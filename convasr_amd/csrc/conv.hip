@@ -175,8 +175,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 	}
 	__syncthreads();
 	if (p.stats && tid < BN && co0 + tid < p.Cout) {
-		unsafeAtomicAdd(p.stats + co0 + tid, (double)red[(0 * 2 + 0) * BN + tid] + (double)red[(0 * 2 + 1) * BN + tid]);
-		unsafeAtomicAdd(p.stats + p.Cout + co0 + tid, (double)red[(1 * 2 + 0) * BN + tid] + (double)red[(1 * 2 + 1) * BN + tid]);
+		// per-(m tile) partial row, [mtile][2][Cout]: summed in a fixed order by bn_finalize (no atomics: run-to-run identical bits)
+		double* const prow = p.stats + (int64_t)mtile * 2 * p.Cout;
+		prow[co0 + tid] = (double)red[(0 * 2 + 0) * BN + tid] + (double)red[(0 * 2 + 1) * BN + tid];
+		prow[p.Cout + co0 + tid] = (double)red[(1 * 2 + 0) * BN + tid] + (double)red[(1 * 2 + 1) * BN + tid];
 	}
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN / OEPC;
@@ -317,7 +319,7 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 	return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
 }
 
-int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s);  // conv_v2.hip
+int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles_out);  // conv_v2.hip
 int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s);                 // wgrad_v2.hip
 static int g_conv_use_v2 = 1;
 static int g_conv_debug = 0;
@@ -326,7 +328,7 @@ extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_u
 
 static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
                       int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
-                      float act_lo, float act_hi, const float* xlen, const ConvParams* bn_fusion, void* stream) {
+                      float act_lo, float act_hi, const float* xlen, const ConvParams* bn_fusion, int* rows_out, void* stream) {
 	CONVASR_CHECK_ARG(x && wp && y && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_fwd: bad arguments");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd: scale and shift go together");
 	const int64_t expect = ((int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
@@ -348,8 +350,10 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	if (epi > smem) smem = epi;
 	CONVASR_CHECK_ARG(smem <= 160 * 1024, "conv1d_fwd: tile needs %zu B of LDS", smem);
 	hipStream_t s = (hipStream_t)stream;
-	if (x_dtype == CONVASR_BF16 && g_conv_use_v2 && convasr_conv1d_v2_try(p, y_dtype, s)) {
+	int v2_rows = 0;
+	if (x_dtype == CONVASR_BF16 && g_conv_use_v2 && convasr_conv1d_v2_try(p, y_dtype, s, &v2_rows)) {
 		CONVASR_CHECK_LAUNCH("conv1d_fwd (v2)");
+		if (rows_out) *rows_out = v2_rows;
 		return 0;
 	}
 	if (p.bn_y) return 1;  // the fused epilogue lives in the LDS-DMA kernel only: nothing was launched, the caller runs the two steps apart
@@ -360,20 +364,24 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd: dtype %d -> %d", x_dtype, y_dtype);
 	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("conv1d_fwd");
+	if (rows_out) *rows_out = B * p.m_tiles_per_b;
 	return 0;
 }
 
 extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
                                   int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
-                                  float act_lo, float act_hi, const float* xlen, void* stream) {
-	return conv1d_run(x, wp, y, x_dtype, y_dtype, B, Cin, Cout, Tin, Tout, K, stride, dil, pad, bias, stats, scale, shift, act, act_lo, act_hi, xlen, nullptr, stream);
+                                  float act_lo, float act_hi, const float* xlen, int* stats_rows, void* stream) {
+	CONVASR_CHECK_ARG(!stats || stats_rows, "conv1d_fwd: stats needs stats_rows");
+	return conv1d_run(x, wp, y, x_dtype, y_dtype, B, Cin, Cout, Tin, Tout, K, stride, dil, pad, bias, stats, scale, shift, act, act_lo, act_hi, xlen, nullptr, stats_rows, stream);
 }
+
+extern "C" int convasr_conv_stats_max_rows(int B, int Tout) { return B * ((Tout + BM - 1) / BM); }
 
 extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad,
                                               const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                                               int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                                              const float* bn_xlen, double* bn_sums, void* stream) {
-	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0, "conv1d_dgrad_bn_reduce: bad arguments");
+                                              const float* bn_xlen, double* bn_sums, int* bn_rows, void* stream) {
+	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && bn_rows && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0, "conv1d_dgrad_bn_reduce: bad arguments");
 	ConvParams f = {};
 	f.bn_y = bn_y; f.bn_scale = bn_scale; f.bn_shift = bn_shift; f.bn_mean = bn_mean; f.bn_invstd = bn_invstd; f.bn_xlen = bn_xlen; f.bn_sums = bn_sums;
 	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = seed; f.bn_offset = offset;
@@ -381,7 +389,7 @@ extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed
 	if (f.bn_drop_thr > 65535u) f.bn_drop_thr = 65535u;
 	f.bn_keep_scale = 65536.f / (float)(65536u - f.bn_drop_thr);
 	// dgrad = the forward kernel on (dy, flipped packed weights): channels in = Cout, channels out = Cin, stride 1
-	return conv1d_run(dy, packed_dgrad, dx, CONVASR_BF16, CONVASR_BF16, B, Cout, Cin, T_dy, T_dx, K, 1, dil, pad, nullptr, nullptr, nullptr, nullptr, CONVASR_ACT_NONE, 0.f, 0.f, nullptr, &f, stream);
+	return conv1d_run(dy, packed_dgrad, dx, CONVASR_BF16, CONVASR_BF16, B, Cout, Cin, T_dy, T_dx, K, 1, dil, pad, nullptr, nullptr, nullptr, nullptr, CONVASR_ACT_NONE, 0.f, 0.f, nullptr, &f, bn_rows, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -567,8 +575,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 	}
 }
 
-// dbias[c] (+)= sum over rows of a channels-last (rows, C) matrix: blocks own row chunks, one float atomic per (block, channel)
-template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ out, int64_t rows, int C, int rows_per_block) {
+// dbias[c] (+)= sum over rows of a channels-last (rows, C) matrix: blocks own row chunks and store one partial row each; a second
+// launch adds the partial rows in order (no float atomics: the bias gradient is bit-identical from run to run)
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ part, int64_t rows, int C, int rows_per_block) {
 	__shared__ float red[4][64];
 	const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
 	const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -577,7 +586,14 @@ template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const
 		for (int64_t rr = r0 + w; rr < r1; rr += 4) a += Elem<T>::load(y + rr * C + c);
 	red[w][threadIdx.x & 63] = a;
 	__syncthreads();
-	if (w == 0 && c < C) unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+	if (w == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
+	const int c = blockIdx.x * 256 + threadIdx.x;
+	if (c >= C) return;
+	double a = 0;
+	for (int i = 0; i < nparts; ++i) a += (double)part[(int64_t)i * C + c];
+	out[c] = accumulate ? out[c] + (float)a : (float)a;
 }
 
 extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil) {
@@ -593,7 +609,9 @@ extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout
 		wgrad_plan(q, bkt[i], us[i]);
 		if (q.splits > splits) splits = q.splits;
 	}
-	return (int64_t)splits * K * (int64_t)Cout * Cin * 4;
+	const int64_t slabs = (int64_t)splits * K * (int64_t)Cout * Cin * 4;
+	const int64_t dbias_parts = ceil_div64((int64_t)B * Tout, 256) * Cout * 4;  // partial rows of the bias-gradient column sum reuse the buffer
+	return slabs > dbias_parts ? slabs : dbias_parts;
 }
 
 template <typename T, int XI, bool AX, bool AY> static void launch_wgrad(const WgradParams& p, size_t smem, hipStream_t s) {
@@ -640,9 +658,10 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 		const int64_t rows = (int64_t)B * Tout;
 		const int rows_per_block = 256;
 		dim3 grid((Cout + 63) / 64, (unsigned)ceil_div64(rows, rows_per_block));
-		if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "conv1d_dbias: memset failed");
-		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, dbias, rows, Cout, rows_per_block);
-		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, dbias, rows, Cout, rows_per_block);
+		float* part = p.slab;  // the split-K slabs are consumed by now (same stream): reuse the workspace for grid.y partial rows
+		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, part, rows, Cout, rows_per_block);
+		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, part, rows, Cout, rows_per_block);
+		hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, (const float*)part, (int)grid.y, Cout, dbias, accumulate);
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
 	}
 	return 0;

@@ -250,8 +250,9 @@ template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void
 		double a = 0, q2 = 0;
 #pragma unroll
 		for (int m = 0; m < 4; ++m) { a += (double)red[(0 * 4 + m) * BN + tid]; q2 += (double)red[(1 * 4 + m) * BN + tid]; }
-		unsafeAtomicAdd(p.stats + co0 + tid, a);
-		unsafeAtomicAdd(p.stats + p.Cout + co0 + tid, q2);
+		double* const prow = p.stats + (int64_t)mtile * 2 * p.Cout;  // per-(m tile) partial row, summed in a fixed order by bn_finalize
+		prow[co0 + tid] = a;
+		prow[p.Cout + co0 + tid] = q2;
 	}
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN / OEPC;
@@ -272,7 +273,7 @@ const void* convasr_conv_v2s_kernel(int y_dtype);  // conv_v2s.hip
 #define V2_DEFAULT_SMALL_SHAPE 1
 
 // Returns 1 if the v2 kernel took the launch, 0 if the shape is outside its envelope (caller falls back to conv.hip's kernel).
-int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
+int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles_out) {
 	if (p.stride != 1 || (p.Cin & 63) != 0) return 0;
 	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
@@ -305,5 +306,6 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s) {
 	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
 	void* args[] = {&p};
 	if (hipLaunchKernel(kern, dim3(grid), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;
+	if (m_tiles_out) *m_tiles_out = p.B * p.m_tiles_per_b;
 	return 1;
 }

@@ -166,15 +166,16 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 		double a = 0, q2 = 0;
 #pragma unroll
 		for (int m = 0; m < 4; ++m) { a += (double)red[(0 * 4 + m) * BN_ + tid]; q2 += (double)red[(1 * 4 + m) * BN_ + tid]; }
-		unsafeAtomicAdd(p.stats + co0 + tid, a);
-		unsafeAtomicAdd(p.stats + p.Cout + co0 + tid, q2);
+		double* const prow = p.stats + (int64_t)mtile * 2 * p.Cout;  // per-(m tile) partial row, summed in a fixed order by bn_finalize
+		prow[co0 + tid] = a;
+		prow[p.Cout + co0 + tid] = q2;
 	}
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN_ / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
 	// Fused pass 1 of the consumer layer's batch-norm backward (bf16 only): this tile IS dz of that layer; with its conv output y
 	// (same coordinates) g = dz * act'(y * scale + shift) * dropout * mask, and the tile's per-channel sums of g and g * xhat go to
-	// fp64 accumulators -- the separate reduce pass (2 reads of B*T*C) and its launch disappear.  A thread keeps one 8-channel
+	// per-tile fp64 partial rows -- the separate reduce pass (2 reads of B*T*C) and its launch disappear.  A thread keeps one 8-channel
 	// chunk for all its rows (V2_THREADS % OCHUNKS == 0), reads dz back from the LDS tile exactly as it is stored (bf16-rounded).
 	float bs1[8], bs2[8], bsc[8], bsh[8], bmean[8], bistd[8];
 	const int bco = co0 + (tid % OCHUNKS) * OEPC;
@@ -226,8 +227,9 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 			const int chunk = tid >> 3, k = tid & 7;
 			double a = 0, q2 = 0;
 			for (int j = chunk; j < V2_THREADS; j += OCHUNKS) { a += (double)bnred[j * 17 + k]; q2 += (double)bnred[j * 17 + 8 + k]; }
-			unsafeAtomicAdd(p.bn_sums + co0 + tid, a);
-			unsafeAtomicAdd(p.bn_sums + p.Cout + co0 + tid, q2);
+			double* const prow = p.bn_sums + (int64_t)mtile * 2 * p.Cout;  // per-(m tile) partial row, summed by convasr_bn_bwd_finalize
+			prow[co0 + tid] = a;
+			prow[p.Cout + co0 + tid] = q2;
 		}
 	}
 }

@@ -214,7 +214,10 @@ extern "C" int convasr_scale_rows(const float* grad, const float* gscale, float*
 }
 
 // ------------------------------------------------------------------------------------------------ gradient norm + SGD
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+#define SUMSQ_BLOCKS 2048
+// two launches, no atomics: SUMSQ_BLOCKS partial sums, then one workgroup adds them in index order (the clip coefficient, hence every
+// parameter, is bit-identical from run to run)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
 	__shared__ float red[4];
 	float acc = 0.f;
 	const int64_t n4 = n >> 2;
@@ -227,15 +230,27 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 	acc = wave_sum(acc);
 	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	if (threadIdx.x == 0) atomicAdd(out, (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
+	if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
 }
 
-extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream) {
-	CONVASR_CHECK_ARG(g && sumsq && n > 0, "sumsq: bad arguments");
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int blocks, double* __restrict__ out) {
+	__shared__ double red[256];
+	double a = 0;
+	for (int i = threadIdx.x; i < blocks; i += 256) a += part[i];
+	red[threadIdx.x] = a;
+	__syncthreads();
+	if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 256; ++i) s += red[i]; *out = s; }
+}
+
+extern "C" int64_t convasr_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * (int64_t)sizeof(double); }
+
+extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, void* stream) {
+	CONVASR_CHECK_ARG(g && sumsq && workspace && n > 0, "sumsq: bad arguments");
 	CONVASR_CHECK_ARG(((uintptr_t)g & 15) == 0, "sumsq: g must be 16-byte aligned");
 	int64_t blocks = ceil_div64(n, 1024);
-	if (blocks > 2048) blocks = 2048;
-	hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+	if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
+	hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, (double*)workspace);
+	hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, (int)blocks, sumsq);
 	CONVASR_CHECK_LAUNCH("sumsq");
 	return 0;
 }

@@ -138,8 +138,8 @@ def clear_fusion_state():
 	_FUSED.clear()
 
 
-def _bwd_sums_buffer(bn, C, dev):
-	return _stats_buffer(bn, C, dev)[2 * C:]
+def _bwd_sums_buffer(bn, C, dev, B, T):
+	return _stats_buffer(bn, C, dev, B, T, slot = '_convasr_bwd_stats')
 
 
 def _dgrad(x, dy, weight, spec, dt):
@@ -176,10 +176,10 @@ class ConvBnActFunction(torch.autograd.Function):
 		n_res = len(flat_res) // 5
 
 		bn = cfg['bn']
-		stats = _stats_buffer(bn, Cout, dev)
+		stats = _stats_buffer(bn, Cout, dev, B, ops.conv_out_len(Tin, spec.K, spec.stride, spec.dilation, spec.padding))
 		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
 		Tout = y.shape[2]
-		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked, rezero = True)
+		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked)
 
 		res_x, res_y, res_bnp = [], [], []
 		for r in range(n_res):
@@ -191,10 +191,10 @@ class ConvBnActFunction(torch.autograd.Function):
 				res_bnp.append(None)
 			else:
 				rbn = cfg['res_bn'][r]
-				st = _stats_buffer(rbn, Cout, dev)
+				st = _stats_buffer(rbn, Cout, dev, B, Tout)
 				ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
 				res_y.append(ry)
-				res_bnp.append(ops.bn_finalize(st, B * Tout, rg, rbeta, rbn.running_mean, rbn.running_var, _momentum(rbn), rbn.eps, num_batches_tracked = rbn.num_batches_tracked, rezero = True))
+				res_bnp.append(ops.bn_finalize(st, B * Tout, rg, rbeta, rbn.running_mean, rbn.running_var, _momentum(rbn), rbn.eps, num_batches_tracked = rbn.num_batches_tracked))
 
 		p_drop = cfg['dropout_p']
 		seed, offset = _DropoutState.next(B * Cout * Tout) if p_drop > 0 else (0, 0)
@@ -206,7 +206,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
 		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt == torch.bfloat16 and Cout % 8 == 0:
-			_PRODUCERS[z.data_ptr()] = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev))
+			_PRODUCERS[z.data_ptr()] = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout))
 		return z
 
 	@staticmethod
@@ -303,14 +303,14 @@ def _momentum(bn):
 	return bn.momentum
 
 
-def _stats_buffer(bn, C, dev):
-	"""Persistent per-BatchNorm fp64 accumulators, [4C]: (sum, sumsq) of the forward conv epilogue, then (sum g, sum g*xhat) of the
-	fused backward epilogue.  Zero between steps: the forward's bn_finalize re-zeroes BOTH halves (so a backward that died half
-	way cannot leak into the next step), the backward's finalize re-zeroes its half."""
-	buf = getattr(bn, '_convasr_stats', None)
-	if buf is None or buf.device != dev or buf.numel() != 4 * C:
-		buf = bn._convasr_stats = torch.zeros(4 * C, dtype = torch.float64, device = dev)
-	return buf
+def _stats_buffer(bn, C, dev, B, Tout, slot = '_convasr_stats'):
+	"""Persistent per-BatchNorm partial-sum buffer (ops.ConvStats) for the conv epilogue's statistics; `slot` picks the forward
+	one or the one the fused backward epilogue fills.  Nothing to zero: every launch overwrites the rows it reports."""
+	st = getattr(bn, slot, None)
+	if st is None or not st.fits(C, B, Tout, dev):
+		st = ops.ConvStats(C, B, Tout, dev)
+		setattr(bn, slot, st)
+	return st
 
 
 class ConvBiasFunction(torch.autograd.Function):

@@ -125,17 +125,45 @@ def conv_out_len(Tin, K, stride, dil, pad):
 	return (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
 
 
+class ConvStats:
+	"""Per-m-tile partial sums of a conv epilogue: buf is a flat fp64 tensor with room for max_rows x 2 x C, rows is how many the
+	last launch wrote.  No atomics anywhere: the finalize kernels add the rows in a fixed order."""
+
+	def __init__(self, C, B, Tout, device):
+		self.C = C
+		self.max_rows = _lib.load().convasr_conv_stats_max_rows(B, Tout)
+		self.buf = torch.empty(self.max_rows * 2 * C, dtype = torch.float64, device = device)
+		self.rows = 0
+
+	def fits(self, C, B, Tout, device):
+		return self.C == C and self.buf.device == device and self.max_rows >= _lib.load().convasr_conv_stats_max_rows(B, Tout)
+
+	def totals(self):
+		out = torch.empty(2 * self.C, dtype = torch.float64, device = self.buf.device)
+		call('convasr_reduce_rows', ptr(self.buf), self.rows, 2 * self.C, ptr(out), stream_ptr())
+		return out
+
+
 def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None):
-	"""x: channels-last (B, Cin, Tin); wp: packed weights.  Returns channels-last (B, Cout, Tout)."""
+	"""x: channels-last (B, Cin, Tin); wp: packed weights.  Returns channels-last (B, Cout, Tout).
+	stats: None, a ConvStats (the production path: partial rows, consumed by bn_finalize), or a (2 Cout,) fp64 tensor that
+	receives the totals (sum, sum of squares) -- a convenience for tests and tools, one extra tiny launch."""
+	import ctypes
 	B, Cin, Tin = x.shape
 	assert is_cl(x), 'conv1d expects a channels-last activation'
 	Tout = conv_out_len(Tin, K, stride, dil, pad)
 	out_dtype = out_dtype or x.dtype
 	y = empty_cl(B, Cout, Tout, out_dtype, x.device)
+	part = stats if isinstance(stats, ConvStats) or stats is None else ConvStats(Cout, B, Tout, x.device)
+	rows = ctypes.c_int(0)
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
 	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
 	es, osz = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
-	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), ptr(stats), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
+	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
+	if part is not None:
+		part.rows = rows.value
+		if part is not stats:
+			stats.copy_(part.totals())
 	return y
 
 
@@ -165,13 +193,14 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 
 # ------------------------------------------------------------------------------------------------ batch norm + activation
 
-def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked = None, rezero = False):
-	"""stats: [2C] (sum, sumsq) or [4C] (+ the fused backward sums, see functional._stats_buffer); rezero zeroes all of it."""
-	C = running_mean.numel() if running_mean is not None else (gamma.numel() if gamma is not None else stats.numel() // 2)
-	blocks = stats.numel() // (2 * C)
-	dev = stats.device
-	out = torch.empty(4, C, dtype = torch.float32, device = dev)  # mean, invstd, scale, shift
-	call('convasr_bn_finalize', ptr(stats), n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, ptr(num_batches_tracked), blocks if rezero else 0, stream_ptr())
+def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked = None):
+	"""stats: a ConvStats (partial rows of the conv launch) or a (2 C,) fp64 tensor of totals."""
+	if isinstance(stats, ConvStats):
+		buf, rows, C = stats.buf, stats.rows, stats.C
+	else:
+		buf, rows, C = stats, 1, stats.numel() // 2
+	out = torch.empty(4, C, dtype = torch.float32, device = buf.device)  # mean, invstd, scale, shift
+	call('convasr_bn_finalize', ptr(buf), rows, n, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C, ptr(num_batches_tracked), stream_ptr())
 	return out
 
 
@@ -288,8 +317,9 @@ def argmax(log_probs):
 # ------------------------------------------------------------------------------------------------ optimizer
 
 def sumsq(flat_grad, out = None):
-	out = out if out is not None else torch.zeros(1, dtype = torch.float64, device = flat_grad.device)
-	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), stream_ptr())
+	out = out if out is not None else torch.empty(1, dtype = torch.float64, device = flat_grad.device)
+	ws = workspace(_lib.load().convasr_sumsq_workspace_bytes(), flat_grad.device, 'sumsq')
+	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), ptr(ws), stream_ptr())
 	return out
 
 
@@ -301,21 +331,24 @@ def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nest
 def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums):
 	"""dx = dgrad(dy) with pass 1 of the consumer layer's batch-norm backward fused into the epilogue (bn_sums += per-channel sums).
 	Returns dx, or None when the shape is outside the fused kernel's envelope (nothing was launched)."""
+	import ctypes
 	B, Cout, Tdy = dy.shape
 	T = conv_out_len(Tdy, K, 1, dil, pad)
-	assert is_cl(dy) and dy.dtype == torch.bfloat16 and is_cl(bn_y) and bn_y.dtype == torch.bfloat16 and tuple(bn_y.shape) == (B, Cin, T) and bn_sums.dtype == torch.float64, (dy.shape, bn_y.shape, Cin, T)
+	assert is_cl(dy) and dy.dtype == torch.bfloat16 and is_cl(bn_y) and bn_y.dtype == torch.bfloat16 and tuple(bn_y.shape) == (B, Cin, T) and isinstance(bn_sums, ConvStats) and bn_sums.fits(Cin, B, T, dy.device), (dy.shape, bn_y.shape, Cin, T)
+	rows = ctypes.c_int(0)
 	dx = empty_cl(B, Cin, T, torch.bfloat16, dy.device)
 	rc = [0]
 	def run():
-		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums), stream_ptr())
+		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), stream_ptr())
 	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if (Cout % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
 	_lib.timed(family, 2.0 * B * T * Cout * Cin * K, run, nbytes = float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2))
+	bn_sums.rows = rows.value
 	return dx if rc[0] == 0 else None
 
 
-def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, dbeta = None, accumulate = False, rezero = True):
-	C = mean.numel()
-	call('convasr_bn_bwd_finalize', ptr(sums), ptr(gamma), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), int(n), C, int(rezero), stream_ptr())
+def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, dbeta = None, accumulate = False):
+	"""sums: the ConvStats the fused dgrad epilogue filled (partial rows of sum g, sum g*xhat)."""
+	call('convasr_bn_bwd_finalize', ptr(sums.buf), sums.rows, ptr(gamma), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), int(n), sums.C, stream_ptr())
 
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows

@@ -58,7 +58,6 @@ class FlatParameters:
 		"""torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:777): one reduction launch now; the scaling itself is
 		folded into the optimizer kernel.  Returns the total norm as a 0-d device tensor (no host sync)."""
 		self.finalize_grads()
-		self._sumsq.zero_()
 		ops.sumsq(self.grad, self._sumsq)
 		self.clip = (self._sumsq, float(max_norm))
 		return (self._sumsq.sqrt() * self.grad_scale).to(torch.float32).squeeze(0)

@@ -75,14 +75,17 @@ int convasr_conv_cout_pad(int cout);
 int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
 
 /* y[b,t,co] = epilogue( sum_{k,ci} x[b, t*stride + k*dil - pad, ci] * wp[k][co][ci] ), zero outside [0, Tin).
- * epilogue: acc -> (+ bias[co] if bias) -> (stats of that value: sum[co] += v, sumsq[co] += v*v over all valid
- * (b,t) if stats) -> (* scale[co] + shift[co] if scale) -> activation -> (zero frames t >= ceil(xlen[b]*Tout) if xlen)
- * -> store as y_dtype.  stats points at 2*Cout doubles (sum then sumsq) that the caller zeroed.
+ * epilogue: acc -> (+ bias[co] if bias) -> (stats of that value over the tile's valid (b,t) if stats) -> (* scale[co] + shift[co]
+ * if scale) -> activation -> (zero frames t >= ceil(xlen[b]*Tout) if xlen) -> store as y_dtype.
+ * stats (may be NULL): per-m-tile partial sums, [rows][2][Cout] doubles (sum then sum of squares), rows written = *stats_rows
+ * (<= convasr_conv_stats_max_rows(B, Tout), the size to allocate).  No atomics: convasr_bn_finalize / convasr_reduce_rows add the
+ * rows in a fixed order, so batch statistics are bit-identical from run to run.
  * Used for forward (mode FWD weights) and for dgrad (mode DGRAD weights, stride must be 1, pad' = dil*(K-1) - pad). */
 int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype,
                        int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil, int pad,
                        const float* bias, double* stats, const float* scale, const float* shift,
-                       int act, float act_lo, float act_hi, const float* xlen, void* stream);
+                       int act, float act_lo, float act_hi, const float* xlen, int* stats_rows, void* stream);
+int convasr_conv_stats_max_rows(int B, int Tout);
 
 /* A/B and test hook: 0 routes bf16 launches through the general register-staged kernel instead of the LDS-DMA kernel.
  * Returns the previous setting. */
@@ -102,13 +105,14 @@ int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
 /* From the conv epilogue's stats (sum, sumsq over n = B*T values per channel): batch mean / biased var ->
  * scale = gamma * invstd, shift = beta - mean * scale; mean/invstd saved for backward; running stats updated
  * with momentum (running_var with the unbiased estimate), exactly nn.BatchNorm1d training semantics.
- * num_batches_tracked (may be NULL) is incremented; rezero_stats = r > 0 zeroes the first r blocks of 2C doubles of `stats` after
- * reading block 0 (r = 2: a 4C buffer whose second half holds the fused BN-backward sums) so that a persistent
- * per-layer statistics buffer is ready for the next step's conv epilogue without a separate memset. */
-int convasr_bn_finalize(const double* stats, int64_t n, const float* gamma, const float* beta,
+ * stats: [stats_rows][2][C] partial sums as the conv epilogue writes them (stats_rows = 1: plain totals), added in a fixed order.
+ * num_batches_tracked (may be NULL) is incremented. */
+int convasr_bn_finalize(const double* stats, int stats_rows, int64_t n, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps,
                         float* mean, float* invstd, float* scale, float* shift, int C,
-                        int64_t* num_batches_tracked, int rezero_stats, void* stream);
+                        int64_t* num_batches_tracked, void* stream);
+/* out[c] = sum over rows of part[r][c] (fp64, the same fixed order): totals of a partial-sum buffer for callers that want them. */
+int convasr_reduce_rows(const double* part, int rows, int width, double* out, void* stream);
 
 /* eval: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale. */
 int convasr_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -173,8 +177,9 @@ int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, vo
 
 /* ---- optimizer: train.py:777-782 (clip_grad_norm_, SGD step), optimizers.py:66-90 (NovoGrad) ------------------- */
 
-/* sumsq[0] += sum g^2 over n fp32 values (double accumulator the caller zeroed). */
-int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* stream);
+/* sumsq[0] = sum g^2 over n fp32 values, in double, added in a fixed order (partial sums in `workspace`, no atomics). */
+int64_t convasr_sumsq_workspace_bytes(void);
+int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, void* stream);
 /* torch.optim.SGD step with clip folded in: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (c = 1 if sumsq NULL);
  * g' = c*g + wd*p; buf = first ? g' : mom*buf + g'; p -= lr * (nesterov ? g' + mom*buf : buf).
  * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad).
@@ -189,17 +194,18 @@ int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int6
 /* Fused backward step (bf16, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
  * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:
  * g = dx * act'(bn_y*bn_scale+bn_shift) * dropout * mask(bn_xlen); bn_sums[c] += sum g, bn_sums[C+c] += sum g*(bn_y-mean)*invstd
- * (C = Cin of this conv; fp64 accumulators the caller keeps zeroed: convasr_bn_bwd_finalize re-zeroes them).  It replaces
+
+ * (C = Cin of this conv) written as per-m-tile partial rows bn_sums[rows][2][C], *bn_rows rows (<= convasr_conv_stats_max_rows(B, T_dx)).  It replaces
  * convasr_conv1d_fwd(dy, packed_dgrad) + convasr_bn_act_bwd_reduce(write_g = 0) (models.py:111-139 backward) when dx has this
  * single consumer.  dy is (B, T_dy, Cout), dx and bn_y are (B, T_dx, Cin); pad = dil*(K-1) - padding of the forward conv.  Returns 1 (nothing launched) when the shape is outside the
  * LDS-DMA kernel's envelope (Cout % 64 != 0 or K < 2): run the two calls separately. */
 int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
                                    int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                    const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
-                                   uint64_t offset, const float* bn_xlen, double* bn_sums, void* stream);
-/* coef / dgamma / dbeta from directly accumulated sums (the second half of convasr_bn_act_bwd_reduce); n = B*T. */
-int convasr_bn_bwd_finalize(double* sums, const float* gamma, const float* mean, const float* invstd, float* coef, float* dgamma,
-                            float* dbeta, int accumulate, int64_t n, int C, int rezero_sums, void* stream);
+                                   uint64_t offset, const float* bn_xlen, double* bn_sums, int* bn_rows, void* stream);
+/* coef / dgamma / dbeta from those partial rows (the second half of convasr_bn_act_bwd_reduce), added in a fixed order; n = B*T. */
+int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamma, const float* mean, const float* invstd, float* coef,
+                            float* dgamma, float* dbeta, int accumulate, int64_t n, int C, void* stream);
 
 /* ---- SURVEY 8(f) "next" rows ------------------------------------------------------------------------------------ */
 

@@ -33,7 +33,7 @@ for spec in a.layers.split(';'):
     dy = ops.as_cl(torch.randn(a.B, cout, Tout, device = d), dt)
     dw = torch.empty_like(w)
     flops = 2.0 * a.B * Tout * cout * cin * k
-    stats = torch.zeros(2 * cout, dtype = torch.float64, device = d)
+    stats = ops.ConvStats(cout, a.B, Tout, d)
     res = []
     if 'fwd' in a.what:
         ms = timeit(lambda: ops.conv1d(x, fwd, cout, k, stride, dil, pad, stats = None if a.nostats else stats), a.iters); res.append(f'fwd {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s')

@@ -383,3 +383,32 @@ def test_cross_layer_backward_fusion_matches_separate_reduce():
 	# activations' gradients by one bf16 ulp downstream, so the comparison is in norm, not element by element
 	rel = float((a - b).norm() / b.norm())
 	assert rel < 2e-3 and float((a - b).abs().max()) < 2e-3 * float(b.abs().max()), (rel, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_training_is_bitwise_reproducible():
+	"""No floating-point atomics on the SGD training path: two runs of the same bf16 program (dropout on, masks on, fused
+	backward epilogue on) end with bit-identical parameters and report the same loss at every step."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	finals, losses = [], []
+	for run in range(2):
+		torch.manual_seed(0)
+		ca.functional.manual_seed(7)
+		fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+		model = ca.models.JasperNet(64, [38], base_width = 64, kernel_sizes = [11, 13], out_width_factors = [2, 3], dropouts = [0.2, 0.2], out_width_factors_large = [4, 4], residual = False, repeat = 2, dropout = 0.2, frontend = fe, check_time_dim_padded = False, nonlinearity = ('hardtanh', 0, 20), compute_dtype = torch.bfloat16).to(d).train()
+		flat = ca.train.FlatParameters(model)
+		model._convasr_flat = flat
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		g = torch.Generator().manual_seed(3)
+		x = (torch.rand(6, 16000 * 3, generator = g) * 2 - 1).to(d)
+		xlen = torch.tensor([1.0, 0.9, 0.55, 0.7, 1.0, 0.8], device = d)
+		y = torch.randint(0, 37, (6, 1, 25), generator = g).to(d)
+		ylen = torch.randint(10, 26, (6, 1), generator = g).to(d)
+		ls = []
+		for it in range(4):
+			r = ca.train.train_step(model, opt, x, xlen, y, ylen, iteration = it)
+			ls.append((float(r['loss_cur']), float(r['grad_norm'])))
+		finals.append(flat.data.clone())
+		losses.append(ls)
+	assert losses[0] == losses[1], losses
+	assert torch.equal(finals[0], finals[1])
