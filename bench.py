@@ -160,7 +160,7 @@ def main():
 				hit = [v for name, v in tj.items() if 'conv1d_igemm_v2s_kernel<unsigned short>' in name]
 				if hit:
 					traffic, traffic_src = round(hit[0]['hbm_bytes_per_launch'] / 1e6, 1), 'profiles/r01_bench_hbm_traffic.csv (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<unsigned short> (forward + dgrad launches of the stride-1 K>=2 layers; the 16 dgrads also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<unsigned short> (16 forward + 17 dgrad launches; the dgrads also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
 			hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
 			kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
 			if plain is not None and plain is not k:

@@ -278,7 +278,7 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles
 	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
-	int mode = p.K < 2 ? 0 : ((p.debug & 64) ? 1 : 2);
+	int mode = (p.K < 2 && !p.bn_y) ? 0 : ((p.debug & 64) ? 1 : 2);  // a K = 1 dgrad that carries the fused BN-backward epilogue runs in conv_v2s.hip's loop (5 % slower than the K = 1 path, but it saves the separate reduce pass)
 	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (mode == 0 ? 3 : 4) * V2_WSLOT;
 	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
 	if (epi > smem) smem = epi;

@@ -340,7 +340,7 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 	rc = [0]
 	def run():
 		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), stream_ptr())
-	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if (Cout % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
+	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if Cout % 64 == 0 else 'conv1d_igemm (other variants)'
 	_lib.timed(family, 2.0 * B * T * Cout * Cin * K, run, nbytes = float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2))
 	bn_sums.rows = rows.value
 	return dx if rc[0] == 0 else None

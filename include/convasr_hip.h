@@ -198,7 +198,7 @@ int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int6
  * (C = Cin of this conv) written as per-m-tile partial rows bn_sums[rows][2][C], *bn_rows rows (<= convasr_conv_stats_max_rows(B, T_dx)).  It replaces
  * convasr_conv1d_fwd(dy, packed_dgrad) + convasr_bn_act_bwd_reduce(write_g = 0) (models.py:111-139 backward) when dx has this
  * single consumer.  dy is (B, T_dy, Cout), dx and bn_y are (B, T_dx, Cin); pad = dil*(K-1) - padding of the forward conv.  Returns 1 (nothing launched) when the shape is outside the
- * LDS-DMA kernel's envelope (Cout % 64 != 0 or K < 2): run the two calls separately. */
+ * LDS-DMA kernel's envelope (Cout % 64 != 0): run the two calls separately. */
 int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
                                    int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                    const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
