@@ -193,6 +193,11 @@ template <typename T> __device__ __forceinline__ void pre_act8(const BnActParams
 	}
 }
 
+// One row per trip (the residual variant of the reduce kernel: 183 VGPRs with two rows in flight, half the occupancy).
+template <typename L, typename U> __device__ __forceinline__ void walk_rows1(const BnActParams& p, int rl, int c, L load, U use) {
+	for (RowWalk w(p, rl, c); w.live(); w.next(p)) use(w, load(w));
+}
+
 // Two rows per trip: both rows' loads are issued (through `load`) before the first is consumed (by `use`).
 template <typename L, typename U> __device__ __forceinline__ void walk_rows2(const BnActParams& p, int rl, int c, L load, U use) {
 	for (RowWalk w(p, rl, c); w.live();) {
@@ -306,10 +311,9 @@ template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bw
 		struct Pair { Raw8<T> y, dz; };
 		const T* const py = reinterpret_cast<const T*>(p.y);
 		const T* const pdz = reinterpret_cast<const T*>(p.dz);
-		if (cok)
-			walk_rows2(p, rl, c,
-				[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); return q; },
-				[&](const RowWalk& w, const Pair& q) {
+		{
+			auto load_row = [&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); return q; };
+			auto use_row = [&](const RowWalk& w, const Pair& q) {
 					float g[8];
 					if (w.masked()) {
 #pragma unroll
@@ -342,7 +346,9 @@ template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bw
 						}
 					}
 					if (p.out) store8<T>(reinterpret_cast<T*>(p.out) + w.idx, g);
-				});
+				};
+			if (cok) { if (RES) walk_rows1(p, rl, c, load_row, use_row); else walk_rows2(p, rl, c, load_row, use_row); }
+		}
 		// block reduction over the row-lanes that share a channel group
 		auto reduce_to = [&](float (&a)[8], float (&bq)[8], int set) {
 #pragma unroll

@@ -588,12 +588,18 @@ template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const
 	__syncthreads();
 	if (w == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
-	const int c = blockIdx.x * 256 + threadIdx.x;
-	if (c >= C) return;
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
+	__shared__ double red[16][64];  // 64 channels x 16 row-lanes, combined in a fixed order
+	const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, w = threadIdx.x >> 6;
 	double a = 0;
-	for (int i = 0; i < nparts; ++i) a += (double)part[(int64_t)i * C + c];
-	out[c] = accumulate ? out[c] + (float)a : (float)a;
+	if (c < C)
+		for (int i = w; i < nparts; i += 16) a += (double)part[(int64_t)i * C + c];
+	red[w][cl] = a;
+	__syncthreads();
+	if (w != 0 || c >= C) return;
+	double s = 0;
+	for (int i = 0; i < 16; ++i) s += red[i][cl];
+	out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil) {
@@ -661,7 +667,7 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 		float* part = p.slab;  // the split-K slabs are consumed by now (same stream): reuse the workspace for grid.y partial rows
 		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, part, rows, Cout, rows_per_block);
 		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, part, rows, Cout, rows_per_block);
-		hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, (const float*)part, (int)grid.y, Cout, dbias, accumulate);
+		hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 63) / 64), dim3(1024), 0, s, (const float*)part, (int)grid.y, Cout, dbias, accumulate);
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
 	}
 	return 0;
