@@ -260,10 +260,9 @@ class ConvBnActFunction(torch.autograd.Function):
 			rest = [r for r in bn_idx if r >= 2]
 			while rest:
 				batch, rest = rest[:2], rest[2:]
-				# re-order so the residuals being reduced sit in slots 0/1 of the kernel's argument list
-				order = batch + [r for r in range(n_res) if r not in batch]
-				pick = lambda lst: [lst[r] for r in order]
-				ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], None, None, act, xlen = xl, res = pick(res_y), rscale = pick(common['rscale']), rshift = pick(common['rshift']), rmean = pick(common['rmean']), rinvstd = pick(common['rinvstd']), rsums = [rsum_of[r] if r in batch else None for r in order], dropout_p = p_drop, seed = seed, offset = offset)
+				# g is materialised by now: the extra passes reduce it against two more residual branches each, reading g and those two
+				# tensors only (identity activation on g itself) instead of re-deriving g from dz and ALL residual inputs
+				ops.bn_act_bwd_reduce(g, g, None, None, None, None, (_lib.ACT_NONE, 0.0, 0.0), res = [res_y[r] for r in batch], rscale = [None] * len(batch), rshift = [None] * len(batch), rmean = [common['rmean'][r] for r in batch], rinvstd = [common['rinvstd'][r] for r in batch], rsums = [rsum_of[r] for r in batch], write_g = False)
 			dgamma, dbeta = _deliver([gamma, beta], lambda outs, acc: ops.bn_bwd_apply(g, y, None, bnp[0], bnp[1], sums[:2 * Cout], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
 			dy = ops.bn_bwd_apply(g, y, gamma, bnp[0], bnp[1], sums[:2 * Cout], inplace = False)
 
