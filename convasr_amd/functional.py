@@ -291,7 +291,14 @@ class ConvBnActFunction(torch.autograd.Function):
 			drg, drbeta = _deliver([rg, rbeta], lambda outs, acc, r = r, p = p: ops.bn_bwd_apply(g, res_y[r], None, p[0], p[1], rsum_of[r], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
 			dry = ops.bn_bwd_apply(g, res_y[r], rg, p[0], p[1], rsum_of[r], inplace = False)
 			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), rx.shape[1], 1, 1, 1, 0) if need_rx else None
-			drw, drb = _deliver([rw, rb], lambda outs, acc, rx = rx, dry = dry: ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], dbias = outs[1], accumulate = acc))
+			# The bias of a conv that feeds a train-mode batch norm has an identically zero gradient: dry sums to zero over (b, t) for
+			# every channel (sum of g minus N times its mean, minus mean(g xhat) times sum of xhat = 0).  The reference's autograd
+			# gets rounding noise around 0 from the column sum of dry; here the entry is set to exact zero and the pass is skipped.
+			def res_wgrad(outs, acc, rx = rx, dry = dry):
+				ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], accumulate = acc)
+				if outs[1] is not None and not acc:
+					outs[1].zero_()
+			drw, drb = _deliver([rw, rb], res_wgrad)
 			res_grads += [drx, drw, drb, drg, drbeta]
 		return (None, dx, dw, dgamma, dbeta, None, *res_grads)
 
