@@ -142,6 +142,19 @@ def _bwd_sums_buffer(bn, C, dev, B, T):
 	return _stats_buffer(bn, C, dev, B, T, slot = '_convasr_bwd_stats')
 
 
+def _bn_backward_from_g(g, y, gamma, beta, bnp, sums, n):
+	"""Pass 2 of a batch-norm backward whose g (gradient at the BN output) is materialised: a per-channel finalize turns the two
+	sums into (dgamma, dbeta) and the coefficients of dy = A*g + Bc*y + D, then one streaming kernel applies them."""
+	coef = torch.empty(3 * y.shape[1], dtype = torch.float32, device = y.device)
+	finalize = lambda outs, acc: ops.bn_bwd_finalize(sums, gamma, bnp[0], bnp[1], n, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc)
+	if (gamma is not None and gamma.requires_grad) or (beta is not None and beta.requires_grad):
+		dgamma, dbeta = _deliver([gamma, beta], finalize)
+	else:
+		finalize([None, None], False)
+		dgamma = dbeta = None
+	return dgamma, dbeta, ops.bn_act_bwd_apply(g, y, coef, False)
+
+
 def _dgrad(x, dy, weight, spec, dt):
 	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer registered for it."""
 	Cin = x.shape[1]
@@ -263,8 +276,7 @@ class ConvBnActFunction(torch.autograd.Function):
 				# g is materialised by now: the extra passes reduce it against two more residual branches each, reading g and those two
 				# tensors only (identity activation on g itself) instead of re-deriving g from dz and ALL residual inputs
 				ops.bn_act_bwd_reduce(g, g, None, None, None, None, (_lib.ACT_NONE, 0.0, 0.0), res = [res_y[r] for r in batch], rscale = [None] * len(batch), rshift = [None] * len(batch), rmean = [common['rmean'][r] for r in batch], rinvstd = [common['rinvstd'][r] for r in batch], rsums = [rsum_of[r] for r in batch], write_g = False)
-			dgamma, dbeta = _deliver([gamma, beta], lambda outs, acc: ops.bn_bwd_apply(g, y, None, bnp[0], bnp[1], sums[:2 * Cout], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
-			dy = ops.bn_bwd_apply(g, y, gamma, bnp[0], bnp[1], sums[:2 * Cout], inplace = False)
+			dgamma, dbeta, dy = _bn_backward_from_g(g, y, gamma, beta, bnp, sums[:2 * Cout], B * Tout)
 
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
 		wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
@@ -288,8 +300,7 @@ class ConvBnActFunction(torch.autograd.Function):
 				res_grads += [g if need_rx else None, None, None, None, None]
 				continue
 			p = res_bnp[r]
-			drg, drbeta = _deliver([rg, rbeta], lambda outs, acc, r = r, p = p: ops.bn_bwd_apply(g, res_y[r], None, p[0], p[1], rsum_of[r], dgamma = outs[0], dbeta = outs[1], accumulate = acc, need_dy = False))
-			dry = ops.bn_bwd_apply(g, res_y[r], rg, p[0], p[1], rsum_of[r], inplace = False)
+			drg, drbeta, dry = _bn_backward_from_g(g, res_y[r], rg, rbeta, p, rsum_of[r], B * Tout)
 			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), rx.shape[1], 1, 1, 1, 0) if need_rx else None
 			# The bias of a conv that feeds a train-mode batch norm has an identically zero gradient: dry sums to zero over (b, t) for
 			# every channel (sum of g minus N times its mean, minus mean(g xhat) times sum of xhat = 0).  The reference's autograd

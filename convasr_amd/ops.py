@@ -347,8 +347,9 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 
 
 def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, dbeta = None, accumulate = False):
-	"""sums: the ConvStats the fused dgrad epilogue filled (partial rows of sum g, sum g*xhat)."""
-	call('convasr_bn_bwd_finalize', ptr(sums.buf), sums.rows, ptr(gamma), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), int(n), sums.C, stream_ptr())
+	"""sums: the ConvStats the fused dgrad epilogue filled (partial rows of sum g, sum g*xhat), or a (2 C,) fp64 tensor of totals."""
+	buf, rows, C = (sums.buf, sums.rows, sums.C) if isinstance(sums, ConvStats) else (sums, 1, sums.numel() // 2)
+	call('convasr_bn_bwd_finalize', ptr(buf), rows, ptr(gamma), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), int(n), C, stream_ptr())
 
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
