@@ -51,7 +51,8 @@ _SIGNATURES = dict(
 	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p]),
 	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p]),
 	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
-	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p]),
+	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p]),
+	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),
 	convasr_ctc_alignment = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),

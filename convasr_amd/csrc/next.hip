@@ -6,9 +6,9 @@
 
 // ------------------------------------------------------------------------------------------------ NovoGrad
 // The arena is a concatenation of segments (one per parameter tensor, offsets[n_seg + 1]); NovoGrad's second moment is one
-// scalar per segment: the EMA of the squared gradient norm of that tensor.  Two launches over the arena: per-segment sums of
-// squares (fp64), then the fused update.  A workgroup owns NG_CHUNK consecutive arena elements; almost every workgroup lies
-// inside one segment (one table lookup, one atomic); the few that straddle a boundary look the segment up per element.
+// scalar per segment: the EMA of the squared gradient norm of that tensor.  Per-segment sums of squares first (item table, no
+// atomics), then the fused update: there a workgroup owns NG_CHUNK consecutive arena elements; almost every workgroup lies
+// inside one segment (one table lookup); the few that straddle a boundary look the segment up per element.
 #define NG_CHUNK 8192
 #define NG_TABLE 2048  // segment offsets are searched in LDS (a dependent chain of global loads per lookup made the launches latency-bound)
 
@@ -28,59 +28,33 @@ __device__ __forceinline__ int ng_segment(const int64_t* offsets, int n_seg, int
 	return lo;
 }
 
-// A workgroup walks a CONTIGUOUS run of chunks and keeps one running sum for the segment it is in: one fp64 atomic per
-// (workgroup, segment) -- ~1000 + n_seg in all.  (One atomic per chunk put 1300 same-address fp64 atomics on every large
-// weight tensor and ran at a tenth of the streaming rate.)
-__global__ __launch_bounds__(256) void ng_sumsq_kernel(const float* __restrict__ g, const int64_t* offsets, int n_seg, int64_t n, int chunks_per_block, double* __restrict__ g2) {
+// Per-segment sums of squares without atomics: the caller cuts every segment into items of at most NG_ITEM elements once
+// (items[i] = {segment, begin, end}, seg_first[s] = first item of segment s); one workgroup reduces one item into item_part[i], then
+// one thread per segment adds its items in order -- the EMAs, hence the parameters, are bit-identical from run to run.
+#define NG_ITEM 65536
+__global__ __launch_bounds__(256) void ng_item_sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ items, double* __restrict__ item_part) {
 	__shared__ double red[4];
-	__shared__ int64_t tab[NG_TABLE];
-	offsets = ng_stage_offsets(offsets, n_seg, tab);
-	const int64_t n_chunks = (n + NG_CHUNK - 1) / NG_CHUNK;
-	const int64_t c0 = (int64_t)blockIdx.x * chunks_per_block, c1 = min(n_chunks, c0 + chunks_per_block);
-	int cur = -1;
-	double acc = 0;
-	auto flush = [&]() {  // workgroup-uniform
-		double v = acc;
+	const int64_t i0 = items[3 * (int64_t)blockIdx.x + 1], i1 = items[3 * (int64_t)blockIdx.x + 2];
+	float a = 0.f;
+	const int64_t head = min(i1, (i0 + 3) & ~(int64_t)3);  // arena offsets are multiples of 64, so i0 is 16-byte aligned in practice
+	for (int64_t i = i0 + threadIdx.x; i < head; i += 256) a += g[i] * g[i];
+	const int64_t n4 = (i1 - head) >> 2;
+	const float4* g4 = reinterpret_cast<const float4*>(g + head);
+	for (int64_t i = threadIdx.x; i < n4; i += 256) { const float4 v = g4[i]; a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+	for (int64_t i = head + n4 * 4 + threadIdx.x; i < i1; i += 256) a += g[i] * g[i];
+	double acc = (double)a;
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-		__syncthreads();
-		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-		__syncthreads();
-		if (threadIdx.x == 0 && cur >= 0) unsafeAtomicAdd(g2 + cur, red[0] + red[1] + red[2] + red[3]);
-		acc = 0;
-	};
-	for (int64_t c = c0; c < c1; ++c) {
-		const int64_t i0 = c * NG_CHUNK, i1 = min(n, i0 + NG_CHUNK);
-		// still inside the current segment?  (one LDS compare instead of two searches per chunk)
-		const bool inside = cur >= 0 && i0 >= offsets[cur] && i1 <= offsets[cur + 1];
-		const int s0 = inside ? cur : ng_segment(offsets, n_seg, i0), s1 = inside ? cur : ng_segment(offsets, n_seg, i1 - 1);
-		if (s0 == s1) {
-			if (s0 != cur) { flush(); cur = s0; }
-			float a = 0.f;
-			if (i1 - i0 == NG_CHUNK) {  // 8 independent 16-byte loads per thread in flight
-				float4 v[8];
-#pragma unroll
-				for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(g + i0 + k * 1024 + threadIdx.x * 4);
-#pragma unroll
-				for (int k = 0; k < 8; ++k) a += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
-			} else {
-				for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) a += g[i] * g[i];
-			}
-			acc += (double)a;
-		} else {  // a chunk that straddles segment boundaries: one workgroup reduction (and one atomic) per segment piece
-			flush();
-			for (int sg = s0; sg <= s1; ++sg) {
-				const int64_t lo = max(i0, offsets[sg]), hi = min(i1, offsets[sg + 1]);
-				float a = 0.f;
-				for (int64_t i = lo + threadIdx.x; i < hi; i += 256) a += g[i] * g[i];
-				acc = (double)a;
-				cur = sg;
-				flush();
-			}
-			cur = -1;
-		}
-	}
-	flush();
+	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) item_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void ng_segment_sum_kernel(const double* __restrict__ item_part, const int64_t* __restrict__ seg_first, int n_seg, double* __restrict__ g2) {
+	const int s = blockIdx.x * 256 + threadIdx.x;
+	if (s >= n_seg) return;
+	double a = 0;
+	for (int64_t i = seg_first[s]; i < seg_first[s + 1]; ++i) a += item_part[i];
+	g2[s] = a;
 }
 
 struct NgParams {
@@ -146,22 +120,23 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 }
 
 extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets, int n_seg,
-                                     int64_t n, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
-                                     const float* loss_gate, float* total_norm, float grad_scale, void* stream) {
-	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && n_seg > 0 && n > 0, "novograd_step: bad arguments");
+                                     int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part, float max_norm, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, int dampening, int first, const float* loss_gate, float* total_norm, float grad_scale,
+                                     void* stream) {
+	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && items && seg_first && item_part && n_seg > 0 && n_items >= n_seg && n > 0, "novograd_step: bad arguments");
 	hipStream_t s = (hipStream_t)stream;
-	if (hipMemsetAsync(g2, 0, sizeof(double) * n_seg, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "novograd_step: memset failed");
-	const unsigned blocks = (unsigned)ceil_div64(n, NG_CHUNK);
-	const int chunks_per_block = (int)ceil_div64(blocks, 1024);
-	hipLaunchKernelGGL(ng_sumsq_kernel, dim3((unsigned)ceil_div64(blocks, chunks_per_block)), dim3(256), 0, s, g, offsets, n_seg, n, chunks_per_block, g2);
+	hipLaunchKernelGGL(ng_item_sumsq_kernel, dim3(n_items), dim3(256), 0, s, g, items, item_part);
+	hipLaunchKernelGGL(ng_segment_sum_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, (const double*)item_part, seg_first, n_seg, g2);
 	NgParams q;
 	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
 	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
 	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale;
-	hipLaunchKernelGGL(ng_step_kernel, dim3(blocks), dim3(256), 0, s, q);
+	hipLaunchKernelGGL(ng_step_kernel, dim3((unsigned)ceil_div64(n, NG_CHUNK)), dim3(256), 0, s, q);
 	CONVASR_CHECK_LAUNCH("novograd_step");
 	return 0;
 }
+
+extern "C" int64_t convasr_novograd_item_elems(void) { return NG_ITEM; }
 
 // ------------------------------------------------------------------------------------------------ forced alignment
 // One wave per utterance; lane l owns states l*NS .. l*NS+NS-1 of the extended target.  The forward variable is the reference's

@@ -354,10 +354,23 @@ def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, db
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8(f) "next" rows
 
-def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0):
-	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]."""
+def novograd_work_table(offsets_host, device):
+	"""Static work table of the fused NovoGrad step: every tensor (segment of the arena) cut into items of bounded size.
+	Returns (items (n_items, 3) int64, seg_first (n_seg + 1,) int64, item_part (n_items,) fp64 scratch), all on `device`."""
+	item = _lib.load().convasr_novograd_item_elems()
+	items, seg_first = [], [0]
+	for s_, (lo, hi) in enumerate(zip(offsets_host[:-1], offsets_host[1:])):
+		for b in range(lo, max(hi, lo + 1), item):
+			items.append((s_, b, min(hi, b + item)))
+		seg_first.append(len(items))
+	return (torch.tensor(items, dtype = torch.int64, device = device), torch.tensor(seg_first, dtype = torch.int64, device = device), torch.empty(len(items), dtype = torch.float64, device = device))
+
+
+def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0):
+	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]; table: novograd_work_table(...)."""
+	items, seg_first, item_part = table
 	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
-	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), offsets.numel() - 1, n, float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), stream_ptr())
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), offsets.numel() - 1, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), stream_ptr())
 
 
 def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):

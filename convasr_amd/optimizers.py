@@ -17,7 +17,9 @@ class NovoGrad:
 		self.param_groups = [dict(params = flat.params, **self.defaults)]
 		dev = flat.data.device
 		n_seg = len(flat.params)
-		self.offsets = torch.tensor(list(flat.offsets) + [flat.numel], dtype = torch.int64, device = dev)
+		host_offsets = list(flat.offsets) + [flat.numel]
+		self.offsets = torch.tensor(host_offsets, dtype = torch.int64, device = dev)
+		self._table = ops.novograd_work_table(host_offsets, dev)
 		self.momentum_buffer = torch.zeros_like(flat.data)
 		self.grads_ema = torch.zeros(2, n_seg, dtype = torch.float32, device = dev)  # [steps & 1] is current
 		self._g2 = torch.zeros(n_seg, dtype = torch.float64, device = dev)
@@ -34,7 +36,7 @@ class NovoGrad:
 			flat.finalize_grads()
 		max_norm = flat.clip[1] if flat.clip is not None else 0.0
 		cur = self.steps & 1
-		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], self.steps == 0, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = flat.grad_scale)
+		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], self.steps == 0, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = flat.grad_scale)
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 		Fn.bump_param_epoch()

@@ -214,11 +214,16 @@ int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamm
  * zero gradients).  Per tensor s: g2 = sum (c*g)^2 with c = min(1, max_norm / (||g||_all + 1e-6)) (c = 1 if max_norm <= 0);
  * ema_out[s] = first ? g2 : ema_in[s]*beta2 + g2*(1-beta2); d = c*g / sqrt(ema_out[s] + eps) (+ wd*p) (* (1-beta1) if
  * dampening); mom = first ? d : mom*beta1 + d; p -= lr*mom.  ema_in / ema_out must be different buffers (the caller swaps
- * them every call); g2 is n_seg doubles of scratch; total_norm (may be NULL) receives ||g||_all; loss_gate and grad_scale as in
+ * them every call); g2 is n_seg doubles of scratch; the per-tensor sums of squares are formed without atomics from a static work table:
+ * items[n_items][3] = {tensor, begin, end} cuts every tensor into pieces of at most convasr_novograd_item_elems() elements, in tensor
+ * order, seg_first[n_seg + 1] indexes the first piece of each tensor, item_part is n_items doubles of scratch (device int64 / fp64); total_norm (may be NULL) receives ||g||_all; loss_gate and grad_scale as in
  * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else). */
 int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets,
-                          int n_seg, int64_t n, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                          int dampening, int first, const float* loss_gate, float* total_norm, float grad_scale, void* stream);
+                          int n_seg, int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part,
+                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
+                          const float* loss_gate, float* total_norm, float grad_scale, void* stream);
+/* largest item the table may hold (elements) */
+int64_t convasr_novograd_item_elems(void);
 
 int64_t convasr_ctc_alignment_workspace_bytes(int B, int T);
 /* ctc.alignment (ctc.py:7-75): forced alignment of targets[b, :target_lengths[b]] to log_probs[b, :input_lengths[b]]
