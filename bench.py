@@ -176,7 +176,7 @@ def main():
 			# the HBM-bound kernels of the path (frontend, BN + activation passes): algorithmic bytes / HIP-event time against 8 TB/s
 			roof['hbm_kernels'] = {name: dict(achieved = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1), peak = PEAK_HBM_GBS, unit = 'GB/s', frac = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), launches_per_step = v['launches'] // args.steps, ms_per_step = round(v['total_ms'] / args.steps, 3)) for name, v in hbm.items()}
 			if 'logmel_kernel' in roof['hbm_kernels']:
-				roof['hbm_kernels']['logmel_kernel']['note'] = 'FFT-issue bound (three radix-8 Stockham passes through LDS per pair of frames), not HBM bound: 1 % of the step'
+				roof['hbm_kernels']['logmel_kernel']['note'] = 'FFT-issue bound (three radix-8 Stockham passes through LDS per pair of frames), not HBM bound: under 1 % of the step'
 		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout {args.dropout:g}', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), roofline = roof)
 		if world == 1 and not args.no_cpu_baseline:
 			line['cpu_baseline'] = cpu_baseline()

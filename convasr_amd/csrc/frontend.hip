@@ -9,8 +9,8 @@
 
 #define FE_NFFT 512
 #define FE_BINS 257
-#define FE_WAVES 8
-#define FE_MELP 65  // LDS pitch of the transposed mel matrix: conflict-free for the transposing store and the per-bin read
+#define FE_WAVES 16
+#define FE_SPAN 64  // LDS rows of the sparse mel table: melS[j][mel] = weight of bin klo[mel] + j (wider filters read the rest from global memory)
 
 // one atomic per workgroup: thousands of wave-level atomicMax on the same B addresses serialise in L2 and cost 5x the streaming time
 template <typename S> __global__ __launch_bounds__(256) void absmax_kernel(const S* __restrict__ x, int T, unsigned* __restrict__ out) {
@@ -75,15 +75,15 @@ template <typename S> __device__ __forceinline__ float sig_load(const S* p, int6
 
 // one sample of the reference's padded signal (models.py:570-582) for utterance row `xs`
 template <typename S>
-__device__ __forceinline__ float padded_sample(const S* xs, int i, int T, int pad, int nvalid, float denom, bool normalize, float preemph) {
+__device__ __forceinline__ float padded_sample(const S* xs, int i, int T, int pad, int nvalid, float inv_denom, bool normalize, float preemph) {
 	int t = i - pad;
 	if (i < pad) t = (pad < T) ? pad - i : -1;  // reflect (edge excluded) when T > pad, constant zeros otherwise
 	if (t < 0 || t >= T || t >= nvalid) return 0.f;
 	float cur = sig_load(xs, t);
-	if (normalize) cur = cur / denom;
+	if (normalize) cur = cur * inv_denom;
 	if (preemph > 0.f && t > 0) {
 		float prev = sig_load(xs, t - 1);
-		if (normalize) prev = prev / denom;
+		if (normalize) prev = prev * inv_denom;
 		cur = cur - preemph * prev;
 	}
 	return cur;
@@ -95,14 +95,23 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
                                                                const float* __restrict__ melb, float* __restrict__ out, int B, int T, int F, int hop, int nmel,
                                                                float preemph, int pairs_per_b, int total_pairs) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float* const melT = reinterpret_cast<float*>(smem);                 // [FE_BINS][FE_MELP]
-	cpx* const tw = reinterpret_cast<cpx*>(melT + FE_BINS * FE_MELP + 1);         // [512] exp(-2 pi i m / 512)
+	float* const melS = reinterpret_cast<float*>(smem);                  // [FE_SPAN][64] sparse mel table
+	cpx* const tw = reinterpret_cast<cpx*>(melS + FE_SPAN * 64);         // [512] exp(-2 pi i m / 512)
 	float* const win = reinterpret_cast<float*>(tw + FE_NFFT);           // [512] window centred in nfft
 	cpx* const work = reinterpret_cast<cpx*>(win + FE_NFFT);             // [FE_WAVES][512]
 	float* const pw = reinterpret_cast<float*>(work + FE_WAVES * FE_NFFT);  // [FE_WAVES][2][FE_BINS + 7]
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-	for (int i = tid; i < FE_BINS * 64; i += blockDim.x) { const int m = i / FE_BINS, k = i - m * FE_BINS; melT[k * FE_MELP + m] = m < nmel ? melw[i] : 0.f; }  // coalesced read, transposing store
+	// support of this lane's mel filter: the filterbank is ~97 % zeros (each triangle spans 3..30 of the 257 bins), so only each
+	// filter's support is kept in LDS (16 KiB instead of the 67 KiB dense matrix: room for 16 waves per CU) and the 257-term dot
+	// product is cut to the widest support in the wave; skipping exact zeros changes no result
+	int klo = FE_BINS, khi = 0;
+	if (lane < nmel)
+		for (int k = 0; k < FE_BINS; ++k)
+			if (melw[lane * FE_BINS + k] != 0.f) { klo = min(klo, k); khi = k + 1; }
+	if (khi <= klo) { klo = 0; khi = 0; }
+	if (wave == 0)
+		for (int j = 0; j < FE_SPAN; ++j) melS[j * 64 + lane] = (lane < nmel && klo + j < khi) ? melw[lane * FE_BINS + klo + j] : 0.f;
 	for (int i = tid; i < FE_NFFT; i += blockDim.x) {
 		float s, c;
 		sincospif((float)i / 256.0f, &s, &c);
@@ -111,13 +120,6 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		win[i] = (i >= left && i < left + win_length) ? window[i - left] : 0.f;
 	}
 	__syncthreads();
-
-	// support of this lane's mel filter: the filterbank is ~97 % zeros (each triangle spans 3..30 of the 257 bins), so the
-	// dense 257-term dot product is cut to the widest support in the wave; skipping exact zeros changes no result
-	int klo = FE_BINS, khi = 0;
-	for (int k = 0; k < FE_BINS; ++k)
-		if (melT[k * FE_MELP + lane] != 0.f) { klo = min(klo, k); khi = k + 1; }
-	if (khi <= klo) { klo = 0; khi = 0; }
 	int span = khi - klo;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) span = max(span, __shfl_xor(span, o, 64));
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		const bool has_f1 = f0 + 1 < F;
 		const S* xs = signal + (int64_t)b * T;
 		const int nvalid = valid_len(xlen, b, T);
-		const float denom = absmax ? absmax[b] + 1e-5f : 1.f;
+		const float denom = absmax ? 1.f / (absmax[b] + 1e-5f) : 1.f;  // reciprocal: one division per utterance instead of two per sample
 		const bool normalize = absmax != nullptr;
 
 		// ---- stage 1 (Ns = 1): no twiddles; inputs straight from global memory
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		float m0 = 0.f, m1 = 0.f;
 		for (int j = 0; j < span; ++j) {
 			const int k = min(klo + j, FE_BINS - 1);
-			const float w = (klo + j < khi) ? melT[k * FE_MELP + lane] : 0.f;
+			const float w = j < FE_SPAN ? melS[j * 64 + lane] : ((klo + j < khi) ? melw[lane * FE_BINS + k] : 0.f);
 			m0 = fmaf(w, p0[k], m0);
 			m1 = fmaf(w, p1[k], m1);
 		}
@@ -212,7 +214,7 @@ extern "C" int convasr_logmel_fwd(const void* signal, int signal_dtype, const fl
 		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft == 512 (window 257..512 samples), nmel <= 64; got nfft %d nmel %d win %d", nfft, nmel, win_length);
 	const int F = 1 + T / hop;  // (T + 2 * pad - nfft) / hop + 1 with pad = nfft / 2
 	const int pairs_per_b = (F + 1) / 2, total_pairs = B * pairs_per_b;
-	const size_t smem = sizeof(float) * (FE_BINS * FE_MELP + 1 + 2 * FE_NFFT + FE_NFFT + 2 * FE_WAVES * FE_NFFT + FE_WAVES * 2 * (FE_BINS + 7));
+	const size_t smem = sizeof(float) * (FE_SPAN * 64 + 2 * FE_NFFT + FE_NFFT + 2 * FE_WAVES * FE_NFFT + FE_WAVES * 2 * (FE_BINS + 7));
 	int grid = (total_pairs + FE_WAVES - 1) / FE_WAVES;
 	if (grid > 256) grid = 256;  // persistent: one workgroup per CU amortises the table set-up (mel transpose, twiddles) over ~190 frame pairs
 	hipStream_t s = (hipStream_t)stream;
