@@ -56,35 +56,34 @@ extern "C" int convasr_convert_layout(const void* src, int src_dtype, int64_t ss
 }
 
 // ------------------------------------------------------------------------------------------------ instance norm
-// One block per (b, 64-channel group); lane = channel, waves stride over time.  Three passes over an L2-resident slab:
-// masked mean, masked sum of squared deviations (two-pass, like the reference), normalise.
+// One block per (b, 16-channel group): lane = (channel = lane & 15, time lane = lane >> 4), 16 waves stride over time.  Three passes
+// over an L2-resident slab: masked mean, masked sum of squared deviations (two-pass, like the reference), normalise.  (16 channels
+// per block instead of 64: four times the workgroups -- 256 for 64 mel channels x 64 utterances, one per CU -- for a latency-bound kernel.)
 template <typename S, typename D>
 __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x, int64_t xsb, int64_t xsc, int64_t xst, D* __restrict__ y,
                                                         int64_t ysb, int64_t ysc, int64_t yst, const float* __restrict__ xlen, int C, int T, float eps) {
-	__shared__ float red[16][64];
-	__shared__ float bc[64];
-	const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	__shared__ float red[64][17];
+	__shared__ float bc[16];
+	const int b = blockIdx.y, cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, tl = threadIdx.x >> 4;  // 64 time lanes
 	const int n = valid_len(xlen, b, T);
 	const bool ok = c < C;
 	const S* xp = x + b * xsb + (ok ? c : 0) * xsc;
+	auto block_sum = [&](float v) {  // sum over the 64 time lanes of each channel, in a fixed order
+		red[tl][cl] = v;
+		__syncthreads();
+		if (threadIdx.x < 16) { float s = 0.f; for (int i = 0; i < 64; ++i) s += red[i][threadIdx.x]; bc[threadIdx.x] = s; }
+		__syncthreads();
+		return bc[cl];
+	};
 	float acc = 0.f;
-	for (int t = w; t < n; t += 16) acc += ok ? Elem<S>::load(xp + t * xst) : 0.f;
-	red[w][lane] = acc;
-	__syncthreads();
-	if (w == 0) { float s = 0.f; for (int i = 0; i < 16; ++i) s += red[i][lane]; bc[lane] = s / (float)n; }
-	__syncthreads();
-	const float mean = bc[lane];
+	for (int t = tl; t < n; t += 64) acc += ok ? Elem<S>::load(xp + t * xst) : 0.f;
+	const float mean = block_sum(acc) / (float)n;
 	acc = 0.f;
-	for (int t = w; t < n; t += 16) { float d = ok ? Elem<S>::load(xp + t * xst) - mean : 0.f; acc += d * d; }
-	__syncthreads();
-	red[w][lane] = acc;
-	__syncthreads();
-	if (w == 0) { float s = 0.f; for (int i = 0; i < 16; ++i) s += red[i][lane]; bc[lane] = sqrtf(s / (float)n + eps); }
-	__syncthreads();
-	const float stdv = bc[lane];
+	for (int t = tl; t < n; t += 64) { float d = ok ? Elem<S>::load(xp + t * xst) - mean : 0.f; acc += d * d; }
+	const float stdv = sqrtf(block_sum(acc) / (float)n + eps);
 	if (!ok) return;
 	D* yp = y + b * ysb + c * ysc;
-	for (int t = w; t < T; t += 16) {
+	for (int t = tl; t < T; t += 64) {
 		float v = t < n ? (Elem<S>::load(xp + t * xst) - mean) / stdv : 0.f;
 		Elem<D>::store(yp + t * yst, v);
 	}
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x,
 extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb,
                                     int64_t ysc, int64_t yst, const float* xlen, int B, int C, int T, float eps, void* stream) {
 	CONVASR_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0, "instnorm_fwd: bad arguments");
-	dim3 grid((C + 63) / 64, B);
+	dim3 grid((C + 15) / 16, B);
 	hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(S, D) hipLaunchKernelGGL((instnorm_kernel<S, D>), grid, dim3(1024), 0, s, (const S*)x, xsb, xsc, xst, (D*)y, ysb, ysc, yst, xlen, C, T, eps)
 	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) LAUNCH(float, float);
