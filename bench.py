@@ -1,6 +1,10 @@
 """bench.py -- BASELINE.json's headline metric on the MI355X-native path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 without WORLD_SIZE in the environment: this process touches no GPU and starts its own N ranks as a CHILD
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, the role of train.py:1057-1073's mp.spawn), relays rank 0's
+JSON line and exits with the child's return code.  Under torch.distributed.run (WORLD_SIZE set) it is one rank of that job.
 
 A step = one full training iteration of the hot path on one synthetic batch per GPU (train.py:745-783 of the reference):
 logmel frontend -> instance norm -> Wav2Letter full (18 x Conv1d+BN+hardtanh+dropout+mask, 1x1 decoder) -> log-softmax ->
@@ -11,12 +15,12 @@ fp32 master weights, dropout 0.2.  Inputs are resident in HBM before the timed r
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL / cross-process GPU buffers need it on this driver (already exported on the pool)
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,9 +29,68 @@ SAMPLE_RATE, SECS, BATCH, TARGET_LEN = 16000, 15, 64, 150
 FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # conv stack, 2*MAC, fwd + dgrad + wgrad
 PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MAIN_KERNEL_SYMBOL = 'conv1d_igemm_v2s_kernel<unsigned short>'
+
+
+def parse_args(argv = None):
+	ap = argparse.ArgumentParser()
+	ap.add_argument('--gpus', type = int, default = 1)
+	ap.add_argument('--steps', type = int, default = 10)
+	ap.add_argument('--warmup', type = int, default = 3)
+	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f32'])
+	ap.add_argument('--dropout', type = float, default = 0.2, help = 'the reference Wav2Letter default is 0.2; other values are for experiments only')
+	ap.add_argument('--no-cpu-baseline', action = 'store_true')
+	ap.add_argument('--no-kernel-timer', action = 'store_true')
+	ap.add_argument('--no-traffic', action = 'store_true', help = 'skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run')
+	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (+1.5-2 % step rate; off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
+	ap.add_argument('--launcher-dry-run', action = 'store_true', help = 'test hook: ranks only rendezvous (gloo, CPU tensors) and rank 0 prints a line; exercises the self-launch path without a GPU')
+	return ap.parse_args(argv)
+
+
+def _free_port():
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	return port
+
+
+def _last_json_line(text):
+	for ln in reversed(text.splitlines()):
+		ln = ln.strip()
+		if ln.startswith('{') and ln.endswith('}'):
+			try:
+				obj = json.loads(ln)
+			except ValueError:
+				continue
+			if 'metric' in obj:
+				return ln
+	return None
+
+
+def launch_ranks(args, argv):
+	"""Parent side of `python bench.py --gpus N`: no GPU call is made here (torch.cuda.device_count() does not initialise the
+	device on this image), the ranks run in a child process tree started by torch.distributed.run."""
+	if not args.launcher_dry_run and os.environ.get('CONVASR_SHARE_GPU') != '1':
+		import torch
+		have = torch.cuda.device_count()
+		if have < args.gpus:
+			print(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible', file = sys.stderr)
+			return 2
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__), *argv]
+	proc = subprocess.run(cmd, stdout = subprocess.PIPE, text = True)  # stderr is inherited
+	line = _last_json_line(proc.stdout or '')
+	if line is not None:
+		print(line, flush = True)
+	elif proc.stdout:
+		sys.stderr.write(proc.stdout)
+	if proc.returncode != 0:
+		return proc.returncode
+	return 0 if line is not None else 1
 
 
 def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
+	import torch
 	g = torch.Generator().manual_seed(seed)
 	x = torch.rand(batch, SAMPLE_RATE * secs, generator = g) * 2 - 1
 	xlen = torch.ones(batch)
@@ -36,12 +99,14 @@ def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
 	return tuple(t.to(device) for t in (x, xlen, y, ylen))
 
 
-def cpu_baseline(secs = SECS, batch = 2, iters = 1):
+def cpu_baseline(secs = SECS, batch = 4, iters = 3):
 	"""The oracle (kind 'port': plain-torch CPU restatement of the reference's path, pinned to the reference by
-	tests/golden) timed on this host's cores on a bounded sample of the same workload: `batch` x 15 s utterances,
-	fwd + CTC + bwd + clip + SGD, 1 warm-up + `iters` timed iterations."""
+	tests/golden) timed on this host's cores on a bounded sample of the same workload: `batch` x 15 s
+	utterances, fwd + CTC + bwd + clip + SGD, 1 warm-up + `iters` timed iterations, mean and min reported.  Threads:
+	os.cpu_count() as BASELINE.md prescribes, unless CONVASR_CPU_THREADS overrides it; the count used is printed."""
+	import torch
 	from oracle import convasr_oracle as O
-	cores = min(os.cpu_count() or 1, 16)  # torch's CPU conv/BN kernels stop scaling (and oversubscribe) well before 256 threads
+	cores = int(os.environ.get('CONVASR_CPU_THREADS', 0)) or (os.cpu_count() or 1)
 	torch.set_num_threads(cores)
 	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
 	fe = O.frontend_config()
@@ -53,21 +118,76 @@ def cpu_baseline(secs = SECS, batch = 2, iters = 1):
 		t0 = time.perf_counter()
 		O.train_step(sd, plan, x, xlen, y, ylen, frontend = fe, momentum_buffers = bufs)
 		times.append(time.perf_counter() - t0)
-	best = min(times[1:])
-	return dict(value = round(batch * secs / best, 2), unit = 'audio-seconds/sec', cores = cores, kind = 'port', sample = f'{batch}x{secs}s utterances, Wav2Letter full fp32, fwd+CTC+bwd+clip+SGD, best of {iters} after 1 warm-up ({best:.2f} s/step)')
+	timed = times[1:]
+	mean, best = sum(timed) / len(timed), min(timed)
+	return dict(value = round(batch * secs / mean, 2), best = round(batch * secs / best, 2), unit = 'audio-seconds/sec', cores = torch.get_num_threads(), host_cpus = os.cpu_count(), kind = 'port', sample = f'{batch}x{secs}s utterances, Wav2Letter full fp32, fwd+CTC+bwd+clip+SGD, mean of {iters} timed iterations after 1 warm-up ({mean:.2f} s/step mean, {best:.2f} s/step best)')
 
 
-def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument('--gpus', type = int, default = 1)
-	ap.add_argument('--steps', type = int, default = 10)
-	ap.add_argument('--warmup', type = int, default = 3)
-	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f32'])
-	ap.add_argument('--dropout', type = float, default = 0.2, help = 'the reference Wav2Letter default is 0.2; other values are for experiments only')
-	ap.add_argument('--no-cpu-baseline', action = 'store_true')
-	ap.add_argument('--no-kernel-timer', action = 'store_true')
-	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (+1.5-2 % step rate; off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
-	args = ap.parse_args()
+def measure_traffic(args):
+	"""roofline.traffic measured in THIS run: two child `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE and WRITE_SIZE
+	separately: they do not fit one pass on gfx950) over `bench.py --steps 1 --warmup 1`, HBM-side bytes per launch of the dominant
+	kernel = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE reads half of a wide streaming read on gfx950: MI355X_MICROARCH.md,
+	HBM).  The children are started as ordinary subprocesses (python itself after `--`); this process is idle meanwhile."""
+	import csv
+	import glob
+	import shutil
+	import tempfile
+	exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+	if not os.path.exists(exe):
+		return None, 'rocprofv3 not found'
+	out = {}
+	env = dict(os.environ, TMPDIR = '/tmp')
+	for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+		d = tempfile.mkdtemp(prefix = f'convasr_pmc_{counter}_', dir = '/tmp')
+		try:
+			cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--dtype', args.dtype, '--dropout', str(args.dropout), '--no-cpu-baseline', '--no-kernel-timer', '--no-traffic']
+			r = subprocess.run(cmd, cwd = '/tmp', env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 600)
+			files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive = True)
+			if r.returncode != 0 or not files:
+				return None, f'rocprofv3 --pmc {counter} failed (rc {r.returncode})'
+			vals = [float(row['Counter_Value']) for row in csv.DictReader(open(files[0])) if MAIN_KERNEL_SYMBOL in row['Kernel_Name'] and row['Counter_Name'] == counter]
+			if not vals:
+				return None, f'no {MAIN_KERNEL_SYMBOL} dispatch in the {counter} pass'
+			out[counter] = (sum(vals) / len(vals), len(vals))
+		except subprocess.TimeoutExpired:
+			return None, f'rocprofv3 --pmc {counter} timed out'
+		finally:
+			shutil.rmtree(d, ignore_errors = True)
+	mb = (2 * out['FETCH_SIZE'][0] + out['WRITE_SIZE'][0]) * 1024 / 1e6
+	return round(mb, 1), f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes over bench.py --steps 1 --warmup 1, mean of {out["FETCH_SIZE"][1]} dispatches, MB per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024'
+
+
+def dry_run_rank(args):
+	"""--launcher-dry-run: rendezvous + one all-reduce on CPU tensors (gloo); rank 0 prints the line the parent relays."""
+	import torch
+	import torch.distributed as dist
+	dist.init_process_group('gloo')
+	rank, world = dist.get_rank(), dist.get_world_size()
+	t = torch.tensor([float(rank + 1)])
+	t0 = time.perf_counter()
+	dist.all_reduce(t)
+	dist.barrier()
+	el = torch.tensor([time.perf_counter() - t0], dtype = torch.float64)
+	dist.all_reduce(el, op = dist.ReduceOp.MAX)
+	backend = dist.get_backend()
+	dist.destroy_process_group()
+	if int(os.environ.get('CONVASR_DRY_RUN_FAIL_RANK', '-1')) == rank:
+		return 3  # test hook: the parent must propagate a rank's failure
+	if rank == 0:
+		assert float(t) == world * (world + 1) / 2
+		print(json.dumps(dict(metric = 'launcher-dry-run', value = float(t), unit = 'sum of rank+1', n_gpus = world, steps = args.steps, warmup = args.warmup, dist = dict(backend = backend, world_size = world, launcher = os.environ.get('TORCHELASTIC_RUN_ID') is not None))), flush = True)
+	return 0
+
+
+def main(argv = None):
+	argv = list(sys.argv[1:] if argv is None else argv)
+	args = parse_args(argv)
+	if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+		return launch_ranks(args, argv)
+	if args.launcher_dry_run:
+		return dry_run_rank(args)
+
+	import torch
 
 	# stdout carries exactly one line, the JSON result of rank 0: native libraries (RCCL prints a version banner through C stdio,
 	# flushed at exit, i.e. AFTER a Python print) are pointed at stderr for the duration of the run
@@ -79,11 +199,12 @@ def main():
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 	if args.gpus > 1 and world != args.gpus:
-		raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE is {world})')
+		raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {world}')
 	# (test hooks for a 1-GPU box: CONVASR_SHARE_GPU=1 puts every rank on cuda:0, CONVASR_DIST_BACKEND=gloo replaces RCCL, which needs one GPU per rank)
 	device = torch.device('cuda', 0 if os.environ.get('CONVASR_SHARE_GPU') == '1' else local_rank)
 	torch.cuda.set_device(device)
 	use_dist = world > 1 or os.environ.get('CONVASR_FORCE_DIST') == '1'  # the latter: single-rank RCCL smoke test of the DP path
+	dist_info = None
 	if use_dist:
 		import torch.distributed as dist
 		os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -95,6 +216,7 @@ def main():
 			dist.init_process_group('nccl', device_id = device)
 		else:
 			dist.init_process_group(backend)
+		dist_info = dict(backend = dist.get_backend() + (' (RCCL)' if backend == 'nccl' else ''), world_size = dist.get_world_size(), launcher = 'torch.distributed.run' if os.environ.get('TORCHELASTIC_RUN_ID') is not None else 'env')
 
 	import convasr_amd as ca
 	from convasr_amd import _lib
@@ -142,33 +264,25 @@ def main():
 		audio_s = world * BATCH * SECS * args.steps
 		value = audio_s / elapsed
 		roof = None
-		main = 'conv1d_igemm_v2s_kernel<bf16>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
-		fused_name = main + '+bn_bwd'  # the same kernel symbol launched as a dgrad with the fused BN-backward epilogue (functional._dgrad)
-		plain = kt.get(main)
-		if main in kt and fused_name in kt:
-			a, f = kt[main], kt.pop(fused_name)
-			kt[main] = dict(launches = a['launches'] + f['launches'], total_ms = a['total_ms'] + f['total_ms'], avg_us = 1e3 * (a['total_ms'] + f['total_ms']) / (a['launches'] + f['launches']), work = a['work'] + f['work'], bytes = a['bytes'] + f['bytes'])
-		if main in kt:
+		main_name = 'conv1d_igemm_v2s_kernel<bf16>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
+		fused_name = main_name + '+bn_bwd'  # the same kernel symbol launched as a dgrad with the fused BN-backward epilogue (functional._dgrad)
+		plain = kt.get(main_name)
+		if main_name in kt and fused_name in kt:
+			a, f = kt[main_name], kt.pop(fused_name)
+			kt[main_name] = dict(launches = a['launches'] + f['launches'], total_ms = a['total_ms'] + f['total_ms'], avg_us = 1e3 * (a['total_ms'] + f['total_ms']) / (a['launches'] + f['launches']), work = a['work'] + f['work'], bytes = a['bytes'] + f['bytes'])
+		if main_name in kt:
 			peak = PEAK_BF16_DENSE / 1e12 if args.dtype == 'bf16' else 157.3
 			tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
-			k = kt[main]
-			# HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction)
-			traffic, traffic_src = None, None
-			tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
-			if args.dtype == 'bf16' and os.path.exists(tpath):
-				tj = json.load(open(tpath))
-				hit = [v for name, v in tj.items() if 'conv1d_igemm_v2s_kernel<unsigned short>' in name]
-				if hit:
-					traffic, traffic_src = round(hit[0]['hbm_bytes_per_launch'] / 1e6, 1), 'profiles/r01_bench_hbm_traffic.csv (MB per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
-			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<unsigned short> (16 forward + 17 dgrad launches; the dgrads also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = traffic, traffic_source = traffic_src, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			k = kt[main_name]
+			roof = dict(bound = 'mfma', kernel = MAIN_KERNEL_SYMBOL + ' (16 forward + 17 dgrad launches; the dgrads also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
 			hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
 			kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
 			if plain is not None and plain is not k:
 				roof['plain_launches'] = dict(note = 'the launches of the same kernel without the fused BN-backward epilogue (forward, and the dgrads whose consumer is not fused): the epilogue adds work that is not counted as FLOPs', achieved = round(tf(plain), 2), frac = round(tf(plain) / peak, 4), launches_per_step = plain['launches'] // args.steps, avg_launch_us = round(plain['avg_us'], 2))
-			others = {name: v for name, v in kt.items() if name != main}
+			others = {name: v for name, v in kt.items() if name != main_name}
 			if 'conv1d_wgrad' in others:
 				w = others['conv1d_wgrad']
-				roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel + wgrad_reduce_kernel (+ general wgrad kernel on 3 small layers)', achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4), launches_per_step = w['launches'] // args.steps, avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
+				roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel incl. its split-K combine (+ general wgrad kernel on 3 small layers)', achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4), launches_per_step = w['launches'] // args.steps, avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
 			allc = [v for v in kt.values()]
 			roof['conv_stack'] = dict(achieved = round(sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12, 2), ms_per_step = round(sum(v['total_ms'] for v in allc) / args.steps, 3))
 			roof['conv_stack']['frac'] = round(roof['conv_stack']['achieved'] / peak, 4)
@@ -177,18 +291,31 @@ def main():
 			roof['hbm_kernels'] = {name: dict(achieved = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1), peak = PEAK_HBM_GBS, unit = 'GB/s', frac = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), launches_per_step = v['launches'] // args.steps, ms_per_step = round(v['total_ms'] / args.steps, 3)) for name, v in hbm.items()}
 			if 'logmel_kernel' in roof['hbm_kernels']:
 				roof['hbm_kernels']['logmel_kernel']['note'] = 'FFT-issue bound (three radix-8 Stockham passes through LDS per pair of frames), not HBM bound: under 1 % of the step'
-		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout {args.dropout:g}', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), roofline = roof)
-		if world == 1 and not args.no_cpu_baseline:
-			line['cpu_baseline'] = cpu_baseline()
+		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout {args.dropout:g}', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), dist = dist_info, roofline = roof)
 	if use_dist:
 		dist.destroy_process_group()
 	if rank == 0:
+		# the legs below start child processes / use the host cores: model, optimizer state and workspaces are released first
+		del model, flat, opt, engine, x, xlen, y, ylen, last
+		torch.cuda.empty_cache()
+		if world == 1 and roof is not None and args.dtype == 'bf16' and not args.no_traffic:
+			traffic, src = measure_traffic(args)
+			if traffic is None:  # fall back to the committed figure, and say so
+				tpath = os.path.join(ROOT, 'profiles', 'r02_conv_traffic.json')
+				if os.path.exists(tpath):
+					hit = [v for name, v in json.load(open(tpath)).items() if MAIN_KERNEL_SYMBOL in name]
+					if hit:
+						traffic, src = round(hit[0]['hbm_bytes_per_launch'] / 1e6, 1), f'committed: profiles/r02_conv_traffic.json ({src})'
+			roof['traffic'], roof['traffic_source'] = traffic, src
+		if world == 1 and not args.no_cpu_baseline:
+			line['cpu_baseline'] = cpu_baseline()
 		import ctypes
 		ctypes.CDLL(None).fflush(None)
 		sys.stdout.flush()
 		os.dup2(real_stdout, 1)
 		print(json.dumps(line), flush = True)
+	return 0
 
 
 if __name__ == '__main__':
-	main()
+	sys.exit(main())

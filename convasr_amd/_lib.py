@@ -45,6 +45,7 @@ _SIGNATURES = dict(
 	convasr_ctc_loss = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_int, c_i64, c_p]),
 	convasr_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_weighted_mean_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_sumsq_workspace_bytes = (c_i64, []),
 	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p]),

@@ -175,6 +175,44 @@ extern "C" int convasr_entropy(const float* log_probs, const int64_t* olen, floa
 	return 0;
 }
 
+// weighted_mean_entropy (models.py:660-682): per frame e = -sum_c p log p and weight w = 1 - p[eps_id] (x mask); per utterance
+// sum(e w) / (eps + sum w).  One workgroup per utterance, one wave per frame (lane = class), 16 frames in flight; the per-wave
+// partial sums are added in wave order: deterministic.
+__global__ __launch_bounds__(1024) void weighted_entropy_kernel(const float* __restrict__ lp, const int64_t* __restrict__ olen, float* __restrict__ out, int T, int C, int eps_id, float eps) {
+	__shared__ float red[2][16];
+	const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int n = olen ? min((int)olen[b], T) : T;
+	const float* p = lp + (int64_t)b * T * C;
+	float num = 0.f, den = 0.f;
+	for (int t = w; t < n; t += 16) {
+		float e = 0.f, sil = 0.f;
+		for (int c = lane; c < C; c += 64) {
+			const float v = p[(int64_t)t * C + c], pr = expf(v);
+			e -= pr * v;
+			if (c == eps_id) sil = pr;
+		}
+		e = wave_sum(e);
+		sil = wave_sum(sil);
+		const float wt = 1.f - sil;
+		num += e * wt;
+		den += wt;
+	}
+	if (lane == 0) { red[0][w] = num; red[1][w] = den; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float a = 0.f, d = 0.f;
+		for (int k = 0; k < 16; ++k) { a += red[0][k]; d += red[1][k]; }
+		out[b] = a / (eps + d);
+	}
+}
+
+extern "C" int convasr_weighted_mean_entropy(const float* log_probs, const int64_t* olen, float* out, int B, int T, int C, int eps_id, float eps, void* stream) {
+	CONVASR_CHECK_ARG(log_probs && out && B > 0 && T > 0 && C > 0 && eps_id >= 0 && eps_id < C, "weighted_mean_entropy: bad arguments");
+	hipLaunchKernelGGL(weighted_entropy_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, log_probs, olen, out, T, C, eps_id, eps);
+	CONVASR_CHECK_LAUNCH("weighted_mean_entropy");
+	return 0;
+}
+
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ lp, int64_t* __restrict__ idx, int64_t rows, int C) {
 	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;

@@ -69,13 +69,21 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 	__shared__ double red[4];
 	__shared__ float s_clip;
 	__shared__ int64_t tab[NG_TABLE];
+	// first < 0: the EMA buffers carry one extra element, the count of steps APPLIED so far (a gated step does not count: the
+	// reference creates no optimizer state on an iteration it skips, optimizers.py:76-80 / train.py:769-772)
+	const int n_carry = q.n_seg + (q.first < 0 ? 1 : 0);
 	if (q.loss_gate) {
 		const float l = *q.loss_gate;
 		if (!(fabsf(l) < INFINITY)) {  // skipped step: nothing changes; the caller still swaps its two EMA buffers, so carry the EMAs over
 			if (blockIdx.x == 0)
-				for (int s = threadIdx.x; s < q.n_seg; s += 256) q.ema_out[s] = q.ema_in[s];
+				for (int s = threadIdx.x; s < n_carry; s += 256) q.ema_out[s] = q.ema_in[s];
 			return;
 		}
+	}
+	if (q.first < 0) {
+		const float applied = q.ema_in[q.n_seg];
+		if (blockIdx.x == 0 && threadIdx.x == 0) q.ema_out[q.n_seg] = fminf(applied + 1.f, 16777216.f);
+		q.first = applied == 0.f;
 	}
 	q.offsets = ng_stage_offsets(q.offsets, q.n_seg, tab);
 	double tot = 0;

@@ -87,3 +87,93 @@ def collate_gpu(batch, time_padding_multiple = 128, device = None, speaker_missi
 	for k, b in enumerate(batch):
 		s[k, :b[1].shape[-1]] = b[1]
 	return metas, s, x, xlen, y, ylen
+
+
+class DistributedSamplerWrapper(torch.utils.data.Sampler):
+	"""datasets.py:431-493 (a DistributedSampler with shuffle = False over the batches of another sampler): rank r of W takes
+	batches r, r + W, r + 2 W, ... of what the wrapped sampler still has to deliver; the list is padded by wrapping around to a
+	multiple of W, as torch's DistributedSampler does.  BucketingBatchSampler emits W consecutive batches per bucket group, so
+	the W ranks of one iteration always get batches of the same bucket (equal padded length: balanced steps)."""
+
+	def __init__(self, sampler, num_replicas = None, rank = None, shuffle = False):
+		import torch.distributed as dist
+		if shuffle:
+			raise ValueError('DistributedSamplerWrapper: shuffle = True is never used by the reference (train.py:643) and is not implemented')
+		self.sampler = sampler
+		self.num_replicas = num_replicas if num_replicas is not None else dist.get_world_size()
+		self.rank = rank if rank is not None else dist.get_rank()
+		self.epoch = 0
+
+	def __iter__(self):
+		batches = list(self.sampler)
+		total = int(math.ceil(len(batches) / self.num_replicas)) * self.num_replicas
+		if batches and total > len(batches):
+			batches = (batches * int(math.ceil(total / len(batches))))[:total]
+		return iter(batches[self.rank:total:self.num_replicas])
+
+	def __len__(self):
+		return int(math.ceil(len(self.sampler) / self.num_replicas))
+
+	def state_dict(self):
+		return self.sampler.state_dict()
+
+	def load_state_dict(self, state_dict):
+		self.sampler.load_state_dict(state_dict)
+
+	def set_epoch(self, epoch):
+		self.epoch = epoch
+		self.sampler.set_epoch(epoch)
+
+	@property
+	def batch_idx(self):
+		return self.sampler.batch_idx
+
+	@batch_idx.setter
+	def batch_idx(self, value):
+		self.sampler.batch_idx = value
+
+
+class SyntheticAudioTextDataset(torch.utils.data.Dataset):
+	"""Stand-in for AudioTextDataset (datasets.py:23-355) with the same sample contract and `bucket` attribute, for benchmarks and
+	tests: there is no audio decoding or text pipeline here (out of scope), utterance k is seeded noise of a fixed random duration
+	and a random label string.  __getitem__ -> (meta, speaker (1,), x (1, T) float32, y (L,) int64), the tuple collate_fn /
+	collate_gpu consume in the default mode; bucket[k] = ceil((duration / window_stride + 1) / time_padding_multiple), the
+	bucket_fn of train.py:597-601."""
+
+	def __init__(self, num_examples, min_duration = 5.0, max_duration = 20.0, sample_rate = 16000, window_stride = 0.01, time_padding_multiple = 128, num_labels = 37, labels_per_second = 5.0, seed = 0):
+		g = torch.Generator().manual_seed(seed)
+		self.sample_rate, self.num_labels, self.seed = sample_rate, num_labels, seed
+		self.time_padding_multiple = time_padding_multiple
+		self.duration = min_duration + (max_duration - min_duration) * torch.rand(num_examples, generator = g)
+		self.num_samples = (self.duration * sample_rate).long()
+		self.duration = self.num_samples.double() / sample_rate
+		self.bucket = ((self.duration / window_stride + 1) / time_padding_multiple).ceil().to(torch.short)
+		self.target_len = (self.duration * labels_per_second).long().clamp(min = 1)
+
+	def __len__(self):
+		return len(self.num_samples)
+
+	def __getitem__(self, k):
+		g = torch.Generator().manual_seed(self.seed * 1000003 + int(k) + 1)
+		T, L = int(self.num_samples[k]), int(self.target_len[k])
+		x = torch.rand(1, T, generator = g) * 2 - 1
+		y = torch.randint(0, self.num_labels, (L, ), generator = g)
+		meta = dict(example_id = int(k), duration = float(self.duration[k]), begin = 0.0, end = float(self.duration[k]))
+		return meta, torch.zeros(1, dtype = torch.int64), x, y
+
+
+def keep_samples(batch):
+	"""DataLoader collate_fn for worker processes: the samples stay a list; padding happens on the GPU (collate_gpu)."""
+	return batch
+
+
+def gpu_batches(dataset, batch_sampler, device, num_workers = 0, time_padding_multiple = None, timeout = 0):
+	"""The reference's train DataLoader (train.py:647-655) with the batch assembly moved to the GPU: worker processes (or the main
+	process) produce lists of ragged CPU samples, collate_gpu packs each list into one pinned buffer, copies it once and pads on
+	the device.  Yields (meta, s, x, xlen, y, ylen) like the reference's loader, with x / xlen / y / ylen already on `device`;
+	x is (B, T) for a one-row waveform dataset (what model(x.squeeze(1), ...) consumes, train.py:748)."""
+	loader = torch.utils.data.DataLoader(dataset, batch_sampler = batch_sampler, collate_fn = keep_samples, num_workers = num_workers, pin_memory = False, timeout = timeout if num_workers > 0 else 0)
+	mult = time_padding_multiple or getattr(dataset, 'time_padding_multiple', 128)
+	for samples in loader:
+		meta, s, x, xlen, y, ylen = collate_gpu(samples, time_padding_multiple = mult, device = device)
+		yield meta, s, (x.squeeze(1) if x.shape[1] == 1 else x), xlen, y, ylen

@@ -98,6 +98,11 @@ def enable_side_stream_wgrad(device, enabled = True):
 	_side_streams[device] = torch.cuda.Stream(device = device) if enabled else None
 
 
+def side_stream(device):
+	"""The wgrad side stream of `device`, or None when it is disabled."""
+	return _side_streams.get(torch.device(device))
+
+
 def join_side_streams():
 	for dev, side in _side_streams.items():
 		if side is not None:
@@ -124,18 +129,20 @@ class ConvSpec:
 
 
 # Cross-layer backward fusion (bf16 training): pass 1 of a layer's batch-norm backward (per-channel sums of g and g * xhat) runs
-# in the epilogue of the dgrad launch that PRODUCES that layer's dz, i.e. in the backward of the layer's consumer.  The producer
-# registers what the epilogue needs under its output's address at forward time; the consumer's backward looks its input up, and
-# tags the dz it returns so that the producer's backward skips its own reduce pass.  Only outputs with exactly one consumer are
-# registered (a gradient that autograd accumulates from several consumers is not the tile the epilogue saw).
-_PRODUCERS = {}
-_FUSED = {}
+# in the epilogue of the dgrad launch that PRODUCES that layer's dz, i.e. in the backward of the layer's consumer.  No global
+# state: the producer's forward hangs a `link` (what the epilogue needs) on its output tensor and keeps it on its autograd ctx;
+# the consumer's forward takes the link off its input (so exactly one consumer can hold it) and keeps it on ITS ctx; the
+# consumer's backward runs the fused dgrad and leaves the dz it returns in the link; the producer's backward skips its own
+# reduce pass only if the gradient autograd hands it is that very tensor (same storage: nothing was accumulated or copied in
+# between).  Only outputs with exactly one consumer get a link (ConvBn1d.single_consumer_output).
 FUSE_BWD = os.environ.get('CONVASR_NO_BWD_FUSION') != '1'  # tests / A-B runs flip this to compare against the separate reduce pass
+_LINK_ATTR = '_convasr_bwd_link'
 
 
-def clear_fusion_state():
-	_PRODUCERS.clear()
-	_FUSED.clear()
+def _take_link(x):
+	"""Remove and return the fusion link the producer of `x` left on it (None if there is none)."""
+	d = getattr(x, '__dict__', None)
+	return d.pop(_LINK_ATTR, None) if d else None
 
 
 def _bwd_sums_buffer(bn, C, dev, B, T):
@@ -155,16 +162,15 @@ def _bn_backward_from_g(g, y, gamma, beta, bnp, sums, n):
 	return dgamma, dbeta, ops.bn_act_bwd_apply(g, y, coef, False)
 
 
-def _dgrad(x, dy, weight, spec, dt):
-	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer registered for it."""
+def _dgrad(x, dy, weight, spec, dt, link = None):
+	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it."""
 	Cin = x.shape[1]
 	pad = spec.dilation * (spec.K - 1) - spec.padding
 	wd = packed_weight(weight, dt, _lib.PACK_DGRAD)
-	info = _PRODUCERS.pop(x.data_ptr(), None)
-	if info is not None and dt == torch.bfloat16 and spec.stride == 1:
-		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, info['y'], info['bnp'][2], info['bnp'][3], info['bnp'][0], info['bnp'][1], info['act'], info['drop'][0], info['drop'][1], info['drop'][2], info['xl'], info['sums'])
+	if link is not None and dt == torch.bfloat16 and spec.stride == 1:
+		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'])
 		if dx is not None:
-			_FUSED[dx.data_ptr()] = info['sums']
+			link['dz'] = dx  # held until the producer's backward has looked at it: the address cannot be recycled meanwhile
 			return dx
 	return ops.conv1d(dy, wd, Cin, spec.K, 1, spec.dilation, pad)
 
@@ -180,6 +186,7 @@ class ConvBnActFunction(torch.autograd.Function):
 	@staticmethod
 	def forward(ctx, cfg, x, weight, gamma, beta, xlen, *flat_res):
 		spec, dt = cfg['spec'], cfg['compute_dtype']
+		ctx.producer_link = _take_link(x)
 		x = ops.as_cl(x, dt)
 		B, Cin, Tin = x.shape
 		Cout = weight.shape[0]
@@ -218,8 +225,10 @@ class ConvBnActFunction(torch.autograd.Function):
 		ctx.x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
+		ctx.bwd_link = None
 		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt == torch.bfloat16 and Cout % 8 == 0:
-			_PRODUCERS[z.data_ptr()] = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout))
+			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None)
+			setattr(z, _LINK_ATTR, ctx.bwd_link)
 		return z
 
 	@staticmethod
@@ -237,7 +246,11 @@ class ConvBnActFunction(torch.autograd.Function):
 		B, Cout, Tout = y.shape
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
-		fused_sums = _FUSED.pop(dz.data_ptr(), None)
+		link, fused_sums = ctx.bwd_link, None
+		if link is not None:
+			if link['dz'] is not None and link['dz'].data_ptr() == dz.data_ptr() and link['dz'].shape == dz.shape:
+				fused_sums = link['sums']
+			link['dz'] = None
 
 		if n_res == 0 and fused_sums is not None:
 			# pass 1 already ran inside the dgrad launch that produced dz: only the per-channel finalize is left
@@ -287,7 +300,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		if ctx.x_needs_grad:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
-			dx = _dgrad(x, dy, weight, spec, dt)
+			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link)
 		if not arena_mode:
 			dw, = wg()
 
@@ -336,6 +349,7 @@ class ConvBiasFunction(torch.autograd.Function):
 	@staticmethod
 	def forward(ctx, cfg, x, weight, bias):
 		spec, dt = cfg['spec'], cfg['compute_dtype']
+		ctx.producer_link = _take_link(x)
 		x = ops.as_cl(x, dt)
 		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), weight.shape[0], spec.K, spec.stride, spec.dilation, spec.padding, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias)
 		ctx.cfg = cfg
@@ -355,7 +369,7 @@ class ConvBiasFunction(torch.autograd.Function):
 		if ctx.needs_input_grad[1]:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented')
-			dx = _dgrad(x, dy, weight, spec, dt)
+			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link)
 		dw, db = _deliver([weight, bias], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], dbias = outs[1], accumulate = acc))
 		return None, dx, dw, db
 

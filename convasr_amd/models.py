@@ -69,8 +69,21 @@ def reset_bn_running_stats_(model):
 	return model
 
 
+def weighted_mean_entropy(log_probs, lengths = None, dim = -2, eps = 1e-9, eps_id = -1):
+	"""models.py:660-682 (the uncertainty measure evaluate_model logs, train.py:137-139): entropy per frame, averaged with weights
+	1 - P(silence token) over the valid frames.  log_probs (B, C, T); dim must be the class axis."""
+	if log_probs.ndim != 3 or dim not in (-2, 1):
+		raise _lib.ConvasrHipError('weighted_mean_entropy: only (B, C, T) log-probs with dim = -2 (the form train.py:137 uses) are implemented')
+	return ops.weighted_mean_entropy(log_probs, lengths, eps, eps_id)
+
+
 def normalize_signal(signal, dim = -1, eps = 1e-5, denom_multiplier = 1.0):
-	raise _lib.ConvasrHipError('normalize_signal is fused into LogFilterBankFrontend.forward on this backend')
+	"""models.py:684-686.  Inside LogFilterBankFrontend.forward the normalisation is fused into the log-mel kernel; this is the
+	standalone function (two launches)."""
+	if dim not in (-1, signal.ndim - 1):
+		raise _lib.ConvasrHipError('normalize_signal: only the time axis (dim = -1) is implemented')
+	shape = signal.shape
+	return ops.normalize_signal(signal.reshape(-1, shape[-1]), eps, denom_multiplier).reshape(shape)
 
 
 # ------------------------------------------------------------------------------------------------ mel filterbank (models.py:522)
@@ -337,7 +350,6 @@ class JasperNet(nn.Module):
 
 	def forward(self, x, xlen = None, y = None, ylen = None):
 		_lib.require_cuda(x)
-		Fn.clear_fusion_state()  # registrations of a forward whose backward never ran
 		if self.frontend is not None:
 			assert (not self.check_time_dim_padded) or (x.shape[-1] % (32 / 2) == 0), 'Shape of input signal is not divisible by 16 '
 			x = x.squeeze(1)

@@ -171,8 +171,10 @@ _workspaces = {}
 
 
 def workspace(nbytes, device, tag = 'default'):
-	"""Grow-only scratch buffer per (device, tag); kernels that use it are ordered on the current stream."""
-	key = (device, tag)
+	"""Grow-only scratch buffer per (device, tag, current stream): kernels that share one are ordered by that stream, and a
+	buffer replaced by a bigger one is released by the caching allocator in the order of the stream it was allocated on (the
+	side-stream wgrad and a main-stream wgrad of the same backward never share or free each other's slabs)."""
+	key = (device, tag, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
 	buf = _workspaces.get(key)
 	if buf is None or buf.numel() < nbytes:
 		buf = torch.empty(max(int(nbytes), 1 << 20), dtype = torch.uint8, device = device)
@@ -306,6 +308,31 @@ def entropy(log_probs, olen = None, eps = 1e-9):
 	return ent
 
 
+def weighted_mean_entropy(log_probs, olen = None, eps = 1e-9, eps_id = -1):
+	B, C, T = log_probs.shape
+	lp = as_cl(log_probs, torch.float32)
+	out = torch.empty(B, dtype = torch.float32, device = lp.device)
+	ol = None if olen is None else olen.to(device = lp.device, dtype = torch.int64).contiguous()
+	call('convasr_weighted_mean_entropy', ptr(lp), ptr(ol), ptr(out), B, T, C, int(eps_id) % C, float(eps), stream_ptr())
+	return out
+
+
+def normalize_signal(signal, eps = 1e-5, denom_multiplier = 1.0):
+	"""models.py:684-686 as a standalone op: per-utterance peak (absmax kernel), then one scaling pass."""
+	require_cuda(signal)
+	assert signal.ndim == 2
+	if signal.numel() == 0:
+		return signal
+	signal = signal.contiguous() if signal.dtype in (torch.float32, torch.int16) else signal.float().contiguous()
+	B, T = signal.shape
+	absmax = torch.empty(B, dtype = torch.float32, device = signal.device)
+	call('convasr_signal_absmax', ptr(signal), dtype_code(signal.dtype), B, T, ptr(absmax), stream_ptr())
+	x = signal if signal.dtype == torch.float32 else signal.float()
+	out = torch.empty_like(x)
+	call('convasr_scale_rows', ptr(x), ptr(((absmax + eps) * denom_multiplier).reciprocal()), ptr(out), B, T, stream_ptr())
+	return out
+
+
 def argmax(log_probs):
 	B, C, T = log_probs.shape
 	lp = as_cl(log_probs, torch.float32)
@@ -370,7 +397,9 @@ def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, l
 	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]; table: novograd_work_table(...)."""
 	items, seg_first, item_part = table
 	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
-	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), offsets.numel() - 1, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), stream_ptr())
+	n_seg = offsets.numel() - 1
+	assert int(first) >= 0 or (ema_in.numel() == n_seg + 1 and ema_out.numel() == n_seg + 1), 'first = -1 (device-side first-step detection) needs the applied-step counter behind the EMAs'
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), stream_ptr())
 
 
 def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):

@@ -21,7 +21,8 @@ class NovoGrad:
 		self.offsets = torch.tensor(host_offsets, dtype = torch.int64, device = dev)
 		self._table = ops.novograd_work_table(host_offsets, dev)
 		self.momentum_buffer = torch.zeros_like(flat.data)
-		self.grads_ema = torch.zeros(2, n_seg, dtype = torch.float32, device = dev)  # [steps & 1] is current
+		self.n_seg = n_seg
+		self.grads_ema = torch.zeros(2, n_seg + 1, dtype = torch.float32, device = dev)  # [steps & 1] is current; last element = number of steps applied so far (a gated step does not count), kept on the device
 		self._g2 = torch.zeros(n_seg, dtype = torch.float64, device = dev)
 		self.total_norm = torch.zeros(1, dtype = torch.float32, device = dev)
 		self.steps = 0
@@ -36,7 +37,7 @@ class NovoGrad:
 			flat.finalize_grads()
 		max_norm = flat.clip[1] if flat.clip is not None else 0.0
 		cur = self.steps & 1
-		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], self.steps == 0, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = flat.grad_scale)
+		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = flat.grad_scale)
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 		Fn.bump_param_epoch()
@@ -44,7 +45,7 @@ class NovoGrad:
 	@property
 	def state(self):
 		"""Per-parameter view in the reference's vocabulary: {'_grads_ema': 0-d tensor, 'momentum_buffer': tensor}."""
-		ema = self.grads_ema[self.steps & 1]
+		ema = self.grads_ema[self.steps & 1, :self.n_seg]
 		return {p: dict(_grads_ema = ema[i], momentum_buffer = self.momentum_buffer[o:o + p.numel()].view(p.shape)) for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets))}
 
 	def state_dict(self):

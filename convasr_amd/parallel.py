@@ -26,6 +26,8 @@ class DataParallelEngine(nn.Module):
 		self.buckets = self._make_buckets(bucket_bytes, min(first_bucket_bytes, bucket_bytes))
 		self._pending = []
 		self._remaining = [len(b['params']) for b in self.buckets]
+		self._main_stream = None  # the stream forward() ran on: dgamma / dbeta and (without a side stream) every weight gradient are produced there
+		self._comm_stream = None  # collectives are issued from here, ordered after BOTH the main stream and the side (wgrad) stream
 		self.fold_mean = fold_mean  # True: the 1 / world_size of the gradient mean rides in the optimizer kernel (flat.grad_scale) instead of a pass over the arena
 		self.sync = True  # False inside no_sync(): gradients accumulate locally, nothing is launched (gradient accumulation)
 		for bi, b in enumerate(self.buckets):
@@ -61,11 +63,27 @@ class DataParallelEngine(nn.Module):
 		return ready
 
 	def _launch(self, bi):
+		"""All-reduce of one complete bucket.  A bucket mixes gradients produced on the main stream (dgamma / dbeta, dgrad-side
+		kernels) with weight gradients that functional._run_wgrad may have produced on the side stream, and this hook fires on
+		whichever of the two delivered the bucket's last parameter.  torch.distributed orders a collective after the CURRENT stream
+		only, so the collective is issued from a dedicated stream that first waits for events recorded on both producers."""
 		if not self.collectives:
 			return
 		b = self.buckets[bi]
 		view = self.flat.grad[b['lo']:b['hi']]
-		self._pending.append((dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True), view))
+		if view.is_cuda:
+			from . import functional as Fn
+			dev = view.device
+			if self._comm_stream is None:
+				self._comm_stream = torch.cuda.Stream(device = dev)
+			producers = {s.cuda_stream: s for s in (self._main_stream, torch.cuda.current_stream(dev), Fn.side_stream(dev)) if s is not None}
+			for s in producers.values():
+				self._comm_stream.wait_stream(s)
+			with torch.cuda.stream(self._comm_stream):
+				work = dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
+		else:
+			work = dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
+		self._pending.append((work, view))
 
 	def no_sync(self):
 		"""Context manager for all but the last backward of a gradient-accumulation group (DDP.no_sync semantics)."""
@@ -93,6 +111,8 @@ class DataParallelEngine(nn.Module):
 				self._launch(bi)
 		for work, view in self._pending:
 			work.wait()
+		if self._comm_stream is not None and self._pending:
+			torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
 		if self.world_size > 1:
 			if self.fold_mean:
 				self.flat.grad_scale = 1.0 / self.world_size  # flat.grad holds the SUM over ranks until the optimizer consumes it
@@ -102,6 +122,8 @@ class DataParallelEngine(nn.Module):
 		self._remaining = [len(b['params']) for b in self.buckets]
 
 	def forward(self, *args, **kwargs):
+		if self.flat.data.is_cuda:
+			self._main_stream = torch.cuda.current_stream(self.flat.data.device)
 		return self.module(*args, **kwargs)
 
 	def state_dict(self, *args, **kwargs):

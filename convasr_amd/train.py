@@ -114,11 +114,17 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	loss = (loss_vec * example_weights).mean() / accumulate_iterations
 	loss_cur = loss_vec.mean()
 	entropy = M.entropy(log_probs[0].detach(), olen[0], dim = 1).mean()
-	if sync_metrics and (world_size > 1 or (sync_metrics is True and __import__('torch').distributed.is_initialized())):
+	engine = model if hasattr(model, 'finish_gradient_sync') else None
+	group = engine.group if engine is not None else None
+	# The two scalar all-reduces of train.py:759-760 as one 2-element all-reduce.  With a data-parallel engine that runs
+	# collectives it is NOT optional: the skip gate below must be the same number on every rank (the gradients are already
+	# averaged; a rank-local inf/NaN would make one replica skip the update the others apply).
+	if (engine is not None and engine.collectives) or (sync_metrics and torch.distributed.is_available() and torch.distributed.is_initialized() and (world_size > 1 or sync_metrics is True)):
 		import torch.distributed as dist
-		stats = torch.stack([loss_cur.detach(), entropy])  # one 2-element all-reduce instead of two scalar ones (train.py:759-760)
-		dist.all_reduce(stats, op = dist.ReduceOp.SUM)
-		loss_cur, entropy = stats[0] / world_size, stats[1] / world_size
+		n_ranks = dist.get_world_size(group)
+		stats = torch.stack([loss_cur.detach(), entropy])
+		dist.all_reduce(stats, op = dist.ReduceOp.SUM, group = group)
+		loss_cur, entropy = stats[0] / n_ranks, stats[1] / n_ranks
 	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = entropy, grad_norm = None, skipped = False)
 	gate = None
 	if device_gate and accumulate_iterations == 1 and hasattr(optimizer, 'flat'):
@@ -127,7 +133,6 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	elif bool(torch.isinf(loss_cur) | torch.isnan(loss_cur)):
 		res['skipped'] = True
 		return res
-	engine = model if hasattr(model, 'finish_gradient_sync') else None
 	last_of_group = iteration % accumulate_iterations == 0
 	if engine is not None and not last_of_group:
 		with engine.no_sync():
@@ -146,3 +151,23 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 			optimizer.step()
 		optimizer.zero_grad()
 	return res
+
+
+def train_epoch(model, optimizer, batches, sampler = None, scheduler = None, iteration = 0, world_size = 1, max_norm = 100.0, accumulate_iterations = 1, max_iterations = None, on_step = None):
+	"""The body of the reference's epoch loop (train.py:739-808) over an iterable of (meta, s, x, xlen, y, ylen) batches whose
+	tensors are already on the device (convasr_amd.datasets.gpu_batches): train_step, scheduler.step(iteration) after every
+	optimizer step (train.py:783), iteration += 1, sampler.batch_idx += world_size (train.py:807-808, what makes a resumed
+	epoch start where it stopped).  Metrics stay on the device; on_step(iteration, batch, result) may read them.
+	Returns the next iteration number."""
+	for meta, s, x, xlen, y, ylen in batches:
+		res = train_step(model, optimizer, x, xlen, y, ylen, max_norm = max_norm, accumulate_iterations = accumulate_iterations, iteration = iteration, world_size = world_size, sync_metrics = world_size > 1)
+		if scheduler is not None and iteration % accumulate_iterations == 0:
+			scheduler.step(iteration)
+		if on_step is not None:
+			on_step(iteration, (meta, s, x, xlen, y, ylen), res)
+		iteration += 1
+		if sampler is not None:
+			sampler.batch_idx += world_size
+		if max_iterations is not None and iteration >= max_iterations:
+			break
+	return iteration

@@ -172,6 +172,9 @@ int convasr_scale_rows(const float* grad, const float* gscale, float* out, int B
 
 /* ent[b] = sum_{t<olen} -sum_c p log p / (eps + olen[b])  (olen NULL: mean over T). */
 int convasr_entropy(const float* log_probs, const int64_t* olen, float* ent, int B, int T, int C, float eps, void* stream);
+/* weighted_mean_entropy (models.py:660-682, logged by train.py:137-139): per frame e = -sum_c p log p, w = 1 - p[eps_id]; out[b] =
+ * sum_{t<olen} e w / (eps + sum_{t<olen} w)  (olen NULL: all T frames). */
+int convasr_weighted_mean_entropy(const float* log_probs, const int64_t* olen, float* out, int B, int T, int C, int eps_id, float eps, void* stream);
 /* idx[b,t] = argmax_c log_probs[b,t,c] (first maximum, like torch.argmax on CPU). */
 int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, void* stream);
 
@@ -217,7 +220,10 @@ int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamm
  * them every call); g2 is n_seg doubles of scratch; the per-tensor sums of squares are formed without atomics from a static work table:
  * items[n_items][3] = {tensor, begin, end} cuts every tensor into pieces of at most convasr_novograd_item_elems() elements, in tensor
  * order, seg_first[n_seg + 1] indexes the first piece of each tensor, item_part is n_items doubles of scratch (device int64 / fp64); total_norm (may be NULL) receives ||g||_all; loss_gate and grad_scale as in
- * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else). */
+ * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else).  first: 1 / 0 decided by the caller, or -1 =
+ * decided on the device: ema_in / ema_out then hold n_seg + 1 floats, the last one the number of steps applied so far (the call
+ * writes ema_out[n_seg] = ema_in[n_seg] + 1 unless gated), and first = (ema_in[n_seg] == 0) -- a gated first iteration then leaves
+ * no optimizer state behind, like the reference, which creates state only when a step runs (optimizers.py:76-80). */
 int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets,
                           int n_seg, int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part,
                           float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,

@@ -393,6 +393,22 @@ def entropy(log_probs_bct, lengths = None, eps = 1e-9):
 	return e.sum(dim = -1) / (eps + lengths.type_as(log_probs_bct))
 
 
+def weighted_mean_entropy(log_probs_bct, lengths = None, eps = 1e-9, eps_id = -1):
+	"""models.py:660-682: entropy per frame, averaged over frames with weights 1 - P(silence token), masked by lengths."""
+	prob = log_probs_bct.exp()
+	e = -(prob * log_probs_bct).sum(dim = 1)
+	weights = 1 - prob[:, eps_id]
+	if lengths is not None:
+		weights = weights * temporal_mask(e.shape[-1], lengths)
+	return (e * weights).sum(dim = -1) / (eps + weights.sum(dim = -1))
+
+
+def normalize_signal(signal, eps = 1e-5, denom_multiplier = 1.0):
+	"""models.py:684-686."""
+	signal_max = signal.abs().max(dim = -1, keepdim = True).values + eps
+	return signal / (signal_max * denom_multiplier) if signal.numel() > 0 else signal
+
+
 CHAR_LEGACY_ALPHABET = 'абвгдеёжзийклмнопрстуфхцчшщъыьэюя'  # configs/ru_text_config.json:10
 
 
@@ -573,7 +589,7 @@ def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum 
 	loss = (loss_vec * ylen[:, 0]).mean()
 	loss_cur = loss_vec.mean()
 	ent = entropy(out['log_probs'].detach(), out['olen']).mean()
-	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = ent, loss_vec = loss_vec.detach(), log_probs = out['log_probs'].detach(), olen = out['olen'])
+	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = ent, loss_vec = loss_vec.detach(), logits = out['logits'].detach(), log_probs = out['log_probs'].detach(), olen = out['olen'])
 	if not (torch.isinf(loss_cur) or torch.isnan(loss_cur)):
 		loss.backward()
 		params = [sd[k] for k in names]

@@ -311,6 +311,24 @@ def test_bn_act_dropout_statistics_and_backward_consistency():
 # ------------------------------------------------------------------------------------------------ head
 
 @gpu
+def test_weighted_mean_entropy_and_normalize_signal_golden():
+	"""models.py:660-686 helpers against vectors produced by the reference (tests/golden/make_golden_r2.py)."""
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'helpers.npz'))
+	d = dev()
+	lp, olen = T_(g['log_probs']).to(d), T_(g['olen']).to(d)
+	close(ca.models.weighted_mean_entropy(lp, olen), T_(g['wme_len']), 2e-5, 1e-6, 'weighted_mean_entropy')
+	close(ca.models.weighted_mean_entropy(lp), T_(g['wme_all']), 2e-5, 1e-6, 'weighted_mean_entropy (no lengths)')
+	close(ca.models.weighted_mean_entropy(lp, olen, eps_id = 3), T_(g['wme_id3']), 2e-5, 1e-6, 'weighted_mean_entropy (eps_id 3)')
+	close(ca.models.entropy(lp, olen, dim = 1), T_(g['ent_len']), 2e-5, 1e-6, 'entropy')
+	sig = T_(g['signal']).to(d)
+	close(ca.models.normalize_signal(sig), T_(g['signal_norm']), 3e-7, 1e-9, 'normalize_signal')  # reciprocal multiply vs division: 1-2 ulp
+	close(ca.models.normalize_signal(sig, denom_multiplier = 2.5), T_(g['signal_norm_mult']), 3e-7, 1e-9, 'normalize_signal (multiplier)')
+	with pytest.raises(ca._lib.ConvasrHipError):
+		ca.models.weighted_mean_entropy(lp, olen, dim = 0)
+
+
+@gpu
 def test_log_softmax_entropy_argmax():
 	from convasr_amd import ops
 	torch.manual_seed(0)

@@ -210,3 +210,15 @@ def test_oracle_bucketing_and_collate_match_reference():
 	s, x, xlen, y, ylen = O.collate(_collate_inputs(g), 128, int(g['collate/speaker_missing']))
 	for name, t in dict(s = s, x = x, xlen = xlen, y = y, ylen = ylen).items():
 		assert torch.equal(t, torch.from_numpy(g[f'collate/{name}'])), name
+
+
+def test_oracle_entropy_helpers_match_reference(golden):
+	"""models.weighted_mean_entropy (models.py:660-682) and models.normalize_signal (684-686): tests/golden/make_golden_r2.py."""
+	g = golden('helpers.npz')
+	lp, olen = T(g['log_probs']), T(g['olen'])
+	close(O.weighted_mean_entropy(lp, olen), g['wme_len'], rtol = 1e-6)
+	close(O.weighted_mean_entropy(lp), g['wme_all'], rtol = 1e-6)
+	close(O.weighted_mean_entropy(lp, olen, eps_id = 3), g['wme_id3'], rtol = 1e-6)
+	close(O.entropy(lp, olen), g['ent_len'], rtol = 1e-6)
+	close(O.normalize_signal(T(g['signal'])), g['signal_norm'], rtol = 1e-7, atol = 0)
+	close(O.normalize_signal(T(g['signal']), denom_multiplier = 2.5), g['signal_norm_mult'], rtol = 1e-7, atol = 0)

@@ -144,3 +144,35 @@ def test_lr_schedules_host_arithmetic():
 	opt_mod.NoopLR(o).step(7); assert o.param_groups[0]['lr'] == 0.1
 	o.param_groups[0]['lr'] = 3.0
 	opt_mod.reset_options(o); assert o.param_groups[0]['lr'] == 0.1
+
+
+def _run_bench(extra_env, *argv):
+	import subprocess, sys
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	env = dict(os.environ, **extra_env)
+	env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+	return subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *argv], env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 300)
+
+
+def test_bench_launches_its_own_ranks_world2():
+	"""`python bench.py --gpus 2` (no WORLD_SIZE): the parent starts torch.distributed.run as a child, relays rank 0's single JSON
+	line and returns the child's code (train.py:1057-1073 spawns its ranks the same way).  --launcher-dry-run keeps the ranks on
+	CPU tensors over gloo so the launch path itself runs here."""
+	import json
+	r = _run_bench({}, '--gpus', '2', '--launcher-dry-run', '--steps', '4', '--warmup', '1')
+	assert r.returncode == 0, r.stderr[-2000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+	assert len(lines) == 1, lines
+	out = json.loads(lines[0])
+	assert out['n_gpus'] == 2 and out['steps'] == 4 and out['warmup'] == 1
+	assert out['dist'] == dict(backend = 'gloo', world_size = 2, launcher = True)
+
+
+def test_bench_launcher_propagates_a_rank_failure():
+	r = _run_bench(dict(CONVASR_DRY_RUN_FAIL_RANK = '1'), '--gpus', '2', '--launcher-dry-run')
+	assert r.returncode != 0
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+	r = _run_bench(dict(CONVASR_SHARE_GPU = '0'), '--gpus', '2')  # no GPU in the CPU container: a clear message, not a hang
+	assert r.returncode == 2 and 'GPU(s) are visible' in r.stderr

@@ -37,7 +37,7 @@ def _batch(rank, d):
 	return x, xlen, y, ylen
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, side = False):
 	os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
 	dist.init_process_group('gloo', rank = rank, world_size = world)
 	import convasr_amd as ca
@@ -49,6 +49,8 @@ def _worker(rank, world, port, out_dir):
 	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
 	engine = ca.parallel.DataParallelEngine(model, device = d, bucket_bytes = 64 << 10)
 	assert len(engine.buckets) >= 2
+	if side:
+		ca.functional.enable_side_stream_wgrad(d)
 	batch = _batch(rank, d)
 	losses = []
 	for it in range(2):
@@ -56,7 +58,7 @@ def _worker(rank, world, port, out_dir):
 		assert not bool(res['skipped'])
 		losses.append(float(res['loss_cur']))
 	torch.cuda.synchronize()
-	torch.save(dict(params = flat.data.cpu(), losses = losses), os.path.join(out_dir, f'rank{rank}.pt'))
+	torch.save(dict(params = flat.data.cpu(), losses = losses), os.path.join(out_dir, f'rank{rank}{"_side" if side else ""}.pt'))
 	dist.barrier()
 	dist.destroy_process_group()
 
@@ -97,3 +99,18 @@ def test_two_ranks_real_kernels_match_sequential_average():
 	ref = flats[0].data.cpu()
 	err = (got[0]['params'] - ref).abs().max().item()
 	assert err <= 2e-6 + 1e-5 * ref.abs().max().item(), err
+
+
+def test_two_ranks_side_stream_wgrad_equals_single_stream_bitwise():
+	"""enable_side_stream_wgrad under the data-parallel engine: a bucket mixes weight gradients produced on the side stream with
+	dgamma / dbeta produced on the main stream; the engine issues each bucket's all-reduce from a stream that waits for BOTH
+	producers (parallel.DataParallelEngine._launch), so the replicas end bit-identical to the single-stream run."""
+	world = 2
+	with tempfile.TemporaryDirectory() as out_dir:
+		mp.spawn(_worker, args = (world, _free_port(), out_dir, False), nprocs = world, join = True)
+		mp.spawn(_worker, args = (world, _free_port(), out_dir, True), nprocs = world, join = True)
+		plain = [torch.load(os.path.join(out_dir, f'rank{r}.pt')) for r in range(world)]
+		side = [torch.load(os.path.join(out_dir, f'rank{r}_side.pt')) for r in range(world)]
+	assert torch.equal(side[0]['params'], side[1]['params']), 'replicas diverged with the side stream on'
+	assert torch.equal(side[0]['params'], plain[0]['params']), float((side[0]['params'] - plain[0]['params']).abs().max())
+	assert side[0]['losses'] == plain[0]['losses']
