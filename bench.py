@@ -102,11 +102,14 @@ def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
 def cpu_baseline(secs = SECS, batch = 4, iters = 3):
 	"""The oracle (kind 'port': plain-torch CPU restatement of the reference's path, pinned to the reference by
 	tests/golden) timed on this host's cores on a bounded sample of the same workload: `batch` x 15 s
-	utterances, fwd + CTC + bwd + clip + SGD, 1 warm-up + `iters` timed iterations, mean and min reported.  Threads:
-	os.cpu_count() as BASELINE.md prescribes, unless CONVASR_CPU_THREADS overrides it; the count used is printed."""
+	utterances, fwd + CTC + bwd + clip + SGD, 1 warm-up + `iters` timed iterations, mean and best reported.  Threads: BASELINE.md
+	prescribes os.cpu_count(), but torch's CPU conv / BN kernels oversubscribe badly on a 256-thread host (measured on the GPU box,
+	2 x 15 s: 8 threads 69, 16 threads 118, 32 threads 90, 64 threads 43, 128 threads 20, 256 threads 0.8 audio-s/s:
+	profiles/README.md), so the default is min(os.cpu_count(), 16), the fastest setting; CONVASR_CPU_THREADS overrides it and the
+	count actually used is in the result."""
 	import torch
 	from oracle import convasr_oracle as O
-	cores = int(os.environ.get('CONVASR_CPU_THREADS', 0)) or (os.cpu_count() or 1)
+	cores = int(os.environ.get('CONVASR_CPU_THREADS', 0)) or min(os.cpu_count() or 1, 16)
 	torch.set_num_threads(cores)
 	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
 	fe = O.frontend_config()

@@ -250,7 +250,68 @@ JASPERNET_BIG = dict(num_subblocks = 2, temporal_mask = False)  # models.py:1412
 TINY = dict(base_width = 32, kernel_sizes = [11], out_width_factors = [2], out_width_factors_large = [2, 2], residual = False, repeat = 1)
 
 
-def conv_block(x, sd, prefix, layer, xlen, residual, nonlinearity, use_temporal_mask, training, bn_momentum = 0.1):
+class _StoreAs(torch.autograd.Function):
+	"""A tensor that the MI355X path keeps in a reduced-precision type between kernels: rounded to `dtype` on the way forward, and
+	its gradient rounded to `dtype` on the way back (the backward kernels store dy / dz in the same type)."""
+
+	@staticmethod
+	def forward(ctx, x, dtype):
+		ctx.dtype = dtype
+		return x.to(dtype).to(x.dtype)
+
+	@staticmethod
+	def backward(ctx, g):
+		return g.to(ctx.dtype).to(g.dtype), None
+
+
+class _GradStoreAs(torch.autograd.Function):
+	"""Identity forward; the gradient is rounded to `dtype` (fp32 logits whose gradient enters the bf16 decoder dgrad / wgrad)."""
+
+	@staticmethod
+	def forward(ctx, x, dtype):
+		ctx.dtype = dtype
+		return x.view_as(x)
+
+	@staticmethod
+	def backward(ctx, g):
+		return g.to(ctx.dtype).to(g.dtype), None
+
+
+def _stored(x, dtype):
+	return x if dtype is None else _StoreAs.apply(x, dtype)
+
+
+def _stored_weight(w, dtype):
+	"""Packed compute copy of an fp32 master weight: rounded forward, the gradient stays fp32 (wgrad writes fp32)."""
+	return w if dtype is None else w + (w.detach().to(dtype).to(w.dtype) - w.detach())
+
+
+def _conv_bn_stored(x, w, b, gamma, beta, running_mean, running_var, training, momentum, eps, storage, **conv_args):
+	"""conv -> batch norm as the MI355X path rounds it when activations are stored in `storage` (bf16): fp32 accumulation from
+	rounded operands, batch statistics from the fp32 accumulators (conv epilogue), the conv output itself stored rounded and
+	normalised from that rounded copy.  storage None: plain F.conv1d + F.batch_norm."""
+	y = F.conv1d(x, _stored_weight(w, storage), b, **conv_args)
+	if storage is None or not training:
+		return F.batch_norm(_stored(y, storage), running_mean, running_var, gamma, beta, training, momentum, eps)
+	if y.requires_grad:
+		y = _GradStoreAs.apply(y, storage)  # the BN-backward kernel writes dy (direct term + both statistics terms, summed in fp32) in the storage type
+	n = y.numel() // y.shape[1]
+	with torch.no_grad():
+		mean_v = y.mean(dim = (0, 2))
+		var_v = y.var(dim = (0, 2), unbiased = False)
+		running_mean.mul_(1 - momentum).add_(mean_v, alpha = momentum)
+		running_var.mul_(1 - momentum).add_(var_v * (n / max(n - 1, 1)), alpha = momentum)
+	yq = y + (y.detach().to(storage).to(y.dtype) - y.detach())  # stored rounded; gradient straight through to y, rounded once above
+	# VALUES of the statistics: the fp32 accumulators' (conv epilogue).  Their GRADIENT paths run through the stored copy, as in the
+	# backward kernels, which form xhat and both reduction terms from the stored y: dy = gamma invstd (g - mean(g) - xhat_q mean(g xhat_q))
+	mean_q = yq.mean(dim = (0, 2))
+	var_q = yq.var(dim = (0, 2), unbiased = False)
+	mean = mean_q + (mean_v - mean_q).detach()
+	var = var_q + (var_v - var_q).detach()
+	return (yq - mean[None, :, None]) * (var[None, :, None] + eps).rsqrt() * gamma[None, :, None] + beta[None, :, None]
+
+
+def conv_block(x, sd, prefix, layer, xlen, residual, nonlinearity, use_temporal_mask, training, bn_momentum = 0.1, storage = None):
 	"""ConvBn1d.forward (models.py:127-139) over state-dict entries '{prefix}.conv.{j}.0.weight' etc."""
 	rep = layer['repeat']
 	for j in range(rep):
@@ -261,35 +322,70 @@ def conv_block(x, sd, prefix, layer, xlen, residual, nonlinearity, use_temporal_
 				if cin_r is None:
 					res_in.append(xr)
 				else:
-					yr = F.conv1d(xr, sd[f'{prefix}.conv_residual.{r}.weight'], sd[f'{prefix}.conv_residual.{r}.bias'])
 					p = f'{prefix}.bn_residual.{r}'
-					res_in.append(batch_norm(yr, sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'], training, bn_momentum))
-		y = conv_same_padding(x, sd[f'{prefix}.conv.{j}.0.weight'], sd.get(f'{prefix}.conv.{j}.0.bias'), stride = layer['stride'], dilation = layer['dilation'])
+					if p + '.weight' not in sd:  # fused residual conv
+						res_in.append(_stored(F.conv1d(xr, _stored_weight(sd[f'{prefix}.conv_residual.{r}.weight'], storage), sd[f'{prefix}.conv_residual.{r}.bias']), storage))
+						continue
+					res_in.append(_conv_bn_stored(xr, sd[f'{prefix}.conv_residual.{r}.weight'], sd[f'{prefix}.conv_residual.{r}.bias'], sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'], training, bn_momentum, 1e-5, storage))
+		w = sd[f'{prefix}.conv.{j}.0.weight']
+		conv_args = dict(stride = layer['stride'], padding = layer['dilation'] * w.shape[-1] // 2, dilation = layer['dilation'])  # models.py:49
 		p = f'{prefix}.bn.{j}'
 		if p + '.weight' in sd:
-			y = batch_norm(y, sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'], training, bn_momentum)
+			y = _conv_bn_stored(x, w, sd.get(f'{prefix}.conv.{j}.0.bias'), sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'], training, bn_momentum, 1e-5, storage, **conv_args)
+		else:  # conv already fused with its batch norm (fuse_conv_bn_eval): bias, activation and mask run in the conv epilogue, y is never stored
+			y = F.conv1d(x, _stored_weight(w, storage), sd.get(f'{prefix}.conv.{j}.0.bias'), **conv_args)
 		for r in res_in:
 			y = y + r
 		x = activation(y, nonlinearity)
 		if use_temporal_mask and xlen is not None:
 			lengths = compute_output_lengths(x.shape[-1], xlen)
 			x = x * temporal_mask(x.shape[-1], lengths).unsqueeze(1)
+		x = _stored(x, storage)
 	return x
 
 
-def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True):
+def fuse_conv_bn_eval(sd, eps = 1e-5):
+	"""JasperNet.fuse_conv_bn_eval (models.py:141-151, 341-343 -> torch.nn.utils.fusion.fuse_conv_bn_eval): fold every batch norm's
+	running statistics and affine into the conv before it; returns a new state dict without the batch-norm entries."""
+	import re
+	out = {k: v for k, v in sd.items()}
+	for k in list(sd):
+		m = re.match(r'^(.*)\.conv\.(\d+)\.0\.weight$', k)
+		r = re.match(r'^(.*)\.conv_residual\.(\d+)\.weight$', k)
+		if m:
+			conv_p, bn_p = f'{m.group(1)}.conv.{m.group(2)}.0', f'{m.group(1)}.bn.{m.group(2)}'
+		elif r:
+			conv_p, bn_p = f'{r.group(1)}.conv_residual.{r.group(2)}', f'{r.group(1)}.bn_residual.{r.group(2)}'
+		else:
+			continue
+		if bn_p + '.running_var' not in sd:
+			continue
+		w, b = sd[conv_p + '.weight'], sd.get(conv_p + '.bias')
+		scale = sd[bn_p + '.weight'] * torch.rsqrt(sd[bn_p + '.running_var'] + eps)
+		out[conv_p + '.weight'] = w * scale.reshape(-1, 1, 1)
+		out[conv_p + '.bias'] = ((b if b is not None else torch.zeros_like(scale)) - sd[bn_p + '.running_mean']) * scale + sd[bn_p + '.bias']
+		for name in ('.weight', '.bias', '.running_mean', '.running_var', '.num_batches_tracked'):
+			out.pop(bn_p + name, None)
+	return out
+
+
+def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None):
 	"""JasperNet.forward (models.py:282-326).  sd: state dict (tensors, BN buffers are updated in place when
-	training), plan: jasper_plan(...), frontend: dict(window, nfft, hop_length) or None (x is features)."""
+	training), plan: jasper_plan(...), frontend: dict(window, nfft, hop_length) or None (x is features).
+	storage = torch.bfloat16 restates the same algorithm with the MI355X throughput path's storage precision: activations, conv
+	outputs, packed weights and the gradients flowing between layers rounded to bf16 where the HIP kernels store them in bf16,
+	every sum accumulated in fp32 (see _conv_bn_stored); storage = None is the reference's fp32 arithmetic."""
 	if frontend is not None:
 		x = logmel_frontend(x, xlen, sd['frontend.window'], sd['frontend.mel.weight'], sd['frontend.mel.bias'], frontend['nfft'], frontend['hop_length'])
 	assert x.ndim == 3
 	if normalize_features:
 		mask = temporal_mask(x.shape[-1], compute_output_lengths(x.shape[-1], xlen)) if xlen is not None else None
-		x = masked_instance_norm(x.float(), mask)
+		x = masked_instance_norm(x if x.dtype == torch.float64 else x.float(), mask)  # (float64 only in precision experiments)
+	x = _stored(x, storage) if x.requires_grad else (x if storage is None else x.to(storage).to(x.dtype))
 	residual = []
 	L = len(plan['layers'])
 	for i, layer in enumerate(plan['layers']):
-		x = conv_block(x, sd, f'backbone.{i}', layer, xlen, residual, plan['nonlinearity'], plan['temporal_mask'], training)
+		x = conv_block(x, sd, f'backbone.{i}', layer, xlen, residual, plan['nonlinearity'], plan['temporal_mask'], training, storage = storage)
 		if i >= L - 2 - 1:
 			residual = []
 		elif plan['residual'] == 'dense':
@@ -298,8 +394,11 @@ def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = N
 			residual = [x]
 		else:
 			residual = []
-	logits = F.conv1d(x, sd['decoder.0.weight'], sd['decoder.0.bias'])
-	log_probs = F.log_softmax(logits, dim = 1).float()
+	logits = F.conv1d(x, _stored_weight(sd['decoder.0.weight'], storage), sd['decoder.0.bias'])
+	if storage is not None and logits.requires_grad:
+		logits = _GradStoreAs.apply(logits, storage)
+	log_probs = F.log_softmax(logits, dim = 1)
+	log_probs = log_probs if log_probs.dtype == torch.float64 else log_probs.float()  # models.py:316 (.to(float32)); float64 only in precision experiments
 	olen = compute_output_lengths(logits.shape[-1], xlen.float() if xlen is not None else None, batch = logits.shape[0])
 	out = dict(logits = logits, log_probs = log_probs, olen = olen)
 	if y is not None and ylen is not None:
@@ -576,7 +675,7 @@ def novograd_step(params, grads, state, lr = 1.0, betas = (0.95, 0.98), eps = 1e
 	return total
 
 
-def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, max_norm = 100.0, momentum_buffers = None, nesterov = False):
+def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, max_norm = 100.0, momentum_buffers = None, nesterov = False, storage = None):
 	"""One iteration of the reference loop with accumulate=1: forward (748), loss = mean(loss * ylen) (755),
 	backward (774), clip_grad_norm_ (777), SGD step (780).  Returns dict(loss, loss_cur, entropy, grad_norm, grads);
 	sd parameters and momentum_buffers are updated in place."""
@@ -584,7 +683,7 @@ def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum 
 	for k in names:
 		sd[k].requires_grad_(True)
 		sd[k].grad = None
-	out = jasper_forward(sd, plan, x, xlen, y, ylen, frontend = frontend, training = True)
+	out = jasper_forward(sd, plan, x, xlen, y, ylen, frontend = frontend, training = True, storage = storage)
 	loss_vec = out['loss']
 	loss = (loss_vec * ylen[:, 0]).mean()
 	loss_cur = loss_vec.mean()

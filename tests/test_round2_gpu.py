@@ -12,91 +12,210 @@ pytestmark = pytest.mark.gpu
 FE = dict(nfft = 512, hop_length = 160)
 
 
+def _dump(name, obj):
+	"""Measured numbers go to gpurun_out/ (scratch) when it exists; the ones quoted in DESIGN.md are copied to profiles/."""
+	import json
+	out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+	if os.path.isdir(out):
+		with open(os.path.join(out, name), 'w') as f:
+			json.dump(obj, f, indent = 1)
+
+
 def _cos_rel(a, b):
 	a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
 	return float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm())
 
 
-def test_full_wav2letter_bf16_logits_loss_and_gradients_vs_fp32_oracle():
-	"""The dtype of the headline number at full model size: Wav2Letter full, 4 x 10 s, dropout 0, bf16 MFMA convolutions with fp32
-	accumulation and bf16 activations between layers, against the fp32 CPU oracle on the same weights and batch.
-	Tolerances (bf16 has 8 significant bits; 18 layers): logits relative L2 <= 2e-2, CTC loss <= 1e-2 relative, weight gradients of
-	the first layer, the k = 29 layer and the decoder: cosine >= 0.999 and relative L2 <= 5e-2."""
-	import convasr_amd as ca
-	torch.manual_seed(1)
-	d = torch.device('cuda:0')
+def _wav2letter_case(ca, seed = 1, B = 4, secs = 10):
+	torch.manual_seed(seed)
 	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
-	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0, check_time_dim_padded = False, compute_dtype = torch.bfloat16)
+	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0, check_time_dim_padded = False)
 	sd = {k: v.clone() for k, v in model.state_dict().items()}
-	B, secs = 4, 10
 	x = torch.rand(B, 16000 * secs) * 2 - 1
 	xlen = torch.linspace(0.5, 1, B)
 	y = torch.randint(0, 37, (B, 1, 10 * secs))
-	ylen = torch.tensor([[50], [60], [80], [100]])
+	ylen = torch.tensor([[50], [60], [80], [100]])[:B]
+	return model, sd, x, xlen, y, ylen
+
+
+def test_full_wav2letter_bf16_every_layer_vs_bf16_storage_oracle():
+	"""The dtype of the headline number, at full model size, kernel by kernel: each of the 18 Conv+BN+hardtanh+mask layers of
+	Wav2Letter full (4 x 10 s: 501 frames, 256..1024 channels, k = 11 / 29 dilated / 1, stride-2 prologue) and the decoder runs
+	forward AND backward in bf16 on the input the fp32 oracle chain produces at that depth, against the oracle's restatement of the
+	same layer with bf16 storage (operands, conv output, layer output and the gradients dy / dz rounded to bf16 where the HIP kernels
+	store bf16; every sum in fp32).
+	Why layer by layer: two bf16 pipelines that differ by 1e-7 anywhere do not stay 1e-7 apart.  A dense relative perturbation e
+	ahead of a bf16 store turns into a fraction e / ulp of elements rounding the other way by a whole ulp, i.e. an L2 error
+	sqrt(e ulp): 2e-5 -> 3e-4 -> 1e-3 -> ... -> the rounding noise itself (ulp = 2^-8).  Measured here with three layers between
+	comparison points: 1-2 % in the deepest gradients.  With the same input on both sides the comparison is about the kernels:
+	outputs agree to 2e-4 relative L2, gradients to 2e-3."""
+	import convasr_amd as ca
+	from convasr_amd import functional as Fn
+	d = torch.device('cuda:0')
+	model, sd, x, xlen, y, ylen = _wav2letter_case(ca)
 	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
-	ref = O.train_step(sd, plan, x, xlen, y, ylen, frontend = FE, lr = 0.0, momentum = 0.0, weight_decay = 0.0, max_norm = 1e30)
-	model.to(d).train()
+	torch.set_num_threads(min(os.cpu_count() or 1, 32))
+	with torch.no_grad():
+		feat = O.logmel_frontend(x, xlen, sd['frontend.window'], sd['frontend.mel.weight'], sd['frontend.mel.bias'], 512, 160)
+		h = O.masked_instance_norm(feat, O.temporal_mask(feat.shape[-1], O.compute_output_lengths(feat.shape[-1], xlen)))
+	model.to(d).train().set_compute_dtype(torch.bfloat16)
+	bf = lambda t: t.to(torch.bfloat16).float()
+	rel = lambda a, b: float((a.detach().double().cpu() - b.detach().double()).norm() / b.detach().double().norm())
+	g = torch.Generator().manual_seed(3)
+	table = {}
+	xlen_d = xlen.to(d)
+	for i, layer in enumerate(plan['layers']):
+		blk = model.backbone[i]
+		for j in range(layer['repeat']):
+			one = dict(layer, repeat = 1, cin = layer['cin'] if j == 0 else layer['cout'], res = [])
+			src = {f'L.conv.0.0.weight': f'backbone.{i}.conv.{j}.0.weight', **{f'L.bn.0.{n}': f'backbone.{i}.bn.{j}.{n}' for n in ('weight', 'bias', 'running_mean', 'running_var')}}
+			lsd = {k: sd[v].clone() for k, v in src.items()}
+			for k in ('L.conv.0.0.weight', 'L.bn.0.weight', 'L.bn.0.bias'):
+				lsd[k].requires_grad_(True)
+			first = i == 0 and j == 0  # the stride-2 prologue: its input (the features) needs no gradient
+			xq = bf(h)
+			xin = xq.clone().requires_grad_(not first)
+			z_ref = O.conv_block(xin, lsd, 'L', one, xlen, [], plan['nonlinearity'], plan['temporal_mask'], True, storage = torch.bfloat16)
+			# upstream gradient with a common mode, like a real one (purely zero-mean noise makes dbeta a sum of cancelling terms)
+			dz = bf((0.5 * torch.randn(z_ref.shape, generator = g) + 1.0) * (torch.rand(z_ref.shape, generator = g) < 0.7))
+			z_ref.backward(dz)
+			conv, bn = blk.conv[j][-1], blk.bn[j]
+			for p in (conv.weight, bn.weight, bn.bias):
+				p.grad = None
+			xg = ca.ops.as_cl(xq.to(d), torch.bfloat16).requires_grad_(not first)
+			z = Fn.ConvBnActFunction.apply(blk._cfg(j, j == layer['repeat'] - 1), xg, conv.weight, bn.weight, bn.bias, xlen_d)
+			z.backward(dz.to(d))
+			r = dict(z = rel(z, z_ref), dw = rel(conv.weight.grad, lsd['L.conv.0.0.weight'].grad), dgamma = rel(bn.weight.grad, lsd['L.bn.0.weight'].grad), dbeta = rel(bn.bias.grad, lsd['L.bn.0.bias'].grad))
+			if not first:
+				r['dx'] = rel(xg.grad, bf(xin.grad))  # the dgrad kernel stores dx in bf16
+			table[f'backbone.{i}.{j}'] = {k: float(f'{v:.2e}') for k, v in r.items()}
+			with torch.no_grad():  # the next layer's input comes from the fp32 chain
+				h = O.conv_block(h, {k: v.detach() for k, v in lsd.items()}, 'L', one, xlen, [], plan['nonlinearity'], plan['temporal_mask'], True)
+	# decoder head: bf16 operands, fp32 logits
+	hq = bf(h)
+	w, b = sd['decoder.0.weight'].clone().requires_grad_(True), sd['decoder.0.bias'].clone().requires_grad_(True)
+	hin = hq.clone().requires_grad_(True)
+	logits_ref = torch.nn.functional.conv1d(hin, O._stored_weight(w, torch.bfloat16), b)
+	dl = bf(torch.randn(logits_ref.shape, generator = g))
+	logits_ref.backward(dl)
+	for p in model.decoder.parameters():
+		p.grad = None
+	hg = ca.ops.as_cl(hq.to(d), torch.bfloat16).requires_grad_(True)
+	logits = model.decoder(hg)[0]
+	logits.backward(dl.to(d))
+	dec = dict(z = rel(logits, logits_ref), dx = rel(hg.grad, bf(hin.grad)), dw = rel(model.decoder[0].weight.grad, w.grad), dbeta = rel(model.decoder[0].bias.grad, b.grad))
+	table['decoder'] = {k: float(f'{v:.2e}') for k, v in dec.items()}
+	print('bf16 per-layer relative L2 vs bf16-storage oracle (same inputs on both sides):')
+	for k, v in table.items():
+		print(' ', k, v)
+	_dump('r02_bf16_per_layer.json', table)
+	# (a layer where one or two elements sit on a hardtanh boundary in one pipeline and not in the other -- backbone.4.0 here -- shows
+	# it as dbeta ~1e-4 instead of ~1e-8 and a few more rounding flips in dy, hence in dw / dx)
+	for k, v in table.items():
+		assert v['z'] <= 2e-4 and v['dw'] <= 1e-3 and v['dbeta'] <= 5e-4 and v.get('dgamma', 0) <= 5e-4 and v.get('dx', 0) <= 4e-3, (k, v)
+
+
+def test_full_wav2letter_bf16_whole_network_deviation_is_the_storage_types_own():
+	"""Whole network, bf16 vs the fp32 oracle, Wav2Letter full at 4 x 10 s, dropout 0.  A random-init network of 18 batch-normed
+	layers is an amplifier: in EXACT fp32 the MI355X path and the CPU oracle agree to 5e-5 in the logits but only to ~1.4e-2 in
+	the first layer's weight gradient, and bf16 storage (8 significant bits) moves the logits by ~12 % and decorrelates the
+	early-layer gradients -- for ANY implementation: the oracle's own bf16-storage restatement, run on the CPU, deviates from its
+	fp32 self by the same amounts.  So the bar here is: (1) the CTC loss (what BASELINE's metric pins) within 2e-3 relative of the
+	fp32 oracle, olen equal; (2) the MI355X bf16 path is no further from fp32 than the CPU bf16-storage restatement is (15 %
+	slack), in logits and in every gradient checked; (3) the decoder gradient, which sees no amplification behind it, within 1e-2.
+	Per-kernel bf16 accuracy is pinned by the teacher-forced test above; the measured numbers are in profiles/r02_bf16_parity.json."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	model, sd, x, xlen, y, ylen = _wav2letter_case(ca)
+	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
+	torch.set_num_threads(min(os.cpu_count() or 1, 32))
+	kw = dict(frontend = FE, lr = 0.0, momentum = 0.0, weight_decay = 0.0, max_norm = 1e30)
+	clone = lambda: {k: v.clone() for k, v in sd.items()}
+	ref32 = O.train_step(clone(), plan, x, xlen, y, ylen, **kw)
+	ref16 = O.train_step(clone(), plan, x, xlen, y, ylen, storage = torch.bfloat16, **kw)
+	model.to(d).train().set_compute_dtype(torch.bfloat16)
 	flat = ca.train.FlatParameters(model)
 	out = model(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
 	(out['loss'] * ylen.to(d)[:, 0]).mean().backward()
 	flat.finalize_grads()
-	assert torch.equal(out['olen'][0].cpu(), ref['olen'])
-	_, rel = _cos_rel(out['logits'][0], ref['logits'])
-	assert rel <= 2e-2, ('logits rel L2', rel)
-	loss_rel = float(((out['loss'].cpu() - ref['loss_vec']).abs() / ref['loss_vec'].abs()).max())
-	assert loss_rel <= 1e-2, ('CTC loss rel', loss_rel)
+	assert torch.equal(out['olen'][0].cpu(), ref32['olen'])
+	loss_rel = float(((out['loss'].detach().cpu() - ref32['loss_vec']).abs() / ref32['loss_vec'].abs()).max())
+	assert loss_rel <= 2e-3, ('CTC loss rel', loss_rel)
+	_, gpu_logits = _cos_rel(out['logits'][0], ref32['logits'])
+	_, emu_logits = _cos_rel(ref16['logits'], ref32['logits'])
+	assert gpu_logits <= 1.15 * emu_logits + 1e-3, (gpu_logits, emu_logits)
 	params = dict(model.named_parameters())
-	report = {}
-	for k in ['backbone.0.conv.0.0.weight', 'backbone.6.conv.0.0.weight', 'backbone.3.conv.1.0.weight', 'decoder.0.weight', 'backbone.5.bn.2.weight']:
-		cos, rel = _cos_rel(params[k].grad, ref['grads'][k])
-		report[k] = (round(cos, 5), round(rel, 4))
-	print('bf16 vs fp32 oracle (cosine, rel L2):', report, 'logits rel', rel, 'loss rel', loss_rel)
-	for k, (cos, rel) in report.items():
-		assert cos >= 0.999 and rel <= 5e-2, report
+	report = dict(loss_rel = loss_rel, logits_rel_gpu = gpu_logits, logits_rel_cpu_bf16_storage = emu_logits)
+	for k in ['backbone.0.conv.0.0.weight', 'backbone.3.conv.1.0.weight', 'backbone.6.conv.0.0.weight', 'backbone.7.conv.0.0.weight', 'decoder.0.weight', 'backbone.5.bn.2.weight']:
+		cos_g, rel_g = _cos_rel(params[k].grad, ref32['grads'][k])
+		cos_e, rel_e = _cos_rel(ref16['grads'][k], ref32['grads'][k])
+		report[k] = dict(gpu = (round(cos_g, 4), round(rel_g, 4)), cpu_bf16_storage = (round(cos_e, 4), round(rel_e, 4)))
+		assert rel_g <= 1.15 * rel_e + 1e-3 and cos_g >= cos_e - 0.03, (k, report[k])
+	print('bf16 whole-network deviation from the fp32 oracle (cosine, relative L2):', report)
+	_dump('r02_bf16_whole_network.json', report)
+	assert report['decoder.0.weight']['gpu'][1] <= 1e-2
 
 
-def test_bf16_fused_eval_greedy_strings_match_fp32_oracle_4x10s():
-	"""Inference path of SURVEY 8(f1) at full size: after a few train-mode forwards (non-degenerate running statistics) the
-	fused-eval bf16 model's greedy strings equal the fp32 oracle's eval strings on 4 x 10 s."""
+def _edit_distance(a, b):
+	prev = list(range(len(b) + 1))
+	for i, ca_ in enumerate(a, 1):
+		cur = [i]
+		for j, cb in enumerate(b, 1):
+			cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca_ != cb)))
+		prev = cur
+	return prev[-1]
+
+
+def test_fused_eval_greedy_strings_fp32_and_bf16_4x10s():
+	"""Inference path of SURVEY 8(f1) at full size (Wav2Letter full, 4 x 10 s): batch-norm statistics re-estimated
+	(reset_bn_running_stats_, models.py:726-733, then train-mode forwards: non-degenerate eval logits), fuse_conv_bn_eval, greedy
+	decode.  fp32: strings IDENTICAL to the fp32 oracle's eval strings.  bf16: a random-init network decides many frames by margins
+	smaller than what 8-bit storage moves the log-probs by, so the bar is (1) the argmax equals the fp32 oracle's on every frame
+	the oracle decides by more than twice the observed log-prob deviation, and (2) the character error rate of the bf16 strings
+	against the fp32 oracle's is no larger than that of the oracle's own bf16-storage restatement of the fused network (folded
+	weights rounded to bf16, bf16 activations, fp32 sums) plus one point."""
 	import convasr_amd as ca
 	from convasr_amd.transcript_generators import GreedyCTCGenerator, CharTokenizerLegacy
-	torch.manual_seed(2)
 	d = torch.device('cuda:0')
-	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
-	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0, check_time_dim_padded = False)
-	# a random-init network decodes to (near-)constant strings; a decoder bias spread makes the argmax frame-dependent
-	with torch.no_grad():
-		model.decoder[0].weight.mul_(8.0)
-	B, secs = 4, 10
-	x = torch.rand(B, 16000 * secs) * 2 - 1
+	model, sd0, x, xlen, y, ylen = _wav2letter_case(ca, seed = 2)
 	xlen = torch.tensor([1.0, 0.9, 0.6, 0.75])
-	model.to(d).train()
+	B = x.shape[0]
+	model.to(d)
+	ca.models.reset_bn_running_stats_(model)
 	with torch.no_grad():
-		for _ in range(3):
+		for _ in range(2):
 			model(x.to(d), xlen.to(d))
 	sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
+	torch.set_num_threads(min(os.cpu_count() or 1, 32))
+	fused = O.fuse_conv_bn_eval(sd)
 	with torch.no_grad():
-		ref = O.jasper_forward(sd, plan, x, xlen, frontend = FE, training = False)
-	want = O.greedy_decode(ref['log_probs'], ref['olen'])
+		ref32 = O.jasper_forward(fused, plan, x, xlen, frontend = FE, training = False)
+		ref16 = O.jasper_forward(fused, plan, x, xlen, frontend = FE, training = False, storage = torch.bfloat16)
+	want32, want16 = O.greedy_decode(ref32['log_probs'], ref32['olen']), O.greedy_decode(ref16['log_probs'], ref16['olen'])
+	assert len(set(want32)) > 1 and all(len(w) > 20 for w in want32), want32
+	cer = lambda hyp, ref: sum(_edit_distance(h, r) for h, r in zip(hyp, ref)) / sum(len(r) for r in ref)
 	model.eval()
 	model.fuse_conv_bn_eval()
 	tok, gen = CharTokenizerLegacy(O.CHAR_LEGACY_ALPHABET), GreedyCTCGenerator()
-	got = {}
 	for dt in (torch.float32, torch.bfloat16):
 		model.set_compute_dtype(dt)
 		with torch.no_grad():
 			out = model(x.to(d), xlen.to(d))
-		got[dt] = [t[0][0]['hyp'] if len(t[0]) else '' for t in gen.generate(tok, out['log_probs'][0], torch.zeros(B), torch.ones(B), output_lengths = out['olen'][0])]
-		# frames whose top-2 margin is inside the compute dtype's noise may flip; the decode is compared where the oracle is decisive
-		margin = ref['log_probs'].topk(2, dim = 1).values
-		decisive = float(((margin[:, 0] - margin[:, 1]) > (0.05 if dt == torch.bfloat16 else 1e-3)).float().mean())
-		agree = float((out['log_probs'][0].argmax(dim = 1).cpu() == ref['log_probs'].argmax(dim = 1)).float().mean())
-		print(dt, 'argmax agreement', agree, 'decisive frames', decisive)
-		assert agree >= decisive - 1e-3
-	assert got[torch.float32] == want
-	assert len(set(want)) > 1 and any(len(w) > 3 for w in want), want
-	assert got[torch.bfloat16] == want, (got[torch.bfloat16], want)
+		got = [t[0][0]['hyp'] if len(t[0]) else '' for t in gen.generate(tok, out['log_probs'][0], torch.zeros(B), torch.ones(B), output_lengths = out['olen'][0])]
+		assert torch.equal(out['olen'][0].cpu(), ref32['olen'])
+		lp32 = ref32['log_probs']
+		top2 = lp32.topk(2, dim = 1).values
+		dev = float((out['log_probs'][0].cpu() - lp32).abs().max())
+		decisive = (top2[:, 0] - top2[:, 1]) > 2 * dev
+		agree = out['log_probs'][0].argmax(dim = 1).cpu() == lp32.argmax(dim = 1)
+		print(dt, 'max |log_prob - fp32 oracle|', dev, 'decisive frames', float(decisive.float().mean()), 'argmax agreement', float(agree.float().mean()), 'CER vs fp32 oracle', cer(got, want32), '(CPU bf16-storage restatement:', cer(want16, want32), ')')
+		assert bool(agree[decisive].all())
+		if dt == torch.float32:
+			assert got == want32
+		else:
+			assert cer(got, want32) <= cer(want16, want32) + 0.01, (cer(got, want32), cer(want16, want32))
+			assert cer(got, want16) <= cer(want16, want32), (cer(got, want16), cer(want16, want32))  # the two bf16 pipelines are closer to each other than either is to fp32
 
 
 def test_jaspernet_large_config4_bucketed_mixed_lengths_novograd():
@@ -165,15 +284,18 @@ def test_jaspernet_large_dense_residual_gradients_vs_oracle_2x5s():
 	(out['loss'] * ylen.to(d)[:, 0]).mean().backward()
 	flat.finalize_grads()
 	scale = float(ref['logits'].abs().max())
-	err = float((out['logits'][0].cpu() - ref['logits']).abs().max())
+	err = float((out['logits'][0].detach().cpu() - ref['logits']).abs().max())
 	assert err <= 1e-3 * max(scale, 1.0), ('logits', err, scale)
-	loss_rel = float(((out['loss'].cpu() - ref['loss_vec']).abs() / ref['loss_vec'].abs()).max())
+	loss_rel = float(((out['loss'].detach().cpu() - ref['loss_vec']).abs() / ref['loss_vec'].abs()).max())
 	assert loss_rel <= 1e-4, loss_rel
 	params = dict(model.named_parameters())
 	names = ['backbone.10.conv_residual.0.weight', 'backbone.10.conv.4.0.weight', 'backbone.5.conv_residual.2.weight', 'backbone.0.conv.0.0.weight', 'backbone.1.bn.0.weight']
+	# 55 batch-normed conv layers deep, two fp32 implementations with different summation orders agree to 0.4-1.5 % in these gradients
+	# (logits to 1e-3 of their range): the random-init network amplifies rounding differences layer by layer.  Against the same
+	# oracle run in float64 the MI355X fp32 path is 0.26-1.9 % off and the fp32 CPU oracle 0.31-1.1 % (profiles/r02_fp64_reference.json)
 	for k in names:
 		cos, rel = _cos_rel(params[k].grad, ref['grads'][k])
-		assert cos >= 0.99999 and rel <= 2e-3, (k, cos, rel)
+		assert cos >= 0.9995 and rel <= 3e-2, (k, cos, rel)
 
 
 def _residual_model(ca, d):
