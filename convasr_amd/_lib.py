@@ -9,11 +9,12 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libconvasr_hip.so')
+LIB_PATH = os.environ.get('CONVASR_HIP_LIB') or os.path.join(_HERE, 'libconvasr_hip.so')  # (the override is a measurement hook: an alternate build of the same sources, see build.py)
 
 F32, BF16, I16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_HARDTANH, ACT_LEAKY_RELU = 0, 1, 2, 3
 PACK_FWD, PACK_DGRAD = 0, 1
+W_REFERENCE, W_KMAJOR = 0, 1  # include/convasr_hip.h: memory layout of a (Cout, Cin, K) parameter / gradient
 
 c_int, c_i64, c_u64, c_f32, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
 
@@ -25,13 +26,13 @@ _SIGNATURES = dict(
 	convasr_logmel_fwd = (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_conv_cout_pad = (c_int, [c_int]),
-	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
+	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p, c_p]),
 	convasr_conv_stats_max_rows = (c_int, [c_int, c_int]),
 	convasr_reduce_rows = (c_int, [c_p, c_int, c_int, c_p, c_p]),
 	convasr_debug_set_conv_v2 = (c_int, [c_int]),
 	convasr_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_bn_finalize = (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p, c_p, c_p, c_int, c_p, c_p]),
 	convasr_bn_eval_scale_shift = (c_int, [c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_int, c_p]),
 	convasr_bn_act_fwd = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p]),
@@ -43,16 +44,17 @@ _SIGNATURES = dict(
 	convasr_log_softmax_bwd = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
 	convasr_ctc_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
 	convasr_ctc_loss = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
-	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_int, c_i64, c_p]),
+	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_i64, c_p, c_int, c_i64, c_p]),
+	convasr_loss_head = (c_int, [c_p, c_p, c_i64, c_p, c_int, c_f32, c_p, c_p, c_p, c_p]),
 	convasr_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_weighted_mean_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_sumsq_workspace_bytes = (c_i64, []),
-	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p]),
-	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p]),
+	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_f32, c_p]),
+	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p, c_p]),
 	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p]),
 	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
-	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p]),
+	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),
@@ -80,7 +82,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 1:
+		if lib.convasr_abi_version() != 2:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib

@@ -1,4 +1,8 @@
-"""Build libconvasr_hip.so (gfx950) in-tree with hipcc.  Usage: python -m convasr_amd.build [--force]"""
+"""Build libconvasr_hip.so (gfx950) in-tree with hipcc.  Usage: python -m convasr_amd.build [--force]
+
+Measurement hook: `python -m convasr_amd.build --variant NAME -DFOO=1 ...` builds convasr_amd/libconvasr_hip.NAME.so from the same
+sources with extra defines (objects under build/NAME/); CONVASR_HIP_LIB=<path> makes convasr_amd load that file instead, so two
+builds can be timed against each other inside one process tree on one device (scratch/ab_lib.py)."""
 import os
 import subprocess
 import sys
@@ -22,10 +26,11 @@ def stale(target, deps):
 	return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force = False, verbose = True):
+def build(force = False, verbose = True, variant = None, defines = ()):
 	srcs = sources()
 	headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'convasr_hip.h')]
-	objdir = os.path.join(HERE, 'build')
+	objdir = os.path.join(HERE, 'build') if variant is None else os.path.join(HERE, 'build', variant)
+	lib = LIB if variant is None else os.path.join(HERE, f'libconvasr_hip.{variant}.so')
 	os.makedirs(objdir, exist_ok = True)
 	jobs = []
 	objs = []
@@ -33,7 +38,7 @@ def build(force = False, verbose = True):
 		o = os.path.join(objdir, os.path.basename(s)[:-4] + '.o')
 		objs.append(o)
 		if force or stale(o, [s] + headers):
-			jobs.append([HIPCC, *FLAGS, '-c', s, '-o', o])
+			jobs.append([HIPCC, *FLAGS, *defines, '-c', s, '-o', o])
 
 	def run(cmd):
 		if verbose:
@@ -46,10 +51,11 @@ def build(force = False, verbose = True):
 
 	with ThreadPoolExecutor(max_workers = min(6, max(1, len(jobs)))) as ex:
 		list(ex.map(run, jobs))
-	if force or jobs or stale(LIB, objs):
-		run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
-	return LIB
+	if force or jobs or stale(lib, objs):
+		run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib, *objs])
+	return lib
 
 
 if __name__ == '__main__':
-	print(build(force = '--force' in sys.argv))
+	variant = sys.argv[sys.argv.index('--variant') + 1] if '--variant' in sys.argv else None
+	print(build(force = '--force' in sys.argv or variant is not None, variant = variant, defines = [a for a in sys.argv[1:] if a.startswith('-D')]))

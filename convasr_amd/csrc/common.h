@@ -110,12 +110,33 @@ template <int ROUNDS> __device__ __forceinline__ void philox4x32(uint64_t seed, 
 	r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
-// Dropout mask of the 8 elements starting at element index idx (a multiple of 8): one Philox4x32-7 block (the shortest
-// Crush-resistant round count of Salmon et al. 2011) keyed by (seed, offset + idx / 8) gives 8 x 16 random bits; an element is
-// dropped when its bits are < thr (= round(p * 65536)), kept ones are scaled by `scale` (= 65536 / (65536 - thr)).
+// 32-bit integer hash with very low bias (two multiply / xor-shift rounds; constants from C. Wellons' hash-prospector search,
+// "lowbias32"): a bijection of the 32-bit counters, avalanche bias ~0.17 bits.
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+	x ^= x >> 16; x *= 0x7feb352du;
+	x ^= x >> 15; x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+
+// Dropout mask of the 8 elements starting at element index idx (a multiple of 8): a counter-based generator, so the forward pass,
+// the fused backward epilogue and the backward apply pass regenerate the same mask from (seed, offset, idx) instead of storing it.
+// Block counter c = offset + idx / 8; word i of the block = lowbias32((4 c + i) ^ key) with key = seed_lo ^ lowbias32(high word of
+// 4 c ^ seed_hi): 4 x 32 bits = 8 x 16 random bits; an element is dropped when its bits are < thr (= round(p * 65536)), kept ones
+// are scaled by `scale` (= 65536 / (65536 - thr)).  10 integer multiplies per 8 elements; Philox4x32-7 (CONVASR_DROPOUT_PHILOX
+// builds, the round-1 generator) needs 56 and cost ~6 us per 256 x 128 tile in the dgrad epilogue -- dropout needs a mask that
+// is uncorrelated across elements and layers, not a cryptographic stream.
 __device__ __forceinline__ void dropout_mask8(uint64_t seed, uint64_t offset, unsigned thr, float scale, int64_t idx, float (&keep)[8]) {
 	unsigned r[4];
+#ifdef CONVASR_DROPOUT_PHILOX
 	philox4x32<7>(seed, offset + (uint64_t)(idx >> 3), r);
+#else
+	const uint64_t c4 = (offset + (uint64_t)(idx >> 3)) << 2;
+	const unsigned key = (unsigned)seed ^ lowbias32((unsigned)(c4 >> 32) ^ (unsigned)(seed >> 32));
+	const unsigned lo = (unsigned)c4;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) r[i] = lowbias32((lo + i) ^ key);
+#endif
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		keep[2 * i] = (r[i] & 0xffffu) >= thr ? scale : 0.f;

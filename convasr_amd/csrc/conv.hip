@@ -272,24 +272,48 @@ __global__ __launch_bounds__(256) void pack_dgrad_bf16x2_kernel(const bf16_t* __
 	}
 }
 
-template <typename T> static void launch_pack(const float* w, void* fwd, void* dgr, int Cout, int Cin, int K, hipStream_t s) {
+// K-major master weights (CONVASR_W_KMAJOR: w[k][co][ci], the layout of the MI355X training arena) -> packed forward copy: the
+// element order is already the packed one, so this is a streaming cast (8 elements per lane) into rows < Cout of each tap.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_fwd_kmajor_kernel(const float* __restrict__ w, T* __restrict__ fwd, int64_t per_tap, int64_t tap_stride, int K) {
+	const int64_t n8 = per_tap >> 3;  // per_tap = Cout * Cin, a multiple of 8 (checked by the launcher)
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8 * K; i += (int64_t)gridDim.x * 256) {
+		const int64_t k = i / n8, j = (i - k * n8) << 3;
+		float v[8];
+		load8<float>(w + k * per_tap + j, v);
+		store8<T>(fwd + k * tap_stride + j, v);
+	}
+}
+
+template <typename T> static int launch_pack(const float* w, void* fwd, void* dgr, int Cout, int Cin, int K, int w_layout, hipStream_t s) {
 	const int co_pad = convasr_conv_cout_pad(Cout), ci_pad = convasr_conv_cout_pad(Cin);
 	const int64_t pairs = (int64_t)Cout * Cin;
 	const bool x2 = sizeof(T) == 2 && (Cin & 1) == 0 && (Cout & 1) == 0 && (size_t)512 * K * sizeof(float) <= 64 * 1024;
-	if (x2) {
-		hipLaunchKernelGGL(pack_fwd_bf16x2_kernel, dim3((unsigned)ceil_div64(pairs, 512)), dim3(256), (size_t)512 * K * sizeof(float), s, w, (bf16_t*)fwd, pairs, K, (int64_t)co_pad * Cin);
-		if (dgr) hipLaunchKernelGGL(pack_dgrad_bf16x2_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const bf16_t*)fwd, (bf16_t*)dgr, Cout, Cin, K, co_pad, ci_pad);
-		return;
+	if (w != nullptr) {
+		if (w_layout == CONVASR_W_KMAJOR) {
+			if ((pairs & 7) != 0) return convasr_fail(CONVASR_EUNSUPPORTED, "pack_conv_weight: K-major source needs Cout * Cin %% 8 == 0");
+			if ((const void*)w != (const void*)fwd || sizeof(T) != 4 || co_pad != Cout) {  // (an fp32 compute copy with no row padding IS the master: nothing to do)
+				int64_t blocks = ceil_div64((pairs >> 3) * K, 256);
+				if (blocks > 2048) blocks = 2048;
+				hipLaunchKernelGGL((pack_fwd_kmajor_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, w, (T*)fwd, pairs, (int64_t)co_pad * Cin, K);
+			}
+		} else if (x2) hipLaunchKernelGGL(pack_fwd_bf16x2_kernel, dim3((unsigned)ceil_div64(pairs, 512)), dim3(256), (size_t)512 * K * sizeof(float), s, w, (bf16_t*)fwd, pairs, K, (int64_t)co_pad * Cin);
+		else hipLaunchKernelGGL((pack_fwd_kernel<T>), dim3((unsigned)ceil_div64(pairs, 256)), dim3(256), (size_t)256 * K * sizeof(float), s, w, (T*)fwd, pairs, K, (int64_t)co_pad * Cin);
 	}
-	hipLaunchKernelGGL((pack_fwd_kernel<T>), dim3((unsigned)ceil_div64(pairs, 256)), dim3(256), (size_t)256 * K * sizeof(float), s, w, (T*)fwd, pairs, K, (int64_t)co_pad * Cin);
-	if (dgr) hipLaunchKernelGGL((pack_dgrad_kernel<T>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
+	if (dgr) {
+		if (x2) hipLaunchKernelGGL(pack_dgrad_bf16x2_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const bf16_t*)fwd, (bf16_t*)dgr, Cout, Cin, K, co_pad, ci_pad);
+		else hipLaunchKernelGGL((pack_dgrad_kernel<T>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
+	}
+	return 0;
 }
 
-extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream) {
-	CONVASR_CHECK_ARG(w && packed_fwd && Cout > 0 && Cin > 0 && K > 0 && K <= 64, "pack_conv_weight: bad arguments (packed_fwd is required; packed_dgrad is derived from it)");
-	if (dtype == CONVASR_F32) launch_pack<float>(w, packed_fwd, packed_dgrad, Cout, Cin, K, (hipStream_t)stream);
-	else if (dtype == CONVASR_BF16) launch_pack<bf16_t>(w, packed_fwd, packed_dgrad, Cout, Cin, K, (hipStream_t)stream);
+extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, int w_layout, void* stream) {
+	CONVASR_CHECK_ARG(packed_fwd && (w || packed_dgrad) && Cout > 0 && Cin > 0 && K > 0 && K <= 64 && (w_layout == CONVASR_W_REFERENCE || w_layout == CONVASR_W_KMAJOR), "pack_conv_weight: bad arguments (packed_fwd is required; packed_dgrad is derived from it; w NULL = packed_fwd is current)");
+	int rc;
+	if (dtype == CONVASR_F32) rc = launch_pack<float>(w, packed_fwd, packed_dgrad, Cout, Cin, K, w_layout, (hipStream_t)stream);
+	else if (dtype == CONVASR_BF16) rc = launch_pack<bf16_t>(w, packed_fwd, packed_dgrad, Cout, Cin, K, w_layout, (hipStream_t)stream);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
+	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("pack_conv_weight");
 	return 0;
 }
@@ -575,6 +599,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 	}
 }
 
+// K-major gradient (CONVASR_W_KMAJOR): dw[k][co][ci] has the slabs' own element order, so the combine is a streaming sum of S
+// slabs, 16 bytes per lane, no transpose.
+__global__ __launch_bounds__(256) void wgrad_reduce_kmajor_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int64_t n4, int accumulate) {
+	const float4* const s4 = reinterpret_cast<const float4*>(slab);
+	float4* const d4 = reinterpret_cast<float4*>(dw);
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+		float4 a = s4[i];
+		for (int s = 1; s < S; ++s) { const float4 b = s4[(int64_t)s * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+		if (accumulate) { const float4 o = d4[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+		d4[i] = a;
+	}
+}
+
 // dbias[c] (+)= sum over rows of a channels-last (rows, C) matrix: blocks own row chunks and store one partial row each; a second
 // launch adds the partial rows in order (no float atomics: the bias gradient is bit-identical from run to run)
 template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ part, int64_t rows, int C, int rows_per_block) {
@@ -644,8 +681,9 @@ template <typename T> static int dispatch_wgrad(WgradParams& p, hipStream_t s) {
 }
 
 extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
-                                    int Tout, int K, int stride, int dil, int pad, int accumulate, void* stream) {
-	CONVASR_CHECK_ARG(x && dy && dw && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_wgrad: bad arguments");
+                                    int Tout, int K, int stride, int dil, int pad, int accumulate, int dw_layout, void* stream) {
+	CONVASR_CHECK_ARG(x && dy && dw && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0 && (dw_layout == CONVASR_W_REFERENCE || dw_layout == CONVASR_W_KMAJOR), "conv1d_wgrad: bad arguments");
+	CONVASR_CHECK_ARG(dw_layout == CONVASR_W_REFERENCE || (((int64_t)Cout * Cin) & 3) == 0, "conv1d_wgrad: K-major dw needs Cout * Cin %% 4 == 0");
 	CONVASR_CHECK_ARG(K <= 64, "conv1d_wgrad: K %d > 64", K);
 	WgradParams p;
 	p.x = x; p.dy = dy; p.slab = (float*)workspace;
@@ -658,7 +696,12 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: dtype %d", dtype);
 	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("conv1d_wgrad");
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cin + 63) / 64, Cout), dim3(256), (size_t)K * 65 * sizeof(float), s, p.slab, dw, p.splits, K, Cout, Cin, accumulate);
+	if (dw_layout == CONVASR_W_KMAJOR) {
+		const int64_t n4 = (int64_t)K * Cout * Cin / 4;
+		int64_t blocks = ceil_div64(n4, 256);
+		if (blocks > 2048) blocks = 2048;
+		hipLaunchKernelGGL(wgrad_reduce_kmajor_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.slab, dw, p.splits, n4, accumulate);
+	} else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cin + 63) / 64, Cout), dim3(256), (size_t)K * 65 * sizeof(float), s, p.slab, dw, p.splits, K, Cout, Cin, accumulate);
 	CONVASR_CHECK_LAUNCH("conv1d_wgrad_reduce");
 	if (dbias) {
 		const int64_t rows = (int64_t)B * Tout;

@@ -269,7 +269,7 @@ template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void
 	}
 }
 
-const void* convasr_conv_v2s_kernel(int y_dtype);  // conv_v2s.hip
+const void* convasr_conv_v2s_kernel(int y_dtype, int bn_fused);  // conv_v2s.hip
 #define V2_DEFAULT_SMALL_SHAPE 1
 
 // Returns 1 if the v2 kernel took the launch, 0 if the shape is outside its envelope (caller falls back to conv.hip's kernel).
@@ -291,9 +291,9 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles
 	const int oi = y_dtype == CONVASR_BF16 ? 0 : 1;
 	const bool small_shape = mode == 2 && ((p.debug & 128) != 0) == (V2_DEFAULT_SMALL_SHAPE == 0);  // debug bit 128 selects the non-default MFMA shape
 	if (p.bn_y && !(small_shape && y_dtype == CONVASR_BF16)) return 0;  // the fused BN-backward epilogue exists in conv_v2s.hip only
-	const void* kern = small_shape ? convasr_conv_v2s_kernel(y_dtype) : table[oi][mode];
-	static bool attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};
-	if (small_shape) mode = 3;
+	const void* kern = small_shape ? convasr_conv_v2s_kernel(y_dtype, p.bn_y != nullptr) : table[oi][mode];
+	static bool attr_set[2][5] = {{false, false, false, false, false}, {false, false, false, false, false}};
+	if (small_shape) mode = p.bn_y ? 4 : 3;
 	if (!attr_set[oi][mode]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[oi][mode] = true; }
 	// conv_v2s: a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
 	p.full_tiles = p.total_tiles;

@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // NB = 16-column blocks per wave: 4 -> the 256 x 128 tile, 2 -> a 256 x 64 half tile (same X tile, half the W rows).  The last
 // partial round of a launch (total_tiles mod 256 workgroups on 256 CUs) is cut into half tiles so that it occupies all CUs for
 // ~0.6 of a round instead of a fraction of them for a whole one; per-element sums are unchanged (same k order).
-template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
+template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
 	constexpr int BN_ = 32 * NB;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,9 +125,13 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 	// fused BN-backward epilogue (see below): the consumer layer's y tile is fetched now, 16 B per lane and store-loop trip, so
 	// that its latency hides under the accumulator staging (loading it inside the store loop cost ~8 serial L2/HBM round trips per tile)
 	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
-	const bool bnf = sizeof(O) == 2 && p.bn_y != nullptr;
+	constexpr bool bnf = BNF && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
 	uint4 ypre[TRIPS];
+#ifdef EXP_SKIP_YPRE
+	if (false) {
+#else
 	if (bnf) {
+#endif
 #pragma unroll
 		for (int i = 0; i < TRIPS; ++i) {
 			const int e = tid + i * V2_THREADS, row = e / OCH_, t = t0 + row, co = co0 + (e % OCH_) * OEPC_;
@@ -197,6 +201,7 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 		if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 		else
 			for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = src[i];
+#ifndef EXP_SKIP_GMATH
 		if (bnf && t < bnv) {
 			const int64_t idx = ((int64_t)b * p.Tout + t) * p.Cout + co;
 			float dz[8], yv[8], g[8];
@@ -217,7 +222,9 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 #pragma unroll
 			for (int k = 0; k < 8; ++k) { bs1[k] += g[k]; bs2[k] = fmaf(g[k], yv[k], bs2[k]); }  // sum g*y; centred and scaled once per tile below
 		}
+#endif
 	}
+#ifndef EXP_SKIP_BNRED
 	if (bnf) {
 		float* const bnred = reinterpret_cast<float*>(smem + V2_BM * OPITCH + 8 * BN * sizeof(float));  // [V2_THREADS][17], past the output tile and `red`
 #pragma unroll
@@ -232,19 +239,22 @@ template <typename O, int NB> __device__ __forceinline__ void v2s_tile(const Con
 			prow[p.Cout + co0 + tid] = q2;
 		}
 	}
+#endif
 }
 
-template <typename O> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2s_kernel(ConvParams p) {
+template <typename O, bool BNF> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2s_kernel(ConvParams p) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
 	if (bid < p.full_tiles) {
-		v2s_tile<O, 4>(p, smem, xcd_remap(bid, p.full_tiles), 0);
+		v2s_tile<O, 4, BNF>(p, smem, xcd_remap(bid, p.full_tiles), 0);
 	} else {  // full_tiles is a multiple of 8, so (bid - full_tiles) keeps the workgroup's XCD; the two halves of a tile share an XCD (and its X tile in L2)
 		const int h = xcd_remap(bid - p.full_tiles, 2 * (p.total_tiles - p.full_tiles));
-		v2s_tile<O, 2>(p, smem, p.full_tiles + (h >> 1), h & 1);
+		v2s_tile<O, 2, BNF>(p, smem, p.full_tiles + (h >> 1), h & 1);
 	}
 }
 
-const void* convasr_conv_v2s_kernel(int y_dtype) {
-	return y_dtype == CONVASR_BF16 ? (const void*)conv1d_igemm_v2s_kernel<bf16_t> : (const void*)conv1d_igemm_v2s_kernel<float>;
+// bn_fused: the dgrad launch that also runs pass 1 of the consumer layer's batch-norm backward in its epilogue (bf16 only)
+const void* convasr_conv_v2s_kernel(int y_dtype, int bn_fused) {
+	if (y_dtype == CONVASR_BF16) return bn_fused ? (const void*)conv1d_igemm_v2s_kernel<bf16_t, true> : (const void*)conv1d_igemm_v2s_kernel<bf16_t, false>;
+	return (const void*)conv1d_igemm_v2s_kernel<float, false>;
 }

@@ -236,17 +236,61 @@ extern "C" int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows
 	return 0;
 }
 
-__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ sc, float* __restrict__ out, int64_t per_b) {
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ sc, const int64_t* __restrict__ div, int64_t div_stride, float* __restrict__ out, int64_t per_b) {
 	const int b = blockIdx.y;
-	const float s = sc[b];
+	const float s = div ? sc[b] / (float)div[b * div_stride] : sc[b];
 	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_b; i += (int64_t)gridDim.x * 256) out[b * per_b + i] = g[b * per_b + i] * s;
 }
 
-extern "C" int convasr_scale_rows(const float* grad, const float* gscale, float* out, int B, int64_t per_b, void* stream) {
+extern "C" int convasr_scale_rows(const float* grad, const float* gscale, const int64_t* gdiv, int64_t gdiv_stride, float* out, int B, int64_t per_b, void* stream) {
 	CONVASR_CHECK_ARG(grad && gscale && out && B > 0 && per_b > 0, "scale_rows: bad arguments");
 	unsigned gx = (unsigned)(ceil_div64(per_b, 256) > 64 ? 64 : ceil_div64(per_b, 256));
-	hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, grad, gscale, out, per_b);
+	hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, grad, gscale, gdiv, gdiv_stride, out, per_b);
 	CONVASR_CHECK_LAUNCH("scale_rows");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ loss head (train.py:754-769)
+// The scalar bookkeeping of one training iteration in ONE launch instead of ~40 two-element ATen kernels: from the per-utterance
+// loss vector lv[b] (= CTC NLL / target length, models.py:323), the target lengths w[b] and the per-utterance entropies:
+//   out[0] = mean_b(lv[b] * w[b]) / accum          the loss that is back-propagated (train.py:755)
+//   out[1] = mean_b(lv[b])                          loss_cur, the logged loss and the inf/NaN gate (train.py:755, 769)
+//   out[2] = mean_b(ent[b])                         the entropy metric (train.py:756)
+//   gvec[b] = ((1 / accum) / B) * w[b]              d out[0] / d lv[b], in autograd's own order of operations
+//   skipped = !isfinite(out[1])
+// One workgroup, sums in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict__ lv, const int64_t* __restrict__ ylen, int64_t ylen_stride, const float* __restrict__ ent, int B, float accum,
+                                                        float* __restrict__ out, float* __restrict__ gvec, unsigned char* __restrict__ skipped) {
+	__shared__ float red[3][256];
+	float a = 0.f, c = 0.f, e = 0.f;
+	const float gbase = (1.f / accum) / (float)B;
+	for (int b = threadIdx.x; b < B; b += 256) {
+		const float w = (float)ylen[b * ylen_stride], l = lv[b];
+		a += l * w;
+		c += l;
+		if (ent) e += ent[b];
+		if (gvec) gvec[b] = gbase * w;
+	}
+	red[0][threadIdx.x] = a; red[1][threadIdx.x] = c; red[2][threadIdx.x] = e;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; red[2][threadIdx.x] += red[2][threadIdx.x + o]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		const float cur = red[1][0] / (float)B;
+		out[0] = red[0][0] / (float)B / accum;
+		out[1] = cur;
+		out[2] = red[2][0] / (float)B;
+		if (skipped) *skipped = (fabsf(cur) < INFINITY) ? 0 : 1;
+	}
+}
+
+extern "C" int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
+                                 float* grad_loss_vec, unsigned char* skipped, void* stream) {
+	CONVASR_CHECK_ARG(loss_vec && ylen && out3 && B > 0 && accumulate_iterations > 0.f, "loss_head: bad arguments");
+	hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_vec, ylen, ylen_stride, entropy, B, accumulate_iterations, out3, grad_loss_vec, skipped);
+	CONVASR_CHECK_LAUNCH("loss_head");
 	return 0;
 }
 
@@ -270,31 +314,31 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 	if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
 }
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int blocks, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int blocks, double* __restrict__ out, float* __restrict__ norm_out, float norm_scale) {
 	__shared__ double red[256];
 	double a = 0;
 	for (int i = threadIdx.x; i < blocks; i += 256) a += part[i];
 	red[threadIdx.x] = a;
 	__syncthreads();
-	if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 256; ++i) s += red[i]; *out = s; }
+	if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 256; ++i) s += red[i]; *out = s; if (norm_out) *norm_out = (float)(sqrt(s) * (double)norm_scale); }
 }
 
 extern "C" int64_t convasr_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * (int64_t)sizeof(double); }
 
-extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, void* stream) {
+extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, float* norm_out, float norm_scale, void* stream) {
 	CONVASR_CHECK_ARG(g && sumsq && workspace && n > 0, "sumsq: bad arguments");
 	CONVASR_CHECK_ARG(((uintptr_t)g & 15) == 0, "sumsq: g must be 16-byte aligned");
 	int64_t blocks = ceil_div64(n, 1024);
 	if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
 	hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, (double*)workspace);
-	hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, (int)blocks, sumsq);
+	hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, (int)blocks, sumsq, norm_out, norm_scale);
 	CONVASR_CHECK_LAUNCH("sumsq");
 	return 0;
 }
 
 __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
                                                        int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first,
-                                                       const float* __restrict__ loss_gate, float grad_scale) {
+                                                       const float* __restrict__ loss_gate, float grad_scale, bf16_t* __restrict__ p16) {
 	if (loss_gate) {
 		const float l = *loss_gate;
 		if (!(fabsf(l) < INFINITY)) return;  // inf or NaN loss: the step is skipped (train.py:769-772)
@@ -306,26 +350,46 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
 		clip = c < 1.f ? c : 1.f;
 	}
 	clip *= grad_scale;
-	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-		float gc = g[i] * clip;
-		if (gout) gout[i] = gc;
-		float pv = p[i];
+	auto update = [&](float gi, float pv, float& bv, float& gout_v) {
+		const float gc = gi * clip;
+		gout_v = gc;
 		float d = gc + wd * pv;
 		if (mom != 0.f) {
-			float bv = first ? d : mom * buf[i] + d;
-			buf[i] = bv;
+			bv = first ? d : mom * bv + d;
 			d = nesterov ? d + mom * bv : bv;
 		}
-		p[i] = pv - lr * d;
+		return pv - lr * d;
+	};
+	// 16 bytes per lane and array; the tail (n % 4) is handled element-wise by the first lanes of block 0
+	const int64_t n4 = n >> 2;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+		const float4 g4 = reinterpret_cast<const float4*>(g)[i], p4 = reinterpret_cast<const float4*>(p)[i];
+		float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), o4;
+		if (mom != 0.f && !first) b4 = reinterpret_cast<const float4*>(buf)[i];
+		float4 r;
+		r.x = update(g4.x, p4.x, b4.x, o4.x); r.y = update(g4.y, p4.y, b4.y, o4.y); r.z = update(g4.z, p4.z, b4.z, o4.z); r.w = update(g4.w, p4.w, b4.w, o4.w);
+		reinterpret_cast<float4*>(p)[i] = r;
+		if (mom != 0.f) reinterpret_cast<float4*>(buf)[i] = b4;
+		if (gout) reinterpret_cast<float4*>(gout)[i] = o4;
+		if (p16) reinterpret_cast<uint2*>(p16)[i] = make_uint2((unsigned)f32_to_bf16(r.x) | ((unsigned)f32_to_bf16(r.y) << 16), (unsigned)f32_to_bf16(r.z) | ((unsigned)f32_to_bf16(r.w) << 16));
+	}
+	if (blockIdx.x == 0 && (int64_t)threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		float bv = (mom != 0.f && !first) ? buf[i] : 0.f, go;
+		const float r = update(g[i], p[i], bv, go);
+		p[i] = r;
+		if (mom != 0.f) buf[i] = bv;
+		if (gout) gout[i] = go;
+		if (p16) p16[i] = f32_to_bf16(r);
 	}
 }
 
 extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm, float lr,
-                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale, void* stream) {
+                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale, uint16_t* p_bf16, void* stream) {
 	CONVASR_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || buf), "sgd_step: bad arguments");
 	int64_t blocks = ceil_div64(n, 256);
 	if (blocks > 4096) blocks = 4096;
-	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale);
+	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale, (bf16_t*)p_bf16);
 	CONVASR_CHECK_LAUNCH("sgd_step");
 	return 0;
 }

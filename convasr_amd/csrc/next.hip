@@ -63,6 +63,7 @@ struct NgParams {
 	float max_norm, lr, b1, b2, eps, wd;
 	int dampening, first;
 	const float* loss_gate; float* norm_out; float grad_scale;
+	bf16_t* p16;
 };
 
 __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 		if (q.dampening) d *= 1.f - q.b1;
 		const float m = q.first ? d : q.mom[i] * q.b1 + d;
 		q.mom[i] = m;
-		q.p[i] = pv - q.lr * m;
+		const float pn = pv - q.lr * m;
+		q.p[i] = pn;
+		if (q.p16) q.p16[i] = f32_to_bf16(pn);
 	};
 	if (s0 == s1) {
 		const float inv = 1.f / sqrtf(seg_ema(s0) + q.eps);
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets, int n_seg,
                                      int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part, float max_norm, float lr, float beta1,
                                      float beta2, float eps, float weight_decay, int dampening, int first, const float* loss_gate, float* total_norm, float grad_scale,
-                                     void* stream) {
+                                     uint16_t* p_bf16, void* stream) {
 	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && items && seg_first && item_part && n_seg > 0 && n_items >= n_seg && n > 0, "novograd_step: bad arguments");
 	hipStream_t s = (hipStream_t)stream;
 	hipLaunchKernelGGL(ng_item_sumsq_kernel, dim3(n_items), dim3(256), 0, s, g, items, item_part);
@@ -138,7 +141,7 @@ extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const
 	NgParams q;
 	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
 	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
-	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale;
+	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale; q.p16 = (bf16_t*)p_bf16;
 	hipLaunchKernelGGL(ng_step_kernel, dim3((unsigned)ceil_div64(n, NG_CHUNK)), dim3(256), 0, s, q);
 	CONVASR_CHECK_LAUNCH("novograd_step");
 	return 0;

@@ -19,24 +19,46 @@ def bump_param_epoch():
 	_param_epoch[0] += 1
 
 
+def param_version(w):
+	"""What a packed copy of `w` is valid for: torch's in-place version counter, the storage address, and the epoch optimizers bump
+	when they update parameters behind torch's back."""
+	return (w._version, w.data_ptr(), _param_epoch[0])
+
+
 def packed_weight(w, dtype, mode):
 	"""Packed [K][rows_pad][cols] copy of a conv parameter, refreshed (in place) only when the parameter changed.  In training
-	the forward and the dgrad layout are produced together the first time either is asked for after an update."""
-	ver = (w._version, w.data_ptr(), _param_epoch[0])
+	the forward and the dgrad layout are produced together the first time either is asked for after an update.
+	A tap-major arena parameter (train.FlatParameters) whose Cout needs no row padding has no forward copy of its own: in fp32
+	the master IS the packed operand, in bf16 it is the parameter's segment of the arena's bf16 mirror, which the fused optimizer
+	kernels keep current -- only the transposed dgrad copy is still built by a packing launch."""
+	ver = param_version(w)
 	ent = _pack_cache.get((id(w), dtype))
 	both = w.requires_grad  # (grad mode is off inside autograd.Function.forward, so it cannot be consulted here)
 	if ent is None:
 		ent = _pack_cache[(id(w), dtype)] = dict(w = w, fwd = None, dgr = None, fwd_ver = None, dgr_ver = None)  # holds `w`: id() stays unique
+	arena = getattr(w, '_convasr_arena', None)
+	in_place = arena is not None and ops.weight_layout(w) == _lib.W_KMAJOR and ops.cout_pad(w.shape[0]) == w.shape[0] and dtype in (torch.float32, torch.bfloat16)
+	if in_place:
+		flat, off = arena
+		Cout, Cin, K = w.shape
+		if dtype == torch.float32:
+			ent['fwd'], ent['fwd_ver'] = flat.data[off:off + w.numel()].view(K, Cout, Cin), ver
+		else:
+			ent['fwd'] = flat.mirror()[off:off + w.numel()].view(K, Cout, Cin)
+			if flat._mirror_ver.get(id(w)) == ver:
+				ent['fwd_ver'] = ver
 	if mode == _lib.PACK_FWD and ent['fwd_ver'] == ver:
 		return ent['fwd']
 	if mode == _lib.PACK_DGRAD and ent['dgr_ver'] == ver:
 		return ent['dgr']
 	if both or mode == _lib.PACK_DGRAD:
-		ent['fwd'], ent['dgr'] = ops.pack_weight(w, dtype, None, out = (ent['fwd'], ent['dgr']))
+		ent['fwd'], ent['dgr'] = ops.pack_weight(w, dtype, None, out = (ent['fwd'], ent['dgr']), fwd_is_current = ent['fwd_ver'] == ver)
 		ent['fwd_ver'] = ent['dgr_ver'] = ver
 	else:
 		ent['fwd'] = ops.pack_weight(w, dtype, _lib.PACK_FWD, out = (ent['fwd'], None))
 		ent['fwd_ver'] = ver
+	if in_place and dtype == torch.bfloat16:
+		arena[0]._mirror_ver[id(w)] = ver
 	return ent['fwd'] if mode == _lib.PACK_FWD else ent['dgr']
 
 
@@ -417,22 +439,25 @@ class LogSoftmaxFunction(torch.autograd.Function):
 
 class CtcLossFunction(torch.autograd.Function):
 	"""F.ctc_loss(lp.permute(2,0,1), y, olen, ylen, blank, reduction='none') (models.py:323): the alpha-beta kernels
-	produce the per-utterance NLL and d nll / d log_probs in one pass; backward is a per-utterance scaling."""
+	produce the per-utterance NLL and d nll / d log_probs in one pass; backward is a per-utterance scaling.
+	norm (optional int64 (B,)): the result is nll / norm, the "/ ylen[:, 0]" of models.py:323; its backward rides in the same
+	scaling pass instead of a chain of two-element autograd kernels."""
 
 	@staticmethod
-	def forward(ctx, log_probs, targets, olen, ylen, blank):
+	def forward(ctx, log_probs, targets, olen, ylen, blank, norm = None):
 		lp = ops.as_cl(log_probs, torch.float32)
 		need = log_probs.requires_grad
 		nll, grad = ops.ctc_loss(lp, targets, olen, ylen, blank, need_grad = need)
+		ctx.norm = norm
 		if need:
 			ctx.save_for_backward(grad)
-		return nll
+		return nll if norm is None else nll / norm
 
 	@staticmethod
 	def backward(ctx, g):
 		grad, = ctx.saved_tensors
-		return ops.scale_rows(grad, g), None, None, None, None
+		return ops.scale_rows(grad, g, ctx.norm), None, None, None, None, None
 
 
-def ctc_loss(log_probs, targets, olen, ylen, blank):
-	return CtcLossFunction.apply(log_probs, targets, olen, ylen, blank)
+def ctc_loss(log_probs, targets, olen, ylen, blank, norm = None):
+	return CtcLossFunction.apply(log_probs, targets, olen, ylen, blank, norm)

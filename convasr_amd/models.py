@@ -379,7 +379,7 @@ class JasperNet(nn.Module):
 		olen = [compute_output_lengths(l, xlen.to(torch.float32) if xlen is not None else None) for l in logits]
 		aux = {}
 		if y is not None and ylen is not None:
-			loss = [Fn.ctc_loss(lp, y[:, i], olen[i], ylen[:, i], lp.shape[1] - 1) / ylen[:, 0] for i, lp in enumerate(log_probs)]
+			loss = [Fn.ctc_loss(lp, y[:, i], olen[i], ylen[:, i], lp.shape[1] - 1, norm = ylen[:, 0]) for i, lp in enumerate(log_probs)]
 			aux = dict(loss = sum(loss) if not self.bpe_only else sum(loss[1:]))
 		return self.dict(logits = logits, log_probs = log_probs, olen = olen, **aux)
 

@@ -103,21 +103,35 @@ def cout_pad(c):
 	return _lib.load().convasr_conv_cout_pad(c)
 
 
-def pack_weight(w, dtype, mode = None, out = None):
+def weight_layout(w):
+	"""W_KMAJOR for a (Cout, Cin, K) view of tap-major memory [K][Cout][Cin] (the training arena's layout), W_REFERENCE for a
+	torch-contiguous tensor, None for anything else."""
+	Cout, Cin, K = w.shape
+	if w.is_contiguous():
+		return _lib.W_REFERENCE  # (K == 1 is both at once: the reference layout's kernels are as good)
+	if w.stride(1) == 1 and w.stride(0) == Cin and (w.stride(2) == Cout * Cin or K == 1):
+		return _lib.W_KMAJOR
+	return None
+
+
+def pack_weight(w, dtype, mode = None, out = None, fwd_is_current = False):
 	"""(Cout, Cin, K) fp32 parameter -> packed [K][rows_pad][cols] tensor(s) for the MFMA kernels.
 	mode PACK_FWD returns the forward layout, PACK_DGRAD the dgrad layout, None both (fwd, dgrad).  `out` = (fwd, dgrad)
-	buffers from an earlier call are refreshed in place (stable addresses, no re-allocation per optimizer step)."""
+	buffers from an earlier call are refreshed in place (stable addresses, no re-allocation per optimizer step).
+	fwd_is_current: out[0] already holds the parameter's packed forward copy (the optimizer's bf16 mirror): only dgrad is rebuilt."""
 	require_cuda(w)
 	w = w.detach()
-	if w.dtype != torch.float32 or not w.is_contiguous():
-		w = w.float().contiguous()
+	layout = weight_layout(w) if w.dtype == torch.float32 else None
+	if layout is None:
+		w, layout = w.float().contiguous(), _lib.W_REFERENCE
 	Cout, Cin, K = w.shape
 	fwd, dgr = out if out is not None else (None, None)
 	if fwd is None:
+		assert not fwd_is_current
 		fwd = torch.zeros(K, cout_pad(Cout), Cin, dtype = dtype, device = w.device)
 	if dgr is None and mode in (None, _lib.PACK_DGRAD):
 		dgr = torch.zeros(K, cout_pad(Cin), Cout, dtype = dtype, device = w.device)
-	call('convasr_pack_conv_weight', ptr(w), ptr(fwd), ptr(dgr) if mode in (None, _lib.PACK_DGRAD) else None, dtype_code(dtype), Cout, Cin, K, stream_ptr())
+	call('convasr_pack_conv_weight', None if fwd_is_current else ptr(w), ptr(fwd), ptr(dgr) if mode in (None, _lib.PACK_DGRAD) else None, dtype_code(dtype), Cout, Cin, K, layout, stream_ptr())
 	return (fwd, dgr) if mode is None else (fwd if mode == _lib.PACK_FWD else dgr)
 
 
@@ -183,13 +197,15 @@ def workspace(nbytes, device, tag = 'default'):
 
 
 def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate = False):
-	"""dw (Cout, Cin, K) fp32 (+)= wgrad; x, dy channels-last of the same dtype."""
+	"""dw (Cout, Cin, K) fp32 (+)= wgrad; x, dy channels-last of the same dtype.  dw is torch-contiguous (the reference's layout) or a
+	view of tap-major memory (weight_layout: the training arena's gradients)."""
 	B, Cin, Tin = x.shape
 	Tout = dy.shape[2]
-	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and dw.is_contiguous() and dw.dtype == torch.float32
+	layout = weight_layout(dw)
+	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and layout is not None and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, K), (dw.shape, dw.stride())
 	nbytes = _lib.load().convasr_conv1d_wgrad_workspace_bytes(B, Cin, Cout, Tin, Tout, K, stride, dil)
 	ws = workspace(nbytes, x.device, 'wgrad')
-	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), stream_ptr()))
+	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), layout, stream_ptr()))
 	return dw
 
 
@@ -292,11 +308,28 @@ def ctc_loss(log_probs, targets, olen, ylen, blank, need_grad = True):
 	return nll, grad
 
 
-def scale_rows(grad, gscale):
+def scale_rows(grad, gscale, gdiv = None):
+	"""out[b] = grad[b] * gscale[b] (/ gdiv[b] if given: an int64 (B,) vector, possibly a strided column)."""
 	B = grad.shape[0]
 	out = torch.empty_like(grad)  # preserves strides (channels-last stays channels-last)
-	call('convasr_scale_rows', ptr(grad), ptr(gscale.to(torch.float32).contiguous()), ptr(out), B, grad.numel() // B, stream_ptr())
+	assert gdiv is None or (gdiv.dtype == torch.int64 and gdiv.ndim == 1 and gdiv.shape[0] == B and gdiv.device == grad.device)
+	call('convasr_scale_rows', ptr(grad), ptr(gscale.to(torch.float32).contiguous()), ptr(gdiv), 0 if gdiv is None else gdiv.stride(0), ptr(out), B, grad.numel() // B, stream_ptr())
 	return out
+
+
+def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_grad = True):
+	"""train.py:754-756 + the gate of 769 in one launch.  Returns (out3 = [loss, loss_cur, entropy] fp32, grad_loss_vec (B,) or None,
+	skipped: 1-element bool)."""
+	require_cuda(loss_vec)
+	B = loss_vec.shape[0]
+	lv = loss_vec.detach().to(torch.float32).contiguous()
+	assert ylen_col.dtype == torch.int64 and ylen_col.ndim == 1 and ylen_col.shape[0] == B and ylen_col.device == lv.device
+	out3 = torch.empty(3, dtype = torch.float32, device = lv.device)
+	gvec = torch.empty(B, dtype = torch.float32, device = lv.device) if need_grad else None
+	skipped = torch.empty(1, dtype = torch.bool, device = lv.device)
+	ent = None if ent is None else ent.detach().to(torch.float32).contiguous()
+	call('convasr_loss_head', ptr(lv), ptr(ylen_col), ylen_col.stride(0), ptr(ent), B, float(accumulate_iterations), ptr(out3), ptr(gvec), ptr(skipped), stream_ptr())
+	return out3, gvec, skipped
 
 
 def entropy(log_probs, olen = None, eps = 1e-9):
@@ -329,7 +362,8 @@ def normalize_signal(signal, eps = 1e-5, denom_multiplier = 1.0):
 	call('convasr_signal_absmax', ptr(signal), dtype_code(signal.dtype), B, T, ptr(absmax), stream_ptr())
 	x = signal if signal.dtype == torch.float32 else signal.float()
 	out = torch.empty_like(x)
-	call('convasr_scale_rows', ptr(x), ptr(((absmax + eps) * denom_multiplier).reciprocal()), ptr(out), B, T, stream_ptr())
+	scale = ((absmax + eps) * denom_multiplier).reciprocal()
+	call('convasr_scale_rows', ptr(x), ptr(scale), None, 0, ptr(out), B, T, stream_ptr())
 	return out
 
 
@@ -343,16 +377,18 @@ def argmax(log_probs):
 
 # ------------------------------------------------------------------------------------------------ optimizer
 
-def sumsq(flat_grad, out = None):
+def sumsq(flat_grad, out = None, norm_out = None, norm_scale = 1.0):
+	"""out[0] = sum of squares (fp64); norm_out (1-element fp32, optional) = sqrt(out) * norm_scale."""
 	out = out if out is not None else torch.empty(1, dtype = torch.float64, device = flat_grad.device)
 	ws = workspace(_lib.load().convasr_sumsq_workspace_bytes(), flat_grad.device, 'sumsq')
-	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), ptr(ws), stream_ptr())
+	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), ptr(ws), ptr(norm_out), float(norm_scale), stream_ptr())
 	return out
 
 
-def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0):
+def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0, p_bf16 = None):
 	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
-	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), stream_ptr())
+	assert p_bf16 is None or (p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == n)
+	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p_bf16), stream_ptr())
 
 
 def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums):
@@ -393,13 +429,13 @@ def novograd_work_table(offsets_host, device):
 	return (torch.tensor(items, dtype = torch.int64, device = device), torch.tensor(seg_first, dtype = torch.int64, device = device), torch.empty(len(items), dtype = torch.float64, device = device))
 
 
-def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0):
+def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0, p_bf16 = None):
 	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]; table: novograd_work_table(...)."""
 	items, seg_first, item_part = table
 	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
 	n_seg = offsets.numel() - 1
 	assert int(first) >= 0 or (ema_in.numel() == n_seg + 1 and ema_out.numel() == n_seg + 1), 'first = -1 (device-side first-step detection) needs the applied-step counter behind the EMAs'
-	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), stream_ptr())
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), ptr(p_bf16), stream_ptr())
 
 
 def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):

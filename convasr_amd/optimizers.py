@@ -37,10 +37,10 @@ class NovoGrad:
 			flat.finalize_grads()
 		max_norm = flat.clip[1] if flat.clip is not None else 0.0
 		cur = self.steps & 1
-		ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = flat.grad_scale)
+		grad_scale = flat.grad_scale
+		flat.mirror_carried_over(lambda p_bf16: ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = grad_scale, p_bf16 = p_bf16))
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
-		Fn.bump_param_epoch()
 
 	@property
 	def state(self):

@@ -37,6 +37,8 @@ class DataParallelEngine(nn.Module):
 			dist.broadcast(self.flat.data, src = 0, group = self.group)  # identical initial replicas
 			for buf in module.buffers():
 				dist.broadcast(buf, src = 0, group = self.group)
+			from . import functional as Fn
+			Fn.bump_param_epoch()  # the arena changed behind torch's version counters: packed compute copies are stale
 
 	def _make_buckets(self, bucket_bytes, first_bucket_bytes):
 		"""Contiguous arena ranges.  Backward completes them from the END of the arena towards its start, so the bucket at the start

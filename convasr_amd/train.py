@@ -3,7 +3,13 @@
 FlatParameters re-homes every trainable parameter into ONE contiguous fp32 buffer with a matching gradient buffer, so that
 gradient clipping is one reduction launch, the optimizer one elementwise launch, and data-parallel all-reduce a handful of
 large contiguous RCCL calls (288 GB of HBM makes the duplicate-free arena trivially affordable).  Backward kernels write
-gradients straight into the arena (convasr_amd.functional._deliver)."""
+gradients straight into the arena (convasr_amd.functional._deliver).
+
+Conv weights live in the arena TAP-MAJOR ([K][Cout][Cin], include/convasr_hip.h CONVASR_W_KMAJOR): the parameter stays a
+(Cout, Cin, K) tensor -- state_dict(), load_state_dict() and checkpoints see the reference's shapes -- but it is a strided view.
+That is the element order of the packed MFMA operand and of the weight-gradient slabs, so (a) the optimizer kernel also writes a
+bf16 mirror of the arena whose conv segments ARE the packed forward weights (no packing launches per step), and (b) the split-K
+combine of the weight gradient is a streaming sum instead of a transpose."""
 import torch
 
 from . import ops, _lib
@@ -29,17 +35,36 @@ class FlatParameters:
 		self.numel = off
 		self.data = torch.zeros(off, dtype = torch.float32, device = dev)
 		self.grad = torch.zeros(off, dtype = torch.float32, device = dev)
+		self.data_bf16 = None  # bf16 mirror of `data`, allocated on first use (mirror()); written by the fused optimizer kernels
+		self._mirror_ver = {}  # id(param) -> version tuple (functional.packed_weight) at which the mirror segment equals bf16(param)
 		for p, o in zip(params, self.offsets):
 			n = p.numel()
-			view = self.data[o:o + n].view(p.shape)
+			kmajor = p.ndim == 3 and p.shape[2] > 1 and (p.shape[0] * p.shape[1]) % 8 == 0 and dev.type == 'cuda'
+			as_param = (lambda flat, p = p: flat[o:o + n].view(p.shape[2], p.shape[0], p.shape[1]).permute(1, 2, 0)) if kmajor else (lambda flat, p = p: flat[o:o + n].view(p.shape))
+			view = as_param(self.data)
 			view.copy_(p.data)
 			p.data = view
-			p._convasr_grad = self.grad[o:o + n].view(p.shape)
+			p._convasr_grad = as_param(self.grad)
 			p._convasr_fresh = True
+			p._convasr_arena = (self, o) if kmajor else None
 			p.grad = p._convasr_grad
+		self._by_id = {id(p): p for p in params}
 		self.clip = None  # (sumsq double buffer, max_norm) set by clip_grad_norm_
 		self.grad_scale = 1.0  # pending scale of .grad (the data-parallel engine's 1 / world_size), consumed by the next optimizer step
 		self._sumsq = torch.zeros(1, dtype = torch.float64, device = dev)
+
+	def mirror(self):
+		if self.data_bf16 is None:
+			self.data_bf16 = torch.zeros(self.numel, dtype = torch.bfloat16, device = self.data.device)
+		return self.data_bf16
+
+	def mirror_carried_over(self, run):
+		"""Run one fused optimizer launch `run(p_bf16)` that rewrites the bf16 mirror together with the parameters (or leaves both
+		untouched when the device-side gate skips the step): segments that were current before it are current after it."""
+		was = {k for k, v in self._mirror_ver.items() if v == Fn.param_version(self._by_id[k])} if self._mirror_ver else set()
+		run(self.data_bf16)
+		Fn.bump_param_epoch()  # packed compute copies other than the mirror are stale now
+		self._mirror_ver = {k: Fn.param_version(self._by_id[k]) for k in was} if self.data_bf16 is not None else {}
 
 	def zero_grad(self):
 		"""No memset: the next backward overwrites (first write per parameter has accumulate = False)."""
@@ -58,9 +83,10 @@ class FlatParameters:
 		"""torch.nn.utils.clip_grad_norm_(params, max_norm) (train.py:777): one reduction launch now; the scaling itself is
 		folded into the optimizer kernel.  Returns the total norm as a 0-d device tensor (no host sync)."""
 		self.finalize_grads()
-		ops.sumsq(self.grad, self._sumsq)
+		norm = torch.empty(1, dtype = torch.float32, device = self.grad.device)
+		ops.sumsq(self.grad, self._sumsq, norm_out = norm, norm_scale = self.grad_scale)
 		self.clip = (self._sumsq, float(max_norm))
-		return (self._sumsq.sqrt() * self.grad_scale).to(torch.float32).squeeze(0)
+		return norm[0]
 
 
 class SGD:
@@ -83,10 +109,10 @@ class SGD:
 		if flat.clip is None:
 			flat.finalize_grads()
 		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
-		ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], self.steps == 0, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = flat.grad_scale)
+		first, grad_scale = self.steps == 0, flat.grad_scale
+		flat.mirror_carried_over(lambda p_bf16: ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], first, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = grad_scale, p_bf16 = p_bf16))
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
-		Fn.bump_param_epoch()  # packed bf16/fp32 weight copies are stale now
 
 	def state_dict(self):
 		return dict(steps = self.steps, momentum_buffer = self.momentum_buffer, param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
@@ -110,10 +136,10 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	device_gate = False) the gate is the reference's host-side check."""
 	out = model(x, xlen, y = y, ylen = ylen)
 	log_probs, olen, loss_vec = out['log_probs'], out['olen'], out['loss']
-	example_weights = ylen[:, 0]
-	loss = (loss_vec * example_weights).mean() / accumulate_iterations
-	loss_cur = loss_vec.mean()
-	entropy = M.entropy(log_probs[0].detach(), olen[0], dim = 1).mean()
+	# train.py:754-756 in one launch (ops.loss_head): loss = mean(loss_vec * ylen[:, 0]) / accum, loss_cur = mean(loss_vec), the mean
+	# entropy, the inf/NaN flag, and d loss / d loss_vec (the vector backward() is seeded with)
+	ent = M.entropy(log_probs[0].detach(), olen[0], dim = 1)
+	scalars, grad_loss_vec, skipped = ops.loss_head(loss_vec, ylen[:, 0], ent, accumulate_iterations)
 	engine = model if hasattr(model, 'finish_gradient_sync') else None
 	group = engine.group if engine is not None else None
 	# The two scalar all-reduces of train.py:759-760 as one 2-element all-reduce.  With a data-parallel engine that runs
@@ -121,24 +147,24 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	# averaged; a rank-local inf/NaN would make one replica skip the update the others apply).
 	if (engine is not None and engine.collectives) or (sync_metrics and torch.distributed.is_available() and torch.distributed.is_initialized() and (world_size > 1 or sync_metrics is True)):
 		import torch.distributed as dist
-		n_ranks = dist.get_world_size(group)
-		stats = torch.stack([loss_cur.detach(), entropy])
+		stats = scalars[1:3]
 		dist.all_reduce(stats, op = dist.ReduceOp.SUM, group = group)
-		loss_cur, entropy = stats[0] / n_ranks, stats[1] / n_ranks
-	res = dict(loss = loss.detach(), loss_cur = loss_cur.detach(), entropy = entropy, grad_norm = None, skipped = False)
+		stats.div_(dist.get_world_size(group))
+		skipped = ~torch.isfinite(scalars[1:2])
+	loss_cur = scalars[1]
+	res = dict(loss = scalars[0], loss_cur = loss_cur, entropy = scalars[2], grad_norm = None, skipped = skipped[0])
 	gate = None
 	if device_gate and accumulate_iterations == 1 and hasattr(optimizer, 'flat'):
-		gate = loss_cur.detach().to(torch.float32).reshape(1)
-		res['skipped'] = ~torch.isfinite(gate[0])
-	elif bool(torch.isinf(loss_cur) | torch.isnan(loss_cur)):
+		gate = scalars[1:2]
+	elif bool(skipped):
 		res['skipped'] = True
 		return res
 	last_of_group = iteration % accumulate_iterations == 0
 	if engine is not None and not last_of_group:
 		with engine.no_sync():
-			loss.backward()
+			loss_vec.backward(grad_loss_vec)
 	else:
-		loss.backward()
+		loss_vec.backward(grad_loss_vec)
 	Fn.join_side_streams()  # weight gradients computed on the side stream are final from here on
 	if last_of_group:
 		if engine is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 1
+#define CONVASR_ABI_VERSION 2
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -67,12 +67,22 @@ int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc,
 /* cout_pad(cout): rows of the packed weight (multiple of the kernel's N tile). */
 int convasr_conv_cout_pad(int cout);
 
-/* (Cout, Cin, K) fp32 parameter -> packed compute-dtype copies:
+/* Memory layout of an fp32 conv parameter / its gradient, logical shape (Cout, Cin, K):
+ *   CONVASR_W_REFERENCE  element (co, ci, k) at (co*Cin + ci)*K + k  -- torch-contiguous, what the reference's state dict holds;
+ *   CONVASR_W_KMAJOR     element (co, ci, k) at (k*Cout + co)*Cin + ci -- tap-major, the element order of the packed compute
+ *                        copies and of the weight-gradient slabs: the layout the MI355X training arena keeps masters and
+ *                        gradients in (a torch view of shape (Cout, Cin, K) with strides (Cin, 1, Cout*Cin)), so that the packed
+ *                        forward weights are a cast of the master and the split-K combine is a streaming sum. */
+#define CONVASR_W_REFERENCE 0
+#define CONVASR_W_KMAJOR 1
+
+/* (Cout, Cin, K) fp32 parameter (in layout w_layout) -> packed compute-dtype copies:
  *   packed_fwd  [K][cout_pad(Cout)][Cin]  : packed_fwd[k][co][ci]   = w[co][ci][k]        (required)
  *   packed_dgrad[K][cout_pad(Cin)][Cout]  : packed_dgrad[k][ci][co] = w[co][ci][K-1-k]    (optional; input gradient = conv
  *                                           with flipped taps; derived from packed_fwd by a tiled transpose)
- * Only rows < Cout (resp. < Cin) are written: the caller zero-fills the buffers once so the padded rows read as zeros. */
-int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
+ * Only rows < Cout (resp. < Cin) are written: the caller zero-fills the buffers once so the padded rows read as zeros.
+ * w == NULL: packed_fwd is already current (e.g. written by convasr_sgd_step's bf16 mirror) and only packed_dgrad is rebuilt. */
+int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, int w_layout, void* stream);
 
 /* y[b,t,co] = epilogue( sum_{k,ci} x[b, t*stride + k*dil - pad, ci] * wp[k][co][ci] ), zero outside [0, Tin).
  * epilogue: acc -> (+ bias[co] if bias) -> (stats of that value over the tile's valid (b,t) if stats) -> (* scale[co] + shift[co]
@@ -94,11 +104,12 @@ int convasr_debug_set_conv_v2(int enable);
 /* Bytes of fp32 workspace convasr_conv1d_wgrad needs (split-K partial slabs). */
 int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil);
 
-/* dw[co][ci][k] (+)= sum_{b,t} dy[b,t,co] * x[b, t*stride + k*dil - pad, ci]; dw is the fp32 (Cout, Cin, K) gradient
- * in the reference's parameter layout.  accumulate != 0 adds to dw.  dbias (Cout fp32, may be NULL) = sum dy. */
+/* dw[co][ci][k] (+)= sum_{b,t} dy[b,t,co] * x[b, t*stride + k*dil - pad, ci]; dw is the fp32 (Cout, Cin, K) gradient in layout
+ * dw_layout (CONVASR_W_REFERENCE: the reference's parameter layout; CONVASR_W_KMAJOR: the training arena's).
+ * accumulate != 0 adds to dw.  dbias (Cout fp32, may be NULL) = sum dy. */
 int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype,
                          int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil, int pad,
-                         int accumulate, void* stream);
+                         int accumulate, int dw_layout, void* stream);
 
 /* ---- BatchNorm1d + ResidualActivation + temporal mask: models.py:111-114, 127-139, 357-371, 436-443 ----------- */
 
@@ -167,8 +178,17 @@ int64_t convasr_ctc_workspace_bytes(int B, int T, int S_max);
  * 0 for t >= olen (may be NULL: forward only).  targets: (B, S_max) int64, olen/ylen int64 (the reference's dtypes). */
 int convasr_ctc_loss(const float* log_probs, const int64_t* targets, const int64_t* olen, const int64_t* ylen,
                      float* nll, float* grad, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);
-/* out[b,t,c] = grad[b,t,c] * gscale[b]   (chain rule for reduction='none'). */
-int convasr_scale_rows(const float* grad, const float* gscale, float* out, int B, int64_t per_b, void* stream);
+/* out[b,t,c] = grad[b,t,c] * gscale[b]   (chain rule for reduction='none'); with gdiv != NULL the factor is
+ * gscale[b] / (float)gdiv[b * gdiv_stride]: the "/ ylen[:, 0]" of models.py:323 folded into the same pass. */
+int convasr_scale_rows(const float* grad, const float* gscale, const int64_t* gdiv, int64_t gdiv_stride, float* out, int B, int64_t per_b, void* stream);
+
+/* The scalar bookkeeping of one training iteration (train.py:754-756, 769) in one launch: loss_vec[b] = per-utterance loss
+ * (models.py:323), w[b] = ylen[b * ylen_stride] (target lengths), entropy[b] (may be NULL) = models.entropy per utterance:
+ *   out3[0] = mean(loss_vec * w) / accumulate_iterations, out3[1] = mean(loss_vec), out3[2] = mean(entropy);
+ *   grad_loss_vec[b] (may be NULL) = d out3[0] / d loss_vec[b] = ((1 / accumulate_iterations) / B) * w[b];
+ *   skipped (may be NULL, one byte) = out3[1] is inf or NaN (the gate of train.py:769). */
+int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
+                      float* grad_loss_vec, unsigned char* skipped, void* stream);
 
 /* ent[b] = sum_{t<olen} -sum_c p log p / (eps + olen[b])  (olen NULL: mean over T). */
 int convasr_entropy(const float* log_probs, const int64_t* olen, float* ent, int B, int T, int C, float eps, void* stream);
@@ -182,17 +202,20 @@ int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, vo
 
 /* sumsq[0] = sum g^2 over n fp32 values, in double, added in a fixed order (partial sums in `workspace`, no atomics). */
 int64_t convasr_sumsq_workspace_bytes(void);
-int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, void* stream);
+/* norm_out (may be NULL) receives (float)(sqrt(sumsq) * norm_scale): what clip_grad_norm_ returns. */
+int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, float* norm_out, float norm_scale, void* stream);
 /* torch.optim.SGD step with clip folded in: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (c = 1 if sumsq NULL);
  * g' = c*g + wd*p; buf = first ? g' : mom*buf + g'; p -= lr * (nesterov ? g' + mom*buf : buf).
  * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad).
  * grad_scale multiplies g before everything else (1 / world size when g holds rank-SUMMED gradients: the mean is never
  * materialised; sumsq is then the sum of squares of the summed gradient).
  * If loss_gate != NULL and *loss_gate (a device float, the all-reduced loss) is inf or NaN the launch changes nothing: the
- * reference's "skip the step on a non-finite loss" (train.py:769-772) without a host round trip in the middle of the step. */
+ * reference's "skip the step on a non-finite loss" (train.py:769-772) without a host round trip in the middle of the step.
+ * p_bf16 (may be NULL): n bf16 values, receives the updated parameters rounded to bf16 -- with K-major masters that mirror IS the
+ * packed forward weight of every conv whose Cout is a multiple of the kernel's N tile (no per-step packing launches). */
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale,
-                     void* stream);
+                     uint16_t* p_bf16, void* stream);
 
 /* Fused backward step (bf16, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
  * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:
@@ -223,11 +246,12 @@ int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamm
  * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else).  first: 1 / 0 decided by the caller, or -1 =
  * decided on the device: ema_in / ema_out then hold n_seg + 1 floats, the last one the number of steps applied so far (the call
  * writes ema_out[n_seg] = ema_in[n_seg] + 1 unless gated), and first = (ema_in[n_seg] == 0) -- a gated first iteration then leaves
- * no optimizer state behind, like the reference, which creates state only when a step runs (optimizers.py:76-80). */
+ * no optimizer state behind, like the reference, which creates state only when a step runs (optimizers.py:76-80).  p_bf16 as in
+ * convasr_sgd_step. */
 int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets,
                           int n_seg, int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part,
                           float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
-                          const float* loss_gate, float* total_norm, float grad_scale, void* stream);
+                          const float* loss_gate, float* total_norm, float grad_scale, uint16_t* p_bf16, void* stream);
 /* largest item the table may hold (elements) */
 int64_t convasr_novograd_item_elems(void);
 

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 	lib = _lib.load()
 	for name in declared:
 		assert hasattr(lib, name), name
-	assert lib.convasr_abi_version() == 1
+	assert lib.convasr_abi_version() == 2
 	assert lib.convasr_conv_cout_pad(38) == 128 and lib.convasr_conv_cout_pad(256) == 256
 
 
@@ -245,6 +245,50 @@ def test_conv1d_wgrad(case, dtype):
 	close(db, b.grad, what = 'dbias', **tol)
 	ops.conv1d_wgrad(ops.as_cl(x.to(d), dt), ops.as_cl(dy.to(d), dt), Cout, K, stride, dil, pad, dw, dbias = db, accumulate = True)
 	close(dw, 2 * w.grad, what = 'wgrad accumulate', rtol = tol['rtol'], atol = 2 * tol['atol'])
+
+
+@gpu
+@pytest.mark.parametrize('shape', [(256, 128, 11), (384, 256, 3), (128, 128, 29), (40, 64, 5)])
+def test_tap_major_weights_pack_wgrad_and_optimizer_mirror(shape):
+	"""CONVASR_W_KMAJOR (the training arena's weight / gradient layout, include/convasr_hip.h): packing from a tap-major master gives
+	the same packed operands as packing the torch-contiguous tensor, a tap-major weight gradient is the reference-layout one
+	permuted -- bit for bit (same slabs, same summation order) -- and the optimizer's bf16 mirror equals a cast of the parameters."""
+	from convasr_amd import ops, _lib
+	Cout, Cin, K = shape
+	d = dev()
+	torch.manual_seed(Cout + K)
+	w = torch.randn(Cout, Cin, K, device = d)
+	wk = torch.empty(K, Cout, Cin, device = d).permute(1, 2, 0)
+	wk.copy_(w)
+	assert ops.weight_layout(w) == _lib.W_REFERENCE and ops.weight_layout(wk) == _lib.W_KMAJOR and ops.weight_layout(w.permute(0, 2, 1)) is None
+	for dt in (torch.float32, torch.bfloat16):
+		f0, g0 = ops.pack_weight(w, dt, None)
+		f1, g1 = ops.pack_weight(wk, dt, None)
+		assert torch.equal(f0, f1) and torch.equal(g0, g1), dt
+		# only the dgrad copy rebuilt from a forward copy that is already current
+		g2 = torch.zeros_like(g1)
+		ops.pack_weight(wk, dt, None, out = (f1, g2), fwd_is_current = True)
+		assert torch.equal(g2, g0)
+	B, T = 3, 300
+	x = ops.as_cl(torch.randn(B, Cin, T, device = d), torch.bfloat16)
+	dy = ops.as_cl(torch.randn(B, Cout, T, device = d), torch.bfloat16)
+	dw = torch.empty(Cout, Cin, K, device = d)
+	dwk = torch.full((K, Cout, Cin), 3.0, device = d).permute(1, 2, 0)
+	ops.conv1d_wgrad(x, dy, Cout, K, 1, 1, K // 2, dw)
+	ops.conv1d_wgrad(x, dy, Cout, K, 1, 1, K // 2, dwk)
+	assert torch.equal(dw, dwk.contiguous())
+	ops.conv1d_wgrad(x, dy, Cout, K, 1, 1, K // 2, dwk, accumulate = True)
+	close(dwk.contiguous(), 2 * dw, 1e-6, 1e-6, 'tap-major accumulate')
+	# optimizer mirror
+	n = 4096 + 64
+	p_, g_, buf = torch.randn(n, device = d), torch.randn(n, device = d), torch.zeros(n, device = d)
+	mirror = torch.zeros(n, dtype = torch.bfloat16, device = d)
+	ref = p_.clone()
+	ops.sgd_step(p_, g_, buf, n, ops.sumsq(g_), 100.0, 1e-2, 0.9, 1e-3, False, True, p_bf16 = mirror)
+	assert not torch.equal(p_, ref) and torch.equal(mirror, p_.to(torch.bfloat16))
+	keep = mirror.clone()
+	ops.sgd_step(p_, g_, buf, n, ops.sumsq(g_), 100.0, 1e-2, 0.9, 1e-3, False, False, loss_gate = torch.tensor([float('inf')], device = d), p_bf16 = mirror)
+	assert torch.equal(mirror, keep)
 
 
 # ------------------------------------------------------------------------------------------------ batch norm + activation
@@ -510,3 +554,45 @@ def test_ctc_properties_at_benchmark_size():
 	assert float((grad.abs().amax(dim = 1) * tmask).max()) == 0.0
 	nll2, _ = ops.ctc_loss(ops.as_cl(lp - 0.25), y, olen, ylen, C - 1, need_grad = False)
 	close(nll2 - nll, 0.25 * olen.float(), 1e-4, 1e-2, 'shift property')
+
+
+@gpu
+def test_loss_head_matches_the_reference_expressions():
+	"""train.py:754-756 + 769: loss = (loss * ylen[:, 0]).mean() / accum, loss_cur = loss.mean(), entropy mean, the inf/NaN flag, and
+	the gradient autograd would hand back to the loss vector."""
+	from convasr_amd import ops
+	d = dev()
+	g = torch.Generator().manual_seed(3)
+	for B, accum in ((64, 1), (7, 4), (300, 2)):
+		lv = (torch.rand(B, generator = g) * 5 + 0.1).requires_grad_(True)
+		ylen = torch.randint(1, 200, (B, 2), generator = g)
+		ent = torch.rand(B, generator = g)
+		loss = (lv * ylen[:, 0]).mean() / accum
+		loss.backward()
+		out3, gvec, skipped = ops.loss_head(lv.detach().to(d), ylen.to(d)[:, 0], ent.to(d), accum)
+		close(out3, torch.stack([loss.detach(), lv.detach().mean(), ent.mean()]), 2e-6, 1e-7, 'loss head scalars')
+		close(gvec, lv.grad, 1e-6, 0, 'd loss / d loss_vec')
+		assert not bool(skipped)
+	bad = lv.detach().clone(); bad[3] = float('inf')
+	assert bool(ops.loss_head(bad.to(d), ylen.to(d)[:, 0], None, 1)[2])
+	bad[3] = float('nan')
+	assert bool(ops.loss_head(bad.to(d), ylen.to(d)[:, 0], None, 1)[2])
+	# clip_grad_norm_'s return value straight from the reduction kernel
+	gflat = torch.randn(10007, generator = g).to(d)
+	norm = torch.empty(1, device = d)
+	ops.sumsq(gflat, norm_out = norm, norm_scale = 0.5)
+	close(norm[0], gflat.double().norm() * 0.5, 1e-6, 0, 'grad norm')
+	# nll / ylen[:, 0] folded into the CTC function: value and gradient equal the two-step form
+	from convasr_amd import functional as Fn
+	B, C, T, S = 4, 38, 60, 9
+	lp = torch.randn(B, C, T, generator = g).log_softmax(dim = 1).to(d)
+	y = torch.randint(0, 37, (B, S), generator = g).to(d)
+	olen, yl = torch.tensor([60, 50, 41, 33]).to(d), torch.tensor([[9], [7], [5], [3]]).to(d)
+	a = ops.as_cl(lp).clone().requires_grad_(True)
+	b_ = ops.as_cl(lp).clone().requires_grad_(True)
+	la = Fn.ctc_loss(a, y, olen, yl[:, 0], 37, norm = yl[:, 0])
+	lb = Fn.ctc_loss(b_, y, olen, yl[:, 0], 37) / yl[:, 0]
+	w = torch.rand(B, generator = g).to(d)
+	la.backward(w); lb.backward(w)
+	close(la, lb, 1e-7, 0, 'normalised CTC loss')
+	close(a.grad, b_.grad, 1e-6, 1e-9, 'normalised CTC gradient')
