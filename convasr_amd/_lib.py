@@ -79,6 +79,8 @@ def load():
 		if not os.path.exists(LIB_PATH):
 			raise ConvasrHipError(f'{LIB_PATH} not found: build it with `python -m convasr_amd.build` (hipcc --offload-arch=gfx950)')
 		lib = ctypes.CDLL(LIB_PATH)
+		if hasattr(lib, 'convasr_debug_read_stamps'):  # diagnostic builds only (build.py --variant ... -DCONVASR_STAMPS=1)
+			lib.convasr_debug_read_stamps.restype, lib.convasr_debug_read_stamps.argtypes = c_int, [c_p, c_int]
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args

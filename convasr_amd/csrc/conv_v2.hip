@@ -279,7 +279,8 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
 	int mode = (p.K < 2 && !p.bn_y) ? 0 : ((p.debug & 64) ? 1 : 2);  // a K = 1 dgrad that carries the fused BN-backward epilogue runs in conv_v2s.hip's loop (5 % slower than the K = 1 path, but it saves the separate reduce pass)
-	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (mode == 0 ? 3 : 4) * V2_WSLOT;
+	const bool small_shape_ = mode == 2 && ((p.debug & 128) != 0) == (V2_DEFAULT_SMALL_SHAPE == 0);
+	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (mode == 0 ? 3 : (small_shape_ ? 5 : 4)) * V2_WSLOT;  // conv_v2s.hip: 3 + 2 weight slots
 	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
 	if (epi > smem) smem = epi;
 	if (smem > 160 * 1024) return 0;
@@ -305,7 +306,7 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles
 	}
 	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
 	void* args[] = {&p};
-	if (hipLaunchKernel(kern, dim3(grid), dim3(V2_THREADS), args, smem, s) != hipSuccess) return 0;
+	if (hipLaunchKernel(kern, dim3(grid), dim3(small_shape ? V2S_THREADS : V2_THREADS), args, smem, s) != hipSuccess) return 0;
 	if (m_tiles_out) *m_tiles_out = p.B * p.m_tiles_per_b;
 	return 1;
 }

@@ -5,6 +5,7 @@
 #define V2_BM 256
 #define V2_THREADS 512
 #define V2_WSLOT (BN * ROW_BYTES)  // 16 KiB
+#define V2S_THREADS (V2_THREADS + 256)  // conv_v2s.hip: 8 computing waves + 4 loader waves
 
 // 1 KiB (one wave-instruction) of a swizzled tile: LDS slot p of the tile <- global (row, chunk) with
 // lds_off(row, chunk) == 16 * p.  Returns the byte offset of that lane's 16 bytes relative to the tile's row 0 / chunk 0.

@@ -3,8 +3,23 @@
 // a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP; our conv loops run clock-limited
 // (1.8-2.0 GHz measured), so both shapes are built and the faster one by wall time is the default (see conv.hip's dispatcher).
 #include "conv_v2_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+
+#ifdef CONVASR_STAMPS
+// Diagnostic build only (python -m convasr_amd.build --variant stamps -DCONVASR_STAMPS=1; scratch/stamps.py): per-wave cycle sums of the
+// main loop's segments, written to a buffer of their own that no kernel reads.  The stamps forbid overlaps the real kernel has:
+// read the SHARES, never the run time (cdna_hip_programming.md section 7, In-kernel stamps).
+__device__ unsigned long long g_v2s_stamps[256 * 8 * 8];
+extern "C" int convasr_debug_read_stamps(unsigned long long* host, int count) {
+	return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_v2s_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(var)
+#endif
 
 // NB = 16-column blocks per wave: 4 -> the 256 x 128 tile, 2 -> a 256 x 64 half tile (same X tile, half the W rows).  The last
 // partial round of a launch (total_tiles mod 256 workgroups on 256 CUs) is cut into half tiles so that it occupies all CUs for
@@ -28,22 +43,29 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	const int n_cib = p.Cin >> 6;
 	const int x_units = p.x_rows >> 3;
 
-	const int xlane = v2_src_offset(lane, row_bytes);
+	// Waves 0-7 compute; waves 8-11 (one per SIMD) only issue the LDS-DMA pieces.  A piece costs its issuing wave ~100 cycles
+	// (M0 hand-over, address math, the buffer_load itself) during which an in-order wave issues no MFMA: with the 38 pieces of an
+	// interval spread over the computing waves, each of them spent ~470 of its ~2700 cycles per interval issuing DMA (in-kernel
+	// stamps, scratch/stamps.py).  A loader wave's SALU / VMEM issue does not take the matrix pipe from the two computing waves
+	// of its SIMD.
+	const bool loader = wave >= 8;
+	const int lw = wave - 8;
+	const int xlane = v2_src_offset(lane, row_bytes), xlane_odd = v2_src_offset(64 + lane, row_bytes) - 8 * row_bytes;
 	auto issue_x = [&](int cib) {
 		const unsigned dst = lds_base + (cib & 1) * xbytes;
 		const int base = tin0 * row_bytes + cib * 128;
-		for (int u = wave; u < x_units; u += 8) {
-			const int off = (u & 1) ? v2_src_offset(64 + lane, row_bytes) - 8 * row_bytes : xlane;
-			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + off);
-		}
+		for (int u = lw; u < x_units; u += 4)
+			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + ((u & 1) ? xlane_odd : xlane));
 	};
-	constexpr int WPW = NB / 2;  // 1-KiB pieces of a W slot per wave
-	const int wl0 = v2_src_offset(wave * (64 * WPW) + lane, row_bytes), wl1 = v2_src_offset(wave * (64 * WPW) + 64 + lane, row_bytes);
+	constexpr int PPL = NB;  // 1-KiB pieces of a W slot (BN_ rows x 128 B = 4 NB pieces) per loader wave
+	int wl[PPL];
+#pragma unroll
+	for (int j = 0; j < PPL; ++j) wl[j] = v2_src_offset((lw * PPL + j) * 64 + lane, row_bytes);
 	auto issue_w = [&](int q_cib, int q_tap, int slot) {
-		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * xbytes + slot * V2_WSLOT + wave * (1024 * WPW));
+		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * xbytes + slot * V2_WSLOT + lw * (1024 * PPL));
 		const int base = (q_tap * p.CoutPad + co0) * row_bytes + q_cib * 128;
-		dma16(wsrc, dst, base + wl0);
-		if (WPW == 2) dma16(wsrc, dst + 1024, base + wl1);
+#pragma unroll
+		for (int j = 0; j < PPL; ++j) dma16(wsrc, dst + j * 1024, base + wl[j]);
 	};
 
 	f32x4 acc[4][NB];
@@ -76,47 +98,90 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 			for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
 	};
 
+#ifdef CONVASR_STAMPS
+	unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, acc_issue = 0, acc_work = 0, acc_vm = 0, acc_bar = 0, t_loop0 = 0, t_start = 0, t_end = 0;
+	STAMP(t_start)
+#endif
 	{
+		// One barrier interval = the (up to) two taps of one tap pair on one 64-channel slab.  W slots: a ring of THREE for the first
+		// ("even") tap of a pair and a ring of TWO for the second: the even tap of interval s + 2 and the odd tap of interval s + 1 are
+		// issued at the start of interval s and have landed by the barrier that ends it, so the first fragments of interval s + 1 are
+		// read BEFORE that barrier (under the last MFMA group of interval s) and every interval opens with MFMAs instead of an LDS
+		// round trip.  (In-kernel stamps, scratch/stamps.py: the DMA itself never makes a wave wait; the barrier and the restart
+		// after it were ~15 % of an interval.)
 		const int npb = (p.K + 1) >> 1, P = n_cib * npb;
-		issue_x(0);
-		issue_w(0, 0, 0);
-		if (p.K > 1) issue_w(0, 1, 1);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__builtin_amdgcn_s_barrier();
-		const bool late = wave >= 4;
-		int cib = 0, pi = 0;
-		Frag f0, f1;
-		for (int sidx = 0; sidx < P; ++sidx) {
-			const int t0_ = 2 * pi, nt = min(2, p.K - t0_);
-			int cib1 = cib, pi1 = pi + 1;
-			if (pi1 == npb) { pi1 = 0; ++cib1; }
-			const unsigned xs = (cib & 1) * xbytes, ws0 = ((sidx & 1) * 2) * V2_WSLOT, ws1 = ws0 + V2_WSLOT;
-			auto issue_step = [&]() {
-				if (pi == 0 && cib + 1 < n_cib) issue_x(cib + 1);
-				if (sidx + 1 < P) {
-					const int sl = ((sidx + 1) & 1) * 2;
-					issue_w(cib1, 2 * pi1, sl);
-					if (2 * pi1 + 1 < p.K) issue_w(cib1, 2 * pi1 + 1, sl + 1);
-				}
-			};
-			if (!late) issue_step();
-			load_frag(xs, ws0, t0_, 0, f0);
-			load_frag(xs, ws0, t0_, 1, f1);
-			mma_frag(f0);
-			if (late) issue_step();
-			if (nt == 2) {
-				load_frag(xs, ws1, t0_ + 1, 0, f0);
-				mma_frag(f1);
-				load_frag(xs, ws1, t0_ + 1, 1, f1);
-				mma_frag(f0);
-			}
-			mma_frag(f1);
+		auto e_slot = [](int s_) { return (unsigned)((s_ % 3) * V2_WSLOT); };
+		auto o_slot = [](int s_) { return (unsigned)((3 + (s_ & 1)) * V2_WSLOT); };
+		if (loader) {
+			issue_x(0);
+			issue_w(0, 0, 0);
+			if (p.K > 1) issue_w(0, 1, 3);
+			if (P > 1) { if (npb > 1) issue_w(0, 2, 1); else issue_w(1, 0, 1); }
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
-			cib = cib1; pi = pi1;
+			int cib = 0, pi = 0;
+			for (int sidx = 0; sidx < P; ++sidx) {
+				int cib1 = cib, pi1 = pi + 1;  // interval sidx + 1
+				if (pi1 == npb) { pi1 = 0; ++cib1; }
+				int cib2 = cib1, pi2 = pi1 + 1;  // interval sidx + 2
+				if (pi2 == npb) { pi2 = 0; ++cib2; }
+				if (sidx + 2 < P) issue_w(cib2, 2 * pi2, (sidx + 2) % 3);
+				if (sidx + 1 < P && 2 * pi1 + 1 < p.K) issue_w(cib1, 2 * pi1 + 1, 3 + ((sidx + 1) & 1));
+				if (pi == 0 && cib + 1 < n_cib) issue_x(cib + 1);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__builtin_amdgcn_s_barrier();
+				cib = cib1; pi = pi1;
+			}
+			// the epilogue's workgroup barriers (the loaders have nothing else to do there)
+			__builtin_amdgcn_s_barrier();
+			if (BNF && sizeof(O) == 2) __builtin_amdgcn_s_barrier();
+			return;
 		}
+		__builtin_amdgcn_s_barrier();
+		Frag f0, f1;
+		load_frag(0, e_slot(0), 0, 0, f0);
+		STAMP(t_loop0)
+		// The loop is instantiated per `pre` so that the read-ahead is unconditional inside it: a conditional LDS load makes hipcc
+		// wait for ALL outstanding LDS reads at the branch join (ahead of the last MFMA group), which costs more than the read-ahead
+		// saves.  In the last interval the read-ahead fetches a slot nobody needs (its registers are dead).
+		auto main_loop = [&](auto PRE_) {
+			constexpr bool PRE = decltype(PRE_)::value;
+			int cib = 0, pi = 0;
+			for (int sidx = 0; sidx < P; ++sidx) {
+				const int t0_ = 2 * pi, nt = min(2, p.K - t0_);
+				int cib1 = cib, pi1 = pi + 1;  // interval sidx + 1
+				if (pi1 == npb) { pi1 = 0; ++cib1; }
+				const unsigned xs = (cib & 1) * xbytes, xs1 = (cib1 & 1) * xbytes;
+				STAMP(ta)
+				STAMP(tb)
+				load_frag(xs, e_slot(sidx), t0_, 1, f1);
+				mma_frag(f0);
+				if (nt == 2) {
+					load_frag(xs, o_slot(sidx), t0_ + 1, 0, f0);
+					mma_frag(f1);
+					load_frag(xs, o_slot(sidx), t0_ + 1, 1, f1);
+					mma_frag(f0);
+				}
+				if (PRE) load_frag(xs1, e_slot(sidx + 1), 2 * pi1, 0, f0);
+				mma_frag(f1);
+				STAMP(tc)
+				STAMP(td)
+				__builtin_amdgcn_s_barrier();
+				if (!PRE) load_frag(xs1, e_slot(sidx + 1), 2 * pi1, 0, f0);
+				STAMP(te)
+#ifdef CONVASR_STAMPS
+				acc_issue += tb - ta; acc_work += tc - tb; acc_vm += td - tc; acc_bar += te - td;
+#endif
+				cib = cib1; pi = pi1;
+			}
+		};
+		if (npb > 1) main_loop(std::true_type()); else main_loop(std::false_type());  // K <= 2: every interval opens a new slab, whose X rows land only at this interval's barrier: no read-ahead
 	}
 
+#ifdef CONVASR_STAMPS
+	unsigned long long t_epi0 = 0;
+	STAMP(t_epi0)
+#endif
 	// ---------------- epilogue: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg
 	constexpr int OPITCH = BN_ * sizeof(O) + 16;
 	char* const otile = smem;
@@ -127,11 +192,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
 	constexpr bool bnf = BNF && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
 	uint4 ypre[TRIPS];
-#ifdef EXP_SKIP_YPRE
-	if (false) {
-#else
 	if (bnf) {
-#endif
 #pragma unroll
 		for (int i = 0; i < TRIPS; ++i) {
 			const int e = tid + i * V2_THREADS, row = e / OCH_, t = t0 + row, co = co0 + (e % OCH_) * OEPC_;
@@ -201,7 +262,6 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 		else
 			for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = src[i];
-#ifndef EXP_SKIP_GMATH
 		if (bnf && t < bnv) {
 			const int64_t idx = ((int64_t)b * p.Tout + t) * p.Cout + co;
 			float dz[8], yv[8], g[8];
@@ -222,9 +282,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 #pragma unroll
 			for (int k = 0; k < 8; ++k) { bs1[k] += g[k]; bs2[k] = fmaf(g[k], yv[k], bs2[k]); }  // sum g*y; centred and scaled once per tile below
 		}
-#endif
 	}
-#ifndef EXP_SKIP_BNRED
 	if (bnf) {
 		float* const bnred = reinterpret_cast<float*>(smem + V2_BM * OPITCH + 8 * BN * sizeof(float));  // [V2_THREADS][17], past the output tile and `red`
 #pragma unroll
@@ -239,10 +297,17 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 			prow[p.Cout + co0 + tid] = q2;
 		}
 	}
+#ifdef CONVASR_STAMPS
+	STAMP(t_end)
+	if (blockIdx.x < 256 && lane == 0) {
+		unsigned long long* o = g_v2s_stamps + (blockIdx.x * 8 + wave) * 8;
+		o[0] = t_loop0 - t_start; o[1] = acc_issue; o[2] = acc_work; o[3] = acc_vm; o[4] = acc_bar; o[5] = t_epi0 - t_loop0; o[6] = t_end - t_epi0; o[7] = t_end - t_start;
+	}
 #endif
 }
 
-template <typename O, bool BNF> __global__ __launch_bounds__(V2_THREADS, 2) void conv1d_igemm_v2s_kernel(ConvParams p) {
+template <typename O, bool BNF> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
+
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
 	if (bid < p.full_tiles) {

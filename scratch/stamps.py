@@ -1,0 +1,24 @@
+"""Where a main-loop interval of conv1d_igemm_v2s_kernel spends its cycles (diagnostic build: CONVASR_HIP_LIB=...stamps.so).
+Per wave of the first 256 workgroups of ONE forward launch: prologue, [DMA issue, LDS reads + MFMA, vmcnt wait, barrier wait] summed
+over the intervals, epilogue.  Shares only: the stamps serialise what the real kernel overlaps."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from convasr_amd import ops, _lib
+d = torch.device('cuda:0'); dt = torch.bfloat16
+lib = _lib.load()
+for (cin, cout, k, dil) in [(768, 768, 11, 1), (256, 256, 11, 1), (512, 512, 11, 1), (768, 896, 29, 2)]:
+	B, T = 64, 751
+	x = ops.as_cl(torch.randn(B, cin, T, device = d), dt)
+	w = torch.randn(cout, cin, k, device = d) / (cin * k) ** 0.5
+	fwd = ops.pack_weight(w, dt, _lib.PACK_FWD)
+	for _ in range(3): ops.conv1d(x, fwd, cout, k, 1, dil, dil * k // 2)
+	torch.cuda.synchronize()
+	buf = np.zeros(256 * 8 * 8, dtype = np.uint64)
+	assert lib.convasr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
+	s = buf.reshape(256, 8, 8).astype(np.float64)
+	names = ['prologue', 'dma_issue', 'lds+mfma', 'vmcnt_wait', 'barrier_wait', 'loop_total', 'epilogue', 'tile_total']
+	P = (cin // 64) * ((k + 1) // 2)
+	for grp, sl in (('waves 0-3', slice(0, 4)), ('waves 4-7', slice(4, 8))):
+		m = s[:, sl, :].mean(axis = (0, 1))
+		print(f'{cin}->{cout} k{k} {grp}: intervals {P}, per interval: ' + ', '.join(f'{n} {m[i] / P:.0f}' for i, n in enumerate(names) if 1 <= i <= 4) + f' | prologue {m[0]:.0f} epilogue {m[6]:.0f} loop {m[5]:.0f} tile {m[7]:.0f} cycles; MFMA-only floor per interval {64 * 16 if k > 1 else 32 * 16}', flush = True)
