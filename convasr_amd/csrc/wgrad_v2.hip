@@ -18,7 +18,8 @@
 #include "conv_common.h"
 #include <type_traits>
 
-#define W2_THREADS 512
+#define W2_THREADS 512             // computing waves 0-7
+#define W2_ALL_THREADS (512 + 256)  // + loader waves 8-11 (one per SIMD), which only issue the LDS-DMA pieces: see conv_v2s.hip
 #define W2_BKT 64
 #define W2_YBYTES (W2_BKT * 256)
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ uint4 w2_tr_frag(const char* p0, const char* p1) {
 	return make_uint4(l.x, l.y, h.x, h.y);
 }
 
-__global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradParams p) {
+__global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(WgradParams p) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 	const int y_row_bytes = p.Cout * 2, x_row_bytes = p.Cin * 2;
 	const int y_pieces = W2_BKT / 4, x_pieces = p.x_rows >> 2, pieces = y_pieces + x_pieces;
-	const int my_pieces = (pieces - wave + 7) >> 3;  // pieces j = wave + 8 i
+	const bool loader = wave >= 8;
+	const int lw = wave - 8;
+	const int my_pieces = (pieces - lw + 3) >> 2;  // loader wave lw issues pieces j = lw + 4 i
 	// per-lane source offset inside a 4-row piece: row (lane >> 4), 16-byte chunk (lane & 15) ^ (row << 2)
 	const int prow = lane >> 4, pchunk = (lane & 15) ^ (prow << 2);
 	const int ylane = prow * y_row_bytes + pchunk * 16 + co0 * 2, xlane = prow * x_row_bytes + pchunk * 16 + ci0 * 2;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 		const v4i32 xsrd = w2_make_srd(reinterpret_cast<const char*>(p.x) + (int64_t)b * p.Tin * x_row_bytes, (unsigned)(p.Tin * x_row_bytes));
 		const unsigned dst = lds_base + stage * stage_bytes;
 		const int tin0 = t0 - p.pad + tap0 * p.dil;
-		for (int j = wave; j < pieces; j += 8) {
+		for (int j = lw; j < pieces; j += 4) {
 			if (j < y_pieces) w2_dma16(ysrd, __builtin_amdgcn_readfirstlane(dst + j * 1024), (t0 + j * 4) * y_row_bytes + ylane);
 			else w2_dma16(xsrd, __builtin_amdgcn_readfirstlane(dst + W2_YBYTES + (j - y_pieces) * 1024), (tin0 + (j - y_pieces) * 4) * x_row_bytes + xlane);
 		}
@@ -106,9 +109,32 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 
 	// 4-stage ring, chunks issued THREE ahead: chunk c + 1 is already published while chunk c runs, so the first fragments
 	// of the next chunk are read before the barrier that ends this one (same software pipeline as conv_v2.hip).
-	for (int i = 0; i < 3; ++i)
-		if (c_begin + i < c_end) issue(c_begin + i, i);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (loader) {
+		for (int i = 0; i < 3; ++i)
+			if (c_begin + i < c_end) issue(c_begin + i, i);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		int stage = 0;
+		for (int c = c_begin; c < c_end; ++c) {
+			const bool more = c + 3 < c_end;
+			if (more) issue(c + 3, (stage + 3) & 3);
+			// leave only the pieces issued in this iteration (chunk c + 3) in flight
+			if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			else switch (my_pieces) {
+				case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+				case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+				case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+				case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+				case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+				case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+				default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+			}
+			__builtin_amdgcn_s_barrier();
+			stage = (stage + 1) & 3;
+		}
+		if (ntaps == 3 || ntaps == 1) __builtin_amdgcn_s_barrier();  // the epilogue's barrier of a tap shared by the two wave halves
+		return;
+	}
 	__builtin_amdgcn_s_barrier();
 
 	// fragment addressing: 16-lane group g4 -> (column block (g4 & 1) * 16, k block 8 * (g4 >> 1)); lane 4q + pc in the group
@@ -141,7 +167,6 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 		Mma<bf16_t>::run(a.u1, bq.u1, c[1][1]);
 	};
 
-	const bool late = wave >= 4;  // waves 4-7 issue their DMA pieces mid-chunk, waves 0-3 up front
 	// The chunk loop is instantiated per (slot A mask, slot B mask) so that every fragment load and MFMA group is unconditional
 	// inside it (runtime masks cost 5-14 %: waits at every branch join).
 	auto chunk_loop = [&](auto MA_, auto MB_) {
@@ -151,8 +176,6 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 		const unsigned st0 = lds_base;
 		if (c_begin < c_end) { if (MAB & 1u) load_a(st0, 0, fa0); if (MA & 1u) load_bA(st0, 0, fbA); }
 		for (int c = c_begin; c < c_end; ++c) {
-			const bool more = c + 3 < c_end;
-			if (more && !late) issue(c + 3, (stage + 3) & 3);
 			const unsigned st = lds_base + stage * stage_bytes, stn = lds_base + ((stage + 1) & 3) * stage_bytes;
 			const bool has_next = c + 1 < c_end;
 			// unit (kk, A): MFMAs on (fa, fbA) while the slot-B fragments arrive; unit (kk, B): MFMAs on (fa, fbB) while the next
@@ -165,15 +188,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv1d_wgrad_v2_kernel(WgradPar
 			if ((MB >> KK) & 1u) mma4(FA_CUR, fbB, acc[1]);
 			W2_SUBSTEP(0, fa0, fa1)
 			W2_SUBSTEP(1, fa1, fa0)
-			if (more && late) issue(c + 3, (stage + 3) & 3);
 			W2_SUBSTEP(2, fa0, fa1)
 			W2_SUBSTEP(3, fa1, fa0)
 #undef W2_SUBSTEP
-			// leave only the pieces issued in this iteration (chunk c + 3) in flight
-			if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-			else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();
 			stage = (stage + 1) & 3;
 		}
@@ -239,12 +256,12 @@ int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s) {
 	wgrad_plan(q, W2_BKT, 1.6);
 	q.x_rows = (q.x_rows + 3) & ~3;
 	const int pieces = W2_BKT / 4 + q.x_rows / 4;
-	if (pieces > 40) return 0;  // at most 5 pieces per wave: the counted waits above
+	if (pieces > 40) return 0;  // at most 10 pieces per loader wave: the counted waits above
 	const size_t smem = 4 * (size_t)(W2_YBYTES + q.x_rows * 256);
 	if (smem > 160 * 1024) return 0;
 	static bool set = false;
 	if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-	hipLaunchKernelGGL(conv1d_wgrad_v2_kernel, dim3(q.units * q.splits), dim3(W2_THREADS), smem, s, q);
+	hipLaunchKernelGGL(conv1d_wgrad_v2_kernel, dim3(q.units * q.splits), dim3(W2_ALL_THREADS), smem, s, q);
 	p = q;
 	return 1;
 }
