@@ -215,6 +215,7 @@ template <typename L, typename U> __device__ __forceinline__ void walk_rows2(con
 __device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) { dropout_mask8(p.seed, p.offset, p.drop_thr, p.keep_scale, idx, keep); }
 
 template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra) {
+	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	const int c8 = p.C >> 3;
 	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
 	for (int cbase = blockIdx.y * p.cgroups; cbase < c8; cbase += gridDim.y * p.cgroups) {
@@ -234,7 +235,7 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(B
 					float yv[8], pre[8];
 					pre_act8<T>(p, ra, w.idx, c, sc, sh, yraw, yv, pre);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], p.act, p.lo, p.hi);
+					for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], ac);
 					if (p.drop_thr) {
 						float keep[8];
 						dropout_keep8(p, w.idx, keep);
@@ -295,6 +296,7 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 // workspace [set][block][2C]; bn_bwd_finalize_kernel sums the blocks in fp64: deterministic, and no contended fp64 atomics
 // (4096 blocks x 2C atomics per call cost 4x the streaming time).
 template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, float* __restrict__ ws) {
+	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	__shared__ float red[256][17];
 	const int c8 = p.C >> 3;
 	const int cgroups = p.cgroups, rlanes = p.rlanes;
@@ -323,7 +325,7 @@ template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bw
 						pre_act8<T>(p, ra, w.idx, c, sc, sh, q.y, yv, pre);
 						unpack8(q.dz, dz);
 #pragma unroll
-						for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+						for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], ac);
 						if (p.drop_thr) {
 							float keep[8];
 							dropout_keep8(p, w.idx, keep);
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 // dy = A[c] * g + Bc[c] * y + D[c] with g either given (FROM_DZ = false) or recomputed from dz: g = dz * act'(pre) * dropout * mask
 template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
+	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	const int c8 = p.C >> 3;
 	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
 	ResArgs none;
@@ -577,7 +580,7 @@ template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_ac
 						float dz[8];
 						unpack8(q.dz, dz);
 #pragma unroll
-						for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], p.act, p.lo, p.hi);
+						for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(pre[k], ac);
 						if (p.drop_thr) {
 							float keep[8];
 							dropout_keep8(p, w.idx, keep);

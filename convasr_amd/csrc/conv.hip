@@ -147,6 +147,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 	char* const otile = smem;
 	float* const red = reinterpret_cast<float*>(smem + BM * OPITCH);  // [2 (sum, sumsq)][2 (wm)][BN]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
+	const ActConst ac = act_const(p.act, p.act_lo, p.act_hi);
 #pragma unroll
 	for (int ni = 0; ni < 2; ++ni) {
 		const int col = wn * 64 + ni * 32 + r, co = co0 + col;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 				const int t = t0 + row;
 				float val = acc[mi][ni][g] + bias;
 				if (t < p.Tout) { s1 += val; s2 += val * val; }
-				val = apply_act(val * sc + sh, p.act, p.act_lo, p.act_hi);
+				val = apply_act(val * sc + sh, ac);
 				if (t >= nvalid) val = 0.f;
 				Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
 			}

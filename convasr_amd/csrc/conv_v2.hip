@@ -219,6 +219,7 @@ template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void
 	char* const otile = smem;
 	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
+	const ActConst ac = act_const(p.act, p.act_lo, p.act_hi);
 #pragma unroll
 	for (int ni = 0; ni < 2; ++ni) {
 		const int col = wn * 64 + ni * 32 + r, co = co0 + col;
@@ -234,7 +235,7 @@ template <typename O, int MODE> __global__ __launch_bounds__(V2_THREADS, 2) void
 				const int t = t0 + row;
 				float val = acc[mi][ni][g] + bias;
 				if (t < p.Tout) { s1 += val; s2 += val * val; }
-				val = apply_act(val * sc + sh, p.act, p.act_lo, p.act_hi);
+				val = apply_act(val * sc + sh, ac);
 				if (t >= nvalid) val = 0.f;
 				Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
 			}

@@ -187,6 +187,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	char* const otile = smem;
 	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN_]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
+	const ActConst ac = act_const(p.act, p.act_lo, p.act_hi), bn_ac = act_const(p.bn_act, p.bn_lo, p.bn_hi);
 	// fused BN-backward epilogue (see below): the consumer layer's y tile is fetched now, 16 B per lane and store-loop trip, so
 	// that its latency hides under the accumulator staging (loading it inside the store loop cost ~8 serial L2/HBM round trips per tile)
 	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
@@ -215,7 +216,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				const int t = t0 + row;
 				float val = acc[mi][ni][g] + bias;
 				if (t < p.Tout) { s1 += val; s2 += val * val; }
-				val = apply_act(val * sc + sh, p.act, p.act_lo, p.act_hi);
+				val = apply_act(val * sc + sh, ac);
 				if (t >= nvalid) val = 0.f;
 				Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
 			}
@@ -226,7 +227,12 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 			if (kb == 0) { red[(0 * 4 + wm) * BN_ + col] = s1; red[(1 * 4 + wm) * BN_ + col] = s2; }
 		}
 	}
+#ifdef CONVASR_STAMPS
+	unsigned long long t_e1 = 0, t_e2 = 0, t_e3 = 0;
+	STAMP(t_e1)
+#endif
 	__syncthreads();
+	STAMP(t_e2)
 	if (p.stats && tid < BN_ && co0 + tid < p.Cout) {
 		double a = 0, q2 = 0;
 #pragma unroll
@@ -235,6 +241,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		prow[co0 + tid] = a;
 		prow[p.Cout + co0 + tid] = q2;
 	}
+	STAMP(t_e3)
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN_ / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
@@ -272,7 +279,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(w[k] << 16); yv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
 			}
 #pragma unroll
-			for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(fmaf(yv[k], bsc[k], bsh[k]), p.bn_act, p.bn_lo, p.bn_hi);
+			for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(fmaf(yv[k], bsc[k], bsh[k]), bn_ac);
 			if (p.bn_drop_thr) {
 				float keep[8];
 				dropout_mask8(p.bn_seed, p.bn_offset, p.bn_drop_thr, p.bn_keep_scale, idx, keep);
@@ -301,7 +308,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	STAMP(t_end)
 	if (blockIdx.x < 256 && lane == 0) {
 		unsigned long long* o = g_v2s_stamps + (blockIdx.x * 8 + wave) * 8;
-		o[0] = t_loop0 - t_start; o[1] = acc_issue; o[2] = acc_work; o[3] = acc_vm; o[4] = acc_bar; o[5] = t_epi0 - t_loop0; o[6] = t_end - t_epi0; o[7] = t_end - t_start;
+		o[0] = t_loop0 - t_start; o[1] = t_e1 - t_epi0; o[2] = acc_work; o[3] = t_e2 - t_e1; o[4] = acc_bar; o[5] = t_e3 - t_e2; o[6] = t_end - t_e3; o[7] = t_end - t_start;
 	}
 #endif
 }

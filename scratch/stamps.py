@@ -17,8 +17,8 @@ for (cin, cout, k, dil) in [(768, 768, 11, 1), (256, 256, 11, 1), (512, 512, 11,
 	buf = np.zeros(256 * 8 * 8, dtype = np.uint64)
 	assert lib.convasr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
 	s = buf.reshape(256, 8, 8).astype(np.float64)
-	names = ['prologue', 'dma_issue', 'lds+mfma', 'vmcnt_wait', 'barrier_wait', 'loop_total', 'epilogue', 'tile_total']
+	names = ['prologue', 'epi_acc_to_lds', 'lds+mfma', 'epi_barrier', 'barrier_wait', 'epi_stats', 'epi_store_loop', 'tile_total']
 	P = (cin // 64) * ((k + 1) // 2)
 	for grp, sl in (('waves 0-3', slice(0, 4)), ('waves 4-7', slice(4, 8))):
 		m = s[:, sl, :].mean(axis = (0, 1))
-		print(f'{cin}->{cout} k{k} {grp}: intervals {P}, per interval: ' + ', '.join(f'{n} {m[i] / P:.0f}' for i, n in enumerate(names) if 1 <= i <= 4) + f' | prologue {m[0]:.0f} epilogue {m[6]:.0f} loop {m[5]:.0f} tile {m[7]:.0f} cycles; MFMA-only floor per interval {64 * 16 if k > 1 else 32 * 16}', flush = True)
+		print(f'{cin}->{cout} k{k} {grp}: intervals {P}, per interval: ' + f'lds+mfma {m[2] / P:.0f} barrier_wait {m[4] / P:.0f} | prologue {m[0]:.0f} | epilogue: acc->LDS {m[1]:.0f} barrier {m[3]:.0f} stats {m[5]:.0f} store loop {m[6]:.0f} | tile {m[7]:.0f} cycles', flush = True)
