@@ -201,31 +201,50 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 			if (t < p.Tout && co < p.Cout) ypre[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + ((int64_t)b * p.Tout + t) * p.Cout + co);
 		}
 	}
+	// Accumulators -> bf16 / fp32 output tile in LDS (+ the BN statistics of a forward launch).  64 values per lane: this phase is
+	// VALU-issue bound (in-kernel stamps: ~6,500 cycles per tile in its general form), so the launches of a training step -- no bias,
+	// no folded scale / shift, no activation, no length mask in the conv itself -- take a specialised instantiation that does
+	// nothing but (statistics,) convert and store; tiles that end inside the utterance also drop the row predicate.  Same
+	// arithmetic on the same values in the same order: bit-identical to the general form.
+	auto stage = [&](auto PLAIN_, auto FULL_, auto STATS_) {
+		constexpr bool PLAIN = decltype(PLAIN_)::value, FULL = decltype(FULL_)::value, STATS = decltype(STATS_)::value;
 #pragma unroll
-	for (int ni = 0; ni < NB; ++ni) {
-		const int col = wn * (16 * NB) + ni * 16 + r16, co = co0 + col;
-		const bool cok = co < p.Cout;
-		const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
-		const float sc = (p.scale && cok) ? p.scale[co] : 1.f, sh = (p.scale && cok) ? p.shift[co] : 0.f;
-		float s1 = 0.f, s2 = 0.f;
+		for (int ni = 0; ni < NB; ++ni) {
+			const int col = wn * (16 * NB) + ni * 16 + r16, co = co0 + col;
+			const bool cok = co < p.Cout;
+			const float bias = (!PLAIN && p.bias && cok) ? p.bias[co] : 0.f;
+			const float sc = (!PLAIN && p.scale && cok) ? p.scale[co] : 1.f, sh = (!PLAIN && p.scale && cok) ? p.shift[co] : 0.f;
+			float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-		for (int mi = 0; mi < 4; ++mi) {
+			for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				const int row = wm * 64 + mi * 16 + kb * 4 + g;
-				const int t = t0 + row;
-				float val = acc[mi][ni][g] + bias;
-				if (t < p.Tout) { s1 += val; s2 += val * val; }
-				val = apply_act(val * sc + sh, ac);
-				if (t >= nvalid) val = 0.f;
-				Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
+				for (int g = 0; g < 4; ++g) {
+					const int row = wm * 64 + mi * 16 + kb * 4 + g;
+					const int t = t0 + row;
+					float val = acc[mi][ni][g];
+					if (!PLAIN) val += bias;
+					if (STATS && (FULL || t < p.Tout)) { s1 += val; s2 += val * val; }
+					if (!PLAIN) {
+						val = apply_act(val * sc + sh, ac);
+						if (t >= nvalid) val = 0.f;
+					}
+					Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
+				}
+			}
+			if (STATS) {
+				s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+				s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+				if (kb == 0) { red[(0 * 4 + wm) * BN_ + col] = s1; red[(1 * 4 + wm) * BN_ + col] = s2; }
 			}
 		}
-		if (p.stats) {
-			s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-			s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-			if (kb == 0) { red[(0 * 4 + wm) * BN_ + col] = s1; red[(1 * 4 + wm) * BN_ + col] = s2; }
-		}
+	};
+	{
+		typedef std::true_type Y;
+		typedef std::false_type N;
+		const bool plain = !p.bias && !p.scale && p.act == CONVASR_ACT_NONE && !p.xlen, full = t0 + V2_BM <= p.Tout;
+		if (!plain) { if (p.stats) stage(N(), N(), Y()); else stage(N(), N(), N()); }
+		else if (p.stats) { if (full) stage(Y(), Y(), Y()); else stage(Y(), N(), Y()); }
+		else stage(Y(), Y(), N());
 	}
 #ifdef CONVASR_STAMPS
 	unsigned long long t_e1 = 0, t_e2 = 0, t_e3 = 0;
