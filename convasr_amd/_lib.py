@@ -81,6 +81,7 @@ def load():
 		lib = ctypes.CDLL(LIB_PATH)
 		if hasattr(lib, 'convasr_debug_read_stamps'):  # diagnostic builds only (build.py --variant ... -DCONVASR_STAMPS=1)
 			lib.convasr_debug_read_stamps.restype, lib.convasr_debug_read_stamps.argtypes = c_int, [c_p, c_int]
+			lib.convasr_debug_read_wgrad_stamps.restype, lib.convasr_debug_read_wgrad_stamps.argtypes = c_int, [c_p, c_int]
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args

@@ -25,6 +25,17 @@
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
+#ifdef CONVASR_STAMPS
+// diagnostic build only (see conv_v2s.hip): per-wave cycle sums of the chunk loop's segments
+__device__ unsigned long long g_w2_stamps[256 * 8 * 8];
+extern "C" int convasr_debug_read_wgrad_stamps(unsigned long long* host, int count) {
+	return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w2_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#define WSTAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WSTAMP(var)
+#endif
+
 __device__ __forceinline__ v4i32 w2_make_srd(const char* base, unsigned num_bytes) {
 	const unsigned long long a = (unsigned long long)base;
 	v4i32 d;
@@ -136,6 +147,10 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 		return;
 	}
 	__builtin_amdgcn_s_barrier();
+#ifdef CONVASR_STAMPS
+	unsigned long long wa = 0, wb = 0, wc = 0, w_work = 0, w_bar = 0, w_t0 = 0, w_t1 = 0, w_t2 = 0;
+	WSTAMP(w_t0)
+#endif
 
 	// fragment addressing: 16-lane group g4 -> (column block (g4 & 1) * 16, k block 8 * (g4 >> 1)); lane 4q + pc in the group
 	// supplies row q, columns 4 pc .. 4 pc + 3 of the 4 x 16 block (ds_read_b64_tr_b16 contract).  Row (r & 3) is q for every
@@ -176,22 +191,27 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 		const unsigned st0 = lds_base;
 		if (c_begin < c_end) { if (MAB & 1u) load_a(st0, 0, fa0); if (MA & 1u) load_bA(st0, 0, fbA); }
 		for (int c = c_begin; c < c_end; ++c) {
+			WSTAMP(wa)
 			const unsigned st = lds_base + stage * stage_bytes, stn = lds_base + ((stage + 1) & 3) * stage_bytes;
-			const bool has_next = c + 1 < c_end;
 			// unit (kk, A): MFMAs on (fa, fbA) while the slot-B fragments arrive; unit (kk, B): MFMAs on (fa, fbB) while the next
 			// substep's dY and slot-A fragments arrive.  fa0 / fa1 alternate by kk parity.
 #define W2_SUBSTEP(KK, FA_CUR, FA_NXT)                                                                                              \
 			if ((MB >> KK) & 1u) load_bB(st, KK, fbB);                                                                                  \
 			if ((MA >> KK) & 1u) mma4(FA_CUR, fbA, acc[0]);                                                                             \
 			if (KK < 3) { if ((MAB >> ((KK + 1) & 3)) & 1u) load_a(st, KK + 1, FA_NXT); if ((MA >> ((KK + 1) & 3)) & 1u) load_bA(st, KK + 1, fbA); } \
-			else if (has_next) { if (MAB & 1u) load_a(stn, 0, FA_NXT); if (MA & 1u) load_bA(stn, 0, fbA); }                             \
+			else { if (MAB & 1u) load_a(stn, 0, FA_NXT); if (MA & 1u) load_bA(stn, 0, fbA); }  /* unconditional: after the last chunk it reads a stage nobody needs (a conditional LDS load costs a full lgkmcnt drain at the join) */ \
 			if ((MB >> KK) & 1u) mma4(FA_CUR, fbB, acc[1]);
 			W2_SUBSTEP(0, fa0, fa1)
 			W2_SUBSTEP(1, fa1, fa0)
 			W2_SUBSTEP(2, fa0, fa1)
 			W2_SUBSTEP(3, fa1, fa0)
 #undef W2_SUBSTEP
+			WSTAMP(wb)
 			__builtin_amdgcn_s_barrier();
+			WSTAMP(wc)
+#ifdef CONVASR_STAMPS
+			w_work += wb - wa; w_bar += wc - wb;
+#endif
 			stage = (stage + 1) & 3;
 		}
 	};
@@ -204,6 +224,7 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 	else if (ntaps == 2) chunk_loop(M15(), M0());
 	else { if (tp) chunk_loop(M12(), M0()); else chunk_loop(M3(), M0()); }
 
+	WSTAMP(w_t1)
 	// epilogue: a tap shared by the two wave halves is summed through LDS (the ring is dead after the last barrier), the lower
 	// half stores it; [wave & 3][register][lane] floats = 64 KiB
 	const int r = lane & 31, h = lane >> 5;
@@ -246,6 +267,13 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 				}
 			}
 	}
+#ifdef CONVASR_STAMPS
+	WSTAMP(w_t2)
+	if (blockIdx.x < 256 && lane == 0) {
+		unsigned long long* o = g_w2_stamps + (blockIdx.x * 8 + wave) * 8;
+		o[0] = w_work; o[1] = w_bar; o[2] = w_t1 - w_t0; o[3] = w_t2 - w_t1; o[4] = (unsigned long long)(c_end - c_begin);
+	}
+#endif
 }
 
 // Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
