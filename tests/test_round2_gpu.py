@@ -387,3 +387,47 @@ def test_bench_launches_two_ranks_sharing_the_gpu():
 	out = json.loads(lines[0])
 	assert out['n_gpus'] == 2 and out['dist']['world_size'] == 2 and out['dist']['backend'] == 'gloo' and out['config']['global_batch'] == 128
 	assert out['value'] > 0 and np.isfinite(out['loss'])
+
+
+def test_transcribe_setup_and_batch_match_the_reference_body():
+	"""convasr_amd.transcribe against vectors produced by running the reference's own classes through the body of transcribe.main
+	(tests/golden/make_golden_r2.py: fused-eval forward with the (log_probs, logits, olen) dict of transcribe.setup, time stamps,
+	GreedyCTCGenerator with time stamps, ctc.alignment of the targets, ref segments).  fp32: log-probs to 1e-4, olen equal, every
+	hyp segment's text identical and its begin / end to 1e-5 s, the alignment bit-exact, ref segments identical.  bf16 (args.fp16
+	= 'O2'): character error rate of the joined strings against the fp32 reference <= 3 % (one or two frames flip on near-ties)."""
+	import json
+	import types
+	import convasr_amd as ca
+	root = os.path.dirname(os.path.abspath(__file__))
+	g = np.load(os.path.join(root, 'golden', 'transcribe.npz'))
+	j = json.load(open(os.path.join(root, 'golden', 'transcribe.json')))
+	T_ = lambda a: torch.as_tensor(np.asarray(a))
+	sd = {k[3:]: T_(g[k]) for k in g.files if k.startswith('sd/')}
+	ckpt_args = dict(j['args'], alphabet = j['alphabet'], model_kwargs = dict(base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.2], out_width_factors_large = [2, 2], residual = False, repeat = 1, nonlinearity = ('hardtanh', 0, 20), dilation = 2))
+	want_segments, want_ref = j['hyp_segments'], j['ref_segments']
+	for opt_level in (None, 'O2'):
+		args = types.SimpleNamespace(checkpoint = dict(args = dict(ckpt_args), model_state_dict = {k: v.clone() for k, v in sd.items()}), device = 'cuda:0', fp16 = opt_level, frontend_in_model = True, model = None, align = True)
+		text_pipeline, frontend, model, generator = ca.transcribe.setup(args)
+		assert not torch.is_grad_enabled() and not model.training and isinstance(model.backbone[0].bn[0], torch.nn.Identity)
+		assert model.compute_dtype == (torch.float32 if opt_level is None else torch.bfloat16) and args.sample_rate == 16000
+		res = ca.transcribe.transcribe_batch(args, text_pipeline, model, generator, T_(g['wav']).unsqueeze(1), T_(g['xlen']), T_(g['begin']), T_(g['end']), y = T_(g['y']), ylen = T_(g['ylen']), segment_extra_info = j['extra'])
+		assert torch.equal(res.olen.cpu(), T_(g['olen']))
+		if opt_level is None:
+			err = float((res.log_probs.cpu() - T_(g['log_probs'])).abs().max())
+			assert err <= 1e-4, err
+			assert float((res.ts.cpu() - T_(g['ts'])).abs().max()) <= 1e-6
+			assert torch.equal(res.alignment.cpu(), T_(g['alignment']))
+			for got_list, want_list, key in ((res.hyp_segments, want_segments, 'hyp'), (res.ref_segments, want_ref, 'ref')):
+				assert [len(s) for s in got_list] == [len(s) for s in want_list]
+				for got, want in zip(sum(got_list, []), sum(want_list, [])):
+					assert got[key] == want[key] and got['speaker'] == want['speaker'] and got['channel'] == want['channel'], (got, want)
+					assert abs(got['begin'] - want['begin']) <= 1e-5 and abs(got['end'] - want['end']) <= 1e-5, (got, want)
+		if opt_level is None:
+			assert res.hyp == j['hyp'], (res.hyp, j['hyp'])
+		else:  # bf16: a frame whose top-2 margin is inside bf16's noise may flip; character error rate against the fp32 reference strings
+			cer = sum(_edit_distance(a, b) for a, b in zip(res.hyp, j['hyp'])) / sum(len(b) for b in j['hyp'])
+			agree = float((res.log_probs.argmax(dim = 1).cpu() == T_(g['log_probs']).argmax(dim = 1)).float().mean())
+			print('bf16 transcribe: CER vs fp32 reference', cer, 'argmax agreement', agree)
+			assert cer <= 0.03 and agree >= 0.97, (cer, agree, res.hyp, j['hyp'])
+		assert all(len(h) > 20 for h in res.hyp)
+	torch.set_grad_enabled(True)
