@@ -249,8 +249,13 @@ def main(argv = None):
 	for i in range(args.warmup):
 		last = step(i)
 	fence()
+	# HIP events (on the launching stream) bracket every launch of the DOMINANT kernel inside the timed region.  The other kernel
+	# families (wgrad, the HBM-bound passes, the small layers) are event-timed in a second, untimed pass of a few steps right after
+	# it: an event pair costs ~5 us of stream time, and bracketing all ~110 launches of a step slowed the headline by 3.4 %
+	# (18.06 vs 17.47 ms per step on one device; bracketing the dominant kernel only: ~1 %).
+	main_family = 'conv1d_igemm_v2s_kernel<bf16>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
 	if not args.no_kernel_timer and rank == 0:
-		_lib.timer = _lib.KernelTimer()
+		_lib.timer = _lib.KernelTimer(only = [main_family, main_family + '+bn_bwd'])
 	t0 = time.perf_counter()
 	for i in range(args.steps):
 		last = step(args.warmup + i)
@@ -258,6 +263,17 @@ def main(argv = None):
 	elapsed = time.perf_counter() - t0
 	kt = _lib.timer.summary() if _lib.timer is not None else {}
 	_lib.timer = None
+	steps2 = 0
+	if not args.no_kernel_timer:
+		steps2 = min(args.steps, 5)
+		if rank == 0:
+			_lib.timer = _lib.KernelTimer()
+		for i in range(steps2):
+			step(args.warmup + args.steps + i)
+		fence()
+		if rank == 0:
+			kt2 = _lib.timer.summary()
+			_lib.timer = None
 	if use_dist:
 		t = torch.tensor([elapsed], dtype = torch.float64, device = device)
 		dist.all_reduce(t, op = dist.ReduceOp.MAX)
@@ -267,8 +283,12 @@ def main(argv = None):
 		audio_s = world * BATCH * SECS * args.steps
 		value = audio_s / elapsed
 		roof = None
-		main_name = 'conv1d_igemm_v2s_kernel<bf16>' if args.dtype == 'bf16' else 'conv1d_igemm (other variants)'
+		main_name = main_family
 		fused_name = main_name + '+bn_bwd'  # the same kernel symbol launched as a dgrad with the fused BN-backward epilogue (functional._dgrad)
+		if kt:  # every other family comes from the second pass (per-step figures use its own step count)
+			for name, v in kt2.items():
+				if name not in (main_name, fused_name):
+					kt[name] = dict(v, launches = v['launches'] * args.steps // steps2, total_ms = v['total_ms'] * args.steps / steps2, work = v['work'] * args.steps / steps2, bytes = v['bytes'] * args.steps / steps2)
 		plain = kt.get(main_name)
 		if main_name in kt and fused_name in kt:
 			a, f = kt[main_name], kt.pop(fused_name)
@@ -277,7 +297,7 @@ def main(argv = None):
 			peak = PEAK_BF16_DENSE / 1e12 if args.dtype == 'bf16' else 157.3
 			tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
 			k = kt[main_name]
-			roof = dict(bound = 'mfma', kernel = MAIN_KERNEL_SYMBOL + ' (16 forward + 17 dgrad launches; the dgrads also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3))
+			roof = dict(bound = 'mfma', kernel = MAIN_KERNEL_SYMBOL + ' (16 forward + 17 dgrad launches; the dgrads also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3), timing = f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it')
 			hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
 			kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
 			if plain is not None and plain is not k:

@@ -111,10 +111,13 @@ class KernelTimer:
 	"""HIP-event timing of selected launches on the stream they are launched on (bench.py's roofline leg).  Events are
 	recorded around the C-ABI call; elapsed times are read after the caller synchronises."""
 
-	def __init__(self):
+	def __init__(self, only = None):
 		self.records = {}
+		self.only = None if only is None else set(only)  # families to time; launches of other families run untouched (an event pair costs ~5 us of stream time)
 
 	def timed(self, family, work, fn, nbytes = 0.0):
+		if self.only is not None and family not in self.only:
+			return fn()
 		start, end = torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True)
 		start.record()
 		fn()
