@@ -1,30 +1,64 @@
-"""Turn the rocprofv3 CSVs under gpurun_out/ into the small committed summaries under profiles/."""
-import csv, glob, json, collections, sys, os
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-stats = glob.glob('gpurun_out/prof_r1e/*/*kernel_stats.csv')[0]
+"""Turn the rocprofv3 CSVs under gpurun_out/<tag>_* (scratch/r02_profiles.sh) into the small committed summaries under profiles/."""
+import csv, glob, json, collections, sys, os, shutil
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+G = 'gpurun_out'
+stats = glob.glob(f'{G}/{tag}_stats/**/*kernel_stats.csv', recursive = True)[0]
 rows = list(csv.DictReader(open(stats)))
 with open(f'profiles/{tag}_bench_kernel_stats.csv', 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (7 steps incl. warm-up)\n')
-    w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
-    for r in rows: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+	f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic   (7 steps of the headline region incl. warm-up + 5 steps of the second event pass = 12 training steps)\n')
+	w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+	for r in rows: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 traffic = {}
 for c in ['FETCH_SIZE', 'WRITE_SIZE']:
-    f = glob.glob(f'gpurun_out/pmc_bench_{c}/*/*counter_collection.csv')[0]
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)): agg[r['Kernel_Name']].append(float(r['Counter_Value']))
-    for k, v in agg.items(): traffic.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+	f = glob.glob(f'{G}/{tag}_pmc_{c}/**/*counter_collection.csv', recursive = True)[0]
+	agg = collections.defaultdict(list)
+	for r in csv.DictReader(open(f)): agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+	for k, v in agg.items(): traffic.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
 out = {}
 with open(f'profiles/{tag}_bench_hbm_traffic.csv', 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer\n')
-    f.write('# units: KB per dispatch (mean).  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE reports half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM)\n')
-    f.write('kernel,dispatches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_per_launch_corrected\n')
-    for k, v in sorted(traffic.items(), key = lambda kv: -(kv[1].get('FETCH_SIZE', (0, 0))[0])):
-        fs, n = v.get('FETCH_SIZE', (0, 0)); ws, _ = v.get('WRITE_SIZE', (0, 0))
-        hb = (2 * fs + ws) * 1024
-        f.write('"%s",%d,%.1f,%.1f,%.4g\n' % (k, n, fs, ws, hb))
-        out[k] = dict(dispatches = n, fetch_kb = fs, write_kb = ws, hbm_bytes_per_launch = hb)
-json.dump({k: v for k, v in out.items() if 'conv1d' in k}, open(f'profiles/{tag}_conv_traffic.json', 'w'), indent = 1)
-for k, v in out.items():
-    if 'conv1d' in k: print(k[:70], v)
+	f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-traffic\n')
+	f.write('# units: KB per dispatch (mean).  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE reports half of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM)\n')
+	f.write('kernel,dispatches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_per_launch_corrected\n')
+	for k, v in sorted(traffic.items(), key = lambda kv: -(kv[1].get('FETCH_SIZE', (0, 0))[0])):
+		fs, n = v.get('FETCH_SIZE', (0, 0)); ws, _ = v.get('WRITE_SIZE', (0, 0))
+		hb = (2 * fs + ws) * 1024
+		f.write('"%s",%d,%.1f,%.1f,%.4g\n' % (k, n, fs, ws, hb))
+		out[k] = dict(dispatches = n, fetch_kb = fs, write_kb = ws, hbm_bytes_per_launch = hb)
+conv = {k: v for k, v in out.items() if 'conv1d' in k or 'wgrad' in k}
+# both instantiations of the dominant kernel together (what bench.py's roofline.traffic reports)
+both = [v for k, v in conv.items() if 'conv1d_igemm_v2s_kernel<unsigned short' in k]
+if both:
+	n = sum(v['dispatches'] for v in both)
+	conv['conv1d_igemm_v2s_kernel<unsigned short, false / true> (all launches)'] = dict(dispatches = n, fetch_kb = sum(v['fetch_kb'] * v['dispatches'] for v in both) / n, write_kb = sum(v['write_kb'] * v['dispatches'] for v in both) / n, hbm_bytes_per_launch = sum(v['hbm_bytes_per_launch'] * v['dispatches'] for v in both) / n)
+json.dump(conv, open(f'profiles/{tag}_conv_traffic.json', 'w'), indent = 1)
+# SQ counters + clocks of the MFMA kernels
+def pmc(dirname):
+	f = glob.glob(f'{G}/{dirname}/**/*counter_collection.csv', recursive = True)[0]
+	agg = collections.defaultdict(lambda: collections.defaultdict(list))
+	for r in csv.DictReader(open(f)): agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+	kt = glob.glob(f'{G}/{dirname}/**/*kernel_trace.csv', recursive = True)[0]
+	dur = collections.defaultdict(list)
+	for r in csv.DictReader(open(kt)): dur[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+	return agg, dur
+sq, _ = pmc(f'{tag}_pmc_sq')
+clk, dur = pmc(f'{tag}_pmc_clk')
+summary = {}
+for k in sq:
+	if not any(s in k for s in ('conv1d_igemm_v2s', 'conv1d_wgrad_v2', 'bn_act_fwd', 'bn_act_bwd_apply')): continue
+	m = {c: sum(v) / len(v) for c, v in sq[k].items()}
+	w = m['SQ_WAVE_CYCLES']
+	e = dict(dispatches = len(sq[k]['SQ_WAVE_CYCLES']), **{c: round(v) for c, v in m.items()})
+	e['wait_any_over_wave_cycles'] = round(m['SQ_WAIT_ANY'] / w, 4); e['wait_inst_any_over_wave_cycles'] = round(m['SQ_WAIT_INST_ANY'] / w, 4); e['active_inst_over_wave_cycles'] = round(m['SQ_ACTIVE_INST_ANY'] / w, 4)
+	if m.get('SQ_LDS_IDX_ACTIVE'): e['lds_bank_conflict_over_lds_active'] = round(m['SQ_LDS_BANK_CONFLICT'] / m['SQ_LDS_IDX_ACTIVE'], 4)
+	if k in clk:
+		g = sum(clk[k]['GRBM_GUI_ACTIVE']) / len(clk[k]['GRBM_GUI_ACTIVE']); d = sum(dur[k]) / len(dur[k]); mf = sum(clk[k]['SQ_VALU_MFMA_BUSY_CYCLES']) / len(clk[k]['SQ_VALU_MFMA_BUSY_CYCLES'])
+		e['avg_duration_us_under_pmc'] = round(d / 1e3, 1); e['effective_clock_ghz'] = round(g / 8 / d, 3); e['mfma_busy_over_simd_cycles'] = round(mf / (1024 * g / 8), 4)
+	summary[k] = e
+json.dump(dict(note = 'rocprofv3 --kernel-trace --pmc (8 SQ counters in one pass; GRBM_GUI_ACTIVE + SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES in a second) over bench.py --steps 2 --warmup 1; means per dispatch.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles; effective clock = GRBM_GUI_ACTIVE / 8 / duration; mfma_busy_over_simd_cycles = MFMA busy cycles / (1024 SIMDs x kernel cycles)', kernels = summary), open(f'profiles/{tag}_pmc_sq.json', 'w'), indent = 1)
+for name in ('bench_line', 'launcher_n1', 'rccl_world1', 'plain_n1'):
+	src = f'{G}/{tag}_{name}.json'
+	if os.path.exists(src) and os.path.getsize(src) > 0: shutil.copy(src, f'profiles/{tag}_{name}.json')
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-for r in rows[:12]: print('%-80s %6s calls  avg %8.1f us  %5.1f%%' % (r['Name'][:80], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
+for r in rows[:14]: print('%-80s %6s calls  avg %8.1f us  %5.1f%%' % (r['Name'][:80], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
+for k, v in conv.items(): print(k[:75], round(v['hbm_bytes_per_launch'] / 1e6, 1), 'MB/launch')
+for k, v in summary.items(): print(k[:60], {a: b for a, b in v.items() if 'over' in a or 'clock' in a})
