@@ -42,6 +42,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Virtual tile id -> (m tile, n tile), blocked for the per-XCD L2: consecutive ids walk a 16 (m) x 2 (n) block of tiles, so the ~32
+// workgroups an XCD runs at a time share 16 X tiles and the weight tiles of 2 n tiles (~11 MB of L2 fills per round of a 768-channel
+// layer) instead of ~5 X tiles and ALL n tiles (~15 MB).  m blocks outermost, then n pairs, then m, n fastest; any M, N.
+__device__ __forceinline__ void tile_coords(int v, int M, int N, int& m, int& n) {
+	constexpr int MB = 16, NT = 2;
+	const int mb = v / (MB * N);
+	const int rows = min(MB, M - mb * MB);
+	const int w = v - mb * MB * N;
+	const int ng = w / (rows * NT);
+	const int width = min(NT, N - ng * NT);
+	const int w2 = w - ng * rows * NT;
+	m = mb * MB + w2 / width;
+	n = ng * NT + w2 % width;
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
 	static constexpr int EPC = 8;  // elements per 16-byte chunk

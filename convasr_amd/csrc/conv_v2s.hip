@@ -30,7 +30,8 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
 
-	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
+	int ntile, mtile;
+	tile_coords(v, p.B * p.m_tiles_per_b, p.n_tiles, mtile, ntile);
 	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * V2_BM;
 	const int co0 = ntile * BN + half * BN_;
 	const int tin0 = t0 - p.pad;
