@@ -279,9 +279,10 @@ int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles
 	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
-	int mode = (p.K < 2 && !p.bn_y) ? 0 : ((p.debug & 64) ? 1 : 2);  // a K = 1 dgrad that carries the fused BN-backward epilogue runs in conv_v2s.hip's loop (5 % slower than the K = 1 path, but it saves the separate reduce pass)
+	int mode = (p.K < 2 && (p.debug & 16)) ? 0 : ((p.debug & 64) ? 1 : 2);  // K = 1 runs in conv_v2s.hip's loop too (three X slab buffers, read-ahead across the barrier); debug bit 16: the older K = 1 kernel
 	const bool small_shape_ = mode == 2 && ((p.debug & 128) != 0) == (V2_DEFAULT_SMALL_SHAPE == 0);
 	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + (mode == 0 ? 3 : (small_shape_ ? 5 : 4)) * V2_WSLOT;  // conv_v2s.hip: 3 + 2 weight slots
+	if (small_shape_ && p.K == 1) smem = 3 * (size_t)p.x_rows * ROW_BYTES + 3 * V2_WSLOT;  // ... and for K = 1 three X slab buffers + the 3-slot ring
 	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
 	if (epi > smem) smem = epi;
 	if (smem > 160 * 1024) return 0;

@@ -37,6 +37,11 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	const int tin0 = t0 - p.pad;
 
 	const int xbytes = p.x_rows * ROW_BYTES;
+	// X slab buffers: two (the slab being read + the next one landing); K = 1 has ONE interval per slab, so reading the next interval's first
+	// fragments ahead of the barrier needs the next slab resident one interval earlier: three buffers (and only the 3-slot weight ring)
+	const bool k1 = p.K == 1;
+	auto xoff = [&](int c) { return (unsigned)((k1 ? c % 3 : (c & 1)) * xbytes); };
+	const unsigned wbase = (k1 ? 3 : 2) * xbytes;
 	const int row_bytes = p.Cin * 2;
 	const v4i32 xsrc = make_srd(reinterpret_cast<const bf16_t*>(p.x) + (int64_t)b * p.Tin * p.Cin, (unsigned)(p.Tin * row_bytes));
 	const v4i32 wsrc = make_srd(p.w, (unsigned)(p.K * p.CoutPad * row_bytes));
@@ -53,7 +58,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	const int lw = wave - 8;
 	const int xlane = v2_src_offset(lane, row_bytes), xlane_odd = v2_src_offset(64 + lane, row_bytes) - 8 * row_bytes;
 	auto issue_x = [&](int cib) {
-		const unsigned dst = lds_base + (cib & 1) * xbytes;
+		const unsigned dst = lds_base + xoff(cib);
 		const int base = tin0 * row_bytes + cib * 128;
 		for (int u = lw; u < x_units; u += 4)
 			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + ((u & 1) ? xlane_odd : xlane));
@@ -63,7 +68,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 #pragma unroll
 	for (int j = 0; j < PPL; ++j) wl[j] = v2_src_offset((lw * PPL + j) * 64 + lane, row_bytes);
 	auto issue_w = [&](int q_cib, int q_tap, int slot) {
-		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * xbytes + slot * V2_WSLOT + lw * (1024 * PPL));
+		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wbase + slot * V2_WSLOT + lw * (1024 * PPL));
 		const int base = (q_tap * p.CoutPad + co0) * row_bytes + q_cib * 128;
 #pragma unroll
 		for (int j = 0; j < PPL; ++j) dma16(wsrc, dst + j * 1024, base + wl[j]);
@@ -81,7 +86,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	// lane (r16, kb) holds k = 8 kb .. 8 kb + 7 of row r16: 16-byte chunk (ks * 4 + kb) of the 128-byte slab row.  Rows 16 apart
 	// share the swizzle term (+2048 B immediates); the second k32 substep is `address ^ 64`.
 	const int wrow = wn * (16 * NB) + r16;
-	const unsigned w0 = lds_base + 2 * xbytes + ((wrow >> 1) << 8) + ((((wrow & 1) << 3) | (kb ^ ((wrow >> 1) & 7))) << 4);
+	const unsigned w0 = lds_base + wbase + ((wrow >> 1) << 8) + ((((wrow & 1) << 3) | (kb ^ ((wrow >> 1) & 7))) << 4);
 	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int ks, Frag& f) {
 		const int xrow = wm * 64 + r16 + tap_ * p.dil;
 		const unsigned xa = (lds_base + xs_off + ((xrow >> 1) << 8) + ((((xrow & 1) << 3) | (kb ^ ((xrow >> 1) & 7))) << 4)) ^ (ks << 6);
@@ -115,6 +120,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		auto o_slot = [](int s_) { return (unsigned)((3 + (s_ & 1)) * V2_WSLOT); };
 		if (loader) {
 			issue_x(0);
+			if (k1 && n_cib > 1) issue_x(1);
 			issue_w(0, 0, 0);
 			if (p.K > 1) issue_w(0, 1, 3);
 			if (P > 1) { if (npb > 1) issue_w(0, 2, 1); else issue_w(1, 0, 1); }
@@ -128,7 +134,8 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				if (pi2 == npb) { pi2 = 0; ++cib2; }
 				if (sidx + 2 < P) issue_w(cib2, 2 * pi2, (sidx + 2) % 3);
 				if (sidx + 1 < P && 2 * pi1 + 1 < p.K) issue_w(cib1, 2 * pi1 + 1, 3 + ((sidx + 1) & 1));
-				if (pi == 0 && cib + 1 < n_cib) issue_x(cib + 1);
+				if (k1) { if (cib + 2 < n_cib) issue_x(cib + 2); }
+				else if (pi == 0 && cib + 1 < n_cib) issue_x(cib + 1);
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				__builtin_amdgcn_s_barrier();
 				cib = cib1; pi = pi1;
@@ -152,7 +159,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				const int t0_ = 2 * pi, nt = min(2, p.K - t0_);
 				int cib1 = cib, pi1 = pi + 1;  // interval sidx + 1
 				if (pi1 == npb) { pi1 = 0; ++cib1; }
-				const unsigned xs = (cib & 1) * xbytes, xs1 = (cib1 & 1) * xbytes;
+				const unsigned xs = xoff(cib), xs1 = xoff(cib1);
 				STAMP(ta)
 				STAMP(tb)
 				load_frag(xs, e_slot(sidx), t0_, 1, f1);
@@ -176,7 +183,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				cib = cib1; pi = pi1;
 			}
 		};
-		if (npb > 1) main_loop(std::true_type()); else main_loop(std::false_type());  // K <= 2: every interval opens a new slab, whose X rows land only at this interval's barrier: no read-ahead
+		if (npb > 1 || k1) main_loop(std::true_type()); else main_loop(std::false_type());  // K = 2: every interval opens a new slab, whose X rows land only at this interval's barrier: no read-ahead
 	}
 
 #ifdef CONVASR_STAMPS
