@@ -184,11 +184,12 @@ def _bn_backward_from_g(g, y, gamma, beta, bnp, sums, n):
 	return dgamma, dbeta, ops.bn_act_bwd_apply(g, y, coef, False)
 
 
-def _dgrad(x, dy, weight, spec, dt, link = None):
-	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it."""
+def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
+	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it.
+	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad)."""
 	Cin = x.shape[1]
 	pad = spec.dilation * (spec.K - 1) - spec.padding
-	wd = packed_weight(weight, dt, _lib.PACK_DGRAD)
+	wd = packed_weight(weight, dt, _lib.PACK_DGRAD) if wd is None else wd
 	if link is not None and dt == torch.bfloat16 and spec.stride == 1:
 		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'])
 		if dx is not None:
@@ -365,6 +366,40 @@ def _stats_buffer(bn, C, dev, B, Tout, slot = '_convasr_stats'):
 	return st
 
 
+HEAD_PAD = 128  # channels the gradient of a narrow 1x1 head is padded to in backward
+
+
+class _HeadPad:
+	"""Backward of a 1x1 conv head with a ragged class count (the 38-class decoder, models.py:26) through the LDS-DMA kernels: the
+	head's output gradient is converted to bf16 into a zero-padded (B, 128, T) tensor, the head's weight is transposed into a
+	zero-padded [Cin][128] dgrad operand, and dgrad / wgrad run as 128-channel problems (the padding contributes exact zeros;
+	rows 38.. of the padded weight gradient are dropped).  The general register-staged kernels took 61 + 109 us per step for the
+	3.75 GFLOP involved; these are memory-bound launches of ~30 / ~45 us, and the dgrad can carry the BN-backward sums of the last
+	encoder layer in its epilogue like every other dgrad."""
+	_cache = {}
+
+	@classmethod
+	def dgrad_weight(cls, weight):
+		Cout, Cin, K = weight.shape
+		ver = param_version(weight)
+		ent = cls._cache.get(id(weight))
+		if ent is None:
+			ent = cls._cache[id(weight)] = dict(w = weight, ver = None, wd = torch.zeros(1, ops.cout_pad(Cin), HEAD_PAD, dtype = torch.bfloat16, device = weight.device))
+		if ent['ver'] != ver:
+			src = weight.detach()
+			# wd[0][ci][co] = w[co][ci][0]: the layout kernel reads (C = co, T = ci) and writes it channels-last with a row pitch of 128
+			_lib.call('convasr_convert_layout', _lib.ptr(src), _lib.F32, 0, src.stride(0), src.stride(1), _lib.ptr(ent['wd']), _lib.BF16, 0, 1, HEAD_PAD, 1, Cout, Cin, _lib.stream_ptr())
+			ent['ver'] = ver
+		return ent['wd']
+
+	@staticmethod
+	def pad_grad(dy, dt):
+		B, Cout, T = dy.shape
+		out = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)
+		_lib.call('convasr_convert_layout', _lib.ptr(dy), _lib.dtype_code(dy.dtype), dy.stride(0), dy.stride(1), dy.stride(2), _lib.ptr(out), _lib.dtype_code(dt), out.stride(0), out.stride(1), out.stride(2), B, Cout, T, _lib.stream_ptr())
+		return out
+
+
 class ConvBiasFunction(torch.autograd.Function):
 	"""Plain Conv1d with optional bias and fp32 output: the decoder head (models.py:26, 40)."""
 
@@ -386,6 +421,19 @@ class ConvBiasFunction(torch.autograd.Function):
 		weight, bias = ctx.params
 		x, = ctx.saved_tensors
 		Cout = weight.shape[0]
+		if dt == torch.bfloat16 and spec.K == 1 and spec.stride == 1 and spec.padding == 0 and Cout < HEAD_PAD and x.shape[1] % 128 == 0 and os.environ.get('CONVASR_NO_HEAD_PAD') != '1':
+			dyp = _HeadPad.pad_grad(dy, dt)
+			dx = _dgrad(x, dyp, weight, spec, dt, ctx.producer_link, wd = _HeadPad.dgrad_weight(weight)) if ctx.needs_input_grad[1] else None
+
+			def wgrad(outs, acc):
+				dwp = torch.empty(HEAD_PAD, x.shape[1], 1, dtype = torch.float32, device = x.device)
+				dbp = torch.empty(HEAD_PAD, dtype = torch.float32, device = x.device) if outs[1] is not None else None
+				ops.conv1d_wgrad(x, dyp, HEAD_PAD, 1, 1, 1, 0, dwp, dbias = dbp)
+				for o, v in ((outs[0], dwp[:Cout]), (outs[1], None if dbp is None else dbp[:Cout])):
+					if o is not None:
+						o.add_(v) if acc else o.copy_(v)
+			dw, db = _deliver([weight, bias], wgrad)
+			return None, dx, dw, db
 		dy = ops.as_cl(dy, dt)
 		dx = None
 		if ctx.needs_input_grad[1]:
