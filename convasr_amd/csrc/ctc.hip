@@ -35,6 +35,20 @@ __device__ __forceinline__ float wave_shl1(float v, float fill) {
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// max over the 64 lanes by DPP moves (two quad permutes, the two row mirrors, the two row broadcasts) and one readlane: no LDS round
+// trip, where the ds_bpermute butterfly of wave_max() costs six of them in the middle of a latency-bound recurrence
+__device__ __forceinline__ float wave_max_dpp(float v) {
+#define CTC_DPP_MAX(ctrl, rows) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, rows, 0xf, false)))
+	CTC_DPP_MAX(0xB1, 0xf);   // quad_perm [1,0,3,2]
+	CTC_DPP_MAX(0x4E, 0xf);   // quad_perm [2,3,0,1]
+	CTC_DPP_MAX(0x141, 0xf);  // row_half_mirror
+	CTC_DPP_MAX(0x140, 0xf);  // row_mirror: every lane holds its row's max
+	CTC_DPP_MAX(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+	CTC_DPP_MAX(0x143, 0xc);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's max
+#undef CTC_DPP_MAX
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // LP_LDS: the utterance's whole (T, C) log-prob slab is first copied into LDS (114 KB at T = 753, C = 38) so that the T-step
 // recurrences read their per-frame class scores at LDS latency instead of L2 latency (the sweeps are latency-bound).
 // offs: [2][B][T] integer-valued offsets (true log2 alpha(t, s) = lattice value + offs[0][b][t]; beta: offs[1]);
@@ -79,12 +93,16 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 	}
 
 	float a[NS], cur[NS], nxt[NS];
+	// The per-frame score of a state beyond the extended target is -inf, so the state update below needs no validity test: every
+	// state runs the same straight-line code and the NS independent log-sum-exp chains of a lane interleave (a test per state
+	// compiles to NS exec-masked blocks executed one after the other, each a serial chain of dependent transcendental ops).
+	auto score = [&](float v, int i) { return valid[i] ? v * lps : CTC_NEG; };
 	float cum = 0.f;  // integer-valued: sum of the offsets subtracted so far
 	auto renorm = [&](float (&v)[NS]) {
 		float m = v[0];
 #pragma unroll
 		for (int i = 1; i < NS; ++i) m = fmaxf(m, v[i]);
-		m = wave_max(m);
+		m = wave_max_dpp(m);
 		if (m > CTC_NEG) {
 			const float k = floorf(m);
 #pragma unroll
@@ -102,12 +120,12 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 		if (lane == 0) off[0] = 0.f;
 		if (Tb > 1) {
 #pragma unroll
-			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)1 * C + cls[i]] * lps;
+			for (int i = 0; i < NS; ++i) cur[i] = score(lpb[(int64_t)1 * C + cls[i]], i);
 		}
 		for (int t = 1; t < Tb; ++t) {
 			if (t + 1 < Tb) {
 #pragma unroll
-				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t + 1) * C + cls[i]] * lps;
+				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t + 1) * C + cls[i]];
 			}
 			const float p1 = wave_shr1(a[NS - 1], CTC_NEG);
 			const float p2 = NS >= 2 ? wave_shr1(a[NS >= 2 ? NS - 2 : 0], CTC_NEG) : wave_shr1(p1, CTC_NEG);
@@ -116,11 +134,11 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 			for (int i = NS - 1; i >= 0; --i) {
 				const float m1 = i >= 1 ? a[i - 1] : p1;
 				const float m2 = i >= 2 ? a[i - 2] : (i == 1 ? p1 : p2);
-				n[i] = valid[i] ? lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i] : CTC_NEG;
+				n[i] = lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i];
 			}
 			if ((t & (CTC_RENORM - 1)) == 0) renorm(n);
 #pragma unroll
-			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + i * 64 + lane] = n[i]; cur[i] = nxt[i]; }
+			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + i * 64 + lane] = n[i]; cur[i] = score(nxt[i], i); }  // the wait for the read-ahead is here, after the step's arithmetic
 			if (lane == 0) off[t] = cum;
 		}
 #pragma unroll
@@ -146,12 +164,12 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 		if (lane == 0) off[Tb - 1] = 0.f;
 		if (Tb > 1) {
 #pragma unroll
-			for (int i = 0; i < NS; ++i) cur[i] = lpb[(int64_t)(Tb - 2) * C + cls[i]] * lps;
+			for (int i = 0; i < NS; ++i) cur[i] = score(lpb[(int64_t)(Tb - 2) * C + cls[i]], i);
 		}
 		for (int t = Tb - 2; t >= 0; --t) {
 			if (t > 0) {
 #pragma unroll
-				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t - 1) * C + cls[i]] * lps;
+				for (int i = 0; i < NS; ++i) nxt[i] = lpb[(int64_t)(t - 1) * C + cls[i]];
 			}
 			const float p1 = wave_shl1(a[0], CTC_NEG);
 			const float p2 = NS >= 2 ? wave_shl1(a[NS >= 2 ? 1 : 0], CTC_NEG) : wave_shl1(p1, CTC_NEG);
@@ -160,11 +178,11 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 			for (int i = 0; i < NS; ++i) {
 				const float m1 = i + 1 < NS ? a[i + 1 < NS ? i + 1 : 0] : p1;
 				const float m2 = i + 2 < NS ? a[i + 2 < NS ? i + 2 : 0] : (i + 2 == NS ? p1 : p2);
-				n[i] = valid[i] ? lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i] : CTC_NEG;
+				n[i] = lse3(a[i], m1, skip[i] ? m2 : CTC_NEG) + cur[i];
 			}
 			if ((t & (CTC_RENORM - 1)) == 0) renorm(n);
 #pragma unroll
-			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + i * 64 + lane] = n[i]; cur[i] = nxt[i]; }
+			for (int i = 0; i < NS; ++i) { a[i] = n[i]; lat[(int64_t)t * LP + i * 64 + lane] = n[i]; cur[i] = score(nxt[i], i); }  // the wait for the read-ahead is here, after the step's arithmetic
 			if (lane == 0) off[t] = cum;
 		}
 	}
