@@ -27,6 +27,9 @@ _SIGNATURES = dict(
 	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_conv_cout_pad = (c_int, [c_int]),
 	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_fold2_geometry = (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+	convasr_fold2_pack_weight = (c_int, [c_p, c_int, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_fold2_unfold_wgrad = (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p, c_p]),
 	convasr_conv_stats_max_rows = (c_int, [c_int, c_int]),
 	convasr_reduce_rows = (c_int, [c_p, c_int, c_int, c_p, c_p]),
@@ -85,7 +88,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 2:
+		if lib.convasr_abi_version() != 3:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib

@@ -357,7 +357,8 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	CONVASR_CHECK_ARG(x && wp && y && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_fwd: bad arguments");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd: scale and shift go together");
 	const int64_t expect = ((int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
-	CONVASR_CHECK_ARG(expect == Tout, "conv1d_fwd: Tout %d inconsistent with Tin %d K %d stride %d dil %d pad %d (expect %lld)", Tout, Tin, K, stride, dil, pad, (long long)expect);
+	// a caller may ask for the first Tout < expect frames only (the stride-2 fold below needs one frame less than its even folded kernel yields)
+	CONVASR_CHECK_ARG(Tout <= expect, "conv1d_fwd: Tout %d inconsistent with Tin %d K %d stride %d dil %d pad %d (at most %lld)", Tout, Tin, K, stride, dil, pad, (long long)expect);
 	CONVASR_CHECK_ARG(x_dtype == CONVASR_F32 || x_dtype == CONVASR_BF16, "conv1d_fwd: x dtype %d", x_dtype);
 	ConvParams p = {};
 	if (bn_fusion) p = *bn_fusion;  // only the bn_* fields are set in it
@@ -714,5 +715,78 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 		hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 63) / 64), dim3(1024), 0, s, (const float*)part, (int)grid.y, Cout, dbias, accumulate);
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
 	}
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ stride-2 fold
+// A stride-2, dilation-1 conv over an even number of frames is a stride-1 conv over the same memory read as (T / 2) rows of
+// 2 Cin channels (row r = frames 2r, 2r + 1 side by side: a view, no copy): with P' = ceil(pad / 2), s0 = 2 P' - pad and
+// K' = (K - 1 + s0) / 2 + 1,   y[t] = sum_{j < K'} sum_{p < 2} sum_ci  V[t + j - P'][p Cin + ci] * w[co][ci][2 j + p - s0]
+// (taps outside [0, K) are zero weights).  The prologue conv of every model (models.py:312: K = 11, stride 2, 64 mel channels) becomes
+// a K' = 6, 128-channel stride-1 problem, which is inside the envelope of the LDS-DMA kernels (conv_v2s.hip, wgrad_v2.hip).
+static bool fold2_geometry(int K, int pad, int* Kf, int* Pf, int* s0) {
+	if (K < 1 || pad < 0) return false;
+	*Pf = (pad + 1) / 2;
+	*s0 = 2 * *Pf - pad;
+	*Kf = (K - 1 + *s0) / 2 + 1;
+	return true;
+}
+
+extern "C" int convasr_fold2_geometry(int K, int pad, int* K_folded, int* pad_folded) {
+	int s0;
+	CONVASR_CHECK_ARG(K_folded && pad_folded && fold2_geometry(K, pad, K_folded, pad_folded, &s0), "fold2_geometry: bad arguments");
+	return 0;
+}
+
+// wf[j][co][p Cin + ci] = w[co][ci][2 j + p - s0]; rows co >= Cout of the packed operand are zero
+template <typename T>
+__global__ __launch_bounds__(256) void fold2_pack_kernel(const float* __restrict__ w, int kmajor, T* __restrict__ wf, int Cout, int CoutPad, int Cin, int K, int Kf, int s0) {
+	const int64_t n = (int64_t)Kf * CoutPad * 2 * Cin;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+		const int c2 = (int)(i % (2 * Cin));
+		const int64_t r = i / (2 * Cin);
+		const int co = (int)(r % CoutPad), j = (int)(r / CoutPad);
+		const int p = c2 >= Cin ? 1 : 0, ci = c2 - p * Cin, k = 2 * j + p - s0;
+		float v = 0.f;
+		if (co < Cout && k >= 0 && k < K) v = kmajor ? w[((int64_t)k * Cout + co) * Cin + ci] : w[((int64_t)co * Cin + ci) * K + k];
+		if (sizeof(T) == 2) reinterpret_cast<bf16_t*>(wf)[i] = f32_to_bf16(v);
+		else reinterpret_cast<float*>(wf)[i] = v;
+	}
+}
+
+extern "C" int convasr_fold2_pack_weight(const float* w, int w_layout, void* packed_fwd, int dtype, int Cout, int Cin, int K, int pad, void* stream) {
+	int Kf, Pf, s0;
+	CONVASR_CHECK_ARG(w && packed_fwd && Cout > 0 && Cin > 0 && fold2_geometry(K, pad, &Kf, &Pf, &s0) && (w_layout == CONVASR_W_REFERENCE || w_layout == CONVASR_W_KMAJOR), "fold2_pack_weight: bad arguments");
+	const int co_pad = convasr_conv_cout_pad(Cout);
+	int64_t blocks = ceil_div64((int64_t)Kf * co_pad * 2 * Cin, 256);
+	if (blocks > 2048) blocks = 2048;
+	if (dtype == CONVASR_BF16) hipLaunchKernelGGL((fold2_pack_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, w_layout == CONVASR_W_KMAJOR, (bf16_t*)packed_fwd, Cout, co_pad, Cin, K, Kf, s0);
+	else if (dtype == CONVASR_F32) hipLaunchKernelGGL((fold2_pack_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, w_layout == CONVASR_W_KMAJOR, (float*)packed_fwd, Cout, co_pad, Cin, K, Kf, s0);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "fold2_pack_weight: dtype %d", dtype);
+	CONVASR_CHECK_LAUNCH("fold2_pack_weight");
+	return 0;
+}
+
+// dw[co][ci][k] (+)= dwf[j][co][p Cin + ci] with 2 j + p - s0 = k: the gradient of the folded conv, tap-major [K'][Cout][2 Cin], back
+// in the parameter's own layout (the folded taps outside [0, K) are gradients of structural zeros and are dropped)
+__global__ __launch_bounds__(256) void fold2_unfold_kernel(const float* __restrict__ dwf, float* __restrict__ dw, int kmajor, int Cout, int Cin, int K, int s0, int accumulate) {
+	const int64_t n = (int64_t)K * Cout * Cin;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+		int k, co, ci;
+		if (kmajor) { ci = (int)(i % Cin); const int64_t r = i / Cin; co = (int)(r % Cout); k = (int)(r / Cout); }
+		else { k = (int)(i % K); const int64_t r = i / K; ci = (int)(r % Cin); co = (int)(r / Cin); }
+		const int j = (k + s0) >> 1, p = (k + s0) & 1;
+		const float v = dwf[((int64_t)j * Cout + co) * 2 * Cin + p * Cin + ci];
+		dw[i] = accumulate ? dw[i] + v : v;
+	}
+}
+
+extern "C" int convasr_fold2_unfold_wgrad(const float* dw_folded, float* dw, int dw_layout, int Cout, int Cin, int K, int pad, int accumulate, void* stream) {
+	int Kf, Pf, s0;
+	CONVASR_CHECK_ARG(dw_folded && dw && Cout > 0 && Cin > 0 && fold2_geometry(K, pad, &Kf, &Pf, &s0) && (dw_layout == CONVASR_W_REFERENCE || dw_layout == CONVASR_W_KMAJOR), "fold2_unfold_wgrad: bad arguments");
+	int64_t blocks = ceil_div64((int64_t)K * Cout * Cin, 256);
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(fold2_unfold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dw_folded, dw, dw_layout == CONVASR_W_KMAJOR, Cout, Cin, K, s0, accumulate);
+	CONVASR_CHECK_LAUNCH("fold2_unfold_wgrad");
 	return 0;
 }

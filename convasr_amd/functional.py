@@ -150,6 +150,47 @@ class ConvSpec:
 		self.K, self.stride, self.dilation, self.padding = K, stride, dilation, padding
 
 
+class Fold2:
+	"""The stride-2 prologue conv (models.py:312) as a stride-1 conv over the (T / 2, 2 Cin) view of its input (include/convasr_hip.h,
+	"Stride-2 fold"): the forward and the weight gradient then run in the LDS-DMA kernels like every other layer, where the general
+	register-staged kernels took 73 + 161 us per step for 7 % of one big layer's FLOPs.  Needs an even number of input frames (the
+	instance norm in front of the prologue pads its output by one zero frame for this, ops.instnorm(pad_time_to = 2)) and no input
+	gradient (a strided dgrad does not exist here)."""
+	_cache = {}
+	enabled = os.environ.get('CONVASR_NO_FOLD2') != '1'  # tests / A-B runs flip this
+
+	@classmethod
+	def plan(cls, x, weight, spec, dt, x_needs_grad):
+		"""None, or (view of x, K', P', Tout) when the fold applies."""
+		B, Cin, Tin = x.shape
+		if not (cls.enabled and dt == torch.bfloat16 and spec.stride == 2 and spec.dilation == 1 and Tin % 2 == 0 and (2 * Cin) % 128 == 0 and weight.shape[0] % 128 == 0 and not x_needs_grad and ops.is_cl(x) and x.stride(0) == Tin * Cin):
+			return None
+		Kf, Pf = ops.fold2_geometry(spec.K, spec.padding)
+		Tout = ops.conv_out_len(Tin, spec.K, 2, 1, spec.padding)
+		if Tout > ops.conv_out_len(Tin // 2, Kf, 1, 1, Pf):
+			return None
+		return x.as_strided((B, 2 * Cin, Tin // 2), (Tin * Cin, 1, 2 * Cin)), Kf, Pf, Tout
+
+	@classmethod
+	def packed_weight(cls, weight, dt, pad):
+		ver = param_version(weight)
+		ent = cls._cache.get((id(weight), dt))
+		if ent is None:
+			ent = cls._cache[(id(weight), dt)] = dict(w = weight, ver = None, wp = None)
+		if ent['ver'] != ver:
+			ent['wp'] = ops.fold2_pack_weight(weight, dt, pad, out = ent['wp'])
+			ent['ver'] = ver
+		return ent['wp']
+
+	@staticmethod
+	def wgrad(xv, dy, weight, spec, Kf, Pf, out, accumulate):
+		Cout, Cin, K = weight.shape
+		B, _, Tout = dy.shape
+		dwf = torch.empty(Kf, Cout, 2 * Cin, dtype = torch.float32, device = dy.device)
+		ops.conv1d_wgrad(xv, dy, Cout, Kf, 1, 1, Pf, dwf.permute(1, 2, 0), work = 2.0 * B * Tout * Cout * Cin * K)
+		ops.fold2_unfold_wgrad(dwf, out, spec.padding, accumulate = accumulate)
+
+
 # Cross-layer backward fusion (bf16 training): pass 1 of a layer's batch-norm backward (per-channel sums of g and g * xhat) runs
 # in the epilogue of the dgrad launch that PRODUCES that layer's dz, i.e. in the backward of the layer's consumer.  No global
 # state: the producer's forward hangs a `link` (what the epilogue needs) on its output tensor and keeps it on its autograd ctx;
@@ -220,7 +261,14 @@ class ConvBnActFunction(torch.autograd.Function):
 
 		bn = cfg['bn']
 		stats = _stats_buffer(bn, Cout, dev, B, ops.conv_out_len(Tin, spec.K, spec.stride, spec.dilation, spec.padding))
-		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
+		x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
+		ctx.fold = Fold2.plan(x, weight, spec, dt, x_needs_grad)
+		if ctx.fold is not None:
+			xv, Kf, Pf, Tout = ctx.fold
+			y = ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, stats = stats, Tout = Tout, work = 2.0 * B * Tout * Cout * Cin * spec.K)
+			ctx.fold = (Kf, Pf)
+		else:
+			y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
 		Tout = y.shape[2]
 		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked)
 
@@ -245,7 +293,7 @@ class ConvBnActFunction(torch.autograd.Function):
 
 		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset)
 		ctx.params = (weight, gamma, beta) + tuple(flat_res[5 * r + k] for r in range(n_res) for k in range(1, 5))
-		ctx.x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
+		ctx.x_needs_grad = x_needs_grad
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
 		ctx.bwd_link = None
@@ -315,7 +363,12 @@ class ConvBnActFunction(torch.autograd.Function):
 			dgamma, dbeta, dy = _bn_backward_from_g(g, y, gamma, beta, bnp, sums[:2 * Cout], B * Tout)
 
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
-		wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
+		if ctx.fold is not None:
+			Bx, Cin, Tin = x.shape
+			xv = x.as_strided((Bx, 2 * Cin, Tin // 2), (Tin * Cin, 1, 2 * Cin))
+			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad(xv, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
+		else:
+			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
 		if arena_mode:
 			# enqueue before dgrad: both only read dy, and the side stream can start while dgrad is still being issued
 			dw, = _run_wgrad(dev, (x, dy), wg)
@@ -453,11 +506,17 @@ class ConvBnActEvalFunction:
 		x = ops.as_cl(x, dt)
 		Cout = weight.shape[0]
 		xl = ops.xlen_f32(xlen, x.device) if (cfg['temporal_mask'] and xlen is not None) else None
-		wp = packed_weight(weight, dt, _lib.PACK_FWD)
 		scale, shift = (None, None) if scale_shift is None else (scale_shift[0], scale_shift[1])
+		fold = Fold2.plan(x, weight, spec, dt, False)
+		if fold is not None:
+			xv, Kf, Pf, Tout = fold
+			conv = lambda **epilogue: ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, bias = bias, Tout = Tout, work = 2.0 * x.shape[0] * Tout * Cout * x.shape[1] * spec.K, **epilogue)
+		else:
+			wp = packed_weight(weight, dt, _lib.PACK_FWD)
+			conv = lambda **epilogue: ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, **epilogue)
 		if not res_list:
-			return ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, scale = scale, shift = shift, act = act, xlen = xl)
-		y = ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias)
+			return conv(scale = scale, shift = shift, act = act, xlen = xl)
+		y = conv()
 		res_y, rscale, rshift = [], [], []
 		for rx, rw, rb, rss in res_list:
 			rx = ops.as_cl(rx, dt)

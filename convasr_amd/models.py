@@ -161,7 +161,7 @@ class MaskedInstanceNorm1d(nn.InstanceNorm1d):
 		if self.affine or self.track_running_stats or not legacy:
 			raise _lib.ConvasrHipError('MaskedInstanceNorm1d: only the affine=False, track_running_stats=False, legacy=True form (Wav2Letter / JasperNet* defaults) is implemented')
 
-	def forward(self, x, mask = None, xlen = None, out_dtype = None):
+	def forward(self, x, mask = None, xlen = None, out_dtype = None, pad_time_to = 1):
 		_lib.require_cuda(x)
 		if x.requires_grad:
 			raise _lib.ConvasrHipError('MaskedInstanceNorm1d backward is not implemented (features never require grad on this path)')
@@ -170,7 +170,7 @@ class MaskedInstanceNorm1d(nn.InstanceNorm1d):
 		if xlen is None and mask is not None:
 			n = mask.reshape(mask.shape[0], -1).sum(dim = -1).to(torch.float32)
 			xlen = (n - 0.5) / x.shape[-1]
-		return ops.instnorm(x, xlen, self.eps, out_dtype = out_dtype or x.dtype)
+		return ops.instnorm(x, xlen, self.eps, out_dtype = out_dtype or x.dtype, pad_time_to = pad_time_to)
 
 
 # ------------------------------------------------------------------------------------------------ conv block
@@ -357,7 +357,10 @@ class JasperNet(nn.Module):
 		assert (not self.check_time_dim_padded) or (x.shape[-1] % 32 == 0), 'Shape of features after frontend is not divisible by 32'
 		assert x.ndim == 3
 		if self.normalize_features is not None:
-			x = self.normalize_features(x, xlen = xlen, out_dtype = self.compute_dtype)
+			# an odd number of frames gets one zero frame appended when the prologue conv is strided: the conv's output is the same (the
+			# frame lies in its zero padding) and its even-length input lets the stride-2 fold run (functional.Fold2)
+			stride2 = self.compute_dtype == torch.bfloat16 and Fn.Fold2.enabled and self.backbone[0].conv[0][-1].stride[0] == 2
+			x = self.normalize_features(x, xlen = xlen, out_dtype = self.compute_dtype, pad_time_to = 2 if stride2 else 1)
 		else:
 			x = ops.as_cl(x, self.compute_dtype)
 

@@ -86,15 +86,23 @@ def logmel(signal, xlen, window, mel_weight, mel_bias, nfft, hop, preemphasis = 
 	return out
 
 
-def instnorm(x, xlen, eps, out_dtype = None, channels_last = True):
-	"""MaskedInstanceNorm1d.forward (models.py:694-719); xlen None = legacy unmasked branch."""
+def instnorm(x, xlen, eps, out_dtype = None, channels_last = True, pad_time_to = 1):
+	"""MaskedInstanceNorm1d.forward (models.py:694-719); xlen None = legacy unmasked branch.
+	pad_time_to > 1: the result has its time axis rounded up to a multiple of it, the extra frames zero (a strided conv that follows
+	sees the same zeros its own padding would have supplied; see functional.fold2)."""
 	require_cuda(x)
 	B, C, T = x.shape
 	out_dtype = out_dtype or x.dtype
-	out = empty_cl(B, C, T, out_dtype, x.device) if channels_last else torch.empty(B, C, T, dtype = out_dtype, device = x.device)
+	Tp = -(-T // pad_time_to) * pad_time_to
+	if Tp != T:
+		assert channels_last
+		full = zeros_cl(B, C, Tp, out_dtype, x.device)
+		out = full[:, :, :T]
+	else:
+		full = out = empty_cl(B, C, T, out_dtype, x.device) if channels_last else torch.empty(B, C, T, dtype = out_dtype, device = x.device)
 	xl = xlen_f32(xlen, x.device)
 	call('convasr_instnorm_fwd', ptr(x), dtype_code(x.dtype), x.stride(0), x.stride(1), x.stride(2), ptr(out), dtype_code(out_dtype), out.stride(0), out.stride(1), out.stride(2), ptr(xl), B, C, T, float(eps), stream_ptr())
-	return out
+	return full
 
 
 # ------------------------------------------------------------------------------------------------ conv
@@ -158,14 +166,15 @@ class ConvStats:
 		return out
 
 
-def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None):
+def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, Tout = None, work = None):
 	"""x: channels-last (B, Cin, Tin); wp: packed weights.  Returns channels-last (B, Cout, Tout).
+	Tout (optional): compute only the first Tout frames of the output; work: FLOPs to book for the bench's timer (the stride-2 fold).
 	stats: None, a ConvStats (the production path: partial rows, consumed by bn_finalize), or a (2 Cout,) fp64 tensor that
 	receives the totals (sum, sum of squares) -- a convenience for tests and tools, one extra tiny launch."""
 	import ctypes
 	B, Cin, Tin = x.shape
 	assert is_cl(x), 'conv1d expects a channels-last activation'
-	Tout = conv_out_len(Tin, K, stride, dil, pad)
+	Tout = conv_out_len(Tin, K, stride, dil, pad) if Tout is None else Tout
 	out_dtype = out_dtype or x.dtype
 	y = empty_cl(B, Cout, Tout, out_dtype, x.device)
 	part = stats if isinstance(stats, ConvStats) or stats is None else ConvStats(Cout, B, Tout, x.device)
@@ -173,7 +182,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
 	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
 	es, osz = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
-	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
+	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
 	if part is not None:
 		part.rows = rows.value
 		if part is not stats:
@@ -196,7 +205,38 @@ def workspace(nbytes, device, tag = 'default'):
 	return buf
 
 
-def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate = False):
+def fold2_geometry(K, pad):
+	"""(K', P') of the stride-1 conv over the (T / 2, 2 Cin) view that equals a stride-2 conv (K, pad); include/convasr_hip.h."""
+	import ctypes
+	kf, pf = ctypes.c_int(0), ctypes.c_int(0)
+	call('convasr_fold2_geometry', K, pad, ctypes.byref(kf), ctypes.byref(pf))
+	return kf.value, pf.value
+
+
+def fold2_pack_weight(w, dtype, pad, out = None):
+	"""(Cout, Cin, K) fp32 parameter -> packed forward operand [K'][cout_pad][2 Cin] of the folded conv (refreshed in place if given)."""
+	require_cuda(w)
+	w = w.detach()
+	layout = weight_layout(w) if w.dtype == torch.float32 else None
+	if layout is None:
+		w, layout = w.float().contiguous(), _lib.W_REFERENCE
+	Cout, Cin, K = w.shape
+	if out is None:
+		out = torch.empty(fold2_geometry(K, pad)[0], cout_pad(Cout), 2 * Cin, dtype = dtype, device = w.device)
+	call('convasr_fold2_pack_weight', ptr(w), layout, ptr(out), dtype_code(dtype), Cout, Cin, K, pad, stream_ptr())
+	return out
+
+
+def fold2_unfold_wgrad(dwf, dw, pad, accumulate = False):
+	"""dw (Cout, Cin, K) fp32 (+)= the folded conv's gradient dwf [K'][Cout][2 Cin]."""
+	Cout, Cin, K = dw.shape
+	layout = weight_layout(dw)
+	assert layout is not None and dw.dtype == torch.float32 and dwf.dtype == torch.float32 and dwf.is_contiguous() and tuple(dwf.shape) == (fold2_geometry(K, pad)[0], Cout, 2 * Cin)
+	call('convasr_fold2_unfold_wgrad', ptr(dwf), ptr(dw), layout, Cout, Cin, K, pad, int(accumulate), stream_ptr())
+	return dw
+
+
+def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate = False, work = None):
 	"""dw (Cout, Cin, K) fp32 (+)= wgrad; x, dy channels-last of the same dtype.  dw is torch-contiguous (the reference's layout) or a
 	view of tap-major memory (weight_layout: the training arena's gradients)."""
 	B, Cin, Tin = x.shape
@@ -205,7 +245,7 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and layout is not None and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, K), (dw.shape, dw.stride())
 	nbytes = _lib.load().convasr_conv1d_wgrad_workspace_bytes(B, Cin, Cout, Tin, Tout, K, stride, dil)
 	ws = workspace(nbytes, x.device, 'wgrad')
-	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), layout, stream_ptr()))
+	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), layout, stream_ptr()))
 	return dw
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 2
+#define CONVASR_ABI_VERSION 3
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -90,12 +90,28 @@ int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* packed_dgra
  * stats (may be NULL): per-m-tile partial sums, [rows][2][Cout] doubles (sum then sum of squares), rows written = *stats_rows
  * (<= convasr_conv_stats_max_rows(B, Tout), the size to allocate).  No atomics: convasr_bn_finalize / convasr_reduce_rows add the
  * rows in a fixed order, so batch statistics are bit-identical from run to run.
- * Used for forward (mode FWD weights) and for dgrad (mode DGRAD weights, stride must be 1, pad' = dil*(K-1) - pad). */
+ * Used for forward (mode FWD weights) and for dgrad (mode DGRAD weights, stride must be 1, pad' = dil*(K-1) - pad).
+ * Tout is at most (Tin + 2 pad - dil (K-1) - 1) / stride + 1 (F.conv1d's output length); a smaller Tout computes the first Tout frames only. */
 int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int y_dtype,
                        int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil, int pad,
                        const float* bias, double* stats, const float* scale, const float* shift,
                        int act, float act_lo, float act_hi, const float* xlen, int* stats_rows, void* stream);
 int convasr_conv_stats_max_rows(int B, int Tout);
+
+/* Stride-2 fold (the prologue conv of every model, models.py:312: ConvBn1d(kernel_size_prologue = 11, stride = 2) on the 64 mel
+ * channels).  A stride-2, dilation-1 conv over an EVEN number of frames Tin equals the stride-1 conv with K' taps and padding P'
+ * over the same memory read as (Tin / 2) frames of 2 Cin channels (frames 2r, 2r+1 side by side -- a view, no copy):
+ *   P' = ceil(pad / 2), s0 = 2 P' - pad, K' = (K - 1 + s0) / 2 + 1,   w'[co][p Cin + ci][j] = w[co][ci][2 j + p - s0] (0 outside [0, K)),
+ * called as convasr_conv1d_fwd(x, packed', y, ..., Cin = 2 Cin, Tin = Tin / 2, Tout = the stride-2 conv's own Tout, K', 1, 1, P') and
+ * convasr_conv1d_wgrad the same way.  K = 11, pad = 5, Cin = 64 gives K' = 6, P' = 3, 128 channels: inside the envelope of the
+ * LDS-DMA kernels, which a stride-2 / 64-channel problem is not.
+ *   convasr_fold2_geometry      K, pad -> K', P'
+ *   convasr_fold2_pack_weight   fp32 (Cout, Cin, K) parameter in layout w_layout -> packed forward operand [K'][cout_pad(Cout)][2 Cin]
+ *   convasr_fold2_unfold_wgrad  fp32 gradient of the folded conv, tap-major [K'][Cout][2 Cin] (convasr_conv1d_wgrad with
+ *                               CONVASR_W_KMAJOR) -> dw (+)= the parameter's gradient in layout dw_layout */
+int convasr_fold2_geometry(int K, int pad, int* K_folded, int* pad_folded);
+int convasr_fold2_pack_weight(const float* w, int w_layout, void* packed_fwd, int dtype, int Cout, int Cin, int K, int pad, void* stream);
+int convasr_fold2_unfold_wgrad(const float* dw_folded, float* dw, int dw_layout, int Cout, int Cin, int K, int pad, int accumulate, void* stream);
 
 /* A/B and test hook: 0 routes bf16 launches through the general register-staged kernel instead of the LDS-DMA kernel.
  * Returns the previous setting. */

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 	lib = _lib.load()
 	for name in declared:
 		assert hasattr(lib, name), name
-	assert lib.convasr_abi_version() == 2
+	assert lib.convasr_abi_version() == 3
 	assert lib.convasr_conv_cout_pad(38) == 128 and lib.convasr_conv_cout_pad(256) == 256
 
 
@@ -596,3 +596,98 @@ def test_loss_head_matches_the_reference_expressions():
 	la.backward(w); lb.backward(w)
 	close(la, lb, 1e-7, 0, 'normalised CTC loss')
 	close(a.grad, b_.grad, 1e-6, 1e-9, 'normalised CTC gradient')
+
+
+@gpu
+@pytest.mark.parametrize('case', [(256, 64, 11, 5, 1502), (128, 64, 13, 6, 600), (256, 128, 3, 1, 258), (128, 64, 5, 0, 400), (128, 64, 4, 2, 320)])
+def test_stride2_fold_forward_and_weight_gradient(case):
+	"""The stride-2 fold (include/convasr_hip.h): the folded stride-1 problem over the (T / 2, 2 Cin) view gives F.conv1d(stride = 2)'s
+	output and weight gradient -- against torch fp32 on the bf16-rounded operands, and against the general strided kernel; the folded
+	operand and the unfolded gradient are exact rearrangements (bitwise) in both parameter layouts."""
+	from convasr_amd import ops, _lib
+	import torch.nn.functional as F
+	Cout, Cin, K, pad, T = case
+	d = dev()
+	torch.manual_seed(K * 100 + pad)
+	B = 3
+	w = torch.randn(Cout, Cin, K, device = d) / (Cin * K) ** 0.5
+	wk = torch.empty(K, Cout, Cin, device = d).permute(1, 2, 0)
+	wk.copy_(w)
+	Kf, Pf = ops.fold2_geometry(K, pad)
+	s0 = 2 * Pf - pad
+	assert Pf == (pad + 1) // 2 and Kf == (K - 1 + s0) // 2 + 1
+	# the packed operand is w rearranged
+	expect = torch.zeros(Kf, Cout, 2, Cin, device = d)
+	for j in range(Kf):
+		for p in range(2):
+			k = 2 * j + p - s0
+			if 0 <= k < K:
+				expect[j, :, p, :] = w[:, :, k]
+	for src in (w, wk):
+		for dt in (torch.float32, torch.bfloat16):
+			wp = ops.fold2_pack_weight(src, dt, pad)
+			assert wp.shape == (Kf, ops.cout_pad(Cout), 2 * Cin)
+			assert torch.equal(wp[:, :Cout], expect.view(Kf, Cout, 2 * Cin).to(dt)) and not bool(wp[:, Cout:].any())
+	x = ops.as_cl(torch.randn(B, Cin, T, device = d), torch.bfloat16)
+	xv = x.as_strided((B, 2 * Cin, T // 2), (T * Cin, 1, 2 * Cin))
+	Tout = ops.conv_out_len(T, K, 2, 1, pad)
+	wb = w.to(torch.bfloat16).float()
+	ref = F.conv1d(x.float(), wb, stride = 2, padding = pad)
+	assert ref.shape[2] == Tout
+	y = ops.conv1d(xv, ops.fold2_pack_weight(wk, torch.bfloat16, pad), Cout, Kf, 1, 1, Pf, Tout = Tout, out_dtype = torch.float32)
+	close(y, ref, 1e-3, 1e-3, 'folded forward vs torch')
+	y0 = ops.conv1d(x, ops.pack_weight(w, torch.bfloat16, _lib.PACK_FWD), Cout, K, 2, 1, pad, out_dtype = torch.float32)
+	close(y, y0, 1e-3, 1e-3, 'folded forward vs the strided kernel')
+	# weight gradient
+	dy = ops.as_cl(torch.randn(B, Cout, Tout, device = d), torch.bfloat16)
+	xr = x.float().requires_grad_()
+	wr = wb.clone().requires_grad_()
+	F.conv1d(xr, wr, stride = 2, padding = pad).backward(dy.float())
+	dwf = torch.empty(Kf, Cout, 2 * Cin, device = d)
+	ops.conv1d_wgrad(xv, dy, Cout, Kf, 1, 1, Pf, dwf.permute(1, 2, 0))
+	for layout in ('reference', 'kmajor'):
+		dw = torch.full((Cout, Cin, K), 2.0, device = d) if layout == 'reference' else torch.full((K, Cout, Cin), 2.0, device = d).permute(1, 2, 0)
+		ops.fold2_unfold_wgrad(dwf, dw, pad)
+		for k in range(K):
+			j, p = (k + s0) // 2, (k + s0) % 2
+			assert torch.equal(dw[:, :, k], dwf[j, :, p * Cin:(p + 1) * Cin]), (layout, k)
+		close(dw, wr.grad, 2e-3, 2e-3 * float(wr.grad.abs().max()), 'folded wgrad vs torch')
+		before = dw.clone()
+		ops.fold2_unfold_wgrad(dwf, dw, pad, accumulate = True)
+		assert torch.equal(dw.contiguous(), (2 * before).contiguous())
+	dw0 = torch.empty(Cout, Cin, K, device = d)
+	ops.conv1d_wgrad(x, dy, Cout, K, 2, 1, pad, dw0)
+	close(dw, 2 * dw0, 2e-3, 4e-3 * float(dw0.abs().max()), 'folded wgrad vs the strided kernel')
+
+
+@gpu
+def test_stride2_fold_in_the_model_matches_the_strided_kernels():
+	"""Wav2Letter bf16 training step with the prologue folded (default) against the same step with the general strided kernels
+	(Fold2.enabled = False): same loss and prologue gradient up to bf16 summation order; odd frame counts are padded by one zero frame."""
+	import convasr_amd
+	from convasr_amd import models, functional as Fn
+	d = dev()
+
+	def run(enabled):
+		Fn.Fold2.enabled = enabled
+		try:
+			torch.manual_seed(3)
+			Fn.manual_seed(11)
+			m = models.Wav2Letter(64, [38], dropout = 0.0, compute_dtype = torch.bfloat16, check_time_dim_padded = False).to(d).train()
+			x = torch.randn(2, 64, 301, device = d)
+			xlen = torch.tensor([1.0, 0.7], device = d)
+			y = torch.randint(0, 37, (2, 1, 20), device = d)
+			ylen = torch.tensor([[20], [12]], device = d)
+			out = m(x, xlen, y = y, ylen = ylen)
+			out['loss'].sum().backward()
+			w0 = m.backbone[0].conv[0][-1].weight
+			return out['loss'].detach().clone(), w0.grad.detach().clone(), out['log_probs'][0].detach().clone()
+		finally:
+			Fn.Fold2.enabled = True
+
+	l1, g1, lp1 = run(True)
+	l0, g0, lp0 = run(False)
+	assert lp1.shape == lp0.shape
+	close(l1, l0, 2e-2, 1e-2, 'loss, folded vs strided prologue')
+	cos = float((g1.double().flatten() @ g0.double().flatten()) / (g1.double().norm() * g0.double().norm()))
+	assert cos > 0.999, cos
