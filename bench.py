@@ -297,7 +297,7 @@ def main(argv = None):
 			peak = PEAK_BF16_DENSE / 1e12 if args.dtype == 'bf16' else 157.3
 			tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
 			k = kt[main_name]
-			roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<unsigned short, false / true> (16 forward + 17 dgrad launches; the dgrads, instantiation <.., true>, also run pass 1 of the BN backward of the layer below in their epilogue)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3), timing = f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it')
+			roof = dict(bound = 'mfma', kernel = f'conv1d_igemm_v2s_kernel<O, false / true> ({0 if plain is None else plain["launches"] // args.steps} forward + {(k["launches"] - (0 if plain is None or plain is k else plain["launches"])) // args.steps} dgrad launches per step; the dgrads, instantiation <.., true>, also run pass 1 of the BN backward of the layer below in their epilogue; the prologue conv runs here as its stride-2 fold, the decoder with fp32 output)' if args.dtype == 'bf16' else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3), timing = f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it')
 			hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
 			kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
 			if plain is not None and plain is not k:

@@ -180,7 +180,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	part = stats if isinstance(stats, ConvStats) or stats is None else ConvStats(Cout, B, Tout, x.device)
 	rows = ctypes.c_int(0)
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
-	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0 and K >= 2) else 'conv1d_igemm (other variants)'
+	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0) else 'conv1d_igemm (other variants)'
 	es, osz = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
 	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
 	if part is not None:
@@ -243,6 +243,8 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 	Tout = dy.shape[2]
 	layout = weight_layout(dw)
 	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and layout is not None and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, K), (dw.shape, dw.stride())
+	if K == 1 and (Cout * Cin) % 4 == 0:
+		layout = _lib.W_KMAJOR  # one tap: the two layouts are the same memory, and the tap-major combine is the streaming one
 	nbytes = _lib.load().convasr_conv1d_wgrad_workspace_bytes(B, Cin, Cout, Tin, Tout, K, stride, dil)
 	ws = workspace(nbytes, x.device, 'wgrad')
 	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), layout, stream_ptr()))
