@@ -7,6 +7,19 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// LDS image of a tile: 256-byte lines of two 128-byte rows (row = 2 * pair + s), a row's 16-byte chunk c at position
+// s * 8 + (c ^ swz(pair)) of its line.  A ds_read_b128 fragment read serves lanes {0-3, 12-15, 20-27} (and the three like groups) in
+// one LDS cycle each: 16 rows base + r16, k-block kb for eight of them and kb ^ 1 for the other eight, and it is conflict-free iff
+// the 16 positions are distinct.  With swz = pair & 7 (conv_v2.hip's image, made for its own read pattern) that holds only for
+// base = 0 mod 16, and the X fragments of tap t start at row t * dilation: SQ_LDS_BANK_CONFLICT was 24.5 % of SQ_LDS_IDX_ACTIVE.
+// swz = (pair & 3) << 1 is conflict-free for EVERY base (exhaustive check over bases, groups and k sub-steps: scratch/swizzle_search.py).
+__device__ __forceinline__ int v2s_swz(int pair) { return (pair & 3) << 1; }
+// LDS slot p (16-byte units) of the tile <- global (row, chunk): byte offset of that lane's 16 bytes relative to row 0 / chunk 0
+__device__ __forceinline__ int v2s_src_offset(int p, int row_bytes) {
+	const int pair = p >> 4, s = p & 15;
+	return (2 * pair + (s >> 3)) * row_bytes + (((s & 7) ^ v2s_swz(pair)) << 4);
+}
+
 
 #ifdef CONVASR_STAMPS
 // Diagnostic build only (python -m convasr_amd.build --variant stamps -DCONVASR_STAMPS=1; scratch/stamps.py): per-wave cycle sums of the
@@ -56,17 +69,17 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	// of its SIMD.
 	const bool loader = wave >= 8;
 	const int lw = wave - 8;
-	const int xlane = v2_src_offset(lane, row_bytes), xlane_odd = v2_src_offset(64 + lane, row_bytes) - 8 * row_bytes;
+	const int xlane = v2s_src_offset(lane, row_bytes);  // the swizzle is periodic in 4 pairs = the 8 rows of a piece: every piece has the same lane pattern
 	auto issue_x = [&](int cib) {
 		const unsigned dst = lds_base + xoff(cib);
 		const int base = tin0 * row_bytes + cib * 128;
 		for (int u = lw; u < x_units; u += 4)
-			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + ((u & 1) ? xlane_odd : xlane));
+			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), base + u * 8 * row_bytes + xlane);
 	};
 	constexpr int PPL = NB;  // 1-KiB pieces of a W slot (BN_ rows x 128 B = 4 NB pieces) per loader wave
 	int wl[PPL];
 #pragma unroll
-	for (int j = 0; j < PPL; ++j) wl[j] = v2_src_offset((lw * PPL + j) * 64 + lane, row_bytes);
+	for (int j = 0; j < PPL; ++j) wl[j] = v2s_src_offset((lw * PPL + j) * 64 + lane, row_bytes);
 	auto issue_w = [&](int q_cib, int q_tap, int slot) {
 		const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wbase + slot * V2_WSLOT + lw * (1024 * PPL));
 		const int base = (q_tap * p.CoutPad + co0) * row_bytes + q_cib * 128;
@@ -84,12 +97,12 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	typedef const __attribute__((address_space(3))) u32x4* lds_u4;
 	struct Frag { u32x4 a[4], b[NB]; };
 	// lane (r16, kb) holds k = 8 kb .. 8 kb + 7 of row r16: 16-byte chunk (ks * 4 + kb) of the 128-byte slab row.  Rows 16 apart
-	// share the swizzle term (+2048 B immediates); the second k32 substep is `address ^ 64`.
+	// share the swizzle term (+2048 B immediates); the second k32 substep is `address ^ 64` (kb ^ swz < 8, so the XOR stays inside the row).
 	const int wrow = wn * (16 * NB) + r16;
-	const unsigned w0 = lds_base + wbase + ((wrow >> 1) << 8) + ((((wrow & 1) << 3) | (kb ^ ((wrow >> 1) & 7))) << 4);
+	const unsigned w0 = lds_base + wbase + ((wrow >> 1) << 8) + ((((wrow & 1) << 3) | (kb ^ v2s_swz(wrow >> 1))) << 4);
 	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int ks, Frag& f) {
 		const int xrow = wm * 64 + r16 + tap_ * p.dil;
-		const unsigned xa = (lds_base + xs_off + ((xrow >> 1) << 8) + ((((xrow & 1) << 3) | (kb ^ ((xrow >> 1) & 7))) << 4)) ^ (ks << 6);
+		const unsigned xa = (lds_base + xs_off + ((xrow >> 1) << 8) + ((((xrow & 1) << 3) | (kb ^ v2s_swz(xrow >> 1))) << 4)) ^ (ks << 6);
 		const unsigned wa = (w0 + ws_off) ^ (ks << 6);
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {

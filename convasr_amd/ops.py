@@ -143,6 +143,14 @@ def pack_weight(w, dtype, mode = None, out = None, fwd_is_current = False):
 	return (fwd, dgr) if mode is None else (fwd if mode == _lib.PACK_FWD else dgr)
 
 
+PEAK_BF16_FLOPS, PEAK_HBM_BYTES = 2.5e15, 8.0e12  # MI355X_MICROARCH.md: dense bf16 MFMA, HBM3E
+
+
+def memory_bound(flops, nbytes):
+	"""Which roofline bounds a launch (for the bench's per-kernel timer only): its algorithmic bytes at 8 TB/s against its FLOPs at 2.5 PF."""
+	return nbytes / PEAK_HBM_BYTES > flops / PEAK_BF16_FLOPS
+
+
 def conv_out_len(Tin, K, stride, dil, pad):
 	return (Tin + 2 * pad - dil * (K - 1) - 1) // stride + 1
 
@@ -182,7 +190,10 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
 	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0) else 'conv1d_igemm (other variants)'
 	es, osz = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
-	_lib.timed(family, 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz))
+	flops, nbytes_ = 2.0 * B * Tout * Cout * Cin * K if work is None else work, float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz)
+	if family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
+		family = 'hbm:conv1d_igemm_v2s_kernel (memory-bound launches: the 38-class decoder)'
+	_lib.timed(family, flops, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = nbytes_)
 	if part is not None:
 		part.rows = rows.value
 		if part is not stats:
@@ -433,7 +444,7 @@ def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nest
 	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p_bf16), stream_ptr())
 
 
-def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums):
+def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None):
 	"""dx = dgrad(dy) with pass 1 of the consumer layer's batch-norm backward fused into the epilogue (bn_sums += per-channel sums).
 	Returns dx, or None when the shape is outside the fused kernel's envelope (nothing was launched)."""
 	import ctypes
@@ -446,7 +457,10 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 	def run():
 		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), stream_ptr())
 	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if Cout % 64 == 0 else 'conv1d_igemm (other variants)'
-	_lib.timed(family, 2.0 * B * T * Cout * Cin * K, run, nbytes = float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2))
+	flops, nbytes_ = 2.0 * B * T * Cout * Cin * K if work is None else work, float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2)
+	if family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
+		family = 'hbm:conv1d_igemm_v2s_kernel (memory-bound launches: the 38-class decoder)'
+	_lib.timed(family, flops, run, nbytes = nbytes_)
 	bn_sums.rows = rows.value
 	return dx if rc[0] == 0 else None
 

@@ -12,7 +12,17 @@ for (cin, cout, k, dil) in [(768, 768, 11, 1), (256, 256, 11, 1), (512, 512, 11,
 	x = ops.as_cl(torch.randn(B, cin, T, device = d), dt)
 	w = torch.randn(cout, cin, k, device = d) / (cin * k) ** 0.5
 	fwd = ops.pack_weight(w, dt, _lib.PACK_FWD)
-	for _ in range(3): ops.conv1d(x, fwd, cout, k, 1, dil, dil * k // 2)
+	fused = len(sys.argv) > 1 and sys.argv[1] == 'fused'
+	if fused:  # the dgrad launch with the BN-backward epilogue (dy has cout channels, dx cin)
+		dy = ops.as_cl(torch.randn(B, cout, T, device = d), dt)
+		_, dgr = ops.pack_weight(w, dt, None)
+		yb = ops.as_cl(torch.randn(B, cin, T, device = d), dt)
+		sc, sh, mean, istd = (torch.rand(cin, device = d) + 0.5 for _ in range(4))
+		sums = ops.ConvStats(cin, B, T, d)
+		xl = torch.ones(B, device = d)
+		for _ in range(3): ops.conv1d_dgrad_bn_reduce(dy, dgr, cin, k, dil, dil * (k - 1) - dil * k // 2, yb, sc, sh, mean, istd, (_lib.ACT_HARDTANH, 0.0, 20.0), 0.2, 1, 0, xl, sums)
+	else:
+		for _ in range(3): ops.conv1d(x, fwd, cout, k, 1, dil, dil * k // 2)
 	torch.cuda.synchronize()
 	buf = np.zeros(256 * 8 * 8, dtype = np.uint64)
 	assert lib.convasr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
