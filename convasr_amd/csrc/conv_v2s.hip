@@ -30,8 +30,14 @@ extern "C" int convasr_debug_read_stamps(unsigned long long* host, int count) {
 	return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_v2s_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
 }
 #define STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#if CONVASR_STAMPS == 1
+#define STAMPI(var) STAMP(var)
+#else
+#define STAMPI(var)  // -DCONVASR_STAMPS=2: only the two stamps around the whole tile (tile cycles and in-kernel clock of the otherwise untouched kernel)
+#endif
 #else
 #define STAMP(var)
+#define STAMPI(var)
 #endif
 
 // NB = 16-column blocks per wave: 4 -> the 256 x 128 tile, 2 -> a 256 x 64 half tile (same X tile, half the W rows).  The last
@@ -120,6 +126,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 #ifdef CONVASR_STAMPS
 	unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, acc_issue = 0, acc_work = 0, acc_vm = 0, acc_bar = 0, t_loop0 = 0, t_start = 0, t_end = 0;
 	STAMP(t_start)
+	const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz: in-kernel clock = (t_end - t_start) / (rt_end - rt_start) x 100 MHz
 #endif
 	{
 		// One barrier interval = the (up to) two taps of one tap pair on one 64-channel slab.  W slots: a ring of THREE for the first
@@ -161,7 +168,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		__builtin_amdgcn_s_barrier();
 		Frag f0, f1;
 		load_frag(0, e_slot(0), 0, 0, f0);
-		STAMP(t_loop0)
+		STAMPI(t_loop0)
 		// The loop is instantiated per `pre` so that the read-ahead is unconditional inside it: a conditional LDS load makes hipcc
 		// wait for ALL outstanding LDS reads at the branch join (ahead of the last MFMA group), which costs more than the read-ahead
 		// saves.  In the last interval the read-ahead fetches a slot nobody needs (its registers are dead).
@@ -173,8 +180,8 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				int cib1 = cib, pi1 = pi + 1;  // interval sidx + 1
 				if (pi1 == npb) { pi1 = 0; ++cib1; }
 				const unsigned xs = xoff(cib), xs1 = xoff(cib1);
-				STAMP(ta)
-				STAMP(tb)
+				STAMPI(ta)
+				STAMPI(tb)
 				load_frag(xs, e_slot(sidx), t0_, 1, f1);
 				mma_frag(f0);
 				if (nt == 2) {
@@ -185,11 +192,11 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				}
 				if (PRE) load_frag(xs1, e_slot(sidx + 1), 2 * pi1, 0, f0);
 				mma_frag(f1);
-				STAMP(tc)
-				STAMP(td)
+				STAMPI(tc)
+				STAMPI(td)
 				__builtin_amdgcn_s_barrier();
 				if (!PRE) load_frag(xs1, e_slot(sidx + 1), 2 * pi1, 0, f0);
-				STAMP(te)
+				STAMPI(te)
 #ifdef CONVASR_STAMPS
 				acc_issue += tb - ta; acc_work += tc - tb; acc_vm += td - tc; acc_bar += te - td;
 #endif
@@ -201,7 +208,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 
 #ifdef CONVASR_STAMPS
 	unsigned long long t_epi0 = 0;
-	STAMP(t_epi0)
+	STAMPI(t_epi0)
 #endif
 	// ---------------- epilogue: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg
 	constexpr int OPITCH = BN_ * sizeof(O) + 16;
@@ -269,10 +276,10 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	}
 #ifdef CONVASR_STAMPS
 	unsigned long long t_e1 = 0, t_e2 = 0, t_e3 = 0;
-	STAMP(t_e1)
+	STAMPI(t_e1)
 #endif
 	__syncthreads();
-	STAMP(t_e2)
+	STAMPI(t_e2)
 	if (p.stats && tid < BN_ && co0 + tid < p.Cout) {
 		double a = 0, q2 = 0;
 #pragma unroll
@@ -281,7 +288,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		prow[co0 + tid] = a;
 		prow[p.Cout + co0 + tid] = q2;
 	}
-	STAMP(t_e3)
+	STAMPI(t_e3)
 	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN_ / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
@@ -348,7 +355,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	STAMP(t_end)
 	if (blockIdx.x < 256 && lane == 0) {
 		unsigned long long* o = g_v2s_stamps + (blockIdx.x * 8 + wave) * 8;
-		o[0] = t_loop0 - t_start; o[1] = t_e1 - t_epi0; o[2] = acc_work; o[3] = t_e2 - t_e1; o[4] = acc_bar; o[5] = t_e3 - t_e2; o[6] = t_end - t_e3; o[7] = t_end - t_start;
+		o[0] = t_loop0 - t_start; o[1] = t_e1 - t_epi0; o[2] = acc_work; o[3] = __builtin_amdgcn_s_memrealtime() - rt_start; o[4] = acc_bar; o[5] = CONVASR_STAMPS == 2 ? rt_start : t_e3 - t_e2; o[6] = t_end - t_e3; o[7] = t_end - t_start;
 	}
 #endif
 }
