@@ -691,3 +691,39 @@ def test_stride2_fold_in_the_model_matches_the_strided_kernels():
 	close(l1, l0, 2e-2, 1e-2, 'loss, folded vs strided prologue')
 	cos = float((g1.double().flatten() @ g0.double().flatten()) / (g1.double().norm() * g0.double().norm()))
 	assert cos > 0.999, cos
+
+
+@gpu
+def test_instnorm_time_padding_and_folded_eval_forward():
+	"""ops.instnorm(pad_time_to = 2): the first T frames equal the unpadded result bit for bit, the appended frame is zero; the fused eval
+	forward (BN folded into the conv epilogue) of a model whose prologue runs through the stride-2 fold matches the strided kernels."""
+	from convasr_amd import ops, models, functional as Fn
+	d = dev()
+	torch.manual_seed(5)
+	x = torch.randn(3, 64, 301, device = d)
+	xlen = torch.tensor([1.0, 0.6, 0.83], device = d)
+	for dt in (torch.float32, torch.bfloat16):
+		a = ops.instnorm(x, xlen, 1e-5, out_dtype = dt)
+		b = ops.instnorm(x, xlen, 1e-5, out_dtype = dt, pad_time_to = 2)
+		assert b.shape == (3, 64, 302) and ops.is_cl(b) and torch.equal(b[:, :, :301], a) and not bool(b[:, :, 301].any())
+		assert ops.instnorm(x[:, :, :300], xlen, 1e-5, out_dtype = dt, pad_time_to = 2).shape == (3, 64, 300)
+
+	def run(enabled):
+		Fn.Fold2.enabled = enabled
+		try:
+			torch.manual_seed(3)
+			m = models.Wav2Letter(64, [38], dropout = 0.0, compute_dtype = torch.bfloat16, check_time_dim_padded = False).to(d)
+			m.train()
+			with torch.no_grad():
+				m(x, xlen)  # running statistics
+			m.eval()
+			m.fuse_conv_bn_eval()
+			with torch.no_grad():
+				return m(x, xlen)['log_probs'][0].float()
+		finally:
+			Fn.Fold2.enabled = True
+
+	l1, l0 = run(True), run(False)
+	assert l1.shape == l0.shape
+	err = float((l1 - l0).norm() / l0.norm())
+	assert err < 2e-2, err  # two bf16 pipelines that differ in one layer's summation order (DESIGN.md section 2)
