@@ -116,6 +116,19 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 			if (i < NB) f.b[i] = *(lds_u4)(size_t)(wa + i * 2048);
 		}
 	};
+	// Scheduling hint placed after a (load_frag, mma_frag) pair: the 4 + NB ds_read_b128 of the NEXT fragment go out one per MFMA
+	// from the first MFMA of the current group on.  Left alone, hipcc sinks them behind the 12th-14th MFMA of the group, and the
+	// next group's first MFMA then waits out the LDS latency four times per barrier interval (-3 % per launch; a read after every
+	// second MFMA or two reads per MFMA measured no better than the unhinted schedule; MI355X_MICROARCH.md, LDS: up to two
+	// ds_read_b128 per MFMA gap are hidden).
+	auto interleave = [&]() {
+#pragma unroll
+		for (int i = 0; i < 4 + NB; ++i) {
+			__builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+			__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+		}
+		__builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - (4 + NB), 0);
+	};
 	auto mma_frag = [&](const Frag& f) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
@@ -184,14 +197,18 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				STAMPI(tb)
 				load_frag(xs, e_slot(sidx), t0_, 1, f1);
 				mma_frag(f0);
+				interleave();
 				if (nt == 2) {
 					load_frag(xs, o_slot(sidx), t0_ + 1, 0, f0);
 					mma_frag(f1);
+					interleave();
 					load_frag(xs, o_slot(sidx), t0_ + 1, 1, f1);
 					mma_frag(f0);
+					interleave();
 				}
 				if (PRE) load_frag(xs1, e_slot(sidx + 1), 2 * pi1, 0, f0);
 				mma_frag(f1);
+				if (PRE) interleave();
 				STAMPI(tc)
 				STAMPI(td)
 				__builtin_amdgcn_s_barrier();
