@@ -199,27 +199,22 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 			// from the first MFMA of the slot-A group on, the 8 reads of the next substep two per MFMA of the slot-B group.  Left alone,
 			// hipcc sinks reads to one MFMA ahead of their use and the LDS latency is exposed twice per substep (+1.5-2 % per launch;
 			// four reads per MFMA gap instead made the fragments spill).
-#define W2_HINT() if (MA == 15u && MB == 15u) { \
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
-				__builtin_amdgcn_sched_group_barrier(0x008, 2, 0); \
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
-				__builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+#define W2_DS2_M1 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#define W2_HINT(KK) if (MA == 15u && MB == 15u) { W2_DS2_M1 W2_DS2_M1 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); W2_DS2_M1 W2_DS2_M1 W2_DS2_M1 W2_DS2_M1 }  // (the same hints on the 3- and 2-tap instantiations: no measurable change)
 #define W2_SUBSTEP(KK, FA_CUR, FA_NXT)                                                                                              \
 			if ((MB >> KK) & 1u) load_bB(st, KK, fbB);                                                                                  \
 			if ((MA >> KK) & 1u) mma4(FA_CUR, fbA, acc[0]);                                                                             \
 			if (KK < 3) { if ((MAB >> ((KK + 1) & 3)) & 1u) load_a(st, KK + 1, FA_NXT); if ((MA >> ((KK + 1) & 3)) & 1u) load_bA(st, KK + 1, fbA); } \
 			else { if (MAB & 1u) load_a(stn, 0, FA_NXT); if (MA & 1u) load_bA(stn, 0, fbA); }  /* unconditional: after the last chunk it reads a stage nobody needs (a conditional LDS load costs a full lgkmcnt drain at the join) */ \
 			if ((MB >> KK) & 1u) mma4(FA_CUR, fbB, acc[1]);                                                                             \
-			W2_HINT()
+			W2_HINT(KK)
 			W2_SUBSTEP(0, fa0, fa1)
 			W2_SUBSTEP(1, fa1, fa0)
 			W2_SUBSTEP(2, fa0, fa1)
 			W2_SUBSTEP(3, fa1, fa0)
 #undef W2_SUBSTEP
 #undef W2_HINT
+#undef W2_DS2_M1
 			WSTAMP(wb)
 			__builtin_amdgcn_s_barrier();
 			WSTAMP(wc)

@@ -2,7 +2,7 @@
 import sys, torch
 import convasr_amd
 from convasr_amd import ops, _lib
-d = torch.device('cuda:0'); dt = torch.bfloat16
+d = torch.device("cuda:0"); dt = torch.bfloat16; torch.manual_seed(0)
 for (cin, cout, k, dil) in [(768, 768, 11, 1), (256, 256, 11, 1), (512, 512, 11, 1), (640, 640, 11, 1), (768, 896, 29, 2), (896, 1024, 1, 1)]:
 	B, T = 64, 751
 	pad = dil * (k // 2)
