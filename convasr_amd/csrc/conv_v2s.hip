@@ -104,11 +104,13 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	struct Frag { u32x4 a[4], b[NB]; };
 	// lane (r16, kb) holds k = 8 kb .. 8 kb + 7 of row r16: 16-byte chunk (ks * 4 + kb) of the 128-byte slab row.  Rows 16 apart
 	// share the swizzle term (+2048 B immediates); the second k32 substep is `address ^ 64` (kb ^ swz < 8, so the XOR stays inside the row).
-	const int wrow = wn * (16 * NB) + r16;
-	const unsigned w0 = lds_base + wbase + ((wrow >> 1) << 8) + ((((wrow & 1) << 3) | (kb ^ v2s_swz(wrow >> 1))) << 4);
+	// byte offset of (row, k-block kb) in the image: row * 128 + ((kb ^ swz(row >> 1)) << 4), and (swz(row >> 1) << 4) = (row << 4) & 0x60
+	const int kb4 = kb << 4;
+	auto lane_off = [&](int row) { return (unsigned)((row << 7) + (kb4 ^ ((row << 4) & 0x60))); };
+	unsigned w0 = lds_base + wbase + lane_off(wn * (16 * NB) + r16);
+	asm volatile("" : "+v"(w0));  // ONE opaque loop invariant: left transparent, hipcc keeps three partial forms of this address live through the loop and, at the 168-register limit, reloads one of them from scratch in every barrier interval
 	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int ks, Frag& f) {
-		const int xrow = wm * 64 + r16 + tap_ * p.dil;
-		const unsigned xa = (lds_base + xs_off + ((xrow >> 1) << 8) + ((((xrow & 1) << 3) | (kb ^ v2s_swz(xrow >> 1))) << 4)) ^ (ks << 6);
+		const unsigned xa = (lds_base + xs_off + lane_off(wm * 64 + r16 + tap_ * p.dil)) ^ (ks << 6);
 		const unsigned wa = (w0 + ws_off) ^ (ks << 6);
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
