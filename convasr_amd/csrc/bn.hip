@@ -106,6 +106,8 @@ struct BnActParams {
 	const float* invstd;
 	const float* xlen;
 	double* sums;
+	uint8_t* gate_out;       // forward, optional: bit (element index & 7) of byte (element index >> 3) = the element's gradient gate (below)
+	const uint8_t* gate_in;  // backward, optional: use the stored gate instead of re-deriving act' / dropout / mask
 	int act;
 	float lo, hi, p_drop;
 	unsigned drop_thr;  // an element is dropped when its 16 random bits are < drop_thr (= round(p * 65536))
@@ -228,6 +230,7 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(B
 			[&](const RowWalk& w) { return raw_load8(py + w.idx); },  // unconditional (a masked row is still inside the tensor): no branch between the two rows' loads
 			[&](const RowWalk& w, const Raw8<T>& yraw) {
 				float out[8];
+				unsigned gate = 0;  // bit k: the gradient passes element k (inside the activation's linear range, kept by dropout, frame not masked)
 				if (w.masked()) {
 #pragma unroll
 					for (int k = 0; k < 8; ++k) out[k] = 0.f;
@@ -241,9 +244,17 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(B
 						dropout_keep8(p, w.idx, keep);
 #pragma unroll
 						for (int k = 0; k < 8; ++k) out[k] *= keep[k];
+						if (p.gate_out) {
+#pragma unroll
+							for (int k = 0; k < 8; ++k) gate |= (act_grad(pre[k], ac) != 0.f && keep[k] != 0.f) ? (1u << k) : 0u;
+						}
+					} else if (p.gate_out) {
+#pragma unroll
+						for (int k = 0; k < 8; ++k) gate |= act_grad(pre[k], ac) != 0.f ? (1u << k) : 0u;
 					}
 				}
 				store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
+				if (p.gate_out) p.gate_out[w.idx >> 3] = (uint8_t)gate;
 			});
 	}
 }
@@ -272,12 +283,13 @@ static unsigned ew_grid(int64_t total) {
 
 extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
                                   const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
-                                  uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, void* stream) {
+                                  uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, uint8_t* gate, void* stream) {
 	CONVASR_CHECK_ARG(y && z && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_fwd: bad arguments (C must be a multiple of 8)");
+	CONVASR_CHECK_ARG(!gate || act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE, "bn_act_fwd: the one-bit gate needs an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr) && dropout_p >= 0.f && dropout_p < 1.f, "bn_act_fwd: bad scale/shift/dropout");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_fwd: B * T must fit in 31 bits");
 	BnActParams p = {};
-	p.y = y; p.out = z; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi;
+	p.y = y; p.out = z; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.gate_out = gate;
 	set_dropout(p, dropout_p, seed, offset);
 	p.B = B; p.T = T; p.C = C;
 	ResArgs ra;
@@ -564,14 +576,22 @@ template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_ac
 		load8<float>(coef + p.C + c, Bc);
 		load8<float>(coef + 2 * p.C + c, D);
 		if (FROM_DZ && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
-		struct Pair { Raw8<T> y, dz; };
+		struct Pair { Raw8<T> y, dz; unsigned gate; };
 		const T* const py = reinterpret_cast<const T*>(p.y);
 		const T* const pdz = reinterpret_cast<const T*>(p.dz);
+		const float gate_scale = p.drop_thr ? p.keep_scale : 1.f;
 		walk_rows2(p, rl, c,
-			[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); return q; },
+			[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); q.gate = (FROM_DZ && p.gate_in) ? p.gate_in[w.idx >> 3] : 0u; return q; },
 			[&](const RowWalk& w, const Pair& q) {
 				float yv[8], pre[8], g[8], out[8];
-				if (FROM_DZ) {
+				if (FROM_DZ && p.gate_in) {
+					// the forward pass stored, per element, whether the gradient passes (activation range, dropout, frame mask): g = dz * keep_scale or 0
+					float dz[8];
+					unpack8(q.dz, dz);
+					unpack8(q.y, yv);
+#pragma unroll
+					for (int k = 0; k < 8; ++k) g[k] = ((q.gate >> k) & 1u) ? dz[k] * gate_scale : 0.f;
+				} else if (FROM_DZ) {
 					pre_act8<T>(p, none, w.idx, c, sc, sh, q.y, yv, pre);
 					if (w.masked()) {
 #pragma unroll
@@ -601,11 +621,12 @@ template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_ac
 
 extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
                                         const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                                        const float* xlen, int B, int T, int C, void* stream) {
+                                        const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
 	CONVASR_CHECK_ARG(dz_or_g && y && dy && coef && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_apply: bad arguments (C must be a multiple of 8)");
+	CONVASR_CHECK_ARG(!gate || (from_dz && (act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE)), "bn_act_bwd_apply: the one-bit gate needs from_dz and an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_apply: B * T must fit in 31 bits");
 	BnActParams p = {};
-	p.y = y; p.dz = dz_or_g; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi;
+	p.y = y; p.dz = dz_or_g; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.gate_in = gate;
 	set_dropout(p, dropout_p, seed, offset);
 	p.B = B; p.T = T; p.C = C;
 	dim3 grid, block;

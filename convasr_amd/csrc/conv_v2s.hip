@@ -240,12 +240,18 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
 	constexpr bool bnf = BNF && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
 	uint4 ypre[TRIPS];
+	unsigned gpre[TRIPS];  // the chunk's eight one-bit gradient gates (when the forward pass stored them: bn_gate)
 	if (bnf) {
 #pragma unroll
 		for (int i = 0; i < TRIPS; ++i) {
 			const int e = tid + i * V2_THREADS, row = e / OCH_, t = t0 + row, co = co0 + (e % OCH_) * OEPC_;
 			ypre[i] = make_uint4(0, 0, 0, 0);
-			if (t < p.Tout && co < p.Cout) ypre[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + ((int64_t)b * p.Tout + t) * p.Cout + co);
+			gpre[i] = 0;
+			if (t < p.Tout && co < p.Cout) {
+				const int64_t idx = ((int64_t)b * p.Tout + t) * p.Cout + co;
+				ypre[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + idx);
+				if (p.bn_gate) gpre[i] = p.bn_gate[idx >> 3];
+			}
 		}
 	}
 	// Accumulators -> bf16 / fp32 output tile in LDS (+ the BN statistics of a forward launch).  64 values per lane: this phase is
@@ -324,6 +330,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		if (bco < p.Cout) { load8<float>(p.bn_scale + bco, bsc); load8<float>(p.bn_shift + bco, bsh); load8<float>(p.bn_mean + bco, bmean); load8<float>(p.bn_invstd + bco, bistd); }
 		bnv = valid_len(p.bn_xlen, b, p.Tout);
 	}
+	const float gate_scale = p.bn_drop_thr ? p.bn_keep_scale : 1.f;
 #pragma unroll
 	for (int it = 0; it < TRIPS; ++it) {
 		const int e = tid + it * V2_THREADS;
@@ -344,6 +351,10 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 #pragma unroll
 				for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(w[k] << 16); yv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
 			}
+			if (p.bn_gate) {  // (workgroup-uniform) the stored gates replace act', the dropout hash and the frame mask: g = dz * keep_scale or 0
+#pragma unroll
+				for (int k = 0; k < 8; ++k) g[k] = ((gpre[it] >> k) & 1u) ? dz[k] * gate_scale : 0.f;
+			} else {
 #pragma unroll
 			for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(fmaf(yv[k], bsc[k], bsh[k]), bn_ac);
 			if (p.bn_drop_thr) {
@@ -351,6 +362,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 				dropout_mask8(p.bn_seed, p.bn_offset, p.bn_drop_thr, p.bn_keep_scale, idx, keep);
 #pragma unroll
 				for (int k = 0; k < 8; ++k) g[k] *= keep[k];
+			}
 			}
 #pragma unroll
 			for (int k = 0; k < 8; ++k) { bs1[k] += g[k]; bs2[k] = fmaf(g[k], yv[k], bs2[k]); }  // sum g*y; centred and scaled once per tile below

@@ -199,6 +199,7 @@ class Fold2:
 # reduce pass only if the gradient autograd hands it is that very tensor (same storage: nothing was accumulated or copied in
 # between).  Only outputs with exactly one consumer get a link (ConvBn1d.single_consumer_output).
 FUSE_BWD = os.environ.get('CONVASR_NO_BWD_FUSION') != '1'  # tests / A-B runs flip this to compare against the separate reduce pass
+GATE_BITS = os.environ.get('CONVASR_NO_GATE_BITS') != '1'  # likewise: the stored one-bit gradient gates vs re-deriving them in backward
 _LINK_ATTR = '_convasr_bwd_link'
 
 
@@ -232,7 +233,7 @@ def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
 	pad = spec.dilation * (spec.K - 1) - spec.padding
 	wd = packed_weight(weight, dt, _lib.PACK_DGRAD) if wd is None else wd
 	if link is not None and dt == torch.bfloat16 and spec.stride == 1:
-		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'])
+		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'], gate = link.get('gate'))
 		if dx is not None:
 			link['dz'] = dx  # held until the producer's backward has looked at it: the address cannot be recycled meanwhile
 			return dx
@@ -289,7 +290,13 @@ class ConvBnActFunction(torch.autograd.Function):
 
 		p_drop = cfg['dropout_p']
 		seed, offset = _DropoutState.next(B * Cout * Tout) if p_drop > 0 else (0, 0)
-		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
+		# one bit per element: does the gradient pass it (activation range, dropout, frame mask)?  The backward kernels of a residual-free
+		# layer take the bits back in instead of re-deriving the pre-activation, re-hashing the dropout mask and redoing the frame arithmetic
+		gate = None
+		if GATE_BITS and n_res == 0 and act[0] in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_HARDTANH) and Cout % 8 == 0 and (weight.requires_grad or x_needs_grad or gamma.requires_grad):
+			gate = torch.empty(B * Tout * Cout // 8, dtype = torch.uint8, device = dev)
+		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, gate = gate)
+		ctx.gate = gate
 
 		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset)
 		ctx.params = (weight, gamma, beta) + tuple(flat_res[5 * r + k] for r in range(n_res) for k in range(1, 5))
@@ -298,7 +305,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		ctx.res_has_bn = [p is not None for p in res_bnp]
 		ctx.bwd_link = None
 		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt == torch.bfloat16 and Cout % 8 == 0:
-			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None)
+			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None, gate = gate)
 			setattr(z, _LINK_ATTR, ctx.bwd_link)
 		return z
 
@@ -332,7 +339,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				finalize([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate)
 			g = rsum_of = None
 		elif n_res == 0:
 			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
@@ -344,7 +351,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				reduce([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate)
 			g = rsum_of = None
 		else:
 			bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]

@@ -290,11 +290,13 @@ def _ptr_array(items):
 	return arr
 
 
-def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None):
+def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None):
+	"""gate (optional uint8 (B*T*C/8,)): receives one bit per element, set iff the gradient passes it (include/convasr_hip.h)."""
 	B, C, T = y.shape
+	assert gate is None or (gate.dtype == torch.uint8 and gate.numel() * 8 == B * C * T and gate.is_contiguous())
 	assert is_cl(y) and all(is_cl(r) and r.dtype == y.dtype for r in res)
 	z = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
-	_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res))))
+	_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res))))
 	return z
 
 
@@ -307,10 +309,10 @@ def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res =
 	return g
 
 
-def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None):
+def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None):
 	B, C, T = y.shape
 	dy = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
-	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, stream_ptr()), nbytes = float(B * T * C * y.element_size() * 3))
+	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * 3))
 	return dy
 
 
@@ -444,7 +446,7 @@ def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nest
 	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p_bf16), stream_ptr())
 
 
-def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None):
+def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None, gate = None):
 	"""dx = dgrad(dy) with pass 1 of the consumer layer's batch-norm backward fused into the epilogue (bn_sums += per-channel sums).
 	Returns dx, or None when the shape is outside the fused kernel's envelope (nothing was launched)."""
 	import ctypes
@@ -455,7 +457,7 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 	dx = empty_cl(B, Cin, T, torch.bfloat16, dy.device)
 	rc = [0]
 	def run():
-		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), stream_ptr())
+		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), ptr(gate), stream_ptr())
 	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if Cout % 64 == 0 else 'conv1d_igemm (other variants)'
 	flops, nbytes_ = 2.0 * B * T * Cout * Cin * K if work is None else work, float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2)
 	if family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 3
+#define CONVASR_ABI_VERSION 4
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -147,11 +147,15 @@ int convasr_bn_eval_scale_shift(const float* gamma, const float* beta, const flo
 
 /* z = mask_t( dropout( act( y * scale[c] + shift[c] + sum_r (res_r * rscale_r[c] + rshift_r[c]) ) ) ).
  * y, z, res_r channels-last (B, T, C) of `dtype`.  n_res <= 12; rscale_r NULL means the residual is added as is.
- * dropout_p == 0 disables dropout; otherwise Philox(seed, offset) keyed by element index. */
+ * dropout_p == 0 disables dropout; otherwise a counter-based hash of (seed, offset, element index) decides.
+ * gate (may be NULL; B*T*C/8 bytes; activations with derivative 0 or 1 only: none / relu / hardtanh): bit (e & 7) of byte (e >> 3) for
+ * element e = (b*T + t)*C + c is set iff the gradient passes the element -- inside the activation's linear range, kept by dropout,
+ * frame not masked.  The backward passes below take it back in: g = dz * (1 / (1 - p)) or 0, with no re-derivation of the
+ * pre-activation, no hash and no frame arithmetic (bit-identical to the re-derived g). */
 int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift,
                        int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                        int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                       const float* xlen, int B, int T, int C, void* stream);
+                       const float* xlen, int B, int T, int C, uint8_t* gate, void* stream);
 
 /* Backward of the above, pass 1.  g = dz * mask * dropout * act'(pre), pre recomputed from y (and residuals).
  * Writes g (same dtype; g may be NULL when pass 2 recomputes it from dz) and reduces per channel: sums[0..C) += sum g, sums[C..2C) += sum g * xhat with
@@ -170,10 +174,11 @@ int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype,
                               int accumulate, int B, int T, int C, void* stream);
 
 /* Backward pass 2 in coefficient form: dy = coef[c]*g + coef[C+c]*y + coef[2C+c].  from_dz != 0: g is recomputed on the fly
- * from dz (activation derivative, dropout, temporal mask; no residuals) so pass 1 need not materialise it. */
+ * from dz (activation derivative, dropout, temporal mask; no residuals) so pass 1 need not materialise it; gate (may be NULL): the
+ * one-bit gates convasr_bn_act_fwd stored, used instead of the re-derivation (dropout_p still supplies the 1 / (1 - p)). */
 int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz,
                              const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
-                             uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, void* stream);
+                             uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream);
 
 /* Backward pass 2: dy = gamma * invstd * (g - sum_g / n - xhat * sum_gxhat / n)  (batch-norm training backward);
  * dgamma = sum_gxhat, dbeta = sum_g (written, or added when accumulate).  In place allowed (dy == g). */
@@ -240,11 +245,12 @@ int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int6
  * (C = Cin of this conv) written as per-m-tile partial rows bn_sums[rows][2][C], *bn_rows rows (<= convasr_conv_stats_max_rows(B, T_dx)).  It replaces
  * convasr_conv1d_fwd(dy, packed_dgrad) + convasr_bn_act_bwd_reduce(write_g = 0) (models.py:111-139 backward) when dx has this
  * single consumer.  dy is (B, T_dy, Cout), dx and bn_y are (B, T_dx, Cin); pad = dil*(K-1) - padding of the forward conv.  Returns 1 (nothing launched) when the shape is outside the
- * LDS-DMA kernel's envelope (Cout % 64 != 0): run the two calls separately. */
+ * LDS-DMA kernel's envelope (Cout % 64 != 0): run the two calls separately.  bn_gate (may be NULL): that layer's one-bit gates
+ * from convasr_bn_act_fwd, used instead of re-deriving act' / dropout / mask per element in the epilogue. */
 int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
                                    int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                    const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
-                                   uint64_t offset, const float* bn_xlen, double* bn_sums, int* bn_rows, void* stream);
+                                   uint64_t offset, const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream);
 /* coef / dgamma / dbeta from those partial rows (the second half of convasr_bn_act_bwd_reduce), added in a fixed order; n = B*T. */
 int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamma, const float* mean, const float* invstd, float* coef,
                             float* dgamma, float* dbeta, int accumulate, int64_t n, int C, void* stream);

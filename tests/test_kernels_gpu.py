@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 	lib = _lib.load()
 	for name in declared:
 		assert hasattr(lib, name), name
-	assert lib.convasr_abi_version() == 3
+	assert lib.convasr_abi_version() == 4
 	assert lib.convasr_conv_cout_pad(38) == 128 and lib.convasr_conv_cout_pad(256) == 256
 
 
@@ -727,3 +727,70 @@ def test_instnorm_time_padding_and_folded_eval_forward():
 	assert l1.shape == l0.shape
 	err = float((l1 - l0).norm() / l0.norm())
 	assert err < 2e-2, err  # two bf16 pipelines that differ in one layer's summation order
+
+
+@gpu
+@pytest.mark.parametrize('act', ['hardtanh', 'relu'])
+def test_stored_gradient_gates_equal_the_rederived_ones(act):
+	"""The one-bit gates convasr_bn_act_fwd stores (include/convasr_hip.h): both backward consumers -- the streaming apply pass and the
+	fused dgrad epilogue -- produce bit-identical results from the bits and from re-deriving act' / dropout / frame mask."""
+	from convasr_amd import ops, _lib
+	d = dev()
+	torch.manual_seed(7)
+	B, C, T, Cout, K = 3, 256, 300, 128, 5
+	a = (_lib.ACT_HARDTANH, 0.0, 20.0) if act == 'hardtanh' else (_lib.ACT_RELU, 0.0, 0.0)
+	y = ops.as_cl(torch.randn(B, C, T, device = d) * 8, torch.bfloat16)
+	scale, shift = torch.rand(C, device = d) + 0.5, torch.randn(C, device = d) * 4 + 4
+	mean, invstd = torch.randn(C, device = d), torch.rand(C, device = d) + 0.5
+	xlen = torch.tensor([1.0, 0.55, 0.8], device = d)
+	for p_drop in (0.0, 0.3):
+		gate = torch.zeros(B * T * C // 8, dtype = torch.uint8, device = d)
+		z = ops.bn_act(y, scale, shift, a, xlen = xlen, dropout_p = p_drop, seed = 5, offset = 11, gate = gate)
+		z0 = ops.bn_act(y, scale, shift, a, xlen = xlen, dropout_p = p_drop, seed = 5, offset = 11)
+		assert torch.equal(z, z0)
+		bits = ((gate.view(B, T, C // 8, 1) >> torch.arange(8, device = d, dtype = torch.uint8)) & 1).reshape(B, T, C).permute(0, 2, 1).bool()
+		nz = z.float() != 0
+		assert bool((bits <= nz).all()) and float(bits.float().mean()) > 0.05  # a passing gradient implies a non-zero output (the converse fails at the upper clamp)
+		frames = (xlen * T).ceil().long()
+		for b_ in range(B):
+			assert not bool(bits[b_, :, int(frames[b_]):].any())
+		# streaming apply pass
+		dz = ops.as_cl(torch.randn(B, C, T, device = d), torch.bfloat16)
+		coef = torch.randn(3 * C, device = d)
+		dy0 = ops.bn_act_bwd_apply(dz, y, coef, True, scale, shift, a, xlen = xlen, dropout_p = p_drop, seed = 5, offset = 11)
+		dy1 = ops.bn_act_bwd_apply(dz, y, coef, True, scale, shift, a, xlen = xlen, dropout_p = p_drop, seed = 5, offset = 11, gate = gate)
+		assert torch.equal(dy0, dy1)
+		# fused dgrad epilogue: dx identical, partial sums identical
+		dyc = ops.as_cl(torch.randn(B, Cout, T, device = d), torch.bfloat16)
+		w = torch.randn(Cout, C, K, device = d) / (C * K) ** 0.5
+		_, wd = ops.pack_weight(w, torch.bfloat16, None)
+		s0, s1 = ops.ConvStats(C, B, T, d), ops.ConvStats(C, B, T, d)
+		dx0 = ops.conv1d_dgrad_bn_reduce(dyc, wd, C, K, 1, K - 1 - K // 2, y, scale, shift, mean, invstd, a, p_drop, 5, 11, xlen, s0)
+		dx1 = ops.conv1d_dgrad_bn_reduce(dyc, wd, C, K, 1, K - 1 - K // 2, y, scale, shift, mean, invstd, a, p_drop, 5, 11, xlen, s1, gate = gate)
+		assert dx0 is not None and torch.equal(dx0, dx1) and s0.rows == s1.rows and torch.equal(s0.totals(), s1.totals())
+
+
+@gpu
+def test_training_step_is_bitwise_the_same_with_and_without_stored_gates():
+	from convasr_amd import models, functional as Fn
+	d = dev()
+
+	def run(enabled):
+		Fn.GATE_BITS = enabled
+		try:
+			torch.manual_seed(3)
+			Fn.manual_seed(11)
+			m = models.Wav2Letter(64, [38], dropout = 0.2, compute_dtype = torch.bfloat16, check_time_dim_padded = False).to(d).train()
+			x = torch.randn(2, 64, 302, device = d)
+			xlen = torch.tensor([1.0, 0.7], device = d)
+			y = torch.randint(0, 37, (2, 1, 20), device = d)
+			ylen = torch.tensor([[20], [12]], device = d)
+			out = m(x, xlen, y = y, ylen = ylen)
+			out['loss'].sum().backward()
+			return out['loss'].detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
+		finally:
+			Fn.GATE_BITS = True
+
+	l1, g1 = run(True)
+	l0, g0 = run(False)
+	assert torch.equal(l1, l0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
