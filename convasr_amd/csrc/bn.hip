@@ -216,7 +216,15 @@ template <typename L, typename U> __device__ __forceinline__ void walk_rows2(con
 
 __device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) { dropout_mask8(p.seed, p.offset, p.drop_thr, p.keep_scale, idx, keep); }
 
-template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra) {
+// MODE bit 0: residual inputs present, bit 1: dropout on, bit 2: gate bits wanted, bit 3: BN scale / shift present -- compile-time, so
+// that the training step's launches (no residuals, scale / shift, dropout, gates) run straight-line code without the other cases'
+// branches, register copies and live ranges (the kernel is VALU-bound, not HBM-bound: 16 instantiations instead of one).
+template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra_) {
+	constexpr bool RES = MODE & 1, DROP = (MODE & 2) != 0, GATE = (MODE & 4) != 0, AFFINE = (MODE & 8) != 0;
+	ResArgs ra = ra_;
+	if (!RES) ra.n = 0;
+	if (!AFFINE) p.scale = nullptr;
+	else __builtin_assume(p.scale != nullptr);
 	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	const int c8 = p.C >> 3;
 	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
@@ -224,7 +232,7 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(B
 		if (cbase + cg >= c8) continue;
 		const int c = (cbase + cg) << 3;
 		float sc[8], sh[8];
-		if (p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+		if (AFFINE) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
 		const T* const py = reinterpret_cast<const T*>(p.y);
 		walk_rows2(p, rl, c,
 			[&](const RowWalk& w) { return raw_load8(py + w.idx); },  // unconditional (a masked row is still inside the tensor): no branch between the two rows' loads
@@ -239,22 +247,22 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(B
 					pre_act8<T>(p, ra, w.idx, c, sc, sh, yraw, yv, pre);
 #pragma unroll
 					for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], ac);
-					if (p.drop_thr) {
+					if (DROP) {
 						float keep[8];
 						dropout_keep8(p, w.idx, keep);
 #pragma unroll
 						for (int k = 0; k < 8; ++k) out[k] *= keep[k];
-						if (p.gate_out) {
+						if (GATE) {
 #pragma unroll
 							for (int k = 0; k < 8; ++k) gate |= (act_grad(pre[k], ac) != 0.f && keep[k] != 0.f) ? (1u << k) : 0u;
 						}
-					} else if (p.gate_out) {
+					} else if (GATE) {
 #pragma unroll
 						for (int k = 0; k < 8; ++k) gate |= act_grad(pre[k], ac) != 0.f ? (1u << k) : 0u;
 					}
 				}
 				store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
-				if (p.gate_out) p.gate_out[w.idx >> 3] = (uint8_t)gate;
+				if (GATE) p.gate_out[w.idx >> 3] = (uint8_t)gate;
 			});
 	}
 }
@@ -296,9 +304,17 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, nullptr, nullptr, nullptr)) return rc;
 	dim3 grid, block;
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
-	if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, p, ra);
-	else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, p, ra);
-	else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
+	if (dtype != CONVASR_F32 && dtype != CONVASR_BF16) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
+	const int mode = (n_res > 0 ? 1 : 0) | (p.drop_thr ? 2 : 0) | (gate ? 4 : 0) | (scale ? 8 : 0);
+#define BN_FWD_CASE(M) case M: \
+		if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
+		else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
+		break;
+	switch (mode) {
+		BN_FWD_CASE(0) BN_FWD_CASE(1) BN_FWD_CASE(2) BN_FWD_CASE(3) BN_FWD_CASE(4) BN_FWD_CASE(5) BN_FWD_CASE(6) BN_FWD_CASE(7)
+		BN_FWD_CASE(8) BN_FWD_CASE(9) BN_FWD_CASE(10) BN_FWD_CASE(11) BN_FWD_CASE(12) BN_FWD_CASE(13) BN_FWD_CASE(14) BN_FWD_CASE(15)
+	}
+#undef BN_FWD_CASE
 	CONVASR_CHECK_LAUNCH("bn_act_fwd");
 	return 0;
 }
@@ -562,7 +578,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // dy = A[c] * g + Bc[c] * y + D[c] with g either given (FROM_DZ = false) or recomputed from dz: g = dz * act'(pre) * dropout * mask
-template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
+// SRC 0: g given; 1: g re-derived from dz (act', dropout hash, frame mask); 2: g = dz gated by the forward pass's stored bits (compile-time:
+// the gated form carries none of the re-derivation's registers -- 95 -> ~50 VGPRs -- or code)
+template <typename T, int SRC> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
+	constexpr bool FROM_DZ = SRC != 0, GATED = SRC == 2;
 	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	const int c8 = p.C >> 3;
 	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
@@ -575,16 +594,16 @@ template <typename T, bool FROM_DZ> __global__ __launch_bounds__(256) void bn_ac
 		load8<float>(coef + c, A);
 		load8<float>(coef + p.C + c, Bc);
 		load8<float>(coef + 2 * p.C + c, D);
-		if (FROM_DZ && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
+		if (FROM_DZ && !GATED && p.scale) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
 		struct Pair { Raw8<T> y, dz; unsigned gate; };
 		const T* const py = reinterpret_cast<const T*>(p.y);
 		const T* const pdz = reinterpret_cast<const T*>(p.dz);
 		const float gate_scale = p.drop_thr ? p.keep_scale : 1.f;
 		walk_rows2(p, rl, c,
-			[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); q.gate = (FROM_DZ && p.gate_in) ? p.gate_in[w.idx >> 3] : 0u; return q; },
+			[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); q.gate = GATED ? p.gate_in[w.idx >> 3] : 0u; return q; },
 			[&](const RowWalk& w, const Pair& q) {
 				float yv[8], pre[8], g[8], out[8];
-				if (FROM_DZ && p.gate_in) {
+				if (GATED) {
 					// the forward pass stored, per element, whether the gradient passes (activation range, dropout, frame mask): g = dz * keep_scale or 0
 					float dz[8];
 					unpack8(q.dz, dz);
@@ -633,11 +652,13 @@ extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
 	hipStream_t s = (hipStream_t)stream;
 	if (dtype == CONVASR_F32) {
-		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, true>), grid, block, 0, s, p, coef, (float*)dy);
-		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, false>), grid, block, 0, s, p, coef, (float*)dy);
+		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 2>), grid, block, 0, s, p, coef, (float*)dy);
+		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 1>), grid, block, 0, s, p, coef, (float*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 0>), grid, block, 0, s, p, coef, (float*)dy);
 	} else if (dtype == CONVASR_BF16) {
-		if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, true>), grid, block, 0, s, p, coef, (bf16_t*)dy);
-		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, false>), grid, block, 0, s, p, coef, (bf16_t*)dy);
+		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, 2>), grid, block, 0, s, p, coef, (bf16_t*)dy);
+		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, 1>), grid, block, 0, s, p, coef, (bf16_t*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, 0>), grid, block, 0, s, p, coef, (bf16_t*)dy);
 	} else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_apply: dtype %d", dtype);
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_apply");
 	return 0;
