@@ -216,11 +216,12 @@ template <typename L, typename U> __device__ __forceinline__ void walk_rows2(con
 
 __device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) { dropout_mask8(p.seed, p.offset, p.drop_thr, p.keep_scale, idx, keep); }
 
-// MODE bit 0: residual inputs present, bit 1: dropout on, bit 2: gate bits wanted, bit 3: BN scale / shift present -- compile-time, so
+// MODE bit 0: residual inputs present, bit 1: dropout on, bit 2: gate bits wanted, bit 3: BN scale / shift present, bit 4: the
+// activation may be leaky-relu (else a clamp: one v_med3_f32 per element) -- compile-time, so
 // that the training step's launches (no residuals, scale / shift, dropout, gates) run straight-line code without the other cases'
 // branches, register copies and live ranges (the kernel is VALU-bound, not HBM-bound: 16 instantiations instead of one).
 template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra_) {
-	constexpr bool RES = MODE & 1, DROP = (MODE & 2) != 0, GATE = (MODE & 4) != 0, AFFINE = (MODE & 8) != 0;
+	constexpr bool RES = MODE & 1, DROP = (MODE & 2) != 0, GATE = (MODE & 4) != 0, AFFINE = (MODE & 8) != 0, LEAKY = (MODE & 16) != 0;
 	ResArgs ra = ra_;
 	if (!RES) ra.n = 0;
 	if (!AFFINE) p.scale = nullptr;
@@ -246,7 +247,7 @@ template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fw
 					float yv[8], pre[8];
 					pre_act8<T>(p, ra, w.idx, c, sc, sh, yraw, yv, pre);
 #pragma unroll
-					for (int k = 0; k < 8; ++k) out[k] = apply_act(pre[k], ac);
+					for (int k = 0; k < 8; ++k) out[k] = LEAKY ? apply_act(pre[k], ac) : apply_clamp(pre[k], ac);
 					if (DROP) {
 						float keep[8];
 						dropout_keep8(p, w.idx, keep);
@@ -305,7 +306,7 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 	dim3 grid, block;
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
 	if (dtype != CONVASR_F32 && dtype != CONVASR_BF16) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
-	const int mode = (n_res > 0 ? 1 : 0) | (p.drop_thr ? 2 : 0) | (gate ? 4 : 0) | (scale ? 8 : 0);
+	const int mode = (n_res > 0 ? 1 : 0) | (p.drop_thr ? 2 : 0) | (gate ? 4 : 0) | (scale ? 8 : 0) | (act == CONVASR_ACT_LEAKY_RELU ? 16 : 0);
 #define BN_FWD_CASE(M) case M: \
 		if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
 		else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
@@ -313,6 +314,7 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 	switch (mode) {
 		BN_FWD_CASE(0) BN_FWD_CASE(1) BN_FWD_CASE(2) BN_FWD_CASE(3) BN_FWD_CASE(4) BN_FWD_CASE(5) BN_FWD_CASE(6) BN_FWD_CASE(7)
 		BN_FWD_CASE(8) BN_FWD_CASE(9) BN_FWD_CASE(10) BN_FWD_CASE(11) BN_FWD_CASE(12) BN_FWD_CASE(13) BN_FWD_CASE(14) BN_FWD_CASE(15)
+		BN_FWD_CASE(16) BN_FWD_CASE(17) BN_FWD_CASE(18) BN_FWD_CASE(19) BN_FWD_CASE(24) BN_FWD_CASE(25) BN_FWD_CASE(26) BN_FWD_CASE(27)  // leaky-relu: no gate bits
 	}
 #undef BN_FWD_CASE
 	CONVASR_CHECK_LAUNCH("bn_act_fwd");

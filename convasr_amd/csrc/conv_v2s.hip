@@ -259,8 +259,8 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	// no folded scale / shift, no activation, no length mask in the conv itself -- take a specialised instantiation that does
 	// nothing but (statistics,) convert and store; tiles that end inside the utterance also drop the row predicate.  Same
 	// arithmetic on the same values in the same order: bit-identical to the general form.
-	auto stage = [&](auto PLAIN_, auto FULL_, auto STATS_) {
-		constexpr bool PLAIN = decltype(PLAIN_)::value, FULL = decltype(FULL_)::value, STATS = decltype(STATS_)::value;
+	auto stage = [&](auto PLAIN_, auto FULL_, auto STATS_, auto LEAKY_) {
+		constexpr bool PLAIN = decltype(PLAIN_)::value, FULL = decltype(FULL_)::value, STATS = decltype(STATS_)::value, LEAKY = decltype(LEAKY_)::value;
 #pragma unroll
 		for (int ni = 0; ni < NB; ++ni) {
 			const int col = wn * (16 * NB) + ni * 16 + r16, co = co0 + col;
@@ -278,7 +278,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 					if (!PLAIN) val += bias;
 					if (STATS && (FULL || t < p.Tout)) { s1 += val; s2 += val * val; }
 					if (!PLAIN) {
-						val = apply_act(val * sc + sh, ac);
+						val = LEAKY ? apply_act(val * sc + sh, ac) : apply_clamp(val * sc + sh, ac);  // (not leaky-relu: one v_med3_f32)
 						if (t >= nvalid) val = 0.f;
 					}
 					Elem<O>::store(reinterpret_cast<O*>(otile + row * OPITCH) + col, val);
@@ -295,9 +295,12 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		typedef std::true_type Y;
 		typedef std::false_type N;
 		const bool plain = !p.bias && !p.scale && p.act == CONVASR_ACT_NONE && !p.xlen, full = t0 + V2_BM <= p.Tout;
-		if (!plain) { if (p.stats) stage(N(), N(), Y()); else stage(N(), N(), N()); }
-		else if (p.stats) { if (full) stage(Y(), Y(), Y()); else stage(Y(), N(), Y()); }
-		else stage(Y(), Y(), N());
+		if (!plain) {
+			if (ac.leaky) { if (p.stats) stage(N(), N(), Y(), Y()); else stage(N(), N(), N(), Y()); }
+			else { if (p.stats) stage(N(), N(), Y(), N()); else stage(N(), N(), N(), N()); }
+		}
+		else if (p.stats) { if (full) stage(Y(), Y(), Y(), N()); else stage(Y(), N(), Y(), N()); }
+		else stage(Y(), Y(), N(), N());
 	}
 #ifdef CONVASR_STAMPS
 	unsigned long long t_e1 = 0, t_e2 = 0, t_e3 = 0;
