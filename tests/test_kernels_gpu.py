@@ -794,3 +794,38 @@ def test_training_step_is_bitwise_the_same_with_and_without_stored_gates():
 	l1, g1 = run(True)
 	l0, g0 = run(False)
 	assert torch.equal(l1, l0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
+@gpu
+def test_stride2_fold_adjoint_identity_at_the_bench_size():
+	"""The folded prologue at BASELINE's full size (64 utterances x 1502 frames x 64 mel channels -> 256 channels, K = 11, stride 2):
+	<conv(x; w), dy> = <w, wgrad(x, dy)> -- the forward and the weight gradient are adjoint in w -- evaluated in float64 on the kernels'
+	bf16 / fp32 outputs (size-independent property: no oracle run needed at this size)."""
+	from convasr_amd import ops
+	d = dev()
+	torch.manual_seed(21)
+	B, Cin, Cout, K, pad, T = 64, 64, 256, 11, 5, 1502
+	x = ops.as_cl(torch.randn(B, Cin, T, device = d), torch.bfloat16)
+	w = (torch.randn(Cout, Cin, K, device = d) / (Cin * K) ** 0.5).to(torch.bfloat16).float()  # exactly representable: the packed operand is w itself
+	Kf, Pf = ops.fold2_geometry(K, pad)
+	Tout = ops.conv_out_len(T, K, 2, 1, pad)
+	xv = x.as_strided((B, 2 * Cin, T // 2), (T * Cin, 1, 2 * Cin))
+	y = ops.conv1d(xv, ops.fold2_pack_weight(w, torch.bfloat16, pad), Cout, Kf, 1, 1, Pf, Tout = Tout, out_dtype = torch.float32)
+	assert y.shape == (B, Cout, Tout)
+	dy = ops.as_cl(torch.randn(B, Cout, Tout, device = d), torch.bfloat16)
+	dwf = torch.empty(Kf, Cout, 2 * Cin, device = d)
+	ops.conv1d_wgrad(xv, dy, Cout, Kf, 1, 1, Pf, dwf.permute(1, 2, 0))
+	dw = torch.empty(Cout, Cin, K, device = d)
+	ops.fold2_unfold_wgrad(dwf, dw, pad)
+	lhs = float((y.double() * dy.double()).sum())
+	rhs = float((w.double() * dw.double()).sum())
+	scale = float(y.double().norm() * dy.double().norm())
+	assert abs(lhs - rhs) <= 1e-5 * scale, (lhs, rhs, scale)
+	# linearity in x of the folded forward
+	x2 = ops.as_cl(torch.randn(B, Cin, T, device = d), torch.bfloat16)
+	xs = ops.as_cl((x.float() + x2.float()).to(torch.bfloat16).float(), torch.float32)  # the sum as the kernel will see it (bf16)
+	wp = ops.fold2_pack_weight(w, torch.bfloat16, pad)
+	f = lambda t: ops.conv1d(ops.as_cl(t, torch.bfloat16).as_strided((B, 2 * Cin, T // 2), (T * Cin, 1, 2 * Cin)), wp, Cout, Kf, 1, 1, Pf, Tout = Tout, out_dtype = torch.float32)
+	ya, yb_, ys = f(x), f(x2), f(xs.to(torch.bfloat16))
+	exact = (ops.as_cl(xs, torch.float32) - x.float() - x2.float()).abs().max()  # rounding of the bf16 sum
+	assert float((ys - ya - yb_).abs().max()) <= 64 * K * float(exact) * float(w.abs().max()) + 1e-3
