@@ -11,7 +11,8 @@ import torch  # noqa: F401  (must precede the CDLL below)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CONVASR_HIP_LIB') or os.path.join(_HERE, 'libconvasr_hip.so')  # (the override is a measurement hook: an alternate build of the same sources, see build.py)
 
-F32, BF16, I16 = 0, 1, 2
+F32, BF16, I16, F16 = 0, 1, 2, 3
+LOSS_SCALER_FLOATS = 8  # include/convasr_hip.h: CONVASR_LOSS_SCALER_FLOATS
 ACT_NONE, ACT_RELU, ACT_HARDTANH, ACT_LEAKY_RELU = 0, 1, 2, 3
 PACK_FWD, PACK_DGRAD = 0, 1
 W_REFERENCE, W_KMAJOR = 0, 1  # include/convasr_hip.h: memory layout of a (Cout, Cin, K) parameter / gradient
@@ -48,16 +49,16 @@ _SIGNATURES = dict(
 	convasr_ctc_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
 	convasr_ctc_loss = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_i64, c_p, c_int, c_i64, c_p]),
-	convasr_loss_head = (c_int, [c_p, c_p, c_i64, c_p, c_int, c_f32, c_p, c_p, c_p, c_p]),
+	convasr_loss_head = (c_int, [c_p, c_p, c_i64, c_p, c_int, c_f32, c_p, c_p, c_p, c_p, c_p]),
 	convasr_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_weighted_mean_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_sumsq_workspace_bytes = (c_i64, []),
-	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_f32, c_p]),
-	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p, c_p]),
-	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p]),
+	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_f32, c_p, c_p]),
+	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
+	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p]),
 	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
-	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_p]),
+	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),
@@ -88,7 +89,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 4:
+		if lib.convasr_abi_version() != 5:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib
@@ -117,8 +118,10 @@ class KernelTimer:
 	def __init__(self, only = None):
 		self.records = {}
 		self.only = None if only is None else set(only)  # families to time; launches of other families run untouched (an event pair costs ~5 us of stream time)
+		self.sequence = []  # (family, symbol class) of EVERY launch that came through, in launch order (bench.py maps a profiler's dispatch list onto it)
 
-	def timed(self, family, work, fn, nbytes = 0.0):
+	def timed(self, family, work, fn, nbytes = 0.0, symbol = None):
+		self.sequence.append((family, symbol))
 		if self.only is not None and family not in self.only:
 			return fn()
 		start, end = torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True)
@@ -138,11 +141,13 @@ class KernelTimer:
 timer = None  # set to a KernelTimer by bench.py for the timed region
 
 
-def timed(family, work, fn, nbytes = 0.0):
+def timed(family, work, fn, nbytes = 0.0, symbol = None):
+	"""symbol: which kernel symbol the C side will pick, where a profiler's per-dispatch rows must be told apart ('v2s16' = the
+	LDS-DMA conv kernel with 16-bit input AND output, conv1d_igemm_v2s_kernel<H, H, *>)."""
 	if timer is None:
 		fn()
 	else:
-		timer.timed(family, work, fn, nbytes)
+		timer.timed(family, work, fn, nbytes, symbol)
 
 
 def stream_ptr():
@@ -154,7 +159,7 @@ def ptr(t):
 
 
 def dtype_code(dtype):
-	return {torch.float32: F32, torch.bfloat16: BF16, torch.int16: I16}[dtype]
+	return {torch.float32: F32, torch.bfloat16: BF16, torch.int16: I16, torch.float16: F16}[dtype]
 
 
 def require_cuda(*tensors):

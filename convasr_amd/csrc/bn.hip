@@ -158,18 +158,24 @@ struct RowWalk {
 	}
 };
 
-// 8 consecutive elements as loaded (16 B of bf16 / 32 B of f32): kept raw so that the loads of two rows can be issued back to
+// Storage-type dispatch of the streaming kernels below: runs the statement with T = float / bf16_t / f16_t
+#define BN_DISPATCH(name, dtype, T, ...) \
+	if ((dtype) == CONVASR_F32) { typedef float T; __VA_ARGS__; } \
+	else if ((dtype) == CONVASR_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+	else if ((dtype) == CONVASR_F16) { typedef f16_t T; __VA_ARGS__; } \
+	else return convasr_fail(CONVASR_EUNSUPPORTED, name ": dtype %d", (dtype))
+
+// 8 consecutive elements as loaded (16 B of bf16 / fp16, 32 B of f32): kept raw so that the loads of two rows can be issued back to
 // back before either is unpacked -- the kernels below are latency-bound on bytes in flight, not on arithmetic
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { uint4 v; };
+template <> struct Raw8<f16_t> { uint4 v; };
 template <> struct Raw8<float> { float4 a, b; };
 __device__ __forceinline__ Raw8<bf16_t> raw_load8(const bf16_t* p) { Raw8<bf16_t> r; r.v = *reinterpret_cast<const uint4*>(p); return r; }
+__device__ __forceinline__ Raw8<f16_t> raw_load8(const f16_t* p) { Raw8<f16_t> r; r.v = *reinterpret_cast<const uint4*>(p); return r; }
 __device__ __forceinline__ Raw8<float> raw_load8(const float* p) { Raw8<float> r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r; }
-__device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) {
-	const unsigned w[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
-#pragma unroll
-	for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-}
+__device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) { unpack16<bf16_t>(r.v, v); }
+__device__ __forceinline__ void unpack8(const Raw8<f16_t>& r, float (&v)[8]) { unpack16<f16_t>(r.v, v); }
 __device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&v)[8]) {
 	v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
 }
@@ -305,10 +311,11 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, nullptr, nullptr, nullptr)) return rc;
 	dim3 grid, block;
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
-	if (dtype != CONVASR_F32 && dtype != CONVASR_BF16) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
+	if (dtype != CONVASR_F32 && !convasr_is_half(dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
 	const int mode = (n_res > 0 ? 1 : 0) | (p.drop_thr ? 2 : 0) | (gate ? 4 : 0) | (scale ? 8 : 0) | (act == CONVASR_ACT_LEAKY_RELU ? 16 : 0);
 #define BN_FWD_CASE(M) case M: \
 		if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
+		else if (dtype == CONVASR_F16) hipLaunchKernelGGL((bn_act_fwd_kernel<f16_t, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
 		else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
 		break;
 	switch (mode) {
@@ -532,13 +539,9 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 	hipStream_t st = (hipStream_t)stream;
 	bool res_sums = false;
 	for (int r = 0; r < n_res; ++r) res_sums = res_sums || ra.rsums[r] != nullptr;
-	if (dtype == CONVASR_F32) {
-		if (res_sums) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float, true>), grid, block, 0, st, p, ra, (float*)workspace);
-		else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float, false>), grid, block, 0, st, p, ra, (float*)workspace);
-	} else if (dtype == CONVASR_BF16) {
-		if (res_sums) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t, true>), grid, block, 0, st, p, ra, (float*)workspace);
-		else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<bf16_t, false>), grid, block, 0, st, p, ra, (float*)workspace);
-	} else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: dtype %d", dtype);
+	BN_DISPATCH("bn_act_bwd_reduce", dtype, T,
+		if (res_sums) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, true>), grid, block, 0, st, p, ra, (float*)workspace);
+		else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, false>), grid, block, 0, st, p, ra, (float*)workspace));
 	if (any) {
 		BnFinalizeSets sets;
 		sets.dst[0] = (mean && sums) ? sums : nullptr;
@@ -653,15 +656,10 @@ extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void
 	dim3 grid, block;
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
 	hipStream_t s = (hipStream_t)stream;
-	if (dtype == CONVASR_F32) {
-		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 2>), grid, block, 0, s, p, coef, (float*)dy);
-		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 1>), grid, block, 0, s, p, coef, (float*)dy);
-		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 0>), grid, block, 0, s, p, coef, (float*)dy);
-	} else if (dtype == CONVASR_BF16) {
-		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, 2>), grid, block, 0, s, p, coef, (bf16_t*)dy);
-		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, 1>), grid, block, 0, s, p, coef, (bf16_t*)dy);
-		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<bf16_t, 0>), grid, block, 0, s, p, coef, (bf16_t*)dy);
-	} else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_apply: dtype %d", dtype);
+	BN_DISPATCH("bn_act_bwd_apply", dtype, T,
+		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 2>), grid, block, 0, s, p, coef, (T*)dy);
+		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 1>), grid, block, 0, s, p, coef, (T*)dy);
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 0>), grid, block, 0, s, p, coef, (T*)dy));
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_apply");
 	return 0;
 }
@@ -681,9 +679,7 @@ extern "C" int convasr_bn_bwd_apply(const void* g, const void* y, void* dy, int 
 	const int64_t rows = (int64_t)B * T;
 	if (dy) {
 		const int64_t total = rows * (C >> 3);
-		if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)g, (const float*)y, (float*)dy, gamma, mean, invstd, sums, rows, C);
-		else if (dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)dy, gamma, mean, invstd, sums, rows, C);
-		else return convasr_fail(CONVASR_EUNSUPPORTED, "bn_bwd_apply: dtype %d", dtype);
+		BN_DISPATCH("bn_bwd_apply", dtype, T, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(total)), dim3(256), 0, s, (const T*)g, (const T*)y, (T*)dy, gamma, mean, invstd, sums, rows, C));
 		CONVASR_CHECK_LAUNCH("bn_bwd_apply");
 	}
 	if (dgamma || dbeta) {

@@ -7,6 +7,7 @@
 #include "../../include/convasr_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef _Float16 f16_t;         // IEEE half (CONVASR_F16): a distinct C++ type, so the kernels' storage-type templates tell the two 16-bit formats apart
 
 extern thread_local char g_convasr_err[512];
 int convasr_fail(int code, const char* fmt, ...);
@@ -35,29 +36,52 @@ template <> struct Elem<bf16_t> {
 	__device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-// 8 consecutive elements as fp32 (16 B of bf16 or 32 B of f32)
+template <> struct Elem<f16_t> {
+	static constexpr int dtype = CONVASR_F16;
+	__device__ static __forceinline__ float load(const f16_t* p) { return (float)*p; }
+	__device__ static __forceinline__ void store(f16_t* p, float v) { *p = (f16_t)v; }  // round-to-nearest-even, +-inf beyond 65504 (what the loss scaler's overflow check keys on)
+};
+
+// 16 bytes of a 16-bit storage type <-> 8 floats (element 2i in the low half of word i)
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& raw, float (&v)[8]);
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& raw, float (&v)[8]) {
+	const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& raw, float (&v)[8]) {
+	const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { const f16x2 h = __builtin_bit_cast(f16x2, w[i]); v[2 * i] = (float)h[0]; v[2 * i + 1] = (float)h[1]; }
+}
+template <typename T> __device__ __forceinline__ unsigned pack16(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack16<bf16_t>(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+template <> __device__ __forceinline__ unsigned pack16<f16_t>(float lo, float hi) { f16x2 h; h[0] = (f16_t)lo; h[1] = (f16_t)hi; return __builtin_bit_cast(unsigned, h); }
+
+// 8 consecutive elements as fp32 (16 B of bf16 / fp16 or 32 B of f32)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
 	float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
 	v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
-	uint4 a = *reinterpret_cast<const uint4*>(p);
-	unsigned w[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-	for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) { unpack16<bf16_t>(*reinterpret_cast<const uint4*>(p), v); }
+template <> __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float (&v)[8]) { unpack16<f16_t>(*reinterpret_cast<const uint4*>(p), v); }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
 	*reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 	*reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-	unsigned w[4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
-	*reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+	*reinterpret_cast<uint4*>(p) = make_uint4(pack16<bf16_t>(v[0], v[1]), pack16<bf16_t>(v[2], v[3]), pack16<bf16_t>(v[4], v[5]), pack16<bf16_t>(v[6], v[7]));
 }
+template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&v)[8]) {
+	*reinterpret_cast<uint4*>(p) = make_uint4(pack16<f16_t>(v[0], v[1]), pack16<f16_t>(v[2], v[3]), pack16<f16_t>(v[4], v[5]), pack16<f16_t>(v[6], v[7]));
+}
+
+// Run `fn` with a value of the 16-bit storage type a CONVASR_* dtype code names (callers have checked that it is one of the two).
+#define CONVASR_DISPATCH_HALF(dtype, T, ...) do { if ((dtype) == CONVASR_F16) { typedef f16_t T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)
+static inline bool convasr_is_half(int dtype) { return dtype == CONVASR_BF16 || dtype == CONVASR_F16; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -68,6 +92,40 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
 	return v;
+}
+
+// Dynamic loss scaler (fp16 training; the role of apex.amp's LossScaler behind train.py:770-772): state = CONVASR_LOSS_SCALER_FLOATS
+// floats on the device, read by the loss head (backward seed x scale), the gradient-norm kernel and the fused optimizer steps
+// (gradients x 1 / scale; a non-finite gradient norm = overflow: the step is skipped), and advanced by the optimizer step into a
+// SECOND buffer (in != out; the host swaps the two after every step, like NovoGrad's EMAs) -- apex's update_scale():
+// overflow: scale = max(min_scale, scale / factor), unskipped = 0; else ++unskipped, and at unskipped == window: scale =
+// min(max_scale, scale * factor), unskipped = 0.  window == 0: static scale, no overflow check.
+enum { LS_SCALE = 0, LS_UNSKIPPED = 1, LS_OVERFLOW = 2, LS_WINDOW = 3, LS_MIN = 4, LS_MAX = 5, LS_FACTOR = 6, LS_SKIPPED_STEPS = 7 };
+struct LossScale { float scale, inv; bool overflow; };
+// norm_sq: the squared norm of the (scaled) gradient; NULL scaler: scale 1, never an overflow
+__device__ __forceinline__ LossScale loss_scale_read(const float* __restrict__ scaler, double norm_sq) {
+	LossScale r; r.scale = 1.f; r.inv = 1.f; r.overflow = false;
+	if (scaler) {
+		r.scale = scaler[LS_SCALE];
+		r.inv = 1.f / r.scale;
+		r.overflow = scaler[LS_WINDOW] > 0.f && !(fabs(norm_sq) < (double)INFINITY);
+	}
+	return r;
+}
+// one thread: out = the state after this step (gated: the step was skipped for a non-finite LOSS, backward's result is not looked at)
+__device__ __forceinline__ void loss_scale_advance(const float* __restrict__ in, float* __restrict__ out, bool overflow, bool gated) {
+#pragma unroll
+	for (int i = 0; i < CONVASR_LOSS_SCALER_FLOATS; ++i) out[i] = in[i];
+	if (gated) return;
+	float scale = in[LS_SCALE], unskipped = in[LS_UNSKIPPED];
+	const float window = in[LS_WINDOW], factor = in[LS_FACTOR];
+	out[LS_OVERFLOW] = overflow ? 1.f : 0.f;
+	if (window <= 0.f) return;
+	if (overflow) { scale = fmaxf(in[LS_MIN], scale / factor); unskipped = 0.f; out[LS_SKIPPED_STEPS] = in[LS_SKIPPED_STEPS] + 1.f; }
+	else unskipped += 1.f;
+	if (unskipped >= window) { scale = fminf(in[LS_MAX], scale * factor); unskipped = 0.f; }
+	out[LS_SCALE] = scale;
+	out[LS_UNSKIPPED] = unskipped;
 }
 
 // valid frames of a T-long axis: ceil(frac * T) computed in fp32 like (lengths_fraction * T).ceil().long() (models.py:614)

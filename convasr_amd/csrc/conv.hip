@@ -7,7 +7,7 @@
 // MFMA fragment is one 16-byte LDS read.  One workgroup owns a 128(t) x 128(co) output tile of ONE utterance; per 128-byte
 // slab of input channels it stages the X rows [t0*stride - pad, ...) ONCE (tile + halo) and re-uses them for all K taps --
 // the tap only shifts the LDS row a fragment is read from.  Weight tiles stream through a 2-deep ring, one per (ci-slab, tap).
-// fp32 runs the same schedule on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), bf16 on v_mfma_f32_32x32x16_bf16.
+// fp32 runs the same schedule on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), bf16 / fp16 on v_mfma_f32_32x32x16_{bf16,f16}.
 #include "conv_common.h"
 
 // 16 bytes of a row, zero outside [0, n_valid_elems); scalar path when rows are not 16-byte aligned.
@@ -98,6 +98,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 		for (int j = 0; j < 2; ++j)
 #pragma unroll
 			for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+	// fp32 (the parity path) sums in two levels: one accumulator per 32-channel slab (32 K terms, a chain of 16 K MFMA adds), added to a
+	// running total when the slab ends.  A single chain over all Cin K terms (8448 for 768 channels, K = 11) random-walks to ~sqrt(n) / 2
+	// ulp, 1.7-3x what a blocked CPU sum leaves (profiles/r02_fp64_reference.json: logits 3.4e-5 from float64 against torch-CPU's
+	// 1.1e-5); per-slab chains cut it ~4x for 64 v_add per slab.  16-bit builds keep the single chain: their sums must stay
+	// bit-identical to the LDS-DMA kernel's (tests/test_kernels_gpu.py), and their error is the storage rounding, not the chain.
+	constexpr bool TWO_LEVEL = sizeof(T) == 4;
+	f32x16 total[2][2];
+	if (TWO_LEVEL) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) total[i][j][k] = 0.f;
+	}
 
 	load_x(0);
 	load_w(0, 0);
@@ -138,8 +153,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 
 		if (has_next) store_w((q + 1) & 1);
 		if (next_x) store_x((cib + 1) & 1);
+		if (TWO_LEVEL && last_tap && has_next) {
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+#pragma unroll
+				for (int j = 0; j < 2; ++j) {
+					total[i][j] += acc[i][j];
+#pragma unroll
+					for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+				}
+		}
 		__syncthreads();
 		if (last_tap) { tap = 0; ++cib; } else ++tap;
+	}
+	if (TWO_LEVEL) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
 	}
 
 	// ---------------- epilogue: bias, BN statistics, scale/shift, activation, temporal mask, coalesced store through LDS
@@ -233,9 +264,9 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ f
 	}
 }
 
-// bf16 builds of the two packers with 4-byte accesses on the 2-byte side (two neighbouring elements per lane): half the wave
+// 16-bit builds of the two packers with 4-byte accesses on the 2-byte side (two neighbouring elements per lane): half the wave
 // instructions of the scalar versions above, which remain for fp32 and for odd channel counts.
-__global__ __launch_bounds__(256) void pack_fwd_bf16x2_kernel(const float* __restrict__ w, bf16_t* __restrict__ fwd, int64_t pairs, int K, int64_t tap_stride) {
+template <typename H> __global__ __launch_bounds__(256) void pack_fwd_half2_kernel(const float* __restrict__ w, H* __restrict__ fwd, int64_t pairs, int K, int64_t tap_stride) {
 	extern __shared__ float tile[];  // [512 * K]
 	const int64_t lin0 = (int64_t)blockIdx.x * 512;
 	const int n = (int)min((int64_t)512, pairs - lin0);  // even: pairs = Cout * Cin with Cin even
@@ -244,24 +275,24 @@ __global__ __launch_bounds__(256) void pack_fwd_bf16x2_kernel(const float* __res
 	const int t2 = threadIdx.x * 2;
 	if (t2 < n)
 		for (int k = 0; k < K; ++k) {
-			const unsigned v = (unsigned)f32_to_bf16(tile[t2 * K + k]) | ((unsigned)f32_to_bf16(tile[(t2 + 1) * K + k]) << 16);
-			*reinterpret_cast<unsigned*>(fwd + k * tap_stride + lin0 + t2) = v;
+			*reinterpret_cast<unsigned*>(fwd + k * tap_stride + lin0 + t2) = pack16<H>(tile[t2 * K + k], tile[(t2 + 1) * K + k]);
 		}
 }
 
-__global__ __launch_bounds__(256) void pack_dgrad_bf16x2_kernel(const bf16_t* __restrict__ fwd, bf16_t* __restrict__ dgr, int Cout, int Cin, int K, int co_pad, int ci_pad) {
-	__shared__ bf16_t tile[64][66];
+// (a transpose of raw 16-bit words: one instantiation serves bf16 and fp16)
+__global__ __launch_bounds__(256) void pack_dgrad_half2_kernel(const unsigned short* __restrict__ fwd, unsigned short* __restrict__ dgr, int Cout, int Cin, int K, int co_pad, int ci_pad) {
+	__shared__ unsigned short tile[64][66];
 	const int k = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 element pairs x 8 rows per pass
-	const bf16_t* src = fwd + (int64_t)k * co_pad * Cin;
-	bf16_t* dst = dgr + (int64_t)(K - 1 - k) * ci_pad * Cout;
+	const unsigned short* src = fwd + (int64_t)k * co_pad * Cin;
+	unsigned short* dst = dgr + (int64_t)(K - 1 - k) * ci_pad * Cout;
 #pragma unroll 4
 	for (int i = 0; i < 8; ++i) {
 		const int co = co0 + ty + 8 * i, ci = ci0 + 2 * tx;
 		if (co < Cout && ci < Cin) {
 			const unsigned v = *reinterpret_cast<const unsigned*>(src + (int64_t)co * Cin + ci);
-			tile[ty + 8 * i][2 * tx] = (bf16_t)(v & 0xffffu);
-			tile[ty + 8 * i][2 * tx + 1] = (bf16_t)(v >> 16);
+			tile[ty + 8 * i][2 * tx] = (unsigned short)(v & 0xffffu);
+			tile[ty + 8 * i][2 * tx + 1] = (unsigned short)(v >> 16);
 		}
 	}
 	__syncthreads();
@@ -298,11 +329,11 @@ template <typename T> static int launch_pack(const float* w, void* fwd, void* dg
 				if (blocks > 2048) blocks = 2048;
 				hipLaunchKernelGGL((pack_fwd_kmajor_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, w, (T*)fwd, pairs, (int64_t)co_pad * Cin, K);
 			}
-		} else if (x2) hipLaunchKernelGGL(pack_fwd_bf16x2_kernel, dim3((unsigned)ceil_div64(pairs, 512)), dim3(256), (size_t)512 * K * sizeof(float), s, w, (bf16_t*)fwd, pairs, K, (int64_t)co_pad * Cin);
+		} else if (x2) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((pack_fwd_half2_kernel<T>), dim3((unsigned)ceil_div64(pairs, 512)), dim3(256), (size_t)512 * K * sizeof(float), s, w, (T*)fwd, pairs, K, (int64_t)co_pad * Cin); }
 		else hipLaunchKernelGGL((pack_fwd_kernel<T>), dim3((unsigned)ceil_div64(pairs, 256)), dim3(256), (size_t)256 * K * sizeof(float), s, w, (T*)fwd, pairs, K, (int64_t)co_pad * Cin);
 	}
 	if (dgr) {
-		if (x2) hipLaunchKernelGGL(pack_dgrad_bf16x2_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const bf16_t*)fwd, (bf16_t*)dgr, Cout, Cin, K, co_pad, ci_pad);
+		if (x2) hipLaunchKernelGGL(pack_dgrad_half2_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const unsigned short*)fwd, (unsigned short*)dgr, Cout, Cin, K, co_pad, ci_pad);
 		else hipLaunchKernelGGL((pack_dgrad_kernel<T>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, (const T*)fwd, (T*)dgr, Cout, Cin, K, co_pad, ci_pad);
 	}
 	return 0;
@@ -313,6 +344,7 @@ extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* 
 	int rc;
 	if (dtype == CONVASR_F32) rc = launch_pack<float>(w, packed_fwd, packed_dgrad, Cout, Cin, K, w_layout, (hipStream_t)stream);
 	else if (dtype == CONVASR_BF16) rc = launch_pack<bf16_t>(w, packed_fwd, packed_dgrad, Cout, Cin, K, w_layout, (hipStream_t)stream);
+	else if (dtype == CONVASR_F16) rc = launch_pack<f16_t>(w, packed_fwd, packed_dgrad, Cout, Cin, K, w_layout, (hipStream_t)stream);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "pack_conv_weight: dtype %d", dtype);
 	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("pack_conv_weight");
@@ -344,11 +376,11 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 	return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
 }
 
-int convasr_conv1d_v2_try(ConvParams p, int y_dtype, hipStream_t s, int* m_tiles_out);  // conv_v2.hip
-int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s);                 // wgrad_v2.hip
+int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out);  // conv_v2s.hip
+int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s);      // wgrad_v2.hip
 static int g_conv_use_v2 = 1;
 static int g_conv_debug = 0;
-// test / A-B hook: 0 forces the register-staged kernel for every dtype
+// test / A-B hook: bit 0 clear forces the register-staged kernels for every dtype; bits 8.. are experiment flags (ConvParams::debug)
 extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable & 1; g_conv_debug = enable >> 8; return prev; }
 
 static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
@@ -359,7 +391,7 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	const int64_t expect = ((int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
 	// a caller may ask for the first Tout < expect frames only (the stride-2 fold below needs one frame less than its even folded kernel yields)
 	CONVASR_CHECK_ARG(Tout <= expect, "conv1d_fwd: Tout %d inconsistent with Tin %d K %d stride %d dil %d pad %d (at most %lld)", Tout, Tin, K, stride, dil, pad, (long long)expect);
-	CONVASR_CHECK_ARG(x_dtype == CONVASR_F32 || x_dtype == CONVASR_BF16, "conv1d_fwd: x dtype %d", x_dtype);
+	CONVASR_CHECK_ARG(x_dtype == CONVASR_F32 || convasr_is_half(x_dtype), "conv1d_fwd: x dtype %d", x_dtype);
 	ConvParams p = {};
 	if (bn_fusion) p = *bn_fusion;  // only the bn_* fields are set in it
 	p.x = x; p.w = wp; p.y = y; p.bias = bias; p.stats = stats; p.scale = scale; p.shift = shift; p.xlen = xlen;
@@ -377,7 +409,7 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	CONVASR_CHECK_ARG(smem <= 160 * 1024, "conv1d_fwd: tile needs %zu B of LDS", smem);
 	hipStream_t s = (hipStream_t)stream;
 	int v2_rows = 0;
-	if (x_dtype == CONVASR_BF16 && g_conv_use_v2 && convasr_conv1d_v2_try(p, y_dtype, s, &v2_rows)) {
+	if (convasr_is_half(x_dtype) && g_conv_use_v2 && convasr_conv1d_v2_try(p, x_dtype, y_dtype, s, &v2_rows)) {
 		CONVASR_CHECK_LAUNCH("conv1d_fwd (v2)");
 		if (rows_out) *rows_out = v2_rows;
 		return 0;
@@ -387,6 +419,8 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) rc = dispatch_conv<float, float>(p, smem, s);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_BF16) rc = dispatch_conv<bf16_t, bf16_t>(p, smem, s);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_F32) rc = dispatch_conv<bf16_t, float>(p, smem, s);
+	else if (x_dtype == CONVASR_F16 && y_dtype == CONVASR_F16) rc = dispatch_conv<f16_t, f16_t>(p, smem, s);
+	else if (x_dtype == CONVASR_F16 && y_dtype == CONVASR_F32) rc = dispatch_conv<f16_t, float>(p, smem, s);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd: dtype %d -> %d", x_dtype, y_dtype);
 	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("conv1d_fwd");
@@ -403,12 +437,12 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 
 extern "C" int convasr_conv_stats_max_rows(int B, int Tout) { return B * ((Tout + BM - 1) / BM); }
 
-extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad,
+extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad,
                                               const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                                               int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset,
                                               const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream) {
 	CONVASR_CHECK_ARG(!bn_gate || bn_act == CONVASR_ACT_RELU || bn_act == CONVASR_ACT_HARDTANH || bn_act == CONVASR_ACT_NONE, "conv1d_dgrad_bn_reduce: the one-bit gate needs an activation whose derivative is 0 or 1");
-	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && bn_rows && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0, "conv1d_dgrad_bn_reduce: bad arguments");
+	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && bn_rows && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0 && convasr_is_half(dtype), "conv1d_dgrad_bn_reduce: bad arguments (dtype must be CONVASR_BF16 or CONVASR_F16)");
 	ConvParams f = {};
 	f.bn_y = bn_y; f.bn_scale = bn_scale; f.bn_shift = bn_shift; f.bn_mean = bn_mean; f.bn_invstd = bn_invstd; f.bn_xlen = bn_xlen; f.bn_sums = bn_sums;
 	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = seed; f.bn_offset = offset; f.bn_gate = bn_gate;
@@ -416,7 +450,7 @@ extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed
 	if (f.bn_drop_thr > 65535u) f.bn_drop_thr = 65535u;
 	f.bn_keep_scale = 65536.f / (float)(65536u - f.bn_drop_thr);
 	// dgrad = the forward kernel on (dy, flipped packed weights): channels in = Cout, channels out = Cin, stride 1
-	return conv1d_run(dy, packed_dgrad, dx, CONVASR_BF16, CONVASR_BF16, B, Cout, Cin, T_dy, T_dx, K, 1, dil, pad, nullptr, nullptr, nullptr, nullptr, CONVASR_ACT_NONE, 0.f, 0.f, nullptr, &f, bn_rows, stream);
+	return conv1d_run(dy, packed_dgrad, dx, dtype, dtype, B, Cout, Cin, T_dy, T_dx, K, 1, dil, pad, nullptr, nullptr, nullptr, nullptr, CONVASR_ACT_NONE, 0.f, 0.f, nullptr, &f, bn_rows, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -427,6 +461,7 @@ extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed
 // reference's (Cout, Cin, K) parameter layout) by wgrad_reduce_kernel -- deterministic, no float atomics.
 template <typename T> struct WgTile;
 template <> struct WgTile<bf16_t> { static constexpr int BKT = 64, PITCH = 128 * 2 + 64, CPR = 16; };  // rows of 256 B + 64 B pad: tr reads conflict-free
+template <> struct WgTile<f16_t> : WgTile<bf16_t> {};
 template <> struct WgTile<float> { static constexpr int BKT = 32, PITCH = 128 * 4 + 16, CPR = 32; };
 
 template <typename T, int XI, bool AL_X, bool AL_Y>
@@ -532,7 +567,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv1d_wgrad_kernel(WgradParams p
 #pragma unroll
 						for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-							for (int ni = 0; ni < 2; ++ni) Mma<bf16_t>::run(a[mi], bb[ni], acc[tg_i][mi][ni]);
+							for (int ni = 0; ni < 2; ++ni) Mma<T>::run(a[mi], bb[ni], acc[tg_i][mi][ni]);
 					}
 				}
 			}
@@ -693,9 +728,10 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
 	hipStream_t s = (hipStream_t)stream;
 	int rc;
-	if (dtype == CONVASR_BF16 && g_conv_use_v2 && convasr_wgrad_v2_try(p, s)) rc = 0;
+	if (convasr_is_half(dtype) && g_conv_use_v2 && convasr_wgrad_v2_try(p, dtype, s)) rc = 0;
 	else if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
 	else if (dtype == CONVASR_BF16) rc = dispatch_wgrad<bf16_t>(p, s);
+	else if (dtype == CONVASR_F16) rc = dispatch_wgrad<f16_t>(p, s);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: dtype %d", dtype);
 	if (rc) return rc;
 	CONVASR_CHECK_LAUNCH("conv1d_wgrad");
@@ -712,6 +748,7 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 		dim3 grid((Cout + 63) / 64, (unsigned)ceil_div64(rows, rows_per_block));
 		float* part = p.slab;  // the split-K slabs are consumed by now (same stream): reuse the workspace for grid.y partial rows
 		if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dy, part, rows, Cout, rows_per_block);
+		else if (dtype == CONVASR_F16) hipLaunchKernelGGL((colsum_kernel<f16_t>), grid, dim3(256), 0, s, (const f16_t*)dy, part, rows, Cout, rows_per_block);
 		else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, part, rows, Cout, rows_per_block);
 		hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 63) / 64), dim3(1024), 0, s, (const float*)part, (int)grid.y, Cout, dbias, accumulate);
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
@@ -750,8 +787,7 @@ __global__ __launch_bounds__(256) void fold2_pack_kernel(const float* __restrict
 		const int p = c2 >= Cin ? 1 : 0, ci = c2 - p * Cin, k = 2 * j + p - s0;
 		float v = 0.f;
 		if (co < Cout && k >= 0 && k < K) v = kmajor ? w[((int64_t)k * Cout + co) * Cin + ci] : w[((int64_t)co * Cin + ci) * K + k];
-		if (sizeof(T) == 2) reinterpret_cast<bf16_t*>(wf)[i] = f32_to_bf16(v);
-		else reinterpret_cast<float*>(wf)[i] = v;
+		Elem<T>::store(wf + i, v);
 	}
 }
 
@@ -762,6 +798,7 @@ extern "C" int convasr_fold2_pack_weight(const float* w, int w_layout, void* pac
 	int64_t blocks = ceil_div64((int64_t)Kf * co_pad * 2 * Cin, 256);
 	if (blocks > 2048) blocks = 2048;
 	if (dtype == CONVASR_BF16) hipLaunchKernelGGL((fold2_pack_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, w_layout == CONVASR_W_KMAJOR, (bf16_t*)packed_fwd, Cout, co_pad, Cin, K, Kf, s0);
+	else if (dtype == CONVASR_F16) hipLaunchKernelGGL((fold2_pack_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, w_layout == CONVASR_W_KMAJOR, (f16_t*)packed_fwd, Cout, co_pad, Cin, K, Kf, s0);
 	else if (dtype == CONVASR_F32) hipLaunchKernelGGL((fold2_pack_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, w_layout == CONVASR_W_KMAJOR, (float*)packed_fwd, Cout, co_pad, Cin, K, Kf, s0);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "fold2_pack_weight: dtype %d", dtype);
 	CONVASR_CHECK_LAUNCH("fold2_pack_weight");

@@ -1,9 +1,11 @@
-// Shared pieces of the implicit-GEMM conv kernels (conv.hip: register-staged general kernel; conv_v2.hip: LDS-DMA bf16 kernel).
+// Shared pieces of the implicit-GEMM conv kernels (conv.hip: register-staged general kernel; conv_v2s.hip: LDS-DMA bf16 / fp16 kernel).
 #pragma once
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define BM 128
 #define BN 128
@@ -65,6 +67,12 @@ template <> struct Mma<bf16_t> {
 		c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 	}
 };
+template <> struct Mma<f16_t> {
+	static constexpr int EPC = 8;
+	__device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+		c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+	}
+};
 template <> struct Mma<float> {
 	static constexpr int EPC = 4;
 	// lane half h holds k = {4(2j+h) .. +3}; the i-th of four MFMAs pairs element i of both halves: every k is summed once.
@@ -74,6 +82,16 @@ template <> struct Mma<float> {
 		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
 		c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
 	}
+};
+
+
+// v_mfma_f32_16x16x32_{bf16,f16}: the forward / dgrad kernel's shape (conv_v2s.hip); both run at the same rate on gfx950
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+	template <typename V> __device__ static __forceinline__ f32x4 run(const V& a, const V& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0); }
+};
+template <> struct Mma16<f16_t> {
+	template <typename V> __device__ static __forceinline__ f32x4 run(const V& a, const V& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
 };
 
 

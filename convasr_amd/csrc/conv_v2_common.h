@@ -1,4 +1,4 @@
-// Shared by conv_v2.hip (32x32x16 MFMA) and conv_v2s.hip (16x16x32 MFMA): tile constants, swizzled source offsets, LDS-DMA.
+// Tile constants and the LDS-DMA primitive of conv_v2s.hip (16x16x32 MFMA forward / dgrad kernel).
 #pragma once
 #include "conv_common.h"
 
@@ -6,14 +6,6 @@
 #define V2_THREADS 512
 #define V2_WSLOT (BN * ROW_BYTES)  // 16 KiB
 #define V2S_THREADS (V2_THREADS + 256)  // conv_v2s.hip: 8 computing waves + 4 loader waves
-
-// 1 KiB (one wave-instruction) of a swizzled tile: LDS slot p of the tile <- global (row, chunk) with
-// lds_off(row, chunk) == 16 * p.  Returns the byte offset of that lane's 16 bytes relative to the tile's row 0 / chunk 0.
-__device__ __forceinline__ int v2_src_offset(int p, int row_bytes) {
-	const int pair = p >> 4, s = p & 15;
-	const int row = 2 * pair + (s >> 3), chunk = (s & 7) ^ (pair & 7);
-	return row * row_bytes + chunk * 16;
-}
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 

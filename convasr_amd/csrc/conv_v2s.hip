@@ -1,11 +1,14 @@
-// conv_v2.hip's two-taps-per-barrier LDS-DMA kernel rebuilt on v_mfma_f32_16x16x32_bf16 (same tile, same LDS image, same
-// DMA schedule, same k order => bit-identical sums).  MI355X_MICROARCH.md ("DVFS give-back", item 7): under load the chip can hold
-// a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP; our conv loops run clock-limited
-// (1.8-2.0 GHz measured), so both shapes are built and the faster one by wall time is the default (see conv.hip's dispatcher).
+// 16-bit fast path of the implicit-GEMM conv (forward and dgrad), stride 1, Cin % 64 == 0; bf16 or fp16 storage, fp32 accumulation.
+//
+// Same decomposition as conv.hip (one workgroup = a t x co tile of one utterance; the X rows incl. halo are staged once per
+// 64-channel slab and shared by all K taps) but built around LDS-DMA (`buffer_load_dwordx4 ... lds`):
+//   * 256(t) x 128(co) tile, 8 computing waves (4 x 2, each 64 x 64) on v_mfma_f32_16x16x32_{bf16,f16} + 4 loader waves;
+//   * no staging registers and no ds_write traffic; the conflict-free XOR swizzle is applied on the per-lane SOURCE address (the DMA
+//     destination is lane-linear); the conv's zero padding is the buffer descriptor's range check (rows before 0 / after Tin read 0).
+// (History: a 32x32x16-MFMA build of the same schedule, conv_v2.hip, was bit-identical and 3-7 % slower by wall time -- under load
+// the chip holds a higher clock on the 16x16x32 shape, MI355X_MICROARCH.md "DVFS give-back" -- and was removed in round 3.)
 #include "conv_v2_common.h"
 #include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS image of a tile: 256-byte lines of two 128-byte rows (row = 2 * pair + s), a row's 16-byte chunk c at position
 // s * 8 + (c ^ swz(pair)) of its line.  A ds_read_b128 fragment read serves lanes {0-3, 12-15, 20-27} (and the three like groups) in
@@ -43,7 +46,7 @@ extern "C" int convasr_debug_read_stamps(unsigned long long* host, int count) {
 // NB = 16-column blocks per wave: 4 -> the 256 x 128 tile, 2 -> a 256 x 64 half tile (same X tile, half the W rows).  The last
 // partial round of a launch (total_tiles mod 256 workgroups on 256 CUs) is cut into half tiles so that it occupies all CUs for
 // ~0.6 of a round instead of a fraction of them for a whole one; per-element sums are unchanged (same k order).
-template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
+template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
 	constexpr int BN_ = 32 * NB;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,7 +65,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	auto xoff = [&](int c) { return (unsigned)((k1 ? c % 3 : (c & 1)) * xbytes); };
 	const unsigned wbase = (k1 ? 3 : 2) * xbytes;
 	const int row_bytes = p.Cin * 2;
-	const v4i32 xsrc = make_srd(reinterpret_cast<const bf16_t*>(p.x) + (int64_t)b * p.Tin * p.Cin, (unsigned)(p.Tin * row_bytes));
+	const v4i32 xsrc = make_srd(reinterpret_cast<const I*>(p.x) + (int64_t)b * p.Tin * p.Cin, (unsigned)(p.Tin * row_bytes));
 	const v4i32 wsrc = make_srd(p.w, (unsigned)(p.K * p.CoutPad * row_bytes));
 	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 	const int n_cib = p.Cin >> 6;
@@ -135,7 +138,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 #pragma unroll
-			for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+			for (int j = 0; j < NB; ++j) acc[i][j] = Mma16<I>::run(f.a[i], f.b[j], acc[i][j]);
 	};
 
 #ifdef CONVASR_STAMPS
@@ -239,6 +242,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 	// that its latency hides under the accumulator staging (loading it inside the store loop cost ~8 serial L2/HBM round trips per tile)
 	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
 	constexpr bool bnf = BNF && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
+	typedef typename std::conditional<sizeof(O) == 2, O, I>::type H;  // the 16-bit storage type of the fused epilogue's operands (= O there)
 	uint4 ypre[TRIPS];
 	unsigned gpre[TRIPS];  // the chunk's eight one-bit gradient gates (when the forward pass stored them: bn_gate)
 	if (bnf) {
@@ -249,7 +253,7 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 			gpre[i] = 0;
 			if (t < p.Tout && co < p.Cout) {
 				const int64_t idx = ((int64_t)b * p.Tout + t) * p.Cout + co;
-				ypre[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bn_y) + idx);
+				ypre[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const H*>(p.bn_y) + idx);
 				if (p.bn_gate) gpre[i] = p.bn_gate[idx >> 3];
 			}
 		}
@@ -348,12 +352,8 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 		if (bnf && t < bnv) {
 			const int64_t idx = ((int64_t)b * p.Tout + t) * p.Cout + co;
 			float dz[8], yv[8], g[8];
-			load8<bf16_t>(reinterpret_cast<const bf16_t*>(src), dz);
-			{
-				const unsigned w[4] = {ypre[it].x, ypre[it].y, ypre[it].z, ypre[it].w};
-#pragma unroll
-				for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(w[k] << 16); yv[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
-			}
+			unpack16<H>(*reinterpret_cast<const uint4*>(src), dz);
+			unpack16<H>(ypre[it], yv);
 			if (p.bn_gate) {  // (workgroup-uniform) the stored gates replace act', the dropout hash and the frame mask: g = dz * keep_scale or 0
 #pragma unroll
 				for (int k = 0; k < 8; ++k) g[k] = ((gpre[it] >> k) & 1u) ? dz[k] * gate_scale : 0.f;
@@ -394,20 +394,53 @@ template <typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile
 #endif
 }
 
-template <typename O, bool BNF> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
+template <typename I, typename O, bool BNF> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
 
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
 	if (bid < p.full_tiles) {
-		v2s_tile<O, 4, BNF>(p, smem, xcd_remap(bid, p.full_tiles), 0);
+		v2s_tile<I, O, 4, BNF>(p, smem, xcd_remap(bid, p.full_tiles), 0);
 	} else {  // full_tiles is a multiple of 8, so (bid - full_tiles) keeps the workgroup's XCD; the two halves of a tile share an XCD (and its X tile in L2)
 		const int h = xcd_remap(bid - p.full_tiles, 2 * (p.total_tiles - p.full_tiles));
-		v2s_tile<O, 2, BNF>(p, smem, p.full_tiles + (h >> 1), h & 1);
+		v2s_tile<I, O, 2, BNF>(p, smem, p.full_tiles + (h >> 1), h & 1);
 	}
 }
 
-// bn_fused: the dgrad launch that also runs pass 1 of the consumer layer's batch-norm backward in its epilogue (bf16 only)
-const void* convasr_conv_v2s_kernel(int y_dtype, int bn_fused) {
-	if (y_dtype == CONVASR_BF16) return bn_fused ? (const void*)conv1d_igemm_v2s_kernel<bf16_t, true> : (const void*)conv1d_igemm_v2s_kernel<bf16_t, false>;
-	return (const void*)conv1d_igemm_v2s_kernel<float, false>;
+// Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
+// register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
+int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out) {
+	if (p.stride != 1 || (p.Cin & 63) != 0 || !convasr_is_half(x_dtype) || (y_dtype != x_dtype && y_dtype != CONVASR_F32)) return 0;
+	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
+	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
+	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
+	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 5 * V2_WSLOT;  // two X slab buffers + the 3 + 2 weight slots
+	if (p.K == 1) smem = 3 * (size_t)p.x_rows * ROW_BYTES + 3 * V2_WSLOT;  // K = 1: three X slab buffers + the 3-slot ring
+	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
+	if (epi > smem) smem = epi;
+	if (smem > 160 * 1024) return 0;
+	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
+	p.m_tiles_per_b = (p.Tout + V2_BM - 1) / V2_BM;
+	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
+	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
+	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
+	const void* const table[2][3] = {
+		{(const void*)conv1d_igemm_v2s_kernel<bf16_t, bf16_t, false>, (const void*)conv1d_igemm_v2s_kernel<bf16_t, bf16_t, true>, (const void*)conv1d_igemm_v2s_kernel<bf16_t, float, false>},
+		{(const void*)conv1d_igemm_v2s_kernel<f16_t, f16_t, false>, (const void*)conv1d_igemm_v2s_kernel<f16_t, f16_t, true>, (const void*)conv1d_igemm_v2s_kernel<f16_t, float, false>}};
+	const int ki = wide ? 2 : (fused ? 1 : 0);
+	const void* kern = table[f16][ki];
+	static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+	if (!attr_set[f16][ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[f16][ki] = true; }
+	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
+	p.full_tiles = p.total_tiles;
+	if (!(p.debug & 32)) {
+		static int n_cu = 0;
+		if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+		const int rest = p.total_tiles % n_cu;
+		if (rest > 0 && 2 * rest <= n_cu && ((p.total_tiles - rest) & 7) == 0) p.full_tiles = p.total_tiles - rest;
+	}
+	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
+	void* args[] = {&p};
+	if (hipLaunchKernel(kern, dim3(grid), dim3(V2S_THREADS), args, smem, s) != hipSuccess) return 0;
+	if (m_tiles_out) *m_tiles_out = p.B * p.m_tiles_per_b;
+	return 1;
 }

@@ -49,6 +49,9 @@ extern "C" int convasr_convert_layout(const void* src, int src_dtype, int64_t ss
 	else if (src_dtype == CONVASR_F32 && dst_dtype == CONVASR_BF16) LAUNCH(float, bf16_t);
 	else if (src_dtype == CONVASR_BF16 && dst_dtype == CONVASR_F32) LAUNCH(bf16_t, float);
 	else if (src_dtype == CONVASR_BF16 && dst_dtype == CONVASR_BF16) LAUNCH(bf16_t, bf16_t);
+	else if (src_dtype == CONVASR_F32 && dst_dtype == CONVASR_F16) LAUNCH(float, f16_t);
+	else if (src_dtype == CONVASR_F16 && dst_dtype == CONVASR_F32) LAUNCH(f16_t, float);
+	else if (src_dtype == CONVASR_F16 && dst_dtype == CONVASR_F16) LAUNCH(f16_t, f16_t);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "convert_layout: dtype %d -> %d", src_dtype, dst_dtype);
 #undef LAUNCH
 	CONVASR_CHECK_LAUNCH("convert_layout");
@@ -99,6 +102,9 @@ extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int
 	else if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_BF16) LAUNCH(float, bf16_t);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_F32) LAUNCH(bf16_t, float);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_BF16) LAUNCH(bf16_t, bf16_t);
+	else if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F16) LAUNCH(float, f16_t);
+	else if (x_dtype == CONVASR_F16 && y_dtype == CONVASR_F32) LAUNCH(f16_t, float);
+	else if (x_dtype == CONVASR_F16 && y_dtype == CONVASR_F16) LAUNCH(f16_t, f16_t);
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "instnorm_fwd: dtype %d -> %d", x_dtype, y_dtype);
 #undef LAUNCH
 	CONVASR_CHECK_LAUNCH("instnorm_fwd");
@@ -256,20 +262,21 @@ extern "C" int convasr_scale_rows(const float* grad, const float* gscale, const 
 //   out[0] = mean_b(lv[b] * w[b]) / accum          the loss that is back-propagated (train.py:755)
 //   out[1] = mean_b(lv[b])                          loss_cur, the logged loss and the inf/NaN gate (train.py:755, 769)
 //   out[2] = mean_b(ent[b])                         the entropy metric (train.py:756)
-//   gvec[b] = ((1 / accum) / B) * w[b]              d out[0] / d lv[b], in autograd's own order of operations
+//   gvec[b] = ((1 / accum) / B) * w[b] (* loss scale)  d out[0] / d lv[b], in autograd's own order of operations; fp16 training seeds
+//                                                   backward with the SCALED loss's gradient (apex.amp.scale_loss, train.py:770-772)
 //   skipped = !isfinite(out[1])
 // One workgroup, sums in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict__ lv, const int64_t* __restrict__ ylen, int64_t ylen_stride, const float* __restrict__ ent, int B, float accum,
-                                                        float* __restrict__ out, float* __restrict__ gvec, unsigned char* __restrict__ skipped) {
+                                                        float* __restrict__ out, float* __restrict__ gvec, unsigned char* __restrict__ skipped, const float* __restrict__ scaler) {
 	__shared__ float red[3][256];
 	float a = 0.f, c = 0.f, e = 0.f;
-	const float gbase = (1.f / accum) / (float)B;
+	const float gbase = (1.f / accum) / (float)B, ls = scaler ? scaler[LS_SCALE] : 1.f;
 	for (int b = threadIdx.x; b < B; b += 256) {
 		const float w = (float)ylen[b * ylen_stride], l = lv[b];
 		a += l * w;
 		c += l;
 		if (ent) e += ent[b];
-		if (gvec) gvec[b] = gbase * w;
+		if (gvec) gvec[b] = gbase * w * ls;
 	}
 	red[0][threadIdx.x] = a; red[1][threadIdx.x] = c; red[2][threadIdx.x] = e;
 	__syncthreads();
@@ -287,9 +294,9 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
 }
 
 extern "C" int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
-                                 float* grad_loss_vec, unsigned char* skipped, void* stream) {
+                                 float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, void* stream) {
 	CONVASR_CHECK_ARG(loss_vec && ylen && out3 && B > 0 && accumulate_iterations > 0.f, "loss_head: bad arguments");
-	hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_vec, ylen, ylen_stride, entropy, B, accumulate_iterations, out3, grad_loss_vec, skipped);
+	hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_vec, ylen, ylen_stride, entropy, B, accumulate_iterations, out3, grad_loss_vec, skipped, loss_scaler);
 	CONVASR_CHECK_LAUNCH("loss_head");
 	return 0;
 }
@@ -314,37 +321,38 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 	if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
 }
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int blocks, double* __restrict__ out, float* __restrict__ norm_out, float norm_scale) {
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int blocks, double* __restrict__ out, float* __restrict__ norm_out, float norm_scale, const float* __restrict__ scaler) {
 	__shared__ double red[256];
 	double a = 0;
 	for (int i = threadIdx.x; i < blocks; i += 256) a += part[i];
 	red[threadIdx.x] = a;
 	__syncthreads();
-	if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 256; ++i) s += red[i]; *out = s; if (norm_out) *norm_out = (float)(sqrt(s) * (double)norm_scale); }
+	if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 256; ++i) s += red[i]; *out = s; if (norm_out) *norm_out = (float)(sqrt(s) * (double)norm_scale) * (scaler ? 1.f / scaler[LS_SCALE] : 1.f); }
 }
 
 extern "C" int64_t convasr_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * (int64_t)sizeof(double); }
 
-extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, float* norm_out, float norm_scale, void* stream) {
+extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, float* norm_out, float norm_scale, const float* loss_scaler, void* stream) {
 	CONVASR_CHECK_ARG(g && sumsq && workspace && n > 0, "sumsq: bad arguments");
 	CONVASR_CHECK_ARG(((uintptr_t)g & 15) == 0, "sumsq: g must be 16-byte aligned");
 	int64_t blocks = ceil_div64(n, 1024);
 	if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
 	hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, (double*)workspace);
-	hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, (int)blocks, sumsq, norm_out, norm_scale);
+	hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, (int)blocks, sumsq, norm_out, norm_scale, loss_scaler);
 	CONVASR_CHECK_LAUNCH("sumsq");
 	return 0;
 }
 
-__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
+template <typename H> __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
                                                        int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first,
-                                                       const float* __restrict__ loss_gate, float grad_scale, bf16_t* __restrict__ p16) {
-	if (loss_gate) {
-		const float l = *loss_gate;
-		if (!(fabsf(l) < INFINITY)) return;  // inf or NaN loss: the step is skipped (train.py:769-772)
-	}
+                                                       const float* __restrict__ loss_gate, float grad_scale, H* __restrict__ p16, const float* __restrict__ scaler_in, float* __restrict__ scaler_out) {
+	const bool gated = loss_gate && !(fabsf(*loss_gate) < INFINITY);  // inf or NaN loss: the step is skipped (train.py:769-772)
+	const LossScale ls = loss_scale_read(scaler_in, (scaler_in && sumsq) ? *sumsq : 0.0);
+	if (scaler_in && blockIdx.x == 0 && threadIdx.x == 0) loss_scale_advance(scaler_in, scaler_out, ls.overflow, gated);
+	if (gated || ls.overflow) return;  // (overflow: a non-finite gradient under the current loss scale -- apex skips the step and halves the scale)
+	grad_scale *= ls.inv;
 	float clip = 1.f;
-	if (sumsq) {
+	if (sumsq && max_norm > 0.f) {  // (max_norm <= 0: no clipping; sumsq may still be there for the loss scaler's overflow check)
 		float total = (float)sqrt(*sumsq) * grad_scale;  // norm of the scaled gradient (grad_scale = 1 / world size on summed gradients)
 		float c = max_norm / (total + 1e-6f);
 		clip = c < 1.f ? c : 1.f;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
 		reinterpret_cast<float4*>(p)[i] = r;
 		if (mom != 0.f) reinterpret_cast<float4*>(buf)[i] = b4;
 		if (gout) reinterpret_cast<float4*>(gout)[i] = o4;
-		if (p16) reinterpret_cast<uint2*>(p16)[i] = make_uint2((unsigned)f32_to_bf16(r.x) | ((unsigned)f32_to_bf16(r.y) << 16), (unsigned)f32_to_bf16(r.z) | ((unsigned)f32_to_bf16(r.w) << 16));
+		if (p16) reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack16<H>(r.x, r.y), pack16<H>(r.z, r.w));
 	}
 	if (blockIdx.x == 0 && (int64_t)threadIdx.x < (n & 3)) {
 		const int64_t i = (n4 << 2) + threadIdx.x;
@@ -380,16 +388,19 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
 		p[i] = r;
 		if (mom != 0.f) buf[i] = bv;
 		if (gout) gout[i] = go;
-		if (p16) p16[i] = f32_to_bf16(r);
+		if (p16) Elem<H>::store(p16 + i, r);
 	}
 }
 
 extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm, float lr,
-                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale, uint16_t* p_bf16, void* stream) {
+                                float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale, void* p16, int p16_dtype,
+                                const float* scaler_in, float* scaler_out, void* stream) {
 	CONVASR_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || buf), "sgd_step: bad arguments");
+	CONVASR_CHECK_ARG(!p16 || convasr_is_half(p16_dtype), "sgd_step: the mirror's dtype must be CONVASR_BF16 or CONVASR_F16");
+	CONVASR_CHECK_ARG((scaler_in == nullptr) == (scaler_out == nullptr) && (!scaler_in || (scaler_in != scaler_out && sumsq)), "sgd_step: the loss scaler needs distinct in / out states and the gradient's sum of squares (its overflow check)");
 	int64_t blocks = ceil_div64(n, 256);
 	if (blocks > 4096) blocks = 4096;
-	hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale, (bf16_t*)p_bf16);
+	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((sgd_step_kernel<H>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale, (H*)p16, scaler_in, scaler_out));
 	CONVASR_CHECK_LAUNCH("sgd_step");
 	return 0;
 }

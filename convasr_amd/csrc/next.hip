@@ -63,29 +63,18 @@ struct NgParams {
 	float max_norm, lr, b1, b2, eps, wd;
 	int dampening, first;
 	const float* loss_gate; float* norm_out; float grad_scale;
-	bf16_t* p16;
+	void* p16;
+	const float* scaler_in; float* scaler_out;  // optional dynamic loss scaler (common.h): gradients are multiplied by 1 / scale, a non-finite gradient norm skips the step
 };
 
-__global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
+template <typename H> __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 	__shared__ double red[4];
 	__shared__ float s_clip;
 	__shared__ int64_t tab[NG_TABLE];
 	// first < 0: the EMA buffers carry one extra element, the count of steps APPLIED so far (a gated step does not count: the
 	// reference creates no optimizer state on an iteration it skips, optimizers.py:76-80 / train.py:769-772)
 	const int n_carry = q.n_seg + (q.first < 0 ? 1 : 0);
-	if (q.loss_gate) {
-		const float l = *q.loss_gate;
-		if (!(fabsf(l) < INFINITY)) {  // skipped step: nothing changes; the caller still swaps its two EMA buffers, so carry the EMAs over
-			if (blockIdx.x == 0)
-				for (int s = threadIdx.x; s < n_carry; s += 256) q.ema_out[s] = q.ema_in[s];
-			return;
-		}
-	}
-	if (q.first < 0) {
-		const float applied = q.ema_in[q.n_seg];
-		if (blockIdx.x == 0 && threadIdx.x == 0) q.ema_out[q.n_seg] = fminf(applied + 1.f, 16777216.f);
-		q.first = applied == 0.f;
-	}
+	const bool gated = q.loss_gate && !(fabsf(*q.loss_gate) < INFINITY);
 	q.offsets = ng_stage_offsets(q.offsets, q.n_seg, tab);
 	double tot = 0;
 	for (int s = threadIdx.x; s < q.n_seg; s += 256) tot += q.g2[s];
@@ -93,8 +82,22 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 	for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
 	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
 	__syncthreads();
+	const double total_sq = red[0] + red[1] + red[2] + red[3];
+	const LossScale ls = loss_scale_read(q.scaler_in, q.scaler_in ? total_sq : 0.0);
+	if (q.scaler_in && blockIdx.x == 0 && threadIdx.x == 0) loss_scale_advance(q.scaler_in, q.scaler_out, ls.overflow, gated);
+	if (gated || ls.overflow) {  // skipped step: nothing changes; the caller still swaps its two EMA buffers, so carry the EMAs over
+		if (blockIdx.x == 0)
+			for (int s = threadIdx.x; s < n_carry; s += 256) q.ema_out[s] = q.ema_in[s];
+		return;
+	}
+	q.grad_scale *= ls.inv;
+	if (q.first < 0) {
+		const float applied = q.ema_in[q.n_seg];
+		if (blockIdx.x == 0 && threadIdx.x == 0) q.ema_out[q.n_seg] = fminf(applied + 1.f, 16777216.f);
+		q.first = applied == 0.f;
+	}
 	if (threadIdx.x == 0) {
-		const float total = (float)sqrt(red[0] + red[1] + red[2] + red[3]) * q.grad_scale;  // norm of the scaled (e.g. rank-averaged) gradient
+		const float total = (float)sqrt(total_sq) * q.grad_scale;  // norm of the scaled (e.g. rank-averaged, loss-unscaled) gradient
 		float c = 1.f;
 		if (q.max_norm > 0.f) { c = q.max_norm / (total + 1e-6f); c = c < 1.f ? c : 1.f; }
 		s_clip = c * q.grad_scale;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 		q.mom[i] = m;
 		const float pn = pv - q.lr * m;
 		q.p[i] = pn;
-		if (q.p16) q.p16[i] = f32_to_bf16(pn);
+		if (q.p16) Elem<H>::store(reinterpret_cast<H*>(q.p16) + i, pn);
 	};
 	if (s0 == s1) {
 		const float inv = 1.f / sqrtf(seg_ema(s0) + q.eps);
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(256) void ng_step_kernel(NgParams q) {
 extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets, int n_seg,
                                      int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part, float max_norm, float lr, float beta1,
                                      float beta2, float eps, float weight_decay, int dampening, int first, const float* loss_gate, float* total_norm, float grad_scale,
-                                     uint16_t* p_bf16, void* stream) {
+                                     void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream) {
+	CONVASR_CHECK_ARG(!p16 || convasr_is_half(p16_dtype), "novograd_step: the mirror's dtype must be CONVASR_BF16 or CONVASR_F16");
+	CONVASR_CHECK_ARG((scaler_in == nullptr) == (scaler_out == nullptr) && (!scaler_in || scaler_in != scaler_out), "novograd_step: the loss scaler needs distinct in / out states");
 	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && items && seg_first && item_part && n_seg > 0 && n_items >= n_seg && n > 0, "novograd_step: bad arguments");
 	hipStream_t s = (hipStream_t)stream;
 	hipLaunchKernelGGL(ng_item_sumsq_kernel, dim3(n_items), dim3(256), 0, s, g, items, item_part);
@@ -141,8 +146,8 @@ extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const
 	NgParams q;
 	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
 	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
-	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale; q.p16 = (bf16_t*)p_bf16;
-	hipLaunchKernelGGL(ng_step_kernel, dim3((unsigned)ceil_div64(n, NG_CHUNK)), dim3(256), 0, s, q);
+	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale; q.p16 = p16; q.scaler_in = scaler_in; q.scaler_out = scaler_out;
+	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((ng_step_kernel<H>), dim3((unsigned)ceil_div64(n, NG_CHUNK)), dim3(256), 0, s, q));
 	CONVASR_CHECK_LAUNCH("novograd_step");
 	return 0;
 }

@@ -1,4 +1,4 @@
-// bf16 fast path of the weight gradient (stride 1, Cin % 128 == 0, Cout % 128 == 0).
+// 16-bit (bf16 / fp16 storage) fast path of the weight gradient (stride 1, Cin % 128 == 0, Cout % 128 == 0).
 //
 //   dW[tap][co][ci] = sum_(b,t) dY[b,t,co] * X[b, t + tap*dil - pad, ci]        M = co, N = ci, reduction over (b, t)
 //
@@ -63,7 +63,7 @@ __device__ __forceinline__ uint4 w2_tr_frag(const char* p0, const char* p1) {
 	return make_uint4(l.x, l.y, h.x, h.y);
 }
 
-__global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(WgradParams p) {
+template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(WgradParams p) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 	auto load_bA = [&](unsigned st, int kk, F2& f) { f.u0 = tr8(st + bAoff0 + kk * 4096); f.u1 = tr8(st + bAoff1 + kk * 4096); };
 	auto load_bB = [&](unsigned st, int kk, F2& f) { f.u0 = tr8(st + bBoff0 + kk * 4096); f.u1 = tr8(st + bBoff1 + kk * 4096); };
 	auto mma4 = [&](const F2& a, const F2& bq, f32x16 (&c)[2][2]) {
-		Mma<bf16_t>::run(a.u0, bq.u0, c[0][0]);
-		Mma<bf16_t>::run(a.u0, bq.u1, c[0][1]);
-		Mma<bf16_t>::run(a.u1, bq.u0, c[1][0]);
-		Mma<bf16_t>::run(a.u1, bq.u1, c[1][1]);
+		Mma<H>::run(a.u0, bq.u0, c[0][0]);
+		Mma<H>::run(a.u0, bq.u1, c[0][1]);
+		Mma<H>::run(a.u1, bq.u0, c[1][0]);
+		Mma<H>::run(a.u1, bq.u1, c[1][1]);
 	};
 
 	// The chunk loop is instantiated per (slot A mask, slot B mask) so that every fragment load and MFMA group is unconditional
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(Wgra
 }
 
 // Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
-int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s) {
+int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
 	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0) return 0;
 	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.Tout * p.Cout * 2 >= (1ll << 31)) return 0;
 	WgradParams q = p;
@@ -296,9 +296,12 @@ int convasr_wgrad_v2_try(WgradParams& p, hipStream_t s) {
 	if (pieces > 40) return 0;  // at most 10 pieces per loader wave: the counted waits above
 	const size_t smem = 4 * (size_t)(W2_YBYTES + q.x_rows * 256);
 	if (smem > 160 * 1024) return 0;
-	static bool set = false;
-	if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-	hipLaunchKernelGGL(conv1d_wgrad_v2_kernel, dim3(q.units * q.splits), dim3(W2_ALL_THREADS), smem, s, q);
+	const bool f16 = dtype == CONVASR_F16;
+	const void* kern = f16 ? (const void*)conv1d_wgrad_v2_kernel<f16_t> : (const void*)conv1d_wgrad_v2_kernel<bf16_t>;
+	static bool set[2] = {false, false};
+	if (!set[f16]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set[f16] = true; }
+	void* args[] = {&q};
+	if (hipLaunchKernel(kern, dim3(q.units * q.splits), dim3(W2_ALL_THREADS), args, smem, s) != hipSuccess) return 0;
 	p = q;
 	return 1;
 }

@@ -29,7 +29,7 @@ def packed_weight(w, dtype, mode):
 	"""Packed [K][rows_pad][cols] copy of a conv parameter, refreshed (in place) only when the parameter changed.  In training
 	the forward and the dgrad layout are produced together the first time either is asked for after an update.
 	A tap-major arena parameter (train.FlatParameters) whose Cout needs no row padding has no forward copy of its own: in fp32
-	the master IS the packed operand, in bf16 it is the parameter's segment of the arena's bf16 mirror, which the fused optimizer
+	the master IS the packed operand, in bf16 / fp16 it is the parameter's segment of the arena's 16-bit mirror, which the fused optimizer
 	kernels keep current -- only the transposed dgrad copy is still built by a packing launch."""
 	ver = param_version(w)
 	ent = _pack_cache.get((id(w), dtype))
@@ -37,14 +37,16 @@ def packed_weight(w, dtype, mode):
 	if ent is None:
 		ent = _pack_cache[(id(w), dtype)] = dict(w = w, fwd = None, dgr = None, fwd_ver = None, dgr_ver = None)  # holds `w`: id() stays unique
 	arena = getattr(w, '_convasr_arena', None)
-	in_place = arena is not None and ops.weight_layout(w) == _lib.W_KMAJOR and ops.cout_pad(w.shape[0]) == w.shape[0] and dtype in (torch.float32, torch.bfloat16)
+	# (the address test: p.data may have been replaced since FlatParameters re-homed it -- model.to(), load_state_dict(assign = True) --
+	# with the strides preserved; such a parameter no longer aliases the arena and is packed like any other)
+	in_place = arena is not None and ops.weight_layout(w) == _lib.W_KMAJOR and ops.cout_pad(w.shape[0]) == w.shape[0] and dtype in (torch.float32, ) + ops.HALF_DTYPES and w.device == arena[0].data.device and w.data_ptr() == arena[0].data.data_ptr() + 4 * arena[1]
 	if in_place:
 		flat, off = arena
 		Cout, Cin, K = w.shape
 		if dtype == torch.float32:
 			ent['fwd'], ent['fwd_ver'] = flat.data[off:off + w.numel()].view(K, Cout, Cin), ver
 		else:
-			ent['fwd'] = flat.mirror()[off:off + w.numel()].view(K, Cout, Cin)
+			ent['fwd'] = flat.mirror(dtype)[off:off + w.numel()].view(K, Cout, Cin)
 			if flat._mirror_ver.get(id(w)) == ver:
 				ent['fwd_ver'] = ver
 	if mode == _lib.PACK_FWD and ent['fwd_ver'] == ver:
@@ -57,7 +59,7 @@ def packed_weight(w, dtype, mode):
 	else:
 		ent['fwd'] = ops.pack_weight(w, dtype, _lib.PACK_FWD, out = (ent['fwd'], None))
 		ent['fwd_ver'] = ver
-	if in_place and dtype == torch.bfloat16:
+	if in_place and dtype in ops.HALF_DTYPES:
 		arena[0]._mirror_ver[id(w)] = ver
 	return ent['fwd'] if mode == _lib.PACK_FWD else ent['dgr']
 
@@ -163,13 +165,27 @@ class Fold2:
 	def plan(cls, x, weight, spec, dt, x_needs_grad):
 		"""None, or (view of x, K', P', Tout) when the fold applies."""
 		B, Cin, Tin = x.shape
-		if not (cls.enabled and dt == torch.bfloat16 and spec.stride == 2 and spec.dilation == 1 and Tin % 2 == 0 and (2 * Cin) % 128 == 0 and weight.shape[0] % 128 == 0 and not x_needs_grad and ops.is_cl(x) and x.stride(0) == Tin * Cin):
+		if not (cls.enabled and dt in ops.HALF_DTYPES and spec.stride == 2 and spec.dilation == 1 and Tin % 2 == 0 and (2 * Cin) % 128 == 0 and weight.shape[0] % 128 == 0 and not x_needs_grad and ops.is_cl(x) and x.stride(0) == Tin * Cin):
 			return None
 		Kf, Pf = ops.fold2_geometry(spec.K, spec.padding)
 		Tout = ops.conv_out_len(Tin, spec.K, 2, 1, spec.padding)
 		if Tout > ops.conv_out_len(Tin // 2, Kf, 1, 1, Pf):
 			return None
 		return x.as_strided((B, 2 * Cin, Tin // 2), (Tin * Cin, 1, 2 * Cin)), Kf, Pf, Tout
+
+	@classmethod
+	def wants_even_input(cls, weight_shape, spec, Tin):
+		"""Should an odd-length input (Tin frames) of this conv get one zero frame appended so that plan() applies?  Only when the conv's
+		own output is unchanged by it (the extra frame stays inside the zero padding: the output length is the same, true for odd K
+		with padding K // 2) and the fold's channel / geometry envelope holds."""
+		Cout, Cin, K = weight_shape
+		if not (cls.enabled and spec.stride == 2 and spec.dilation == 1 and Tin % 2 == 1 and (2 * Cin) % 128 == 0 and Cout % 128 == 0):
+			return False
+		Tout = ops.conv_out_len(Tin, spec.K, 2, 1, spec.padding)
+		if ops.conv_out_len(Tin + 1, spec.K, 2, 1, spec.padding) != Tout:
+			return False
+		Kf, Pf = ops.fold2_geometry(spec.K, spec.padding)
+		return Tout <= ops.conv_out_len((Tin + 1) // 2, Kf, 1, 1, Pf)
 
 	@classmethod
 	def packed_weight(cls, weight, dt, pad):
@@ -191,7 +207,7 @@ class Fold2:
 		ops.fold2_unfold_wgrad(dwf, out, spec.padding, accumulate = accumulate)
 
 
-# Cross-layer backward fusion (bf16 training): pass 1 of a layer's batch-norm backward (per-channel sums of g and g * xhat) runs
+# Cross-layer backward fusion (bf16 / fp16 training): pass 1 of a layer's batch-norm backward (per-channel sums of g and g * xhat) runs
 # in the epilogue of the dgrad launch that PRODUCES that layer's dz, i.e. in the backward of the layer's consumer.  No global
 # state: the producer's forward hangs a `link` (what the epilogue needs) on its output tensor and keeps it on its autograd ctx;
 # the consumer's forward takes the link off its input (so exactly one consumer can hold it) and keeps it on ITS ctx; the
@@ -232,7 +248,7 @@ def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
 	Cin = x.shape[1]
 	pad = spec.dilation * (spec.K - 1) - spec.padding
 	wd = packed_weight(weight, dt, _lib.PACK_DGRAD) if wd is None else wd
-	if link is not None and dt == torch.bfloat16 and spec.stride == 1:
+	if link is not None and dt in ops.HALF_DTYPES and spec.stride == 1:
 		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'], gate = link.get('gate'))
 		if dx is not None:
 			link['dz'] = dx  # held until the producer's backward has looked at it: the address cannot be recycled meanwhile
@@ -304,7 +320,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
 		ctx.bwd_link = None
-		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt == torch.bfloat16 and Cout % 8 == 0:
+		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt in ops.HALF_DTYPES and Cout % 8 == 0:
 			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None, gate = gate)
 			setattr(z, _LINK_ATTR, ctx.bwd_link)
 		return z
@@ -431,7 +447,7 @@ HEAD_PAD = 128  # channels the gradient of a narrow 1x1 head is padded to in bac
 
 class _HeadPad:
 	"""Backward of a 1x1 conv head with a ragged class count (the 38-class decoder, models.py:26) through the LDS-DMA kernels: the
-	head's output gradient is converted to bf16 into a zero-padded (B, 128, T) tensor, the head's weight is transposed into a
+	head's output gradient is converted to the 16-bit storage type into a zero-padded (B, 128, T) tensor, the head's weight is transposed into a
 	zero-padded [Cin][128] dgrad operand, and dgrad / wgrad run as 128-channel problems (the padding contributes exact zeros;
 	rows 38.. of the padded weight gradient are dropped).  The general register-staged kernels took 61 + 109 us per step for the
 	3.75 GFLOP involved; these are memory-bound launches of ~30 / ~45 us, and the dgrad can carry the BN-backward sums of the last
@@ -439,16 +455,16 @@ class _HeadPad:
 	_cache = {}
 
 	@classmethod
-	def dgrad_weight(cls, weight):
+	def dgrad_weight(cls, weight, dt):
 		Cout, Cin, K = weight.shape
 		ver = param_version(weight)
-		ent = cls._cache.get(id(weight))
+		ent = cls._cache.get((id(weight), dt))
 		if ent is None:
-			ent = cls._cache[id(weight)] = dict(w = weight, ver = None, wd = torch.zeros(1, ops.cout_pad(Cin), HEAD_PAD, dtype = torch.bfloat16, device = weight.device))
+			ent = cls._cache[(id(weight), dt)] = dict(w = weight, ver = None, wd = torch.zeros(1, ops.cout_pad(Cin), HEAD_PAD, dtype = dt, device = weight.device))
 		if ent['ver'] != ver:
 			src = weight.detach()
 			# wd[0][ci][co] = w[co][ci][0]: the layout kernel reads (C = co, T = ci) and writes it channels-last with a row pitch of 128
-			_lib.call('convasr_convert_layout', _lib.ptr(src), _lib.F32, 0, src.stride(0), src.stride(1), _lib.ptr(ent['wd']), _lib.BF16, 0, 1, HEAD_PAD, 1, Cout, Cin, _lib.stream_ptr())
+			_lib.call('convasr_convert_layout', _lib.ptr(src), _lib.F32, 0, src.stride(0), src.stride(1), _lib.ptr(ent['wd']), _lib.dtype_code(dt), 0, 1, HEAD_PAD, 1, Cout, Cin, _lib.stream_ptr())
 			ent['ver'] = ver
 		return ent['wd']
 
@@ -481,9 +497,9 @@ class ConvBiasFunction(torch.autograd.Function):
 		weight, bias = ctx.params
 		x, = ctx.saved_tensors
 		Cout = weight.shape[0]
-		if dt == torch.bfloat16 and spec.K == 1 and spec.stride == 1 and spec.padding == 0 and Cout < HEAD_PAD and x.shape[1] % 128 == 0 and os.environ.get('CONVASR_NO_HEAD_PAD') != '1':
+		if dt in ops.HALF_DTYPES and spec.K == 1 and spec.stride == 1 and spec.padding == 0 and Cout < HEAD_PAD and x.shape[1] % 128 == 0 and os.environ.get('CONVASR_NO_HEAD_PAD') != '1':
 			dyp = _HeadPad.pad_grad(dy, dt)
-			dx = _dgrad(x, dyp, weight, spec, dt, ctx.producer_link, wd = _HeadPad.dgrad_weight(weight)) if ctx.needs_input_grad[1] else None
+			dx = _dgrad(x, dyp, weight, spec, dt, ctx.producer_link, wd = _HeadPad.dgrad_weight(weight, dt)) if ctx.needs_input_grad[1] else None
 
 			def wgrad(outs, acc):
 				dwp = torch.empty(HEAD_PAD, x.shape[1], 1, dtype = torch.float32, device = x.device)

@@ -340,8 +340,10 @@ class JasperNet(nn.Module):
 		self.set_compute_dtype(compute_dtype)
 
 	def set_compute_dtype(self, dtype):
-		"""fp32 (exact-fp32 MFMA path: parity runs) or bf16 (bf16 MFMA, fp32 accumulate, fp32 master weights: throughput runs)."""
-		assert dtype in (torch.float32, torch.bfloat16)
+		"""fp32 (exact-fp32 MFMA path: parity runs), or bf16 / fp16 (16-bit storage of activations and compute weights, MFMA with fp32
+		accumulation, fp32 master weights: throughput runs; fp16 is what the reference's apex O1-O3 levels compute in and trains under a
+		dynamic loss scaler, convasr_amd.train.LossScaler)."""
+		assert dtype in (torch.float32, ) + ops.HALF_DTYPES
 		self.compute_dtype = dtype
 		for m in self.modules():
 			if isinstance(m, (ConvBn1d, Decoder)):
@@ -357,10 +359,12 @@ class JasperNet(nn.Module):
 		assert (not self.check_time_dim_padded) or (x.shape[-1] % 32 == 0), 'Shape of features after frontend is not divisible by 32'
 		assert x.ndim == 3
 		if self.normalize_features is not None:
-			# an odd number of frames gets one zero frame appended when the prologue conv is strided: the conv's output is the same (the
-			# frame lies in its zero padding) and its even-length input lets the stride-2 fold run (functional.Fold2)
-			stride2 = self.compute_dtype == torch.bfloat16 and Fn.Fold2.enabled and self.backbone[0].conv[0][-1].stride[0] == 2
-			x = self.normalize_features(x, xlen = xlen, out_dtype = self.compute_dtype, pad_time_to = 2 if stride2 else 1)
+			# an odd number of frames gets one zero frame appended when the prologue conv will run as its stride-2 fold (functional.Fold2),
+			# which needs an even-length input: the conv's output is the same -- the frame lies in its zero padding -- exactly when the
+			# output length does not change (odd kernel sizes), which Fold2.wants_even_input checks together with the fold's own envelope
+			conv0 = self.backbone[0].conv[0][-1]
+			pad_even = self.compute_dtype in ops.HALF_DTYPES and x.shape[-1] % 2 == 1 and Fn.Fold2.wants_even_input(conv0.weight.shape, _spec_of(conv0), x.shape[-1])
+			x = self.normalize_features(x, xlen = xlen, out_dtype = self.compute_dtype, pad_time_to = 2 if pad_even else 1)
 		else:
 			x = ops.as_cl(x, self.compute_dtype)
 
@@ -463,10 +467,26 @@ class JasperNetResidualBig(JasperNet):
 
 # ------------------------------------------------------------------------------------------------ wrappers (models.py:736-765)
 
-def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, opt_level = None, **kwargs):
-	"""models.py:736-752.  One process drives one MI355X here, so there is no single-process DataParallel: opt_level selects the
-	compute dtype (None / 'O0' -> fp32; 'O1' / 'O2' / 'O3' -> bf16 MFMA with fp32 master weights, the role apex.amp played)."""
-	master_module(model).set_compute_dtype(torch.float32 if opt_level in (None, '', 'O0') else torch.bfloat16)
+AMP_DTYPE = {'fp16': torch.float16, 'float16': torch.float16, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}[__import__('os').environ.get('CONVASR_AMP_DTYPE', 'fp16')]  # what apex's O1-O3 mean here
+
+
+def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, opt_level = None, compute_dtype = None, loss_scale = None, **kwargs):
+	"""models.py:736-752 (`apex.amp.initialize(model, optimizers, opt_level, **kwargs)`).  One process drives one MI355X here, so there
+	is no single-process DataParallel: opt_level selects the compute dtype -- None / '' / 'O0' -> fp32; 'O1' / 'O2' / 'O3' -> fp16
+	storage + MFMA with fp32 accumulation and fp32 master weights, as under apex (batch norm runs in fp32 in every mode:
+	keep_batchnorm_fp32 is accepted and has nothing left to decide) -- and, given an optimizer, attaches apex's loss scaling to it:
+	dynamic for O1 / O2 (train.LossScaler; overflowed steps are skipped and the scale halves), static 1.0 for O3, `loss_scale`
+	(a number or 'dynamic') overriding either, exactly apex's kwarg.  compute_dtype = torch.bfloat16 (an extension; env
+	CONVASR_AMP_DTYPE=bf16 makes it the default) runs the same kernels on bf16 storage, whose fp32 exponent range needs no loss scale."""
+	amp = opt_level not in (None, '', 'O0')
+	dtype = compute_dtype or (AMP_DTYPE if amp else torch.float32)
+	master_module(model).set_compute_dtype(dtype)
+	flat = getattr(optimizer, 'flat', None)
+	if flat is not None:
+		from .train import LossScaler
+		if loss_scale is None:
+			loss_scale = 'dynamic' if (dtype == torch.float16 and opt_level in ('O1', 'O2')) else None
+		flat.loss_scaler = None if loss_scale in (None, 1, 1.0) else LossScaler(flat.data.device, loss_scale = loss_scale)
 	return model, optimizer
 
 
@@ -475,7 +495,7 @@ def distributed_data_parallel_and_autocast(model, local_rank, optimizer = None, 
 	from .parallel import DataParallelEngine
 	if synchronize_bn:
 		raise _lib.ConvasrHipError('synchronize_bn: the reference trains with per-GPU batch-norm statistics (train.py:704); SyncBatchNorm is not implemented')
-	model, optimizer = data_parallel_and_autocast(model, optimizer, opt_level = opt_level)
+	model, optimizer = data_parallel_and_autocast(model, optimizer, opt_level = opt_level, **kwargs)
 	training = model.training
 	engine = DataParallelEngine(model, device = torch.device('cuda', local_rank))
 	engine.train(training)

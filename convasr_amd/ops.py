@@ -11,6 +11,8 @@ import torch
 from . import _lib
 from ._lib import call, ptr, stream_ptr, dtype_code, require_cuda
 
+HALF_DTYPES = (torch.bfloat16, torch.float16)  # the two 16-bit storage types of the MFMA path (fp32 accumulation, fp32 master weights)
+
 ACT_CODES = dict(none = _lib.ACT_NONE, relu = _lib.ACT_RELU, hardtanh = _lib.ACT_HARDTANH, leaky_relu = _lib.ACT_LEAKY_RELU)
 
 
@@ -188,12 +190,13 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	part = stats if isinstance(stats, ConvStats) or stats is None else ConvStats(Cout, B, Tout, x.device)
 	rows = ctypes.c_int(0)
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
-	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype == torch.bfloat16 and stride == 1 and Cin % 64 == 0) else 'conv1d_igemm (other variants)'
-	es, osz = x.element_size(), (2 if out_dtype == torch.bfloat16 else 4)
+	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype in HALF_DTYPES and stride == 1 and Cin % 64 == 0) else 'conv1d_igemm (other variants)'  # (the family name is a label: fp16 launches of the same kernel are booked under it too)
+	es, osz = x.element_size(), (2 if out_dtype in HALF_DTYPES else 4)
 	flops, nbytes_ = 2.0 * B * Tout * Cout * Cin * K if work is None else work, float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz)
+	symbol = 'v2s16' if family.startswith('conv1d_igemm_v2s') and out_dtype == x.dtype else None
 	if family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
 		family = 'hbm:conv1d_igemm_v2s_kernel (memory-bound launches: the 38-class decoder)'
-	_lib.timed(family, flops, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = nbytes_)
+	_lib.timed(family, flops, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = nbytes_, symbol = symbol)
 	if part is not None:
 		part.rows = rows.value
 		if part is not stats:
@@ -372,9 +375,9 @@ def scale_rows(grad, gscale, gdiv = None):
 	return out
 
 
-def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_grad = True):
+def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_grad = True, loss_scaler = None):
 	"""train.py:754-756 + the gate of 769 in one launch.  Returns (out3 = [loss, loss_cur, entropy] fp32, grad_loss_vec (B,) or None,
-	skipped: 1-element bool)."""
+	skipped: 1-element bool).  loss_scaler: the current state of a dynamic loss scaler (fp16 training): grad_loss_vec is scaled by it."""
 	require_cuda(loss_vec)
 	B = loss_vec.shape[0]
 	lv = loss_vec.detach().to(torch.float32).contiguous()
@@ -383,7 +386,7 @@ def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_gr
 	gvec = torch.empty(B, dtype = torch.float32, device = lv.device) if need_grad else None
 	skipped = torch.empty(1, dtype = torch.bool, device = lv.device)
 	ent = None if ent is None else ent.detach().to(torch.float32).contiguous()
-	call('convasr_loss_head', ptr(lv), ptr(ylen_col), ylen_col.stride(0), ptr(ent), B, float(accumulate_iterations), ptr(out3), ptr(gvec), ptr(skipped), stream_ptr())
+	call('convasr_loss_head', ptr(lv), ptr(ylen_col), ylen_col.stride(0), ptr(ent), B, float(accumulate_iterations), ptr(out3), ptr(gvec), ptr(skipped), ptr(loss_scaler), stream_ptr())
 	return out3, gvec, skipped
 
 
@@ -432,18 +435,29 @@ def argmax(log_probs):
 
 # ------------------------------------------------------------------------------------------------ optimizer
 
-def sumsq(flat_grad, out = None, norm_out = None, norm_scale = 1.0):
-	"""out[0] = sum of squares (fp64); norm_out (1-element fp32, optional) = sqrt(out) * norm_scale."""
+def sumsq(flat_grad, out = None, norm_out = None, norm_scale = 1.0, loss_scaler = None):
+	"""out[0] = sum of squares (fp64); norm_out (1-element fp32, optional) = sqrt(out) * norm_scale (/ the loss scaler's scale)."""
 	out = out if out is not None else torch.empty(1, dtype = torch.float64, device = flat_grad.device)
 	ws = workspace(_lib.load().convasr_sumsq_workspace_bytes(), flat_grad.device, 'sumsq')
-	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), ptr(ws), ptr(norm_out), float(norm_scale), stream_ptr())
+	call('convasr_sumsq', ptr(flat_grad), flat_grad.numel(), ptr(out), ptr(ws), ptr(norm_out), float(norm_scale), ptr(loss_scaler), stream_ptr())
 	return out
 
 
-def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0, p_bf16 = None):
+def _scaler_pair(scaler):
+	"""(state read by this step, state written by it) of a dynamic loss scaler, or (None, None)."""
+	if scaler is None:
+		return None, None
+	s_in, s_out = scaler
+	assert s_in.dtype == s_out.dtype == torch.float32 and s_in.numel() == s_out.numel() == _lib.LOSS_SCALER_FLOATS and s_in.data_ptr() != s_out.data_ptr()
+	return s_in, s_out
+
+
+def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0, p16 = None, scaler = None):
+	"""p16: optional 16-bit mirror of the parameters (bf16 or fp16, n elements); scaler: optional (state_in, state_out) of a dynamic loss scaler."""
 	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
-	assert p_bf16 is None or (p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == n)
-	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p_bf16), stream_ptr())
+	assert p16 is None or (p16.dtype in HALF_DTYPES and p16.numel() == n)
+	s_in, s_out = _scaler_pair(scaler)
+	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
 
 
 def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None, gate = None):
@@ -452,17 +466,18 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 	import ctypes
 	B, Cout, Tdy = dy.shape
 	T = conv_out_len(Tdy, K, 1, dil, pad)
-	assert is_cl(dy) and dy.dtype == torch.bfloat16 and is_cl(bn_y) and bn_y.dtype == torch.bfloat16 and tuple(bn_y.shape) == (B, Cin, T) and isinstance(bn_sums, ConvStats) and bn_sums.fits(Cin, B, T, dy.device), (dy.shape, bn_y.shape, Cin, T)
+	assert is_cl(dy) and dy.dtype in HALF_DTYPES and is_cl(bn_y) and bn_y.dtype == dy.dtype and tuple(bn_y.shape) == (B, Cin, T) and isinstance(bn_sums, ConvStats) and bn_sums.fits(Cin, B, T, dy.device), (dy.shape, bn_y.shape, Cin, T)
 	rows = ctypes.c_int(0)
-	dx = empty_cl(B, Cin, T, torch.bfloat16, dy.device)
+	dx = empty_cl(B, Cin, T, dy.dtype, dy.device)
 	rc = [0]
 	def run():
-		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), ptr(gate), stream_ptr())
+		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), dtype_code(dy.dtype), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), ptr(gate), stream_ptr())
 	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if Cout % 64 == 0 else 'conv1d_igemm (other variants)'
 	flops, nbytes_ = 2.0 * B * T * Cout * Cin * K if work is None else work, float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2)
+	symbol = 'v2s16' if family.startswith('conv1d_igemm_v2s') else None
 	if family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
 		family = 'hbm:conv1d_igemm_v2s_kernel (memory-bound launches: the 38-class decoder)'
-	_lib.timed(family, flops, run, nbytes = nbytes_)
+	_lib.timed(family, flops, run, nbytes = nbytes_, symbol = symbol)
 	bn_sums.rows = rows.value
 	return dx if rc[0] == 0 else None
 
@@ -487,13 +502,15 @@ def novograd_work_table(offsets_host, device):
 	return (torch.tensor(items, dtype = torch.int64, device = device), torch.tensor(seg_first, dtype = torch.int64, device = device), torch.empty(len(items), dtype = torch.float64, device = device))
 
 
-def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0, p_bf16 = None):
+def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0, p16 = None, scaler = None):
 	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]; table: novograd_work_table(...)."""
 	items, seg_first, item_part = table
 	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
 	n_seg = offsets.numel() - 1
+	s_in, s_out = _scaler_pair(scaler)
+	assert p16 is None or (p16.dtype in HALF_DTYPES and p16.numel() == n)
 	assert int(first) >= 0 or (ema_in.numel() == n_seg + 1 and ema_out.numel() == n_seg + 1), 'first = -1 (device-side first-step detection) needs the applied-step counter behind the EMAs'
-	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), ptr(p_bf16), stream_ptr())
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
 
 
 def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):

@@ -38,7 +38,10 @@ class NovoGrad:
 		max_norm = flat.clip[1] if flat.clip is not None else 0.0
 		cur = self.steps & 1
 		grad_scale = flat.grad_scale
-		flat.mirror_carried_over(lambda p_bf16: ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = grad_scale, p_bf16 = p_bf16))
+		scaler = getattr(flat, 'loss_scaler', None)
+		flat.mirror_carried_over(lambda p16: ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair()))
+		if scaler is not None:
+			scaler.advance()
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 
@@ -46,15 +49,26 @@ class NovoGrad:
 	def state(self):
 		"""Per-parameter view in the reference's vocabulary: {'_grads_ema': 0-d tensor, 'momentum_buffer': tensor}."""
 		ema = self.grads_ema[self.steps & 1, :self.n_seg]
-		return {p: dict(_grads_ema = ema[i], momentum_buffer = self.momentum_buffer[o:o + p.numel()].view(p.shape)) for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets))}
+		views = self.flat.param_views(self.momentum_buffer)  # the parameters' logical shapes: conv segments of the arena are tap-major
+		return {p: dict(_grads_ema = ema[i], momentum_buffer = views[i]) for i, p in enumerate(self.flat.params)}
 
 	def state_dict(self):
-		return dict(steps = self.steps, momentum_buffer = self.momentum_buffer, grads_ema = self.grads_ema[self.steps & 1].clone(), param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+		"""format 2: momentum per parameter in the reference's shapes; grads_ema = one value per parameter, steps_applied = how many
+		steps were not skipped by the device-side gates (what decides 'first step' on the device)."""
+		ema = self.grads_ema[self.steps & 1]
+		return dict(format = 2, steps = self.steps, steps_applied = int(ema[self.n_seg].item()), momentum_buffer = self.flat.export_state(self.momentum_buffer), grads_ema = ema[:self.n_seg].clone(), param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
 
 	def load_state_dict(self, sd):
 		self.steps = sd['steps']
-		self.momentum_buffer.copy_(sd['momentum_buffer'])
-		self.grads_ema[self.steps & 1].copy_(sd['grads_ema'])
+		self.flat.import_state(self.momentum_buffer, sd['momentum_buffer'], 'NovoGrad.load_state_dict(momentum_buffer)')
+		ema, cur = sd['grads_ema'], self.grads_ema[self.steps & 1]
+		if ema.numel() == self.n_seg + 1:  # (an earlier layout carried the applied-step counter behind the EMAs)
+			cur.copy_(ema)
+		elif ema.numel() == self.n_seg:
+			cur[:self.n_seg].copy_(ema)
+			cur[self.n_seg] = float(sd.get('steps_applied', sd['steps']))
+		else:
+			raise ValueError(f'NovoGrad.load_state_dict: grads_ema has {ema.numel()} entries for {self.n_seg} parameters')
 		for g, s in zip(self.param_groups, sd['param_groups']):
 			g.update(s)
 

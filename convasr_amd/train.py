@@ -35,12 +35,14 @@ class FlatParameters:
 		self.numel = off
 		self.data = torch.zeros(off, dtype = torch.float32, device = dev)
 		self.grad = torch.zeros(off, dtype = torch.float32, device = dev)
-		self.data_bf16 = None  # bf16 mirror of `data`, allocated on first use (mirror()); written by the fused optimizer kernels
+		self.data16 = None  # 16-bit (bf16 or fp16: the model's compute dtype) mirror of `data`, allocated on first use (mirror()); written by the fused optimizer kernels
 		self._mirror_ver = {}  # id(param) -> version tuple (functional.packed_weight) at which the mirror segment equals bf16(param)
+		self._as_param = []  # per parameter: flat arena-shaped tensor -> view in the parameter's logical (reference) shape
 		for p, o in zip(params, self.offsets):
 			n = p.numel()
 			kmajor = p.ndim == 3 and p.shape[2] > 1 and (p.shape[0] * p.shape[1]) % 8 == 0 and dev.type == 'cuda'
 			as_param = (lambda flat, p = p: flat[o:o + n].view(p.shape[2], p.shape[0], p.shape[1]).permute(1, 2, 0)) if kmajor else (lambda flat, p = p: flat[o:o + n].view(p.shape))
+			self._as_param.append(as_param)
 			view = as_param(self.data)
 			view.copy_(p.data)
 			p.data = view
@@ -52,19 +54,44 @@ class FlatParameters:
 		self.clip = None  # (sumsq double buffer, max_norm) set by clip_grad_norm_
 		self.grad_scale = 1.0  # pending scale of .grad (the data-parallel engine's 1 / world_size), consumed by the next optimizer step
 		self._sumsq = torch.zeros(1, dtype = torch.float64, device = dev)
+		self.loss_scaler = None  # a LossScaler (fp16 training): .grad then holds gradients of the SCALED loss until the optimizer step unscales them
 
-	def mirror(self):
-		if self.data_bf16 is None:
-			self.data_bf16 = torch.zeros(self.numel, dtype = torch.bfloat16, device = self.data.device)
-		return self.data_bf16
+	def mirror(self, dtype = torch.bfloat16):
+		"""The arena's 16-bit mirror in `dtype` (one at a time: asking for the other type re-allocates it and drops what was current)."""
+		if self.data16 is None or self.data16.dtype != dtype:
+			assert dtype in ops.HALF_DTYPES
+			self.data16 = torch.zeros(self.numel, dtype = dtype, device = self.data.device)
+			self._mirror_ver = {}
+		return self.data16
 
 	def mirror_carried_over(self, run):
-		"""Run one fused optimizer launch `run(p_bf16)` that rewrites the bf16 mirror together with the parameters (or leaves both
+		"""Run one fused optimizer launch `run(p16)` that rewrites the 16-bit mirror together with the parameters (or leaves both
 		untouched when the device-side gate skips the step): segments that were current before it are current after it."""
 		was = {k for k, v in self._mirror_ver.items() if v == Fn.param_version(self._by_id[k])} if self._mirror_ver else set()
-		run(self.data_bf16)
+		run(self.data16)
 		Fn.bump_param_epoch()  # packed compute copies other than the mirror are stale now
-		self._mirror_ver = {k: Fn.param_version(self._by_id[k]) for k in was} if self.data_bf16 is not None else {}
+		self._mirror_ver = {k: Fn.param_version(self._by_id[k]) for k in was} if self.data16 is not None else {}
+
+	def param_views(self, flat_tensor):
+		"""Per-parameter views of an arena-shaped tensor (optimizer state) in the parameters' logical shapes -- the reference's
+		(Cout, Cin, K) for conv weights, whatever the arena's element order is."""
+		assert flat_tensor.numel() == self.numel
+		return [f(flat_tensor) for f in self._as_param]
+
+	def export_state(self, flat_tensor):
+		"""Arena-shaped optimizer state -> list of contiguous per-parameter tensors in reference shapes (layout-independent checkpoints)."""
+		return [v.contiguous().clone() for v in self.param_views(flat_tensor)]
+
+	def import_state(self, flat_tensor, per_param, what):
+		if isinstance(per_param, torch.Tensor):
+			raise ValueError(f'{what}: a flat arena-ordered tensor (optimizer state written before format 2) carries no layout tag and cannot be loaded safely: conv segments may be tap-major or reference-ordered')
+		views = self.param_views(flat_tensor)
+		if len(per_param) != len(views):
+			raise ValueError(f'{what}: {len(per_param)} tensors for {len(views)} parameters')
+		for v, t in zip(views, per_param):
+			if tuple(v.shape) != tuple(t.shape):
+				raise ValueError(f'{what}: shape {tuple(t.shape)} does not match parameter shape {tuple(v.shape)}')
+			v.copy_(t)
 
 	def zero_grad(self):
 		"""No memset: the next backward overwrites (first write per parameter has accumulate = False)."""
@@ -84,9 +111,62 @@ class FlatParameters:
 		folded into the optimizer kernel.  Returns the total norm as a 0-d device tensor (no host sync)."""
 		self.finalize_grads()
 		norm = torch.empty(1, dtype = torch.float32, device = self.grad.device)
-		ops.sumsq(self.grad, self._sumsq, norm_out = norm, norm_scale = self.grad_scale)
+		ops.sumsq(self.grad, self._sumsq, norm_out = norm, norm_scale = self.grad_scale, loss_scaler = None if self.loss_scaler is None else self.loss_scaler.current)
 		self.clip = (self._sumsq, float(max_norm))
 		return norm[0]
+
+
+class LossScaler:
+	"""Dynamic loss scaling for fp16 training: the role apex.amp's LossScaler plays behind `apex.amp.initialize(opt_level)`
+	(models.py:744-762) and `with apex.amp.scale_loss(loss, optimizer)` (train.py:770-772), with apex's defaults (initial scale 2^16,
+	x 2 after 2000 clean steps, / 2 and the step skipped on overflow, ceiling 2^24).  The state lives on the device
+	(include/convasr_hip.h, CONVASR_LOSS_SCALER_FLOATS) in two buffers: every optimizer step reads `current` and writes the other one,
+	advance() swaps them -- the host never waits for the overflow verdict.  loss_scale = a number: static scale (apex's
+	loss_scale = 128.0 form), no overflow check."""
+
+	def __init__(self, device, loss_scale = 'dynamic', init_scale = 2.0 ** 16, scale_factor = 2.0, scale_window = 2000, min_loss_scale = None, max_loss_scale = 2.0 ** 24):
+		dynamic = loss_scale in (None, 'dynamic')
+		state = [float(init_scale) if dynamic else float(loss_scale), 0.0, 0.0, float(scale_window) if dynamic else 0.0, float(min_loss_scale or 0.0), float(max_loss_scale), float(scale_factor), 0.0]
+		assert len(state) == _lib.LOSS_SCALER_FLOATS
+		self.state = torch.tensor([state, state], dtype = torch.float32, device = device)
+		self.cur = 0
+
+	@property
+	def current(self):
+		return self.state[self.cur]
+
+	def pair(self):
+		return self.state[self.cur], self.state[1 - self.cur]
+
+	def advance(self):
+		self.cur = 1 - self.cur
+
+	def loss_scale(self):
+		"""Host read (synchronises): apex's `_amp_state.loss_scalers[0].loss_scale()`."""
+		return float(self.current[0])
+
+	def state_dict(self):
+		"""apex.amp.state_dict()'s entry for one scaler (train.py:332 saves it as `amp_state_dict`)."""
+		s = self.current.tolist()
+		return dict(loss_scale = s[0], unskipped = int(s[1]))
+
+	def load_state_dict(self, sd):
+		cur = self.current.clone()
+		cur[0], cur[1] = float(sd['loss_scale']), float(sd['unskipped'])
+		self.state[self.cur].copy_(cur)
+
+
+def amp_state_dict(optimizer):
+	"""apex.amp.state_dict() (train.py:332): {'loss_scaler0': {...}} when the optimizer trains under a loss scaler, else {}."""
+	scaler = getattr(getattr(optimizer, 'flat', None), 'loss_scaler', None)
+	return {} if scaler is None else dict(loss_scaler0 = scaler.state_dict())
+
+
+def amp_load_state_dict(optimizer, sd):
+	"""apex.amp.load_state_dict(checkpoint['amp_state_dict']) (train.py:707-708)."""
+	scaler = getattr(getattr(optimizer, 'flat', None), 'loss_scaler', None)
+	if scaler is not None and sd and 'loss_scaler0' in sd:
+		scaler.load_state_dict(sd['loss_scaler0'])
 
 
 class SGD:
@@ -110,17 +190,23 @@ class SGD:
 			flat.finalize_grads()
 		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
 		first, grad_scale = self.steps == 0, flat.grad_scale
-		flat.mirror_carried_over(lambda p_bf16: ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], first, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = grad_scale, p_bf16 = p_bf16))
+		scaler = flat.loss_scaler
+		if scaler is not None and sumsq is None:  # the overflow check reads the gradient's sum of squares
+			sumsq = ops.sumsq(flat.grad, flat._sumsq)
+		flat.mirror_carried_over(lambda p16: ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], first, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair()))
+		if scaler is not None:
+			scaler.advance()
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 
 	def state_dict(self):
-		return dict(steps = self.steps, momentum_buffer = self.momentum_buffer, param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+		"""format 2: momentum per parameter, in the reference's shapes (independent of the arena's tap-major element order)."""
+		return dict(format = 2, steps = self.steps, momentum_buffer = None if self.momentum_buffer is None else self.flat.export_state(self.momentum_buffer), param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
 
 	def load_state_dict(self, sd):
 		self.steps = sd['steps']
 		if self.momentum_buffer is not None and sd.get('momentum_buffer') is not None:
-			self.momentum_buffer.copy_(sd['momentum_buffer'])
+			self.flat.import_state(self.momentum_buffer, sd['momentum_buffer'], 'SGD.load_state_dict(momentum_buffer)')
 		for g, s in zip(self.param_groups, sd['param_groups']):
 			g.update(s)
 
@@ -139,7 +225,8 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	# train.py:754-756 in one launch (ops.loss_head): loss = mean(loss_vec * ylen[:, 0]) / accum, loss_cur = mean(loss_vec), the mean
 	# entropy, the inf/NaN flag, and d loss / d loss_vec (the vector backward() is seeded with)
 	ent = M.entropy(log_probs[0].detach(), olen[0], dim = 1)
-	scalars, grad_loss_vec, skipped = ops.loss_head(loss_vec, ylen[:, 0], ent, accumulate_iterations)
+	scaler = getattr(getattr(optimizer, 'flat', None), 'loss_scaler', None)  # fp16: backward is seeded with the scaled loss's gradient (train.py:770-772)
+	scalars, grad_loss_vec, skipped = ops.loss_head(loss_vec, ylen[:, 0], ent, accumulate_iterations, loss_scaler = None if scaler is None else scaler.current)
 	engine = model if hasattr(model, 'finish_gradient_sync') else None
 	group = engine.group if engine is not None else None
 	# The two scalar all-reduces of train.py:759-760 as one 2-element all-reduce.  With a data-parallel engine that runs
@@ -187,7 +274,10 @@ def train_epoch(model, optimizer, batches, sampler = None, scheduler = None, ite
 	Returns the next iteration number."""
 	for meta, s, x, xlen, y, ylen in batches:
 		res = train_step(model, optimizer, x, xlen, y, ylen, max_norm = max_norm, accumulate_iterations = accumulate_iterations, iteration = iteration, world_size = world_size, sync_metrics = world_size > 1)
-		if scheduler is not None and iteration % accumulate_iterations == 0:
+		# train.py:769-783: the scheduler steps only inside the not-skipped branch.  Where the host knows the verdict (a host-side gate
+		# returned skipped = True) the reference's behaviour is reproduced exactly; with the device-side gate the host does not wait
+		# for it, and after a skipped iteration the next step's lr is one scheduler tick ahead of the reference's
+		if scheduler is not None and iteration % accumulate_iterations == 0 and res['skipped'] is not True:
 			scheduler.step(iteration)
 		if on_step is not None:
 			on_step(iteration, (meta, s, x, xlen, y, ylen), res)

@@ -2,7 +2,7 @@
 
 * setup(args) -> (text_pipeline, frontend, model, generator)                          transcribe.py:23-60
   checkpoint -> frontend + model (the reference's class names / state-dict keys) -> eval() -> fuse_conv_bn_eval() ->
-  compute dtype from args.fp16 (None / 'O0': exact fp32; 'O1'..'O3': bf16 MFMA, the role apex.amp played) -> greedy generator.
+  compute dtype from args.fp16 (None / 'O0': exact fp32; 'O1'..'O3': fp16 storage + MFMA as under apex.amp, or bf16 when models.AMP_DTYPE says so) -> greedy generator.
 * transcribe_batch(...)                                                                transcribe.py:140-200
   the per-batch body of transcribe.main: forward (every op a HIP kernel; the argmax of the greedy decode too), per-frame time
   stamps, GreedyCTCGenerator with time stamps (one segment per word), optional forced alignment of the reference text

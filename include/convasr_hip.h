@@ -10,7 +10,8 @@
  *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns 0, or a negative
  *     CONVASR_E* code with a message retrievable through convasr_last_error() (thread-local);
  *   - activations are "channels-last": element (b, c, t) of a logical (B, C, T) tensor lives at
- *     ((b * T + t) * C + c); dtype is CONVASR_F32 or CONVASR_BF16.  convasr_convert_layout() moves data between
+ *     ((b * T + t) * C + c); dtype is CONVASR_F32, CONVASR_BF16 or CONVASR_F16 (the two 16-bit storage types run the same
+ *     kernels, instantiated on v_mfma_*_bf16 / v_mfma_*_f16; every sum is accumulated in fp32).  convasr_convert_layout() moves data between
  *     this layout and arbitrary (B, C, T) strides (e.g. torch-contiguous NCW);
  *   - conv weights are consumed in a packed layout [tap][cout_pad][cin] produced by convasr_pack_conv_weight()
  *     from the reference's (Cout, Cin, K) fp32 parameters;
@@ -26,9 +27,9 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 4
+#define CONVASR_ABI_VERSION 5
 
-enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2 };
+enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2, CONVASR_F16 = 3 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
 enum { CONVASR_OK = 0, CONVASR_EINVAL = -1, CONVASR_ELAUNCH = -2, CONVASR_EUNSUPPORTED = -3 };
 
@@ -113,7 +114,7 @@ int convasr_fold2_geometry(int K, int pad, int* K_folded, int* pad_folded);
 int convasr_fold2_pack_weight(const float* w, int w_layout, void* packed_fwd, int dtype, int Cout, int Cin, int K, int pad, void* stream);
 int convasr_fold2_unfold_wgrad(const float* dw_folded, float* dw, int dw_layout, int Cout, int Cin, int K, int pad, int accumulate, void* stream);
 
-/* A/B and test hook: 0 routes bf16 launches through the general register-staged kernel instead of the LDS-DMA kernel.
+/* A/B and test hook: 0 routes bf16 / fp16 launches through the general register-staged kernels instead of the LDS-DMA kernels.
  * Returns the previous setting. */
 int convasr_debug_set_conv_v2(int enable);
 
@@ -207,9 +208,24 @@ int convasr_scale_rows(const float* grad, const float* gscale, const int64_t* gd
  * (models.py:323), w[b] = ylen[b * ylen_stride] (target lengths), entropy[b] (may be NULL) = models.entropy per utterance:
  *   out3[0] = mean(loss_vec * w) / accumulate_iterations, out3[1] = mean(loss_vec), out3[2] = mean(entropy);
  *   grad_loss_vec[b] (may be NULL) = d out3[0] / d loss_vec[b] = ((1 / accumulate_iterations) / B) * w[b];
- *   skipped (may be NULL, one byte) = out3[1] is inf or NaN (the gate of train.py:769). */
+ *   skipped (may be NULL, one byte) = out3[1] is inf or NaN (the gate of train.py:769).
+ * loss_scaler (may be NULL): a dynamic loss scaler's state (below); grad_loss_vec is multiplied by its current scale, i.e. backward is
+ * seeded with the gradient of the SCALED loss (`with apex.amp.scale_loss(loss, optimizer) as scaled_loss: scaled_loss.backward()`,
+ * train.py:770-772). */
 int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
-                      float* grad_loss_vec, unsigned char* skipped, void* stream);
+                      float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, void* stream);
+
+/* Dynamic loss scaler for fp16 training (the role of apex.amp's LossScaler, reference models.py:744-762 `apex.amp.initialize(opt_level)`
+ * and train.py:770-779): CONVASR_LOSS_SCALER_FLOATS floats on the device,
+ *   [0] scale  [1] clean steps since the last change  [2] did the last step overflow (0 / 1)  [3] growth window (0 = static scale)
+ *   [4] min scale  [5] max scale  [6] factor  [7] number of steps skipped for overflow so far
+ * read by convasr_loss_head (backward seed x scale), convasr_sumsq (the reported norm is that of the UNSCALED gradient, what
+ * clip_grad_norm_ sees on apex's master gradients) and the fused optimizer steps (gradients x 1 / scale; a non-finite sum of squares =
+ * overflow: parameters and optimizer state stay untouched).  The optimizer step writes the next state into a SECOND buffer
+ * (scaler_in != scaler_out; the caller swaps them per step) with apex's update_scale(): overflow -> scale = max(min, scale / factor),
+ * clean = 0; otherwise ++clean, and at clean == window: scale = min(max, scale * factor), clean = 0.  A step gated by a non-finite
+ * LOSS (loss_gate) copies the state unchanged: the reference never enters scale_loss on such an iteration. */
+#define CONVASR_LOSS_SCALER_FLOATS 8
 
 /* ent[b] = sum_{t<olen} -sum_c p log p / (eps + olen[b])  (olen NULL: mean over T). */
 int convasr_entropy(const float* log_probs, const int64_t* olen, float* ent, int B, int T, int C, float eps, void* stream);
@@ -223,8 +239,8 @@ int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows, int C, vo
 
 /* sumsq[0] = sum g^2 over n fp32 values, in double, added in a fixed order (partial sums in `workspace`, no atomics). */
 int64_t convasr_sumsq_workspace_bytes(void);
-/* norm_out (may be NULL) receives (float)(sqrt(sumsq) * norm_scale): what clip_grad_norm_ returns. */
-int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, float* norm_out, float norm_scale, void* stream);
+/* norm_out (may be NULL) receives (float)(sqrt(sumsq) * norm_scale) (/ the loss scaler's scale when loss_scaler != NULL): what clip_grad_norm_ returns. */
+int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, float* norm_out, float norm_scale, const float* loss_scaler, void* stream);
 /* torch.optim.SGD step with clip folded in: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (c = 1 if sumsq NULL);
  * g' = c*g + wd*p; buf = first ? g' : mom*buf + g'; p -= lr * (nesterov ? g' + mom*buf : buf).
  * If grad_out != NULL the clipped gradient c*g is written back (what clip_grad_norm_ leaves in .grad).
@@ -232,13 +248,14 @@ int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, flo
  * materialised; sumsq is then the sum of squares of the summed gradient).
  * If loss_gate != NULL and *loss_gate (a device float, the all-reduced loss) is inf or NaN the launch changes nothing: the
  * reference's "skip the step on a non-finite loss" (train.py:769-772) without a host round trip in the middle of the step.
- * p_bf16 (may be NULL): n bf16 values, receives the updated parameters rounded to bf16 -- with K-major masters that mirror IS the
- * packed forward weight of every conv whose Cout is a multiple of the kernel's N tile (no per-step packing launches). */
+ * p16 (may be NULL): n values of p16_dtype (CONVASR_BF16 or CONVASR_F16), receives the updated parameters rounded to that type -- with
+ * K-major masters that mirror IS the packed forward weight of every conv whose Cout is a multiple of the kernel's N tile (no
+ * per-step packing launches).  scaler_in / scaler_out (both or neither): the dynamic loss scaler above; needs sumsq. */
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale,
-                     uint16_t* p_bf16, void* stream);
+                     void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream);
 
-/* Fused backward step (bf16, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
+/* Fused backward step (bf16 / fp16 storage `dtype`, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
  * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:
  * g = dx * act'(bn_y*bn_scale+bn_shift) * dropout * mask(bn_xlen); bn_sums[c] += sum g, bn_sums[C+c] += sum g*(bn_y-mean)*invstd
 
@@ -247,7 +264,7 @@ int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int6
  * single consumer.  dy is (B, T_dy, Cout), dx and bn_y are (B, T_dx, Cin); pad = dil*(K-1) - padding of the forward conv.  Returns 1 (nothing launched) when the shape is outside the
  * LDS-DMA kernel's envelope (Cout % 64 != 0): run the two calls separately.  bn_gate (may be NULL): that layer's one-bit gates
  * from convasr_bn_act_fwd, used instead of re-deriving act' / dropout / mask per element in the epilogue. */
-int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
+int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
                                    int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                    const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
                                    uint64_t offset, const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream);
@@ -268,12 +285,13 @@ int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamm
  * convasr_sgd_step (a gated call copies ema_in to ema_out and changes nothing else).  first: 1 / 0 decided by the caller, or -1 =
  * decided on the device: ema_in / ema_out then hold n_seg + 1 floats, the last one the number of steps applied so far (the call
  * writes ema_out[n_seg] = ema_in[n_seg] + 1 unless gated), and first = (ema_in[n_seg] == 0) -- a gated first iteration then leaves
- * no optimizer state behind, like the reference, which creates state only when a step runs (optimizers.py:76-80).  p_bf16 as in
- * convasr_sgd_step. */
+ * no optimizer state behind, like the reference, which creates state only when a step runs (optimizers.py:76-80).  p16 / p16_dtype and
+ * scaler_in / scaler_out as in convasr_sgd_step (the overflow check uses the per-tensor sums of squares formed here). */
 int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets,
                           int n_seg, int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part,
                           float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
-                          const float* loss_gate, float* total_norm, float grad_scale, uint16_t* p_bf16, void* stream);
+                          const float* loss_gate, float* total_norm, float grad_scale, void* p16, int p16_dtype, const float* scaler_in,
+                          float* scaler_out, void* stream);
 /* largest item the table may hold (elements) */
 int64_t convasr_novograd_item_elems(void);
 

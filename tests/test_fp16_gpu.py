@@ -1,0 +1,205 @@
+"""fp16 storage + dynamic loss scaling on the MI355X (BASELINE configs[4] states fp16; reference: apex.amp at models.py:744-762,
+train.py:770-779): the scaler's device-side state machine against apex's update_scale() restated on the host, the overflow skip on a
+real model, scaled against unscaled training steps, a fp16 training step against the oracle's fp16-storage restatement, and the
+convergence of all compute types on one fixed batch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import convasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+FE = dict(nfft = 512, hop_length = 160)
+
+
+def _dump(name, obj):
+	import json
+	out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+	if os.path.isdir(out):
+		with open(os.path.join(out, name), 'w') as f:
+			json.dump(obj, f, indent = 1)
+
+
+class ApexLossScaler:
+	"""apex/amp/scaler.py LossScaler.update_scale(), restated (dynamic: init 2^16, factor 2, window 2000, max 2^24)."""
+
+	def __init__(self, init = 2.0 ** 16, factor = 2.0, window = 2000, min_scale = None, max_scale = 2.0 ** 24):
+		self.scale, self.unskipped, self.factor, self.window, self.min, self.max = init, 0, factor, window, min_scale, max_scale
+
+	def update(self, overflow):
+		if overflow:
+			self.scale = max(self.min, self.scale / self.factor) if self.min else self.scale / self.factor
+			self.unskipped = 0
+		else:
+			self.unskipped += 1
+		if self.unskipped == self.window:
+			self.scale = min(self.max, self.scale * self.factor)
+			self.unskipped = 0
+		return overflow
+
+
+@pytest.mark.parametrize('optimizer', ['sgd', 'novograd'])
+def test_loss_scaler_state_machine_matches_apex(optimizer):
+	"""A random overflow / clean / gated sequence through the fused optimizer kernels: scale and counter follow apex's update_scale()
+	step for step, an overflowed or gated step leaves parameters and optimizer state bit-identical, an applied step equals the
+	unscaled step on the unscaled gradients (the 1 / scale rides in the kernel's gradient scale), the reported norm is the unscaled one."""
+	import convasr_amd as ca
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(0)
+
+	def make():
+		m = torch.nn.Sequential(torch.nn.Conv1d(8, 16, 3), torch.nn.Conv1d(16, 8, 1)).to(d)
+		flat = ca.train.FlatParameters(m)
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3) if optimizer == 'sgd' else ca.optimizers.NovoGrad(flat, lr = 1e-2, betas = (0.95, 0.98), weight_decay = 1e-3)
+		return m, flat, opt
+
+	torch.manual_seed(1)
+	m1, f1, o1 = make()
+	torch.manual_seed(1)
+	m2, f2, o2 = make()  # the unscaled twin
+	assert torch.equal(f1.data, f2.data)
+	f1.loss_scaler = ca.train.LossScaler(d, scale_window = 3, init_scale = 2.0 ** 10, max_loss_scale = 2.0 ** 12)
+	apex = ApexLossScaler(init = 2.0 ** 10, window = 3, max_scale = 2.0 ** 12)
+	rng = np.random.RandomState(5)
+	events = ['clean'] * 4 + ['overflow', 'gated', 'clean', 'overflow', 'overflow'] + ['clean'] * 9 + ['gated'] + ['clean'] * 5
+	for it, ev in enumerate(events):
+		g = torch.Generator().manual_seed(100 + it)
+		scale = f1.loss_scaler.loss_scale()
+		assert scale == apex.scale, (it, scale, apex.scale)
+		for p1, p2 in zip(f1.params, f2.params):
+			grad = torch.randn(p1.shape, generator = g).to(d)
+			p2._convasr_grad.copy_(grad); p2._convasr_fresh = False
+			p1._convasr_grad.copy_(grad * scale); p1._convasr_fresh = False
+		if ev == 'overflow':
+			f1.params[rng.randint(len(f1.params))]._convasr_grad.view(-1)[3] = float('inf') if it % 2 else float('nan')
+		before = (f1.data.clone(), o1.momentum_buffer.clone())
+		gate = torch.tensor([float('nan') if ev == 'gated' else 1.5], device = d)
+		n1 = f1.clip_grad_norm_(100.0)
+		o1.step(loss_gate = gate)
+		o1.zero_grad()
+		if ev == 'clean':
+			n2 = f2.clip_grad_norm_(100.0)
+			o2.step(loss_gate = gate)
+			o2.zero_grad()
+			assert abs(float(n1) - float(n2)) <= 1e-5 * float(n2), (it, float(n1), float(n2))
+			assert float((f1.data - f2.data).abs().max()) <= 2e-6, (it, float((f1.data - f2.data).abs().max()))  # (g * s) * (1 / s) against g: one rounding apart
+			apex.update(False)
+		else:
+			assert torch.equal(f1.data, before[0]) and torch.equal(o1.momentum_buffer, before[1]), (it, ev)
+			if ev == 'overflow':
+				assert not np.isfinite(float(n1))
+				apex.update(True)
+		sd = ca.train.amp_state_dict(o1)['loss_scaler0']
+		assert sd == dict(loss_scale = apex.scale, unskipped = apex.unskipped), (it, ev, sd, apex.scale, apex.unskipped)
+		assert float(f1.loss_scaler.current[2]) == (1.0 if ev == 'overflow' else 0.0) or ev == 'gated'
+	assert int(f1.loss_scaler.current[7]) == events.count('overflow')
+	# checkpoint round trip (train.py:332, 707-708) and a static scale (apex loss_scale = 128.0: no overflow check, scale constant)
+	f2.loss_scaler = ca.train.LossScaler(d)
+	ca.train.amp_load_state_dict(o2, ca.train.amp_state_dict(o1))
+	assert ca.train.amp_state_dict(o2) == ca.train.amp_state_dict(o1)
+	f2.loss_scaler = ca.train.LossScaler(d, loss_scale = 128.0)
+	for p2 in f2.params:
+		p2._convasr_grad.fill_(float('inf')); p2._convasr_fresh = False
+	f2.clip_grad_norm_(100.0)
+	o2.step()
+	assert f2.loss_scaler.loss_scale() == 128.0 and not bool(torch.isfinite(f2.data).all())  # static scaling does not look: the step is applied, as under apex
+
+
+def test_loss_head_seeds_backward_with_the_scaled_loss():
+	from convasr_amd import ops
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	lv = torch.tensor([3.0, 5.0, 7.5], device = d)
+	ylen = torch.tensor([[10], [20], [30]], device = d)
+	sc = ca.train.LossScaler(d, init_scale = 4096.0)
+	out_a, g_a, _ = ops.loss_head(lv, ylen[:, 0], None, 2)
+	out_b, g_b, _ = ops.loss_head(lv, ylen[:, 0], None, 2, loss_scaler = sc.current)
+	assert torch.equal(out_a, out_b) and torch.equal(g_b, g_a * 4096.0)  # the logged losses are unscaled (train.py:755-765)
+
+
+def _tiny(ca, dtype, dropout = 0.0, seed = 1):
+	torch.manual_seed(seed)
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	model = ca.models.JasperNet(64, [38], base_width = 128, kernel_sizes = [11], out_width_factors = [2], dropouts = [dropout], out_width_factors_large = [2, 2], residual = False, repeat = 2, frontend = fe, check_time_dim_padded = False, nonlinearity = ('hardtanh', 0, 20), dilation = 2, dropout = dropout, compute_dtype = dtype)
+	return model
+
+
+def _batch(B = 4, secs = 3, seed = 2):
+	g = torch.Generator().manual_seed(seed)
+	x = torch.rand(B, 16000 * secs, generator = g) * 2 - 1
+	xlen = torch.tensor([1.0, 0.9, 0.5, 0.75])[:B]
+	y = torch.randint(0, 37, (B, 1, 8 * secs), generator = g)
+	ylen = torch.tensor([[24], [20], [9], [14]])[:B]
+	return x, xlen, y, ylen
+
+
+def test_fp16_training_step_scaled_equals_unscaled_and_overflow_is_skipped():
+	"""One model, three fp16 training steps each way: (a) no scaler, (b) static scale 1024 through the whole backward.  Gradients of
+	the scaled run, unscaled by the optimizer kernel, move the parameters like the unscaled run up to fp16 rounding of the scaled
+	intermediates (relative L2 of the update <= 2e-3).  (c) a dynamic scaler whose scale is far too large: every gradient overflows,
+	the step is skipped -- parameters, momentum and batch-norm running statistics of the optimizer side untouched -- and the scale
+	halves until a step goes through."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = [t.to(d) for t in _batch()]
+	runs = {}
+	for name, scaler in (('plain', None), ('static', dict(loss_scale = 1024.0))):
+		model = _tiny(ca, torch.float16).to(d).train()
+		flat = ca.train.FlatParameters(model)
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		w0 = flat.data.clone()
+		if scaler is not None:
+			flat.loss_scaler = ca.train.LossScaler(d, **scaler)
+		res = [ca.train.train_step(model, opt, x, xlen, y, ylen, iteration = it) for it in range(3)]
+		runs[name] = (flat.data.clone() - w0, [float(r['loss_cur']) for r in res], [float(r['grad_norm']) for r in res])
+	upd_a, upd_b = runs['plain'][0], runs['static'][0]
+	rel = float((upd_a - upd_b).norm() / upd_a.norm())
+	print('fp16 scaled vs unscaled: update rel L2', rel, 'losses', runs['plain'][1], runs['static'][1], 'norms', runs['plain'][2], runs['static'][2])
+	assert rel <= 2e-3 and abs(runs['plain'][2][0] - runs['static'][2][0]) <= 2e-3 * runs['plain'][2][0]
+	# (c) overflow
+	model = _tiny(ca, torch.float16).to(d).train()
+	flat = ca.train.FlatParameters(model)
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	model, opt = ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2')
+	flat.loss_scaler = ca.train.LossScaler(d, init_scale = 2.0 ** 22)
+	w0 = flat.data.clone()
+	history = []
+	for it in range(12):
+		r = ca.train.train_step(model, opt, x, xlen, y, ylen, iteration = it)
+		history.append((flat.loss_scaler.state_dict(), float(r['grad_norm']), bool(torch.equal(flat.data, w0))))
+	print('overflow run:', history)
+	skipped = [h for h in history if not np.isfinite(h[1])]
+	assert len(skipped) >= 1 and all(h[2] for h in history[:len(skipped)]) and not history[-1][2]  # the overflowed steps come first and change nothing
+	assert history[-1][0]['loss_scale'] == 2.0 ** 22 / 2 ** len(skipped)
+	assert float(opt.momentum_buffer.abs().max()) > 0 and bool(torch.isfinite(flat.data).all())
+
+
+def test_fp16_tiny_training_step_vs_fp16_storage_oracle():
+	"""A whole fp16 training step (frontend -> 4 conv layers -> decoder -> CTC -> backward -> clip -> SGD) against the oracle's
+	restatement with storage = torch.float16 on the same inputs: loss within 1e-3, every parameter after the step within fp16's noise."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = _batch()
+	model = _tiny(ca, torch.float16)
+	sd = {k: v.clone() for k, v in model.state_dict().items()}
+	model.to(d).train()
+	flat = ca.train.FlatParameters(model)
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	res = ca.train.train_step(model, opt, x.to(d), xlen.to(d), y.to(d), ylen.to(d))
+	plan = O.jasper_plan(64, [38], **dict(O.TINY, base_width = 128, repeat = 2), nonlinearity = ('hardtanh', 0, 20), dilation = 2)
+	ref32 = O.train_step({k: v.clone() for k, v in sd.items()}, plan, x, xlen, y, ylen, frontend = FE, momentum_buffers = {})
+	ref16 = O.train_step({k: v.clone() for k, v in sd.items()}, plan, x, xlen, y, ylen, frontend = FE, momentum_buffers = {}, storage = torch.float16)
+	l, l16, l32 = float(res['loss']), float(ref16['loss']), float(ref32['loss'])
+	print('fp16 tiny step: loss', l, 'oracle fp16 storage', l16, 'oracle fp32', l32)
+	assert abs(l - l16) <= 1e-3 * abs(l16) and abs(l - l32) <= 2e-3 * abs(l32)
+	got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+	ref_sd16 = {k: v.clone() for k, v in sd.items()}
+	O.train_step(ref_sd16, plan, x, xlen, y, ylen, frontend = FE, momentum_buffers = {}, storage = torch.float16)
+	for k in ('backbone.0.conv.0.0.weight', 'backbone.1.conv.1.0.weight', 'backbone.2.conv.0.0.weight', 'decoder.0.weight', 'backbone.1.bn.0.weight'):
+		upd, upd_ref = got[k] - sd[k], ref_sd16[k] - sd[k]
+		rel = float((upd - upd_ref).norm() / upd_ref.norm())
+		print(' ', k, 'update rel L2 vs fp16-storage oracle', rel)
+		assert rel <= 3e-2, (k, rel)
