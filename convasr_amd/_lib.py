@@ -25,7 +25,8 @@ _SIGNATURES = dict(
 	convasr_convert_layout = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_p]),
 	convasr_signal_absmax = (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_logmel_fwd = (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_f32, c_p]),
-	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_output_lengths = (c_int, [c_p, c_int, c_int, c_p, c_p]),
 	convasr_conv_cout_pad = (c_int, [c_int]),
 	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_fold2_geometry = (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -49,7 +50,7 @@ _SIGNATURES = dict(
 	convasr_ctc_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
 	convasr_ctc_loss = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_scale_rows = (c_int, [c_p, c_p, c_p, c_i64, c_p, c_int, c_i64, c_p]),
-	convasr_loss_head = (c_int, [c_p, c_p, c_i64, c_p, c_int, c_f32, c_p, c_p, c_p, c_p, c_p]),
+	convasr_loss_head = (c_int, [c_p, c_p, c_i64, c_p, c_int, c_f32, c_p, c_p, c_p, c_p, c_f32, c_p]),
 	convasr_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_weighted_mean_entropy = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),

@@ -5,23 +5,45 @@
 
 // ------------------------------------------------------------------------------------------------ statistics -> scale / shift
 // stats: [rows][2][C] fp64 partial sums, one row per m-tile of the conv launch that produced them (rows = 1: plain totals).
-// Block = 64 channels x 16 row-lanes; a lane adds rows w, w + 16, ... in order and the 16 lanes are combined in order: the
-// result does not depend on which workgroup of the conv finished first (the conv epilogue uses no atomics).
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ stats, int rows, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
-                                                            float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt) {
-	__shared__ double red[2][16][64];
-	const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, w = threadIdx.x >> 6;
-	if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+// Block = 16 channels x 64 row-lanes (one 128-byte segment of a partial row per 16 lanes); a lane adds rows w, w + 64, ... in order and
+// the 64 lanes are combined in a fixed two-stage order: the result does not depend on which workgroup of the conv finished first (the
+// conv epilogue uses no atomics).  (Round 2 used 64 channels x 16 row-lanes: 4-16 workgroups per launch, each lane walking 12+ rows one
+// dependent HBM round trip after the other -- 8 us per launch, 36 launches per training step; this shape takes 3-4 loads per lane on
+// C / 16 workgroups.)
+#define FIN_CH 16
+#define FIN_LANES 64
+// Both planes of the 16 channels of this block: returns true on the one thread per channel (row-lane 0) that holds the totals.
+__device__ __forceinline__ bool finalize_rows(const double* __restrict__ part, int rows, int C, double (&red)[2][FIN_LANES][FIN_CH], double& s1, double& s2) {
+	const int cl = threadIdx.x & (FIN_CH - 1), c = blockIdx.x * FIN_CH + cl, w = threadIdx.x >> 4;
 	double a = 0, q2 = 0;
 	if (c < C)
-		for (int r = w; r < rows; r += 16) { a += stats[((int64_t)r * 2) * C + c]; q2 += stats[((int64_t)r * 2 + 1) * C + c]; }
+		for (int r = w; r < rows; r += FIN_LANES) { a += part[((int64_t)r * 2) * C + c]; q2 += part[((int64_t)r * 2 + 1) * C + c]; }
 	red[0][w][cl] = a;
 	red[1][w][cl] = q2;
 	__syncthreads();
-	if (w != 0 || c >= C) return;
-	double s1 = 0, s2 = 0;
-	for (int i = 0; i < 16; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }
+	if (w < 8) {
+		a = 0; q2 = 0;
+#pragma unroll
+		for (int j = 0; j < FIN_LANES / 8; ++j) { a += red[0][w + 8 * j][cl]; q2 += red[1][w + 8 * j][cl]; }
+	}
+	__syncthreads();
+	if (w < 8) { red[0][w][cl] = a; red[1][w][cl] = q2; }
+	__syncthreads();
+	if (w != 0 || c >= C) return false;
+	s1 = 0; s2 = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { s1 += red[0][i][cl]; s2 += red[1][i][cl]; }
+	return true;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ stats, int rows, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt) {
+	__shared__ double red[2][FIN_LANES][FIN_CH];
+	const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+	if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+	double s1, s2;
+	if (!finalize_rows(stats, rows, C, red, s1, s2)) return;
 	const double m = s1 / n;
 	double var = s2 / n - m * m;
 	if (var < 0) var = 0;
@@ -42,7 +64,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 extern "C" int convasr_bn_finalize(const double* stats, int stats_rows, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int64_t* num_batches_tracked, void* stream) {
 	CONVASR_CHECK_ARG(stats && stats_rows > 0 && mean && invstd && scale && shift && n > 0 && C > 0, "bn_finalize: bad arguments");
-	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked);
+	hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, stats, stats_rows, (double)n, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, (long long*)num_batches_tracked);
 	CONVASR_CHECK_LAUNCH("bn_finalize");
 	return 0;
 }
@@ -118,7 +140,7 @@ struct BnActParams {
 };
 
 static void set_dropout(BnActParams& p, float dropout_p, uint64_t seed, uint64_t offset) {
-	p.p_drop = dropout_p; p.seed = seed; p.offset = offset;
+	p.p_drop = dropout_p; p.seed = convasr_mix_seed(seed); p.offset = offset;
 	p.drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
 	if (p.drop_thr > 65535u) p.drop_thr = 65535u;
 	p.keep_scale = 65536.f / (float)(65536u - p.drop_thr);
@@ -459,19 +481,12 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // The same finalize for the per-tile partial rows [rows][2][C] written by the fused dgrad epilogue of conv_v2s.hip: sums them in a
-// fixed order (64 channels x 16 row-lanes per block) and emits coef / dgamma / dbeta.
+// fixed order (finalize_rows: 16 channels x 64 row-lanes per block) and emits coef / dgamma / dbeta.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_sums_kernel(const double* __restrict__ sums, int rows, BnFinalizeSets sets, int C) {
-	__shared__ double red[2][16][64];
-	const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, w = threadIdx.x >> 6;
-	double a = 0, b2 = 0;
-	if (c < C)
-		for (int r = w; r < rows; r += 16) { a += sums[((int64_t)r * 2) * C + c]; b2 += sums[((int64_t)r * 2 + 1) * C + c]; }
-	red[0][w][cl] = a;
-	red[1][w][cl] = b2;
-	__syncthreads();
-	if (w != 0 || c >= C) return;
-	double sg = 0, sgx = 0;
-	for (int i = 0; i < 16; ++i) { sg += red[0][i][cl]; sgx += red[1][i][cl]; }
+	__shared__ double red[2][FIN_LANES][FIN_CH];
+	const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+	double sg, sgx;
+	if (!finalize_rows(sums, rows, C, red, sg, sgx)) return;
 	if (sets.coef) {
 		const float gm = sets.gamma ? sets.gamma[c] : 1.f, is = sets.invstd[c], m = sets.mean[c];
 		const float msg = (float)sg * sets.invn, msgx = (float)sgx * sets.invn;
@@ -489,7 +504,7 @@ extern "C" int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const 
 	BnFinalizeSets sets = {};
 	sets.gamma = gamma; sets.mean = mean; sets.invstd = invstd; sets.coef = coef; sets.dgamma = dgamma; sets.dbeta = dbeta;
 	sets.accumulate = accumulate; sets.invn = 1.0f / (float)n;
-	hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, sums, sums_rows, sets, C);
+	hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, sums, sums_rows, sets, C);
 	CONVASR_CHECK_LAUNCH("bn_bwd_finalize");
 	return 0;
 }

@@ -185,8 +185,9 @@ __device__ __forceinline__ unsigned lowbias32(unsigned x) {
 
 // Dropout mask of the 8 elements starting at element index idx (a multiple of 8): a counter-based generator, so the forward pass,
 // the fused backward epilogue and the backward apply pass regenerate the same mask from (seed, offset, idx) instead of storing it.
-// Block counter c = offset + idx / 8; c4 = 4 c (64 bit).  key = seed_lo ^ lowbias32(high word of c4 ^ seed_hi) (constant for 2^30
-// blocks); word 0 = lowbias32(low word of c4 ^ key), words 1..3 = successive xorshift32 steps of it: 4 x 32 bits = 8 x 16 random bits;
+// Block counter c = offset + idx / 8; c4 = 4 c (64 bit).  seed = the caller's seed whitened on the host (convasr_mix_seed);
+// key = seed_lo ^ lowbias32(high word of c4 ^ seed_hi) (constant for 2^30 blocks); word 0 = lowbias32_keyed(low word of c4, key),
+// words 1..3 = successive xorshift32 steps of it: 4 x 32 bits = 8 x 16 random bits;
 // an element is dropped when its bits are < thr (= round(p * 65536)), kept ones are scaled by `scale` (= 65536 / (65536 - thr)).
 // 4 integer multiplies (quarter-rate instructions) per 8 elements.  History: Philox4x32-7 (CONVASR_DROPOUT_PHILOX builds, the round-1
 // generator) needs 56 and cost ~6 us per 256 x 128 tile in the dgrad epilogue; four hashed words (10 multiplies) made the BN forward
@@ -195,6 +196,24 @@ __device__ __forceinline__ unsigned lowbias32(unsigned x) {
 // max |correlation| within a block 1.1e-3, between consecutive blocks 1.3e-3, between layers 1.1e-3, between seeds 1.5e-3
 // (3 sigma = 1.5e-3), chi-square of the 256 keep patterns against the binomial law 272 (255 dof).
 __device__ __forceinline__ unsigned xorshift32(unsigned x) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; }
+// lowbias32 with the key injected BETWEEN its two multiply rounds: as a function of the counter it is a different bijection for every
+// key.  (hash(counter ^ key), the round-2 form, only XOR-permutes the counters: seeds that agreed in their low two bits gave each other's
+// mask streams with the 8-element blocks permuted -- ranks r and r + 4 of a job seeded 1 + rank.)
+__device__ __forceinline__ unsigned lowbias32_keyed(unsigned x, unsigned key) {
+	x ^= x >> 16; x *= 0x7feb352du;
+	x ^= key;
+	x ^= x >> 15; x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+// host side of the dropout generator: the caller's seed is whitened once per launch (splitmix64), so that seeds 1, 2, 3 ... give
+// unrelated keys; the kernels receive the whitened value
+static inline uint64_t convasr_mix_seed(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
 
 __device__ __forceinline__ void dropout_mask8(uint64_t seed, uint64_t offset, unsigned thr, float scale, int64_t idx, float (&keep)[8]) {
 	unsigned r[4];
@@ -203,7 +222,7 @@ __device__ __forceinline__ void dropout_mask8(uint64_t seed, uint64_t offset, un
 #else
 	const uint64_t c4 = (offset + (uint64_t)(idx >> 3)) << 2;
 	const unsigned key = (unsigned)seed ^ lowbias32((unsigned)(c4 >> 32) ^ (unsigned)(seed >> 32));
-	r[0] = lowbias32((unsigned)c4 ^ key);
+	r[0] = lowbias32_keyed((unsigned)c4, key);
 #pragma unroll
 	for (int i = 1; i < 4; ++i) r[i] = xorshift32(r[i - 1]);
 #endif

@@ -32,7 +32,7 @@ template <typename T, bool ALIGNED> __device__ __forceinline__ uint4 load_chunk(
 }
 
 template <typename T, typename O, int XI, bool ALIGNED_X>
-__global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 1 : 2) void conv1d_igemm_kernel(ConvParams p) {  // (fp32: one workgroup per CU, its fp64 totals below take 128 registers)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int EPC = Mma<T>::EPC;
 	constexpr int BK = ROW_BYTES / sizeof(T);
@@ -98,20 +98,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 		for (int j = 0; j < 2; ++j)
 #pragma unroll
 			for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-	// fp32 (the parity path) sums in two levels: one accumulator per 32-channel slab (32 K terms, a chain of 16 K MFMA adds), added to a
-	// running total when the slab ends.  A single chain over all Cin K terms (8448 for 768 channels, K = 11) random-walks to ~sqrt(n) / 2
-	// ulp, 1.7-3x what a blocked CPU sum leaves (profiles/r02_fp64_reference.json: logits 3.4e-5 from float64 against torch-CPU's
-	// 1.1e-5); per-slab chains cut it ~4x for 64 v_add per slab.  16-bit builds keep the single chain: their sums must stay
-	// bit-identical to the LDS-DMA kernel's (tests/test_kernels_gpu.py), and their error is the storage rounding, not the chain.
+	// fp32 (the parity path) sums in two levels: the MFMA accumulator chain is closed after every (32-channel slab, tap) step -- 32
+	// products, 16 chained MFMA adds -- and added to a running total kept in fp64.  A single fp32 chain over all Cin K terms (8448 for
+	// 768 channels, K = 11) random-walks to ~sqrt(n) / 2 ulp: 768 -> 768, K = 11 measured 1.2e-6 relative L2 from the float64 result even
+	// with one chain per slab, against torch-CPU's 2.1e-7 (its blocked / vectorised sum keeps dozens of short chains; this is why the
+	// round-2 fp32 path sat 1.7-3x further from float64 than the CPU oracle, profiles/r02_fp64_reference.json).  The fp32 path exists
+	// for parity, not speed: 64 v_cvt + 64 v_add_f64 per step beside 64 MFMAs of 64 cycles each.  16-bit builds keep the single chain:
+	// their sums must stay bit-identical to the LDS-DMA kernel's (tests/test_kernels_gpu.py), and their error is the storage rounding.
 	constexpr bool TWO_LEVEL = sizeof(T) == 4;
-	f32x16 total[2][2];
+	double total[2][2][16];
 	if (TWO_LEVEL) {
 #pragma unroll
 		for (int i = 0; i < 2; ++i)
 #pragma unroll
 			for (int j = 0; j < 2; ++j)
 #pragma unroll
-				for (int k = 0; k < 16; ++k) total[i][j][k] = 0.f;
+				for (int k = 0; k < 16; ++k) total[i][j][k] = 0.0;
 	}
 
 	load_x(0);
@@ -153,15 +155,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 
 		if (has_next) store_w((q + 1) & 1);
 		if (next_x) store_x((cib + 1) & 1);
-		if (TWO_LEVEL && last_tap && has_next) {
+		if (TWO_LEVEL) {
 #pragma unroll
 			for (int i = 0; i < 2; ++i)
 #pragma unroll
-				for (int j = 0; j < 2; ++j) {
-					total[i][j] += acc[i][j];
+				for (int j = 0; j < 2; ++j)
 #pragma unroll
-					for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-				}
+					for (int k = 0; k < 16; ++k) { total[i][j][k] += (double)acc[i][j][k]; acc[i][j][k] = 0.f; }
 		}
 		__syncthreads();
 		if (last_tap) { tap = 0; ++cib; } else ++tap;
@@ -170,7 +170,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv1d_igemm_kernel(ConvParams p)
 #pragma unroll
 		for (int i = 0; i < 2; ++i)
 #pragma unroll
-			for (int j = 0; j < 2; ++j) acc[i][j] += total[i][j];
+			for (int j = 0; j < 2; ++j)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) acc[i][j][k] = (float)total[i][j][k];
 	}
 
 	// ---------------- epilogue: bias, BN statistics, scale/shift, activation, temporal mask, coalesced store through LDS
@@ -445,7 +447,7 @@ extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed
 	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && bn_rows && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0 && convasr_is_half(dtype), "conv1d_dgrad_bn_reduce: bad arguments (dtype must be CONVASR_BF16 or CONVASR_F16)");
 	ConvParams f = {};
 	f.bn_y = bn_y; f.bn_scale = bn_scale; f.bn_shift = bn_shift; f.bn_mean = bn_mean; f.bn_invstd = bn_invstd; f.bn_xlen = bn_xlen; f.bn_sums = bn_sums;
-	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = seed; f.bn_offset = offset; f.bn_gate = bn_gate;
+	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = convasr_mix_seed(seed); f.bn_offset = offset; f.bn_gate = bn_gate;
 	f.bn_drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
 	if (f.bn_drop_thr > 65535u) f.bn_drop_thr = 65535u;
 	f.bn_keep_scale = 65536.f / (float)(65536u - f.bn_drop_thr);

@@ -46,15 +46,16 @@ extern "C" int convasr_debug_read_stamps(unsigned long long* host, int count) {
 // NB = 16-column blocks per wave: 4 -> the 256 x 128 tile, 2 -> a 256 x 64 half tile (same X tile, half the W rows).  The last
 // partial round of a launch (total_tiles mod 256 workgroups on 256 CUs) is cut into half tiles so that it occupies all CUs for
 // ~0.6 of a round instead of a fraction of them for a whole one; per-element sums are unchanged (same k order).
-template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
-	constexpr int BN_ = 32 * NB;
+// BM_ = rows (frames) of the tile: 256; 192 (three 16-row blocks per wave instead of four) exists for A/B runs only (see the dispatcher).
+template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
+	constexpr int BN_ = 32 * NB, MI = BM_ / 64, WROWS = 16 * MI;  // MI 16-row blocks = WROWS rows per wave
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
 
 	int ntile, mtile;
 	tile_coords(v, p.B * p.m_tiles_per_b, p.n_tiles, mtile, ntile);
-	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * V2_BM;
+	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * BM_;
 	const int co0 = ntile * BN + half * BN_;
 	const int tin0 = t0 - p.pad;
 
@@ -96,15 +97,15 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 		for (int j = 0; j < PPL; ++j) dma16(wsrc, dst + j * 1024, base + wl[j]);
 	};
 
-	f32x4 acc[4][NB];
+	f32x4 acc[MI][NB];
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < MI; ++i)
 #pragma unroll
 		for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 	typedef const __attribute__((address_space(3))) u32x4* lds_u4;
-	struct Frag { u32x4 a[4], b[NB]; };
+	struct Frag { u32x4 a[MI], b[NB]; };
 	// lane (r16, kb) holds k = 8 kb .. 8 kb + 7 of row r16: 16-byte chunk (ks * 4 + kb) of the 128-byte slab row.  Rows 16 apart
 	// share the swizzle term (+2048 B immediates); the second k32 substep is `address ^ 64` (kb ^ swz < 8, so the XOR stays inside the row).
 	// byte offset of (row, k-block kb) in the image: row * 128 + ((kb ^ swz(row >> 1)) << 4), and (swz(row >> 1) << 4) = (row << 4) & 0x60
@@ -113,30 +114,30 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 	unsigned w0 = lds_base + wbase + lane_off(wn * (16 * NB) + r16);
 	asm volatile("" : "+v"(w0));  // ONE opaque loop invariant: left transparent, hipcc keeps three partial forms of this address live through the loop and, at the 168-register limit, reloads one of them from scratch in every barrier interval
 	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int ks, Frag& f) {
-		const unsigned xa = (lds_base + xs_off + lane_off(wm * 64 + r16 + tap_ * p.dil)) ^ (ks << 6);
+		const unsigned xa = (lds_base + xs_off + lane_off(wm * WROWS + r16 + tap_ * p.dil)) ^ (ks << 6);
 		const unsigned wa = (w0 + ws_off) ^ (ks << 6);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			f.a[i] = *(lds_u4)(size_t)(xa + i * 2048);
+		for (int i = 0; i < (MI > NB ? MI : NB); ++i) {
+			if (i < MI) f.a[i] = *(lds_u4)(size_t)(xa + i * 2048);
 			if (i < NB) f.b[i] = *(lds_u4)(size_t)(wa + i * 2048);
 		}
 	};
-	// Scheduling hint placed after a (load_frag, mma_frag) pair: the 4 + NB ds_read_b128 of the NEXT fragment go out one per MFMA
+	// Scheduling hint placed after a (load_frag, mma_frag) pair: the MI + NB ds_read_b128 of the NEXT fragment go out one per MFMA
 	// from the first MFMA of the current group on.  Left alone, hipcc sinks them behind the 12th-14th MFMA of the group, and the
 	// next group's first MFMA then waits out the LDS latency four times per barrier interval (-3 % per launch; a read after every
 	// second MFMA or two reads per MFMA measured no better than the unhinted schedule; MI355X_MICROARCH.md, LDS: up to two
 	// ds_read_b128 per MFMA gap are hidden).
 	auto interleave = [&]() {
 #pragma unroll
-		for (int i = 0; i < 4 + NB; ++i) {
+		for (int i = 0; i < MI + NB; ++i) {
 			__builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
 			__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
 		}
-		__builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - (4 + NB), 0);
+		__builtin_amdgcn_sched_group_barrier(0x008, MI * NB - (MI + NB), 0);
 	};
 	auto mma_frag = [&](const Frag& f) {
 #pragma unroll
-		for (int i = 0; i < 4; ++i)
+		for (int i = 0; i < MI; ++i)
 #pragma unroll
 			for (int j = 0; j < NB; ++j) acc[i][j] = Mma16<I>::run(f.a[i], f.b[j], acc[i][j]);
 	};
@@ -235,12 +236,13 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 	// ---------------- epilogue: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg
 	constexpr int OPITCH = BN_ * sizeof(O) + 16;
 	char* const otile = smem;
-	float* const red = reinterpret_cast<float*>(smem + V2_BM * OPITCH);  // [2][4 (wm)][BN_]
+	float* const red = reinterpret_cast<float*>(smem + BM_ * OPITCH);  // [2][4 (wm)][BN_]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
 	const ActConst ac = act_const(p.act, p.act_lo, p.act_hi), bn_ac = act_const(p.bn_act, p.bn_lo, p.bn_hi);
 	// fused BN-backward epilogue (see below): the consumer layer's y tile is fetched now, 16 B per lane and store-loop trip, so
 	// that its latency hides under the accumulator staging (loading it inside the store loop cost ~8 serial L2/HBM round trips per tile)
-	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = V2_BM * OCH_ / V2_THREADS;
+	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = BM_ * OCH_ / V2_THREADS;
+	static_assert(BM_ * OCH_ % V2_THREADS == 0, "the store loop covers the tile in whole trips");
 	constexpr bool bnf = BNF && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
 	typedef typename std::conditional<sizeof(O) == 2, O, I>::type H;  // the 16-bit storage type of the fused epilogue's operands (= O there)
 	uint4 ypre[TRIPS];
@@ -273,10 +275,10 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 			const float sc = (!PLAIN && p.scale && cok) ? p.scale[co] : 1.f, sh = (!PLAIN && p.scale && cok) ? p.shift[co] : 0.f;
 			float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-			for (int mi = 0; mi < 4; ++mi) {
+			for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
-					const int row = wm * 64 + mi * 16 + kb * 4 + g;
+					const int row = wm * WROWS + mi * 16 + kb * 4 + g;
 					const int t = t0 + row;
 					float val = acc[mi][ni][g];
 					if (!PLAIN) val += bias;
@@ -298,7 +300,7 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 	{
 		typedef std::true_type Y;
 		typedef std::false_type N;
-		const bool plain = !p.bias && !p.scale && p.act == CONVASR_ACT_NONE && !p.xlen, full = t0 + V2_BM <= p.Tout;
+		const bool plain = !p.bias && !p.scale && p.act == CONVASR_ACT_NONE && !p.xlen, full = t0 + BM_ <= p.Tout;
 		if (!plain) {
 			if (ac.leaky) { if (p.stats) stage(N(), N(), Y(), Y()); else stage(N(), N(), N(), Y()); }
 			else { if (p.stats) stage(N(), N(), Y(), N()); else stage(N(), N(), N(), N()); }
@@ -372,7 +374,7 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 		}
 	}
 	if (bnf) {
-		float* const bnred = reinterpret_cast<float*>(smem + V2_BM * OPITCH + 8 * BN * sizeof(float));  // [V2_THREADS][17], past the output tile and `red`
+		float* const bnred = reinterpret_cast<float*>(smem + BM_ * OPITCH + 8 * BN * sizeof(float));  // [V2_THREADS][17], past the output tile and `red`
 #pragma unroll
 		for (int k = 0; k < 8; ++k) { bnred[tid * 17 + k] = bs1[k]; bnred[tid * 17 + 8 + k] = (bs2[k] - bmean[k] * bs1[k]) * bistd[k]; }  // sum g * xhat of this thread's rows
 		__syncthreads();
@@ -394,47 +396,68 @@ template <typename I, typename O, int NB, bool BNF> __device__ __forceinline__ v
 #endif
 }
 
-template <typename I, typename O, bool BNF> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
+template <typename I, typename O, bool BNF, int BM_> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
 
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
 	if (bid < p.full_tiles) {
-		v2s_tile<I, O, 4, BNF>(p, smem, xcd_remap(bid, p.full_tiles), 0);
+		v2s_tile<I, O, 4, BNF, BM_>(p, smem, xcd_remap(bid, p.full_tiles), 0);
 	} else {  // full_tiles is a multiple of 8, so (bid - full_tiles) keeps the workgroup's XCD; the two halves of a tile share an XCD (and its X tile in L2)
 		const int h = xcd_remap(bid - p.full_tiles, 2 * (p.total_tiles - p.full_tiles));
-		v2s_tile<I, O, 2, BNF>(p, smem, p.full_tiles + (h >> 1), h & 1);
+		v2s_tile<I, O, 2, BNF, BM_>(p, smem, p.full_tiles + (h >> 1), h & 1);
 	}
+}
+
+// Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
+// register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
+template <typename I, int BM_> static const void* v2s_kernel(int ki) {
+	if (ki == 0) return (const void*)conv1d_igemm_v2s_kernel<I, I, false, BM_>;
+	if (ki == 1) return (const void*)conv1d_igemm_v2s_kernel<I, I, true, BM_>;
+	return (const void*)conv1d_igemm_v2s_kernel<I, float, false, BM_>;
 }
 
 // Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
 // register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
 int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out) {
 	if (p.stride != 1 || (p.Cin & 63) != 0 || !convasr_is_half(x_dtype) || (y_dtype != x_dtype && y_dtype != CONVASR_F32)) return 0;
-	const int xr = (V2_BM - 1) + (p.K - 1) * p.dil + 1;
+	static int n_cu = 0;
+	if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+	// Tile height: 256 rows.  A 192-row build of the same kernel (BM_ = 192: 256 x n tiles for 64 x 751 frames = whole rounds on 256
+	// CUs instead of 1.5 n) was measured layer by layer in one process (scratch/ab_bm.py, profiles/r03_ab_tile_height.json): 3-5 %
+	// faster only on the 384-channel layers (2.25 rounds), 5-8 % SLOWER on every layer from 512 channels up -- a partial last round costs
+	// about its fraction of a tile time on this chip (640 channels: 3.75 rounds take 3.77 tile times; the CUs left idle give their power
+	// to the busy ones), so there is no quantisation loss to recover, and 12 MFMAs per 7 fragment reads lose to 16 per 8.  The 192-row
+	// instantiations exist only in a diagnostic build (python -m convasr_amd.build --variant tile192 -DCONVASR_AB_TILE192=1), where
+	// debug bit 64 selects them.
+#ifdef CONVASR_AB_TILE192
+	const int bm = (p.debug & 64) ? 192 : V2_BM;
+#else
+	const int bm = V2_BM;
+#endif
+	const int xr = (bm - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
 	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 5 * V2_WSLOT;  // two X slab buffers + the 3 + 2 weight slots
 	if (p.K == 1) smem = 3 * (size_t)p.x_rows * ROW_BYTES + 3 * V2_WSLOT;  // K = 1: three X slab buffers + the 3-slot ring
-	const size_t epi = (size_t)V2_BM * (BN * osz + 16) + 8 * BN * sizeof(float);
+	const size_t epi = (size_t)bm * (BN * osz + 16) + 8 * BN * sizeof(float) + (p.bn_y ? (size_t)V2_THREADS * 17 * sizeof(float) : 0);
 	if (epi > smem) smem = epi;
 	if (smem > 160 * 1024) return 0;
 	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
-	p.m_tiles_per_b = (p.Tout + V2_BM - 1) / V2_BM;
+	p.m_tiles_per_b = (p.Tout + bm - 1) / bm;
 	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
 	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
 	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
-	const void* const table[2][3] = {
-		{(const void*)conv1d_igemm_v2s_kernel<bf16_t, bf16_t, false>, (const void*)conv1d_igemm_v2s_kernel<bf16_t, bf16_t, true>, (const void*)conv1d_igemm_v2s_kernel<bf16_t, float, false>},
-		{(const void*)conv1d_igemm_v2s_kernel<f16_t, f16_t, false>, (const void*)conv1d_igemm_v2s_kernel<f16_t, f16_t, true>, (const void*)conv1d_igemm_v2s_kernel<f16_t, float, false>}};
-	const int ki = wide ? 2 : (fused ? 1 : 0);
-	const void* kern = table[f16][ki];
-	static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
-	if (!attr_set[f16][ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[f16][ki] = true; }
+	const int ki = wide ? 2 : (fused ? 1 : 0), bi = bm == 192 ? 1 : 0;
+#ifdef CONVASR_AB_TILE192
+	const void* kern = f16 ? (bi ? v2s_kernel<f16_t, 192>(ki) : v2s_kernel<f16_t, V2_BM>(ki)) : (bi ? v2s_kernel<bf16_t, 192>(ki) : v2s_kernel<bf16_t, V2_BM>(ki));
+#else
+	const void* kern = f16 ? v2s_kernel<f16_t, V2_BM>(ki) : v2s_kernel<bf16_t, V2_BM>(ki);
+#endif
+	static bool attr_set[2][2][3] = {};
+	if (!attr_set[f16][bi][ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[f16][bi][ki] = true; }
 	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
 	p.full_tiles = p.total_tiles;
 	if (!(p.debug & 32)) {
-		static int n_cu = 0;
-		if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
 		const int rest = p.total_tiles % n_cu;
 		if (rest > 0 && 2 * rest <= n_cu && ((p.total_tiles - rest) & 7) == 0) p.full_tiles = p.total_tiles - rest;
 	}

@@ -64,7 +64,7 @@ extern "C" int convasr_convert_layout(const void* src, int src_dtype, int64_t ss
 // per block instead of 64: four times the workgroups -- 256 for 64 mel channels x 64 utterances, one per CU -- for a latency-bound kernel.)
 template <typename S, typename D>
 __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x, int64_t xsb, int64_t xsc, int64_t xst, D* __restrict__ y,
-                                                        int64_t ysb, int64_t ysc, int64_t yst, const float* __restrict__ xlen, int C, int T, float eps) {
+                                                        int64_t ysb, int64_t ysc, int64_t yst, const float* __restrict__ xlen, int C, int T, int T_out, float eps) {
 	__shared__ float red[64][17];
 	__shared__ float bc[16];
 	const int b = blockIdx.y, cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, tl = threadIdx.x >> 4;  // 64 time lanes
@@ -86,18 +86,18 @@ __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x,
 	const float stdv = sqrtf(block_sum(acc) / (float)n + eps);
 	if (!ok) return;
 	D* yp = y + b * ysb + c * ysc;
-	for (int t = tl; t < T; t += 64) {
+	for (int t = tl; t < T_out; t += 64) {  // frames T .. T_out - 1 of y: zero padding
 		float v = t < n ? (Elem<S>::load(xp + t * xst) - mean) / stdv : 0.f;
 		Elem<D>::store(yp + t * yst, v);
 	}
 }
 
 extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb,
-                                    int64_t ysc, int64_t yst, const float* xlen, int B, int C, int T, float eps, void* stream) {
-	CONVASR_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0, "instnorm_fwd: bad arguments");
+                                    int64_t ysc, int64_t yst, const float* xlen, int B, int C, int T, int T_out, float eps, void* stream) {
+	CONVASR_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && T_out >= T, "instnorm_fwd: bad arguments");
 	dim3 grid((C + 15) / 16, B);
 	hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(S, D) hipLaunchKernelGGL((instnorm_kernel<S, D>), grid, dim3(1024), 0, s, (const S*)x, xsb, xsc, xst, (D*)y, ysb, ysc, yst, xlen, C, T, eps)
+#define LAUNCH(S, D) hipLaunchKernelGGL((instnorm_kernel<S, D>), grid, dim3(1024), 0, s, (const S*)x, xsb, xsc, xst, (D*)y, ysb, ysc, yst, xlen, C, T, T_out, eps)
 	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) LAUNCH(float, float);
 	else if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_BF16) LAUNCH(float, bf16_t);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_F32) LAUNCH(bf16_t, float);
@@ -108,6 +108,19 @@ extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "instnorm_fwd: dtype %d -> %d", x_dtype, y_dtype);
 #undef LAUNCH
 	CONVASR_CHECK_LAUNCH("instnorm_fwd");
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ output lengths (models.py:611-614)
+__global__ void output_lengths_kernel(const float* __restrict__ xlen, int B, int T, int64_t* __restrict__ out) {
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < B) out[b] = (int64_t)valid_len(xlen, b, T);
+}
+
+extern "C" int convasr_output_lengths(const float* xlen, int B, int T, int64_t* out, void* stream) {
+	CONVASR_CHECK_ARG(out && B > 0 && T >= 0, "output_lengths: bad arguments");
+	hipLaunchKernelGGL(output_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, xlen, B, T, out);
+	CONVASR_CHECK_LAUNCH("output_lengths");
 	return 0;
 }
 
@@ -267,7 +280,7 @@ extern "C" int convasr_scale_rows(const float* grad, const float* gscale, const 
 //   skipped = !isfinite(out[1])
 // One workgroup, sums in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict__ lv, const int64_t* __restrict__ ylen, int64_t ylen_stride, const float* __restrict__ ent, int B, float accum,
-                                                        float* __restrict__ out, float* __restrict__ gvec, unsigned char* __restrict__ skipped, const float* __restrict__ scaler) {
+                                                        float* __restrict__ out, float* __restrict__ gvec, unsigned char* __restrict__ skipped, const float* __restrict__ scaler, float metric_scale) {
 	__shared__ float red[3][256];
 	float a = 0.f, c = 0.f, e = 0.f;
 	const float gbase = (1.f / accum) / (float)B, ls = scaler ? scaler[LS_SCALE] : 1.f;
@@ -287,16 +300,16 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
 	if (threadIdx.x == 0) {
 		const float cur = red[1][0] / (float)B;
 		out[0] = red[0][0] / (float)B / accum;
-		out[1] = cur;
-		out[2] = red[2][0] / (float)B;
+		out[1] = cur * metric_scale;  // (1 / world size when a SUM all-reduce over ranks follows: the result is then the mean, train.py:759-763)
+		out[2] = red[2][0] / (float)B * metric_scale;
 		if (skipped) *skipped = (fabsf(cur) < INFINITY) ? 0 : 1;
 	}
 }
 
 extern "C" int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
-                                 float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, void* stream) {
+                                 float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, float metric_scale, void* stream) {
 	CONVASR_CHECK_ARG(loss_vec && ylen && out3 && B > 0 && accumulate_iterations > 0.f, "loss_head: bad arguments");
-	hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_vec, ylen, ylen_stride, entropy, B, accumulate_iterations, out3, grad_loss_vec, skipped, loss_scaler);
+	hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_vec, ylen, ylen_stride, entropy, B, accumulate_iterations, out3, grad_loss_vec, skipped, loss_scaler, metric_scale);
 	CONVASR_CHECK_LAUNCH("loss_head");
 	return 0;
 }

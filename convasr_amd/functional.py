@@ -68,6 +68,45 @@ def invalidate_pack_cache():
 	_pack_cache.clear()
 
 
+# The transposed, tap-flipped dgrad copies of the weights (one ~8 us memory-bound launch per layer and step) depend on nothing but the
+# parameters, and the step has one stretch where most of the chip idles: the CTC alpha / beta recursion, one workgroup per utterance
+# (64 of 256 CUs, ~0.3 ms of dependent steps).  prepack_dgrad_weights() -- called by the network between the decoder and the loss --
+# runs those launches on a side stream there; the first dgrad of the backward pass joins it (join_prepack).
+PREPACK = os.environ.get('CONVASR_NO_PREPACK') != '1'  # A/B hook
+_prepack_streams = {}  # device -> [side stream, packs pending on it?]
+
+
+def prepack_dgrad_weights(weights, dtype):
+	if not PREPACK or not weights:
+		return
+	dev = weights[0].device
+	stale = []
+	for w in weights:
+		ent = _pack_cache.get((id(w), dtype))
+		if ent is None or ent['dgr'] is None:
+			packed_weight(w, dtype, _lib.PACK_DGRAD)  # first use: buffers are allocated (and stay owned) by the main stream
+		elif ent['dgr_ver'] != param_version(w):
+			stale.append(w)
+	if not stale:
+		return
+	st = _prepack_streams.get(dev)
+	if st is None:
+		st = _prepack_streams[dev] = [torch.cuda.Stream(device = dev), False]
+	side, main = st[0], torch.cuda.current_stream(dev)
+	side.wait_stream(main)  # the parameters, their 16-bit mirror and every earlier reader of the buffers are ordered before the packs
+	with torch.cuda.stream(side):
+		for w in stale:
+			packed_weight(w, dtype, _lib.PACK_DGRAD)
+	st[1] = True
+
+
+def join_prepack(device):
+	st = _prepack_streams.get(device)
+	if st is not None and st[1]:
+		torch.cuda.current_stream(device).wait_stream(st[0])
+		st[1] = False
+
+
 class _DropoutState:
 	seed = 0x5EEDC0DE
 	offset = 0
@@ -111,6 +150,7 @@ def _deliver(params, compute):
 	return outs
 
 
+after_long_launch_hooks = {}  # id -> callable, run right after the backward pass has enqueued a long kernel (a dgrad): the data-parallel engine enqueues its ready collectives there, where their host cost hides behind queued GPU work
 _side_streams = {}  # device -> torch.cuda.Stream running the weight-gradient kernels (None entry = disabled)
 
 
@@ -242,18 +282,27 @@ def _bn_backward_from_g(g, y, gamma, beta, bnp, sums, n):
 	return dgamma, dbeta, ops.bn_act_bwd_apply(g, y, coef, False)
 
 
+def _after_long_launch():
+	for hook in after_long_launch_hooks.values():
+		hook()
+
+
 def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
 	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it.
 	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad)."""
 	Cin = x.shape[1]
 	pad = spec.dilation * (spec.K - 1) - spec.padding
+	join_prepack(dy.device)
 	wd = packed_weight(weight, dt, _lib.PACK_DGRAD) if wd is None else wd
 	if link is not None and dt in ops.HALF_DTYPES and spec.stride == 1:
 		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'], gate = link.get('gate'))
 		if dx is not None:
 			link['dz'] = dx  # held until the producer's backward has looked at it: the address cannot be recycled meanwhile
+			_after_long_launch()
 			return dx
-	return ops.conv1d(dy, wd, Cin, spec.K, 1, spec.dilation, pad)
+	dx = ops.conv1d(dy, wd, Cin, spec.K, 1, spec.dilation, pad)
+	_after_long_launch()
+	return dx
 
 
 class ConvBnActFunction(torch.autograd.Function):
@@ -413,6 +462,7 @@ class ConvBnActFunction(torch.autograd.Function):
 				continue
 			p = res_bnp[r]
 			drg, drbeta, dry = _bn_backward_from_g(g, res_y[r], rg, rbeta, p, rsum_of[r], B * Tout)
+			join_prepack(dry.device)
 			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), rx.shape[1], 1, 1, 1, 0) if need_rx else None
 			# The bias of a conv that feeds a train-mode batch norm has an identically zero gradient: dry sums to zero over (b, t) for
 			# every channel (sum of g minus N times its mean, minus mean(g xhat) times sum of xhat = 0).  The reference's autograd

@@ -382,8 +382,12 @@ class JasperNet(nn.Module):
 				residual = []
 
 		logits = self.decoder(x)
+		if y is not None and ylen is not None and self.training and torch.is_grad_enabled():
+			# the backward pass's transposed weight copies, on a side stream under the CTC recursion that follows (functional.prepack_dgrad_weights)
+			convs = [c[-1] for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv] + [c for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv_residual if isinstance(c, nn.Conv1d)]
+			Fn.prepack_dgrad_weights([c.weight for c in convs[1:] if c.stride[0] == 1], self.compute_dtype)
 		log_probs = [Fn.LogSoftmaxFunction.apply(l) for l in logits]
-		olen = [compute_output_lengths(l, xlen.to(torch.float32) if xlen is not None else None) for l in logits]
+		olen = [ops.output_lengths(xlen, l.shape[0], l.shape[-1], l.device) for l in logits]  # compute_output_lengths (models.py:611-614) as one launch
 		aux = {}
 		if y is not None and ylen is not None:
 			loss = [Fn.ctc_loss(lp, y[:, i], olen[i], ylen[:, i], lp.shape[1] - 1, norm = ylen[:, 0]) for i, lp in enumerate(log_probs)]

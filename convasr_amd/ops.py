@@ -96,15 +96,18 @@ def instnorm(x, xlen, eps, out_dtype = None, channels_last = True, pad_time_to =
 	B, C, T = x.shape
 	out_dtype = out_dtype or x.dtype
 	Tp = -(-T // pad_time_to) * pad_time_to
-	if Tp != T:
-		assert channels_last
-		full = zeros_cl(B, C, Tp, out_dtype, x.device)
-		out = full[:, :, :T]
-	else:
-		full = out = empty_cl(B, C, T, out_dtype, x.device) if channels_last else torch.empty(B, C, T, dtype = out_dtype, device = x.device)
+	assert Tp == T or channels_last
+	out = empty_cl(B, C, Tp, out_dtype, x.device) if channels_last else torch.empty(B, C, T, dtype = out_dtype, device = x.device)
 	xl = xlen_f32(xlen, x.device)
-	call('convasr_instnorm_fwd', ptr(x), dtype_code(x.dtype), x.stride(0), x.stride(1), x.stride(2), ptr(out), dtype_code(out_dtype), out.stride(0), out.stride(1), out.stride(2), ptr(xl), B, C, T, float(eps), stream_ptr())
-	return full
+	call('convasr_instnorm_fwd', ptr(x), dtype_code(x.dtype), x.stride(0), x.stride(1), x.stride(2), ptr(out), dtype_code(out_dtype), out.stride(0), out.stride(1), out.stride(2), ptr(xl), B, C, T, Tp, float(eps), stream_ptr())  # (the kernel writes the padding frames as zeros)
+	return out
+
+
+def output_lengths(xlen, B, T, device):
+	"""compute_output_lengths (models.py:611-614) in one launch: int64 (B,) = ceil(xlen * T) evaluated in fp32 (xlen None: T)."""
+	out = torch.empty(B, dtype = torch.int64, device = device)
+	call('convasr_output_lengths', ptr(xlen_f32(xlen, device)), B, T, ptr(out), stream_ptr())
+	return out
 
 
 # ------------------------------------------------------------------------------------------------ conv
@@ -375,9 +378,10 @@ def scale_rows(grad, gscale, gdiv = None):
 	return out
 
 
-def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_grad = True, loss_scaler = None):
+def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_grad = True, loss_scaler = None, metric_scale = 1.0):
 	"""train.py:754-756 + the gate of 769 in one launch.  Returns (out3 = [loss, loss_cur, entropy] fp32, grad_loss_vec (B,) or None,
-	skipped: 1-element bool).  loss_scaler: the current state of a dynamic loss scaler (fp16 training): grad_loss_vec is scaled by it."""
+	skipped: 1-element bool).  loss_scaler: the current state of a dynamic loss scaler (fp16 training): grad_loss_vec is scaled by it;
+	metric_scale: factor on the two logged means (1 / world size ahead of a SUM all-reduce)."""
 	require_cuda(loss_vec)
 	B = loss_vec.shape[0]
 	lv = loss_vec.detach().to(torch.float32).contiguous()
@@ -386,7 +390,7 @@ def loss_head(loss_vec, ylen_col, ent = None, accumulate_iterations = 1, need_gr
 	gvec = torch.empty(B, dtype = torch.float32, device = lv.device) if need_grad else None
 	skipped = torch.empty(1, dtype = torch.bool, device = lv.device)
 	ent = None if ent is None else ent.detach().to(torch.float32).contiguous()
-	call('convasr_loss_head', ptr(lv), ptr(ylen_col), ylen_col.stride(0), ptr(ent), B, float(accumulate_iterations), ptr(out3), ptr(gvec), ptr(skipped), ptr(loss_scaler), stream_ptr())
+	call('convasr_loss_head', ptr(lv), ptr(ylen_col), ylen_col.stride(0), ptr(ent), B, float(accumulate_iterations), ptr(out3), ptr(gvec), ptr(skipped), ptr(loss_scaler), float(metric_scale), stream_ptr())
 	return out3, gvec, skipped
 
 

@@ -25,6 +25,8 @@ class DataParallelEngine(nn.Module):
 		module._convasr_flat = self.flat
 		self.buckets = self._make_buckets(bucket_bytes, min(first_bucket_bytes, bucket_bytes))
 		self._pending = []
+		self._ready = []  # complete buckets whose collective has not been enqueued yet: (bucket index, events recorded on the producer streams)
+		self._comm_dirty = False  # something was enqueued on the communication stream that the main stream has not joined yet
 		self._remaining = [len(b['params']) for b in self.buckets]
 		self._main_stream = None  # the stream forward() ran on: dgamma / dbeta and (without a side stream) every weight gradient are produced there
 		self._comm_stream = None  # collectives are issued from here, ordered after BOTH the main stream and the side (wgrad) stream
@@ -33,6 +35,8 @@ class DataParallelEngine(nn.Module):
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
 				p._convasr_ready = self._make_hook(bi)
+		from . import functional as Fn
+		Fn.after_long_launch_hooks[id(self)] = self.poll  # the backward pass calls poll() right after it has enqueued a long kernel
 		if self.collectives:
 			dist.broadcast(self.flat.data, src = 0, group = self.group)  # identical initial replicas
 			for buf in module.buffers():
@@ -61,31 +65,71 @@ class DataParallelEngine(nn.Module):
 				return
 			self._remaining[bi] -= 1
 			if self._remaining[bi] == 0:
-				self._launch(bi)
+				self._mark_ready(bi)
 		return ready
 
-	def _launch(self, bi):
-		"""All-reduce of one complete bucket.  A bucket mixes gradients produced on the main stream (dgamma / dbeta, dgrad-side
-		kernels) with weight gradients that functional._run_wgrad may have produced on the side stream, and this hook fires on
-		whichever of the two delivered the bucket's last parameter.  torch.distributed orders a collective after the CURRENT stream
-		only, so the collective is issued from a dedicated stream that first waits for events recorded on both producers."""
+	def _comm(self, dev):
+		if self._comm_stream is None:
+			self._comm_stream = torch.cuda.Stream(device = dev)
+		return self._comm_stream
+
+	def _mark_ready(self, bi):
+		"""Every parameter of bucket bi has its gradient enqueued.  A bucket mixes gradients produced on the main stream (dgamma / dbeta,
+		dgrad-side kernels) with weight gradients that functional._run_wgrad may have produced on the side stream, and this hook fires
+		on whichever of the two delivered the bucket's last parameter: events are recorded on both producers NOW (cheap), the
+		collective itself -- tens of microseconds of host time in torch.distributed / RCCL, during which a short-kernel stretch of the
+		backward pass would drain the GPU's queue: profiles/r03_rccl_world1_trace.json -- is enqueued by poll() right after the backward
+		pass has queued its next long kernel."""
 		if not self.collectives:
 			return
+		view = self.flat.grad[self.buckets[bi]['lo']:self.buckets[bi]['hi']]
+		if not view.is_cuda:
+			self._launch(bi, ())
+			return
+		from . import functional as Fn
+		dev = view.device
+		producers = {s.cuda_stream: s for s in (self._main_stream, torch.cuda.current_stream(dev), Fn.side_stream(dev)) if s is not None}
+		self._ready.append((bi, [s.record_event() for s in producers.values()]))
+
+	def poll(self):
+		"""Enqueue the collectives of the buckets that became complete since the last call (no-op when there are none)."""
+		ready, self._ready = self._ready, []
+		for bi, events in ready:
+			self._launch(bi, events)
+
+	def _launch(self, bi, events):
+		"""All-reduce of one complete bucket.  torch.distributed orders a collective after the CURRENT stream only, so it is issued from a
+		dedicated stream that first waits for the events recorded on the gradient's producer streams."""
 		b = self.buckets[bi]
 		view = self.flat.grad[b['lo']:b['hi']]
 		if view.is_cuda:
-			from . import functional as Fn
-			dev = view.device
-			if self._comm_stream is None:
-				self._comm_stream = torch.cuda.Stream(device = dev)
-			producers = {s.cuda_stream: s for s in (self._main_stream, torch.cuda.current_stream(dev), Fn.side_stream(dev)) if s is not None}
-			for s in producers.values():
-				self._comm_stream.wait_stream(s)
-			with torch.cuda.stream(self._comm_stream):
+			comm = self._comm(view.device)
+			for ev in events:
+				comm.wait_event(ev)
+			with torch.cuda.stream(comm):
 				work = dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
+			self._comm_dirty = True
 		else:
 			work = dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
 		self._pending.append((work, view))
+
+	def all_reduce_async(self, t):
+		"""SUM all-reduce of a small tensor produced on the current stream (the step's two logged means), on the communication stream:
+		the main stream does not wait for it until finish_gradient_sync / join_comm_stream."""
+		if not t.is_cuda:
+			dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
+			return
+		comm = self._comm(t.device)
+		comm.wait_stream(torch.cuda.current_stream(t.device))
+		with torch.cuda.stream(comm):
+			dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
+		t.record_stream(comm)
+		self._comm_dirty = True
+
+	def join_comm_stream(self):
+		if self._comm_stream is not None and self._comm_dirty:
+			torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
+			self._comm_dirty = False
 
 	def no_sync(self):
 		"""Context manager for all but the last backward of a gradient-accumulation group (DDP.no_sync semantics)."""
@@ -110,11 +154,11 @@ class DataParallelEngine(nn.Module):
 					if p._convasr_fresh:
 						p._convasr_grad.zero_()
 						p._convasr_fresh = False
-				self._launch(bi)
+				self._mark_ready(bi)
+		self.poll()
 		for work, view in self._pending:
-			work.wait()
-		if self._comm_stream is not None and self._pending:
-			torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
+			work.wait()  # RCCL: orders the CURRENT stream behind the collective (it ran on the backend's own stream), no host block; gloo: host wait
+		self.join_comm_stream()
 		if self.world_size > 1:
 			if self.fold_mean:
 				self.flat.grad_scale = 1.0 / self.world_size  # flat.grad holds the SUM over ranks until the optimizer consumes it

@@ -41,7 +41,7 @@ class FlatParameters:
 		for p, o in zip(params, self.offsets):
 			n = p.numel()
 			kmajor = p.ndim == 3 and p.shape[2] > 1 and (p.shape[0] * p.shape[1]) % 8 == 0 and dev.type == 'cuda'
-			as_param = (lambda flat, p = p: flat[o:o + n].view(p.shape[2], p.shape[0], p.shape[1]).permute(1, 2, 0)) if kmajor else (lambda flat, p = p: flat[o:o + n].view(p.shape))
+			as_param = (lambda flat, p = p, o = o, n = n: flat[o:o + n].view(p.shape[2], p.shape[0], p.shape[1]).permute(1, 2, 0)) if kmajor else (lambda flat, p = p, o = o, n = n: flat[o:o + n].view(p.shape))  # (o, n bound now: the views are rebuilt later for optimizer state)
 			self._as_param.append(as_param)
 			view = as_param(self.data)
 			view.copy_(p.data)
@@ -211,6 +211,18 @@ class SGD:
 			g.update(s)
 
 
+class _NonFinite:
+	"""`not isfinite(t[i])`, evaluated (with the stream joins and the host read it takes) only when somebody asks: bool(flag)."""
+
+	def __init__(self, t, i, engine = None):
+		self.t, self.i, self.engine = t, i, engine
+
+	def __bool__(self):
+		if self.engine is not None:
+			self.engine.join_comm_stream()
+		return not bool(torch.isfinite(self.t[self.i]))
+
+
 def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_iterations = 1, iteration = 0, world_size = 1, sync_metrics = True, device_gate = True):
 	"""One iteration of the reference loop, train.py:745-783.
 
@@ -226,20 +238,26 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	# entropy, the inf/NaN flag, and d loss / d loss_vec (the vector backward() is seeded with)
 	ent = M.entropy(log_probs[0].detach(), olen[0], dim = 1)
 	scaler = getattr(getattr(optimizer, 'flat', None), 'loss_scaler', None)  # fp16: backward is seeded with the scaled loss's gradient (train.py:770-772)
-	scalars, grad_loss_vec, skipped = ops.loss_head(loss_vec, ylen[:, 0], ent, accumulate_iterations, loss_scaler = None if scaler is None else scaler.current)
 	engine = model if hasattr(model, 'finish_gradient_sync') else None
 	group = engine.group if engine is not None else None
 	# The two scalar all-reduces of train.py:759-760 as one 2-element all-reduce.  With a data-parallel engine that runs
 	# collectives it is NOT optional: the skip gate below must be the same number on every rank (the gradients are already
 	# averaged; a rank-local inf/NaN would make one replica skip the update the others apply).
-	if (engine is not None and engine.collectives) or (sync_metrics and torch.distributed.is_available() and torch.distributed.is_initialized() and (world_size > 1 or sync_metrics is True)):
-		import torch.distributed as dist
-		stats = scalars[1:3]
-		dist.all_reduce(stats, op = dist.ReduceOp.SUM, group = group)
-		stats.div_(dist.get_world_size(group))
-		skipped = ~torch.isfinite(scalars[1:2])
+	reduce_metrics = (engine is not None and engine.collectives) or (sync_metrics and torch.distributed.is_available() and torch.distributed.is_initialized() and (world_size > 1 or sync_metrics is True))
+	ranks = torch.distributed.get_world_size(group) if reduce_metrics else 1
+	scalars, grad_loss_vec, skipped = ops.loss_head(loss_vec, ylen[:, 0], ent, accumulate_iterations, loss_scaler = None if scaler is None else scaler.current, metric_scale = 1.0 / ranks)
+	skipped = skipped[0]
+	if reduce_metrics:
+		# SUM of (local mean / world) = the mean over ranks, with no divide kernel behind it.  With an engine the collective runs on the
+		# engine's communication stream like the gradient buckets (the fused optimizer step, which reads the reduced loss as its skip
+		# gate, is ordered behind that stream by finish_gradient_sync); the host-visible flag is evaluated only if somebody looks.
+		if engine is not None and engine.collectives:
+			engine.all_reduce_async(scalars[1:3])
+		else:
+			torch.distributed.all_reduce(scalars[1:3], op = torch.distributed.ReduceOp.SUM, group = group)
+		skipped = _NonFinite(scalars, 1, engine)
 	loss_cur = scalars[1]
-	res = dict(loss = scalars[0], loss_cur = loss_cur, entropy = scalars[2], grad_norm = None, skipped = skipped[0])
+	res = dict(loss = scalars[0], loss_cur = loss_cur, entropy = scalars[2], grad_norm = None, skipped = skipped)
 	gate = None
 	if device_gate and accumulate_iterations == 1 and hasattr(optimizer, 'flat'):
 		gate = scalars[1:2]

@@ -58,10 +58,16 @@ int convasr_logmel_fwd(const void* signal, int signal_dtype, const float* absmax
 
 /* ---- MaskedInstanceNorm1d.forward: models.py:694-719 ---------------------------------------------------------- */
 
-/* x, y: (B, C, T) with the given element strides.  xlen NULL -> legacy un-masked branch (models.py:704-710). */
+/* x: (B, C, T), y: (B, C, T_out >= T) with the given element strides; frames T .. T_out - 1 of y are written as zeros (the even-length
+ * input the stride-2 fold below wants).  xlen NULL -> legacy un-masked branch (models.py:704-710). */
 int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc, int64_t x_st,
                          void* y, int y_dtype, int64_t y_sb, int64_t y_sc, int64_t y_st,
-                         const float* xlen, int B, int C, int T, float eps, void* stream);
+                         const float* xlen, int B, int C, int T, int T_out, float eps, void* stream);
+
+/* ---- compute_output_lengths: models.py:611-614 ------------------------------------------------------------------ */
+
+/* out[b] = ceil(xlen[b] * T) in fp32 arithmetic, as (lengths_fraction * T).ceil().long() evaluates it (xlen NULL: T). */
+int convasr_output_lengths(const float* xlen, int B, int T, int64_t* out, void* stream);
 
 /* ---- Conv1d: models.py:47-77 (ConvSamePadding -> nn.Conv1d), models.py:23-44 (Decoder 1x1) --------------------- */
 
@@ -211,9 +217,10 @@ int convasr_scale_rows(const float* grad, const float* gscale, const int64_t* gd
  *   skipped (may be NULL, one byte) = out3[1] is inf or NaN (the gate of train.py:769).
  * loss_scaler (may be NULL): a dynamic loss scaler's state (below); grad_loss_vec is multiplied by its current scale, i.e. backward is
  * seeded with the gradient of the SCALED loss (`with apex.amp.scale_loss(loss, optimizer) as scaled_loss: scaled_loss.backward()`,
- * train.py:770-772). */
+ * train.py:770-772).  metric_scale multiplies out3[1] and out3[2] (1 for one process; 1 / world size in data-parallel runs, so that the
+ * SUM all-reduce of train.py:759-760 yields the mean of train.py:761-762 with no further kernel); skipped looks at the local mean. */
 int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
-                      float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, void* stream);
+                      float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, float metric_scale, void* stream);
 
 /* Dynamic loss scaler for fp16 training (the role of apex.amp's LossScaler, reference models.py:744-762 `apex.amp.initialize(opt_level)`
  * and train.py:770-779): CONVASR_LOSS_SCALER_FLOATS floats on the device,

@@ -44,7 +44,7 @@ def _worker(rank, world, port, out):
 
 	launched = []
 	orig = engine._launch
-	engine._launch = lambda bi: (launched.append(bi), orig(bi))[1]
+	engine._launch = lambda bi, events = (): (launched.append(bi), orig(bi, events))[1]
 	params = list(model.parameters())
 	expect = sum(range(1, world + 1)) / world
 	# step 1 -- "backward": gradients become final in reverse layer order; every rank contributes rank + 1
