@@ -42,7 +42,7 @@ _SIGNATURES = dict(
 	convasr_bn_eval_scale_shift = (c_int, [c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_int, c_p]),
 	convasr_bn_act_fwd = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_bwd_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
-	convasr_bn_act_bwd_reduce = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
+	convasr_bn_act_bwd_reduce = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_act_bwd_apply = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_bwd_apply = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_log_softmax_fwd = (c_int, [c_p, c_p, c_i64, c_int, c_p]),

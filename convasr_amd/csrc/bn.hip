@@ -435,6 +435,58 @@ template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bw
 	}
 }
 
+// The same pass for a residual-free layer whose forward stored its one-bit gradient gates: g = gate ? dz * keep_scale : 0, no
+// pre-activation, no hash, no frame arithmetic -- three streams in (dz, y, one gate byte per 8 elements), two sums out.  Sums g and
+// g * y per thread and centres / scales once per block: sum g * xhat = (sum g y - mean sum g) * invstd.
+template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_gated_kernel(BnActParams p, float* __restrict__ ws) {
+	__shared__ float red[256][17];
+	const int c8 = p.C >> 3;
+	const int cgroups = p.cgroups, rlanes = p.rlanes;
+	const int cg = threadIdx.x % cgroups, rl = threadIdx.x / cgroups;
+	const float gate_scale = p.drop_thr ? p.keep_scale : 1.f;
+	for (int cbase = blockIdx.y * cgroups; cbase < c8; cbase += gridDim.y * cgroups) {
+		const int c = (cbase + cg) << 3;
+		const bool cok = cbase + cg < c8;
+		float s1[8], s2[8], mean[8], istd[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+		if (cok) { load8<float>(p.mean + c, mean); load8<float>(p.invstd + c, istd); }
+		struct Trip { Raw8<T> y, dz; unsigned gate; };
+		const T* const py = reinterpret_cast<const T*>(p.y);
+		const T* const pdz = reinterpret_cast<const T*>(p.dz);
+		if (cok)
+			walk_rows2(p, rl, c,
+				[&](const RowWalk& w) { Trip q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); q.gate = p.gate_in[w.idx >> 3]; return q; },
+				[&](const RowWalk& w, const Trip& q) {
+					float dz[8], yv[8];
+					unpack8(q.dz, dz);
+					unpack8(q.y, yv);
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const float g = ((q.gate >> k) & 1u) ? dz[k] * gate_scale : 0.f;
+						s1[k] += g;
+						s2[k] = fmaf(g, yv[k], s2[k]);
+					}
+				});
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][8 + k] = cok ? (s2[k] - mean[k] * s1[k]) * istd[k] : 0.f; }
+		__syncthreads();
+		if (rl == 0 && cok) {
+			float* dst = ws + (int64_t)blockIdx.x * 2 * p.C;
+			float o1[8], o2[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				float u = 0.f, w2 = 0.f;
+				for (int j = 0; j < rlanes; ++j) { u += red[j * cgroups + cg][k]; w2 += red[j * cgroups + cg][8 + k]; }
+				o1[k] = u; o2[k] = w2;
+			}
+			store8<float>(dst + c, o1);
+			store8<float>(dst + p.C + c, o2);
+		}
+		__syncthreads();
+	}
+}
+
 // sums[set][.] = sum over blocks of ws[set][block][.], accumulated in fp64; for the main BN (set 0) optionally also the
 // per-channel coefficients of pass 2 (dy = A*g + Bc*y + D) and the parameter gradients dgamma = sum g*xhat, dbeta = sum g.
 // Block = 32 channels x 16 block-lanes (one 128-byte segment of a partial row per half wave).
@@ -533,7 +585,8 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
                                          const float* invstd, int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                                          const float* const* rmean, const float* const* rinvstd, double* const* rsums, int act, float act_lo, float act_hi,
                                          float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
-                                         int accumulate, int B, int T, int C, void* stream) {
+                                         int accumulate, int B, int T, int C, const uint8_t* gate, void* stream) {
+	CONVASR_CHECK_ARG(!gate || (n_res == 0 && !g && mean && (act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE)), "bn_act_bwd_reduce: the one-bit gate form takes no residuals, writes no g, needs mean / invstd and an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG(dz && y && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG((mean == nullptr) == (invstd == nullptr), "bn_act_bwd_reduce: mean and invstd go together");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_reduce: B * T must fit in 31 bits");
@@ -554,7 +607,9 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 	hipStream_t st = (hipStream_t)stream;
 	bool res_sums = false;
 	for (int r = 0; r < n_res; ++r) res_sums = res_sums || ra.rsums[r] != nullptr;
-	BN_DISPATCH("bn_act_bwd_reduce", dtype, T,
+	p.gate_in = gate;
+	if (gate) { BN_DISPATCH("bn_act_bwd_reduce", dtype, T, hipLaunchKernelGGL((bn_act_bwd_reduce_gated_kernel<T>), grid, block, 0, st, p, (float*)workspace)); }
+	else BN_DISPATCH("bn_act_bwd_reduce", dtype, T,
 		if (res_sums) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, true>), grid, block, 0, st, p, ra, (float*)workspace);
 		else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, false>), grid, block, 0, st, p, ra, (float*)workspace));
 	if (any) {

@@ -410,7 +410,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
 			# per-channel coefficients, pass 2 recomputes g from dz on the fly: dy = A*g + Bc*y + D
 			coef = torch.empty(3 * Cout, dtype = torch.float32, device = dev)
-			reduce = lambda outs, acc: ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, write_g = False, gamma = gamma, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc)
+			reduce = lambda outs, acc: ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, write_g = False, gamma = gamma, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc, gate = ctx.gate)
 			if gamma.requires_grad or beta.requires_grad:
 				dgamma, dbeta = _deliver([gamma, beta], reduce)
 			else:

@@ -306,12 +306,13 @@ def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = ()
 	return z
 
 
-def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None, write_g = True, gamma = None, coef = None, dgamma = None, dbeta = None, accumulate = False):
+def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None, write_g = True, gamma = None, coef = None, dgamma = None, dbeta = None, accumulate = False, gate = None):
+	"""gate: the forward pass's one-bit gradient gates (bn_act(..., gate = ...)); needs write_g = False and no residuals."""
 	B, C, T = y.shape
-	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype
+	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype and (gate is None or (not write_g and not res))
 	g = empty_cl(B, C, T, y.dtype, y.device) if write_g else None
 	ws = workspace(_lib.load().convasr_bn_bwd_workspace_bytes(B, T, C), y.device, 'bn_bwd')
-	_lib.timed('hbm:bn_act_bwd_reduce_kernel', 0.0, lambda: call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res) + (1 if write_g else 0))))
+	_lib.timed('hbm:bn_act_bwd_reduce_kernel', 0.0, lambda: call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res) + (1 if write_g else 0))))
 	return g
 
 

@@ -7,6 +7,10 @@ stream, ordered after the producing kernels by an event) -- so communication ove
 xGMI is point-to-point, so a few large buckets (default 32 MiB) beat many small ones; only the bucket that completes last (the
 first layers, nothing left to overlap it with) is kept small.  Batch-norm statistics stay per GPU,
 exactly as in the reference's training path (train.py:704 does not pass synchronize_bn)."""
+import os
+import queue
+import threading
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -15,7 +19,7 @@ from .train import FlatParameters
 
 
 class DataParallelEngine(nn.Module):
-	def __init__(self, module, device = None, bucket_bytes = 32 << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True):
+	def __init__(self, module, device = None, bucket_bytes = int(os.environ.get('CONVASR_BUCKET_MIB', 64)) << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True, comm_thread = os.environ.get('CONVASR_COMM_THREAD', '1') == '1'):
 		super().__init__()
 		self.module = module
 		self.group = process_group
@@ -26,6 +30,10 @@ class DataParallelEngine(nn.Module):
 		self.buckets = self._make_buckets(bucket_bytes, min(first_bucket_bytes, bucket_bytes))
 		self._pending = []
 		self._ready = []  # complete buckets whose collective has not been enqueued yet: (bucket index, events recorded on the producer streams)
+		# enqueueing a collective costs tens of microseconds of host time inside torch.distributed / RCCL (mostly outside the GIL): a helper
+		# thread does it while this one keeps launching the backward pass's kernels
+		self._jobs = queue.Queue() if (comm_thread and self.collectives and self.flat.data.is_cuda) else None
+		self._worker = None
 		self._comm_dirty = False  # something was enqueued on the communication stream that the main stream has not joined yet
 		self._remaining = [len(b['params']) for b in self.buckets]
 		self._main_stream = None  # the stream forward() ran on: dgamma / dbeta and (without a side stream) every weight gradient are produced there
@@ -95,7 +103,37 @@ class DataParallelEngine(nn.Module):
 		"""Enqueue the collectives of the buckets that became complete since the last call (no-op when there are none)."""
 		ready, self._ready = self._ready, []
 		for bi, events in ready:
-			self._launch(bi, events)
+			if self._jobs is not None:
+				self._submit(lambda bi = bi, events = events: self._launch(bi, events))
+			else:
+				self._launch(bi, events)
+
+	def _submit(self, job):
+		if self._worker is None:
+			def run():
+				torch.cuda.set_device(self.flat.data.device)
+				while True:
+					job = self._jobs.get()
+					try:
+						if job is None:
+							return
+						job()
+					except BaseException as e:  # surfaced by _drain() on the training thread
+						self._worker_error = e
+					finally:
+						self._jobs.task_done()
+			self._worker_error = None
+			self._worker = threading.Thread(target = run, name = 'convasr-comm', daemon = True)
+			self._worker.start()
+		self._jobs.put(job)
+
+	def _drain(self):
+		"""Wait until the helper thread has enqueued everything handed to it (host-side only: nothing here waits for the GPU)."""
+		if self._jobs is not None and self._worker is not None:
+			self._jobs.join()
+			if self._worker_error is not None:
+				e, self._worker_error = self._worker_error, None
+				raise e
 
 	def _launch(self, bi, events):
 		"""All-reduce of one complete bucket.  torch.distributed orders a collective after the CURRENT stream only, so it is issued from a
@@ -120,13 +158,21 @@ class DataParallelEngine(nn.Module):
 			dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
 			return
 		comm = self._comm(t.device)
-		comm.wait_stream(torch.cuda.current_stream(t.device))
-		with torch.cuda.stream(comm):
-			dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
-		t.record_stream(comm)
-		self._comm_dirty = True
+		ev = torch.cuda.current_stream(t.device).record_event()
+
+		def job():
+			comm.wait_event(ev)
+			with torch.cuda.stream(comm):
+				dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
+			t.record_stream(comm)
+			self._comm_dirty = True
+		if self._jobs is not None:
+			self._submit(job)
+		else:
+			job()
 
 	def join_comm_stream(self):
+		self._drain()
 		if self._comm_stream is not None and self._comm_dirty:
 			torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
 			self._comm_dirty = False
@@ -156,6 +202,7 @@ class DataParallelEngine(nn.Module):
 						p._convasr_fresh = False
 				self._mark_ready(bi)
 		self.poll()
+		self._drain()
 		for work, view in self._pending:
 			work.wait()  # RCCL: orders the CURRENT stream behind the collective (it ran on the backend's own stream), no host block; gloo: host wait
 		self.join_comm_stream()

@@ -170,7 +170,9 @@ int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, co
  * rinvstd_r).  sums / rsums_r (2*C doubles each) are WRITTEN (block partials go through `workspace`, then an fp64 sum:
  * deterministic, no contended atomics).  workspace: convasr_bn_bwd_workspace_bytes(B, T, C) bytes.
  * Optional outputs for the main BN (need mean / invstd): coef (3*C floats: dy = coef[c]*g + coef[C+c]*y + coef[2C+c], the
- * batch-norm training backward with `gamma` folded in), dgamma = sum g*xhat, dbeta = sum g (added to when accumulate). */
+ * batch-norm training backward with `gamma` folded in), dgamma = sum g*xhat, dbeta = sum g (added to when accumulate).
+ * gate (may be NULL): the one-bit gates convasr_bn_act_fwd stored; then g = gate ? dz / (1 - p) : 0 with no re-derivation (n_res must be
+ * 0, g NULL, mean / invstd given): three streams in, two sums out. */
 int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C);
 int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift,
                               const float* mean, const float* invstd,
@@ -178,7 +180,7 @@ int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype,
                               const float* const* rmean, const float* const* rinvstd, double* const* rsums,
                               int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
                               const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
-                              int accumulate, int B, int T, int C, void* stream);
+                              int accumulate, int B, int T, int C, const uint8_t* gate, void* stream);
 
 /* Backward pass 2 in coefficient form: dy = coef[c]*g + coef[C+c]*y + coef[2C+c].  from_dz != 0: g is recomputed on the fly
  * from dz (activation derivative, dropout, temporal mask; no residuals) so pass 1 need not materialise it; gate (may be NULL): the

@@ -46,6 +46,12 @@ def test_library_exports_every_declared_symbol():
 		assert hasattr(lib, name), name
 	assert lib.convasr_abi_version() == 5
 	assert lib.convasr_conv_cout_pad(38) == 128 and lib.convasr_conv_cout_pad(256) == 256
+	# every ctypes signature has as many arguments as the header's prototype
+	protos = re.sub(r'/\*.*?\*/', '', header, flags = re.S)
+	for m in re.finditer(r'\b(?:int|int64_t|const char\*)\s+(convasr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;', protos, flags = re.S):
+		name, args = m.group(1), m.group(2).strip()
+		n = 0 if args in ('void', '') else len(args.split(','))
+		assert len(_lib._SIGNATURES[name][1]) == n, (name, n, len(_lib._SIGNATURES[name][1]))
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -777,6 +783,16 @@ def test_stored_gradient_gates_equal_the_rederived_ones(act):
 		dx0 = ops.conv1d_dgrad_bn_reduce(dyc, wd, C, K, 1, K - 1 - K // 2, y, scale, shift, mean, invstd, a, p_drop, 5, 11, xlen, s0)
 		dx1 = ops.conv1d_dgrad_bn_reduce(dyc, wd, C, K, 1, K - 1 - K // 2, y, scale, shift, mean, invstd, a, p_drop, 5, 11, xlen, s1, gate = gate)
 		assert dx0 is not None and torch.equal(dx0, dx1) and s0.rows == s1.rows and torch.equal(s0.totals(), s1.totals())
+		# separate reduce pass (the unfused form): coefficients and parameter gradients from the bits against the re-derived ones
+		# (same g per element; the gated kernel sums g y and centres once per block, the other sums g xhat per element: fp32 rounding apart)
+		gamma = torch.rand(C, device = d) + 0.5
+		outs = []
+		for gt in (None, gate):
+			coef_r, dgm, dbt = torch.empty(3 * C, device = d), torch.empty(C, device = d), torch.empty(C, device = d)
+			ops.bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, a, xlen = xlen, dropout_p = p_drop, seed = 5, offset = 11, write_g = False, gamma = gamma, coef = coef_r, dgamma = dgm, dbeta = dbt, gate = gt)
+			outs.append((coef_r, dgm, dbt))
+		for u, v, what in zip(outs[0], outs[1], ('coef', 'dgamma', 'dbeta')):
+			close(v, u, 1e-4, 1e-3 if what != 'coef' else 1e-5, 'gated reduce ' + what)
 
 
 @gpu

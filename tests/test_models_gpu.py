@@ -180,7 +180,15 @@ def test_full_wav2letter_forward_fp32_vs_oracle_config2_shape_reduced_batch():
 	close(out['loss'], ref['loss'], 1e-4, 0, 'CTC loss')
 	tok, gen = CharTokenizerLegacy(O.CHAR_LEGACY_ALPHABET), GreedyCTCGenerator()
 	got = [t[0][0]['hyp'] if len(t[0]) else '' for t in gen.generate(tok, out['log_probs'][0], torch.zeros(B), torch.ones(B), output_lengths = out['olen'][0])]
-	assert got == O.greedy_decode(ref['log_probs'], ref['olen'])
+	want = O.greedy_decode(ref['log_probs'], ref['olen'])
+	# a random-init network decides a few of its frames by margins below the difference of two fp32 summation orders: the argmax must
+	# agree on every frame the oracle decides by more than twice the observed deviation, and at most one string may differ (the
+	# stated-batch version of this test, tests/test_round3_gpu.py, has the details)
+	lp_dev = float((out['log_probs'][0].cpu() - ref['log_probs']).abs().max())
+	top2 = ref['log_probs'].topk(2, dim = 1).values
+	decisive = (top2[:, 0] - top2[:, 1]) > 2 * lp_dev
+	agree = out['log_probs'][0].argmax(dim = 1).cpu() == ref['log_probs'].argmax(dim = 1)
+	assert bool(agree[decisive].all()) and float(decisive.float().mean()) > 0.99 and sum(a == b for a, b in zip(got, want)) >= B - 1, (got, want)
 	for k, v in model.state_dict().items():
 		if 'running' in k:
 			close(v, sd[k], 1e-3, 1e-5, k)  # oracle updated its copy of the running stats in place
