@@ -13,11 +13,11 @@
 #define FIN_CH 16
 #define FIN_LANES 64
 // Both planes of the 16 channels of this block: returns true on the one thread per channel (row-lane 0) that holds the totals.
-__device__ __forceinline__ bool finalize_rows(const double* __restrict__ part, int rows, int C, double (&red)[2][FIN_LANES][FIN_CH], double& s1, double& s2) {
+template <typename P> __device__ __forceinline__ bool finalize_rows(const P* __restrict__ part, int rows, int C, double (&red)[2][FIN_LANES][FIN_CH], double& s1, double& s2) {
 	const int cl = threadIdx.x & (FIN_CH - 1), c = blockIdx.x * FIN_CH + cl, w = threadIdx.x >> 4;
 	double a = 0, q2 = 0;
 	if (c < C)
-		for (int r = w; r < rows; r += FIN_LANES) { a += part[((int64_t)r * 2) * C + c]; q2 += part[((int64_t)r * 2 + 1) * C + c]; }
+		for (int r = w; r < rows; r += FIN_LANES) { a += (double)part[((int64_t)r * 2) * C + c]; q2 += (double)part[((int64_t)r * 2 + 1) * C + c]; }
 	red[0][w][cl] = a;
 	red[1][w][cl] = q2;
 	__syncthreads();
@@ -242,6 +242,32 @@ template <typename L, typename U> __device__ __forceinline__ void walk_rows2(con
 	}
 }
 
+#ifdef CONVASR_BN_ROWS4  // measurement hook (python -m convasr_amd.build --variant rows4 -DCONVASR_BN_ROWS4=1): four rows in flight in the forward / apply passes too
+#define WALK_ROWS_FWD walk_rows4
+#else
+#define WALK_ROWS_FWD walk_rows2
+#endif
+// Four rows per trip: all four rows' loads are issued before the first is consumed (the gated reduce pass: 33 bytes per row and lane,
+// nothing but bytes in flight limits it).
+template <typename L, typename U> __device__ __forceinline__ void walk_rows4(const BnActParams& p, int rl, int c, L load, U use) {
+	for (RowWalk w(p, rl, c); w.live();) {
+		RowWalk w1 = w; w1.next(p);
+		RowWalk w2 = w1; w2.next(p);
+		RowWalk w3 = w2; w3.next(p);
+		const bool l1 = w1.live(), l2 = w2.live(), l3 = w3.live();
+		auto r0 = load(w);
+		auto r1 = l1 ? load(w1) : r0;
+		auto r2 = l2 ? load(w2) : r0;
+		auto r3 = l3 ? load(w3) : r0;
+		use(w, r0);
+		if (l1) use(w1, r1);
+		if (l2) use(w2, r2);
+		if (l3) use(w3, r3);
+		w = w3;
+		w.next(p);
+	}
+}
+
 __device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) { dropout_mask8(p.seed, p.offset, p.drop_thr, p.keep_scale, idx, keep); }
 
 // MODE bit 0: residual inputs present, bit 1: dropout on, bit 2: gate bits wanted, bit 3: BN scale / shift present, bit 4: the
@@ -263,7 +289,7 @@ template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fw
 		float sc[8], sh[8];
 		if (AFFINE) { load8<float>(p.scale + c, sc); load8<float>(p.shift + c, sh); }
 		const T* const py = reinterpret_cast<const T*>(p.y);
-		walk_rows2(p, rl, c,
+		WALK_ROWS_FWD(p, rl, c,
 			[&](const RowWalk& w) { return raw_load8(py + w.idx); },  // unconditional (a masked row is still inside the tensor): no branch between the two rows' loads
 			[&](const RowWalk& w, const Raw8<T>& yraw) {
 				float out[8];
@@ -455,7 +481,7 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_g
 		const T* const py = reinterpret_cast<const T*>(p.y);
 		const T* const pdz = reinterpret_cast<const T*>(p.dz);
 		if (cok)
-			walk_rows2(p, rl, c,
+			walk_rows4(p, rl, c,
 				[&](const RowWalk& w) { Trip q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); q.gate = p.gate_in[w.idx >> 3]; return q; },
 				[&](const RowWalk& w, const Trip& q) {
 					float dz[8], yv[8];
@@ -489,34 +515,20 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_g
 
 // sums[set][.] = sum over blocks of ws[set][block][.], accumulated in fp64; for the main BN (set 0) optionally also the
 // per-channel coefficients of pass 2 (dy = A*g + Bc*y + D) and the parameter gradients dgamma = sum g*xhat, dbeta = sum g.
-// Block = 32 channels x 16 block-lanes (one 128-byte segment of a partial row per half wave).
+// Block = 16 channels x 64 block-lanes (finalize_rows).
 struct BnFinalizeSets {
 	double* dst[3];
 	const float* gamma; const float* mean; const float* invstd;
 	float* coef; float* dgamma; float* dbeta;
 	int accumulate; float invn;
 };
-__global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C) {
-	__shared__ double red[2][16][32];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ ws, BnFinalizeSets sets, int nblocks, int C) {
+	__shared__ double red[2][FIN_LANES][FIN_CH];
 	const int set = blockIdx.y;
 	if (sets.dst[set] == nullptr && !(set == 0 && (sets.coef || sets.dgamma || sets.dbeta))) return;
-	const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, w = threadIdx.x >> 5;
-	double a = 0, b2 = 0;
-	if (c < C) {
-		const float* base = ws + (int64_t)set * nblocks * 2 * C;
-#pragma unroll 4
-		for (int bq = w; bq < nblocks; bq += 16) {
-			const float* row = base + (int64_t)bq * 2 * C;
-			a += (double)row[c];
-			b2 += (double)row[C + c];
-		}
-	}
-	red[0][w][cl] = a;
-	red[1][w][cl] = b2;
-	__syncthreads();
-	if (w == 0 && c < C) {
-		double sg = 0, sgx = 0;
-		for (int i = 0; i < 16; ++i) { sg += red[0][i][cl]; sgx += red[1][i][cl]; }
+	const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+	double sg, sgx;
+	if (finalize_rows(ws + (int64_t)set * nblocks * 2 * C, nblocks, C, red, sg, sgx)) {
 		if (sets.dst[set]) { sets.dst[set][c] = sg; sets.dst[set][C + c] = sgx; }
 		if (set == 0) {
 			if (sets.coef) {
@@ -561,13 +573,19 @@ extern "C" int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const 
 	return 0;
 }
 
-// at most BN_BWD_MAX_BLOCKS blocks (3 per CU): the finalize kernel reads one partial row per block and set
+// at most BN_BWD_MAX_BLOCKS blocks (3 per CU): the finalize kernel reads one partial row per block and set (more blocks make THAT
+// kernel the cost: 2,048 partial rows of 2 C floats are 12 MB for it to walk); bytes in flight come from rows per trip instead
 #define BN_BWD_MAX_BLOCKS 768
+static int bn_bwd_max_blocks() {
+	static int n = 0;
+	if (!n) { const char* e = getenv("CONVASR_BN_BWD_BLOCKS"); n = e ? atoi(e) : BN_BWD_MAX_BLOCKS; if (n <= 0) n = BN_BWD_MAX_BLOCKS; }  // (measurement hook)
+	return n;
+}
 static void bn_bwd_config(BnActParams& p, dim3& grid, dim3& block) {
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
-	if (grid.x > BN_BWD_MAX_BLOCKS) {
+	if ((int)grid.x > bn_bwd_max_blocks()) {
 		const int64_t rows = (int64_t)p.B * p.T;
-		const int64_t per = ceil_div64(rows, BN_BWD_MAX_BLOCKS);
+		const int64_t per = ceil_div64(rows, bn_bwd_max_blocks());
 		p.rows_per_block = (int)(ceil_div64(per, p.rlanes) * p.rlanes);
 		grid.x = (unsigned)ceil_div64(rows, p.rows_per_block);
 	}
@@ -619,7 +637,7 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 		sets.dst[2] = n_res > 1 ? ra.rsums[1] : nullptr;
 		sets.gamma = gamma; sets.mean = mean; sets.invstd = invstd; sets.coef = coef; sets.dgamma = dgamma; sets.dbeta = dbeta;
 		sets.accumulate = accumulate; sets.invn = 1.0f / (float)((int64_t)B * T);
-		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32, 3), dim3(512), 0, st, (const float*)workspace, sets, (int)grid.x, C);
+		hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH, 3), dim3(FIN_CH * FIN_LANES), 0, st, (const float*)workspace, sets, (int)grid.x, C);
 	}
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_reduce");
 	return 0;
@@ -674,7 +692,7 @@ template <typename T, int SRC> __global__ __launch_bounds__(256) void bn_act_bwd
 		const T* const py = reinterpret_cast<const T*>(p.y);
 		const T* const pdz = reinterpret_cast<const T*>(p.dz);
 		const float gate_scale = p.drop_thr ? p.keep_scale : 1.f;
-		walk_rows2(p, rl, c,
+		WALK_ROWS_FWD(p, rl, c,
 			[&](const RowWalk& w) { Pair q; q.y = raw_load8(py + w.idx); q.dz = raw_load8(pdz + w.idx); q.gate = GATED ? p.gate_in[w.idx >> 3] : 0u; return q; },
 			[&](const RowWalk& w, const Pair& q) {
 				float yv[8], pre[8], g[8], out[8];

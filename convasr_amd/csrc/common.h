@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/convasr_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits

@@ -47,8 +47,19 @@ extern "C" int convasr_debug_read_stamps(unsigned long long* host, int count) {
 // partial round of a launch (total_tiles mod 256 workgroups on 256 CUs) is cut into half tiles so that it occupies all CUs for
 // ~0.6 of a round instead of a fraction of them for a whole one; per-element sums are unchanged (same k order).
 // BM_ = rows (frames) of the tile: 256; 192 (three 16-row blocks per wave instead of four) exists for A/B runs only (see the dispatcher).
-template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
+// BNF: 0 = plain epilogue; 1 = fused BN-backward sums, g re-derived per element on the vector ALU (any activation, no stored gates);
+// 2 = fused BN-backward sums from the stored one-bit gates, summed on the MATRIX pipe (below, "Fused pass 1 ... form 2").
+template <typename T> struct HalfOnes;
+template <> struct HalfOnes<bf16_t> { static constexpr unsigned pair = 0x3F803F80u; };
+template <> struct HalfOnes<f16_t> { static constexpr unsigned pair = 0x3C003C00u; };
+template <> struct HalfOnes<float> { static constexpr unsigned pair = 0u; };  // (never used: the fused epilogues exist for 16-bit outputs only)
+
+template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
 	constexpr int BN_ = 32 * NB, MI = BM_ / 64, WROWS = 16 * MI;  // MI 16-row blocks = WROWS rows per wave
+	// LDS map of the epilogue (everything the main loop used is dead by then): output tile, BN-statistics scratch, and for BNF == 2 the
+	// consumer layer's y tile (row-major, BN_ * 2 bytes per row, brought in by the loader waves) and the 256-entry gate -> mask table
+	constexpr int EPI_OPITCH = BN_ * (int)sizeof(O) + 16, EPI_YOFF = BM_ * EPI_OPITCH + 8 * BN * (int)sizeof(float), EPI_YBYTES = BM_ * BN_ * 2, EPI_LUT = EPI_YOFF + EPI_YBYTES;
+	static_assert(BNF != 2 || (EPI_YOFF % 1024 == 0 && EPI_LUT + 4096 <= 160 * 1024), "fused epilogue (form 2): LDS map");
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
@@ -179,8 +190,19 @@ template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forcei
 				__builtin_amdgcn_s_barrier();
 				cib = cib1; pi = pi1;
 			}
-			// the epilogue's workgroup barriers (the loaders have nothing else to do there)
+			// the epilogue's workgroup barriers.  BNF == 2: the loaders first bring in the consumer layer's y tile (same (b, t, channel)
+			// coordinates as the output tile; rows past the utterance read as zeros through the descriptor's range check), 1 KiB pieces of
+			// whole rows, lane-linear: it lands under the compute waves' accumulator staging and store loop
+			if (BNF == 2 && sizeof(O) == 2) {
+				constexpr int YROW = BN_ * 2, RPP = 1024 / YROW;  // bytes per tile row, rows per piece
+				const int y_row_bytes = p.Cout * 2;
+				const v4i32 ysrc = make_srd(reinterpret_cast<const char*>(p.bn_y) + (int64_t)b * p.Tout * y_row_bytes, (unsigned)(p.Tout * y_row_bytes));
+				const int ylane = ((lane * 16) / YROW) * y_row_bytes + (lane * 16) % YROW + co0 * 2;
+				for (int u = lw; u < EPI_YBYTES / 1024; u += 4)
+					dma16(ysrc, __builtin_amdgcn_readfirstlane(lds_base + EPI_YOFF + u * 1024), (t0 + u * RPP) * y_row_bytes + ylane);
+			}
 			__builtin_amdgcn_s_barrier();
+			if (BNF == 2 && sizeof(O) == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if (BNF && sizeof(O) == 2) __builtin_amdgcn_s_barrier();
 			return;
 		}
@@ -234,7 +256,7 @@ template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forcei
 	STAMPI(t_epi0)
 #endif
 	// ---------------- epilogue: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg
-	constexpr int OPITCH = BN_ * sizeof(O) + 16;
+	constexpr int OPITCH = EPI_OPITCH;
 	char* const otile = smem;
 	float* const red = reinterpret_cast<float*>(smem + BM_ * OPITCH);  // [2][4 (wm)][BN_]
 	const int nvalid = valid_len(p.xlen, b, p.Tout);
@@ -243,10 +265,25 @@ template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forcei
 	// that its latency hides under the accumulator staging (loading it inside the store loop cost ~8 serial L2/HBM round trips per tile)
 	constexpr int OEPC_ = 16 / sizeof(O), OCH_ = BN_ / OEPC_, TRIPS = BM_ * OCH_ / V2_THREADS;
 	static_assert(BM_ * OCH_ % V2_THREADS == 0, "the store loop covers the tile in whole trips");
-	constexpr bool bnf = BNF && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
+	constexpr bool bnf = BNF == 1 && sizeof(O) == 2;  // separate instantiations: the plain launches do not carry the epilogue's registers and code
+	constexpr bool bnm = BNF == 2 && sizeof(O) == 2;  // form 2: gates + matrix-pipe sums
 	typedef typename std::conditional<sizeof(O) == 2, O, I>::type H;  // the 16-bit storage type of the fused epilogue's operands (= O there)
-	uint4 ypre[TRIPS];
+	uint4 ypre[bnf ? TRIPS : 1];
 	unsigned gpre[TRIPS];  // the chunk's eight one-bit gradient gates (when the forward pass stored them: bn_gate)
+	if (bnm) {
+#pragma unroll
+		for (int i = 0; i < TRIPS; ++i) {
+			const int e = tid + i * V2_THREADS, row = e / OCH_, t = t0 + row, co = co0 + (e % OCH_) * OEPC_;
+			gpre[i] = (t < p.Tout && co < p.Cout) ? p.bn_gate[(((int64_t)b * p.Tout + t) * p.Cout + co) >> 3] : 0u;  // (a frame past the utterance, a masked frame: no gradient passes)
+		}
+		// gate byte -> the four dword masks of its 8-element chunk (element 2 i in the low half of word i), once per tile
+		if (tid < 256) {
+			unsigned m[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) m[i] = (((tid >> (2 * i)) & 1) ? 0x0000FFFFu : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0xFFFF0000u : 0u);
+			*reinterpret_cast<uint4*>(smem + EPI_LUT + tid * 16) = make_uint4(m[0], m[1], m[2], m[3]);
+		}
+	}
 	if (bnf) {
 #pragma unroll
 		for (int i = 0; i < TRIPS; ++i) {
@@ -345,6 +382,18 @@ template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forcei
 		const int e = tid + it * V2_THREADS;
 		const int row = e / OCHUNKS, ch = e % OCHUNKS;
 		const int t = t0 + row, co = co0 + ch * OEPC;
+		if (bnm) {  // form 2: the chunk, masked by its gates, goes back into the tile in place: G = gate ? dz : 0 (exact: no arithmetic on the values)
+			uint4* const cell = reinterpret_cast<uint4*>(otile + row * OPITCH + ch * 16);
+			const uint4 dzv = *cell, m = *reinterpret_cast<const uint4*>(smem + EPI_LUT + gpre[it] * 16);
+			if (t < p.Tout && co < p.Cout) {
+				O* dst = yb + (int64_t)t * p.Cout + co;
+				if (vec_ok && co + OEPC <= p.Cout) *reinterpret_cast<uint4*>(dst) = dzv;
+				else
+					for (int i = 0; i < OEPC && co + i < p.Cout; ++i) dst[i] = reinterpret_cast<const O*>(cell)[i];
+			}
+			*cell = make_uint4(dzv.x & m.x, dzv.y & m.y, dzv.z & m.z, dzv.w & m.w);
+			continue;
+		}
 		if (t >= p.Tout || co >= p.Cout) continue;
 		const O* src = reinterpret_cast<const O*>(otile + row * OPITCH) + ch * OEPC;
 		O* dst = yb + (int64_t)t * p.Cout + co;
@@ -387,6 +436,49 @@ template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forcei
 			prow[p.Cout + co0 + tid] = q2;
 		}
 	}
+	if (bnm) {
+		// Fused pass 1 of the consumer layer's batch-norm backward, form 2.  With the stored gates g = gate ? dz / (1 - p) : 0, so
+		//   sum_t g = k sum_t G[t][c],   sum_t g y = k sum_t G[t][c] Y[t][c] = k diag(G^T Y)[c]       (k = 1 / (1 - p), G = gated dz)
+		// are two small matrix products over the tile's rows -- G^T 1 and the diagonal blocks of G^T Y -- which the matrix pipe,
+		// idle in an epilogue, does in 2 x 8 MFMAs per 16-channel block: wave w takes channels [16 w, 16 w + 16), operand fragments are
+		// column reads (ds_read_b64_tr_b16) of the two row-major tiles.  Products of two 16-bit values are exact in fp32 and the sums
+		// are fp32 chains over the tile's 256 rows, like the vector-ALU form's.  That form spent ~56 vector instructions per 8 elements
+		// (unpack, gate, two accumulations) and ~12.4 K cycles per tile; this one masks a chunk with four v_and.
+		__syncthreads();  // G complete; the loaders have waited for the y tile's DMA before arriving here
+		typedef __attribute__((address_space(3))) s16x4* lp;
+		typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+		auto tr8 = [](unsigned addr, unsigned row_stride) {
+			const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(size_t)addr);
+			const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(size_t)(addr + 4 * row_stride));
+			const uint2 l = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+			u32x4_ r; r[0] = l.x; r[1] = l.y; r[2] = h2.x; r[3] = h2.y;
+			return r;
+		};
+		if (wave < BN_ / 16) {
+			// 16-lane group g4 = the MFMA operand's k block (8 rows); lane 4 q + pc of the group supplies row q, columns 4 pc .. 4 pc + 3
+			const int g4 = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+			const unsigned ga = lds_base + (8 * g4 + q) * OPITCH + (16 * wave + 4 * pc) * 2;
+			const unsigned ya = lds_base + EPI_YOFF + (8 * g4 + q) * (BN_ * 2) + (16 * wave + 4 * pc) * 2;
+			u32x4_ ones; ones[0] = ones[1] = ones[2] = ones[3] = HalfOnes<O>::pair;
+			f32x4 a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int ks = 0; ks < BM_ / 32; ++ks) {
+				const u32x4_ gf = tr8(ga + ks * 32 * OPITCH, OPITCH), yf = tr8(ya + ks * 32 * (BN_ * 2), BN_ * 2);
+				a1 = Mma16<H>::run(gf, ones, a1);
+				a2 = Mma16<H>::run(gf, yf, a2);
+			}
+			// D[i][j] sits in lane (j, i >> 2), register i & 3: the diagonal in the 16 lanes with (lane >> 4) == ((lane & 15) >> 2)
+			const int c16 = lane & 15, co = co0 + 16 * wave + c16;
+			if ((lane >> 4) == (c16 >> 2) && co < p.Cout) {
+				const int r = c16 & 3;
+				const float s1 = (r == 0 ? a1[0] : r == 1 ? a1[1] : r == 2 ? a1[2] : a1[3]) * gate_scale;
+				const float s2 = (r == 0 ? a2[0] : r == 1 ? a2[1] : r == 2 ? a2[2] : a2[3]) * gate_scale;
+				double* const prow = p.bn_sums + (int64_t)mtile * 2 * p.Cout;  // per-(m tile) partial row, summed by convasr_bn_bwd_finalize
+				prow[co] = (double)s1;
+				prow[p.Cout + co] = (double)((s2 - p.bn_mean[co] * s1) * p.bn_invstd[co]);  // sum g * xhat
+			}
+		}
+	}
 #ifdef CONVASR_STAMPS
 	STAMP(t_end)
 	if (blockIdx.x < 256 && lane == 0) {
@@ -396,7 +488,7 @@ template <typename I, typename O, int NB, bool BNF, int BM_> __device__ __forcei
 #endif
 }
 
-template <typename I, typename O, bool BNF, int BM_> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
+template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
 
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
@@ -411,9 +503,10 @@ template <typename I, typename O, bool BNF, int BM_> __global__ __launch_bounds_
 // Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
 // register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
 template <typename I, int BM_> static const void* v2s_kernel(int ki) {
-	if (ki == 0) return (const void*)conv1d_igemm_v2s_kernel<I, I, false, BM_>;
-	if (ki == 1) return (const void*)conv1d_igemm_v2s_kernel<I, I, true, BM_>;
-	return (const void*)conv1d_igemm_v2s_kernel<I, float, false, BM_>;
+	if (ki == 0) return (const void*)conv1d_igemm_v2s_kernel<I, I, 0, BM_>;
+	if (ki == 1) return (const void*)conv1d_igemm_v2s_kernel<I, I, 1, BM_>;
+	if (ki == 3) return (const void*)conv1d_igemm_v2s_kernel<I, I, 2, BM_>;
+	return (const void*)conv1d_igemm_v2s_kernel<I, float, 0, BM_>;
 }
 
 // Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
@@ -439,21 +532,22 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
 	size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 5 * V2_WSLOT;  // two X slab buffers + the 3 + 2 weight slots
 	if (p.K == 1) smem = 3 * (size_t)p.x_rows * ROW_BYTES + 3 * V2_WSLOT;  // K = 1: three X slab buffers + the 3-slot ring
-	const size_t epi = (size_t)bm * (BN * osz + 16) + 8 * BN * sizeof(float) + (p.bn_y ? (size_t)V2_THREADS * 17 * sizeof(float) : 0);
+	const bool mfma_sums = p.bn_y && p.bn_gate && !(p.debug & 256);  // (debug bit 256: the vector-ALU form of the fused epilogue even with gates: A/B runs)
+	const size_t epi = (size_t)bm * (BN * osz + 16) + 8 * BN * sizeof(float) + (p.bn_y ? (mfma_sums ? (size_t)bm * BN * 2 + 4096 : (size_t)V2_THREADS * 17 * sizeof(float)) : 0);
 	if (epi > smem) smem = epi;
 	if (smem > 160 * 1024) return 0;
-	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
+	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31) || (int64_t)(p.Tout + bm) * p.Cout * 2 >= (1ll << 31)) return 0;
 	p.m_tiles_per_b = (p.Tout + bm - 1) / bm;
 	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
 	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
 	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
-	const int ki = wide ? 2 : (fused ? 1 : 0), bi = bm == 192 ? 1 : 0;
+	const int ki = wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0), bi = bm == 192 ? 1 : 0;
 #ifdef CONVASR_AB_TILE192
 	const void* kern = f16 ? (bi ? v2s_kernel<f16_t, 192>(ki) : v2s_kernel<f16_t, V2_BM>(ki)) : (bi ? v2s_kernel<bf16_t, 192>(ki) : v2s_kernel<bf16_t, V2_BM>(ki));
 #else
 	const void* kern = f16 ? v2s_kernel<f16_t, V2_BM>(ki) : v2s_kernel<bf16_t, V2_BM>(ki);
 #endif
-	static bool attr_set[2][2][3] = {};
+	static bool attr_set[2][2][4] = {};
 	if (!attr_set[f16][bi][ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[f16][bi][ki] = true; }
 	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
 	p.full_tiles = p.total_tiles;

@@ -120,11 +120,11 @@ class LogFilterBankFrontend(nn.Module):
 
 	def __init__(self, out_channels, sample_rate, window_size, window_stride, window, dither = 1e-5, dither0 = 0.0, preemphasis = 0.97, eps = FP16_TINY, normalize_signal = True, debug_short_long_records_normalize_signal_multiplier = 1.0, stft_mode = None, window_periodic = True, normalize_features = False, **kwargs):
 		super().__init__()
-		if stft_mode not in (None, ''):
-			raise _lib.ConvasrHipError("stft_mode='conv' is an alternative CPU/ONNX formulation of the same STFT; this backend always runs the fused FFT kernel")
+		if stft_mode not in (None, '', 'conv'):
+			raise ValueError(f'stft_mode {stft_mode!r}')
 		if debug_short_long_records_normalize_signal_multiplier != 1.0:
 			raise _lib.ConvasrHipError('debug_short_long_records_normalize_signal_multiplier != 1 is not supported')
-		self.stft_mode, self.dither, self.dither0 = None, dither, dither0
+		self.stft_mode, self.dither, self.dither0 = stft_mode or None, dither, dither0
 		self.preemphasis, self.normalize_signal, self.sample_rate = preemphasis, normalize_signal, sample_rate
 		self.win_length = int(window_size * sample_rate)
 		self.hop_length = int(window_stride * sample_rate)
@@ -136,7 +136,17 @@ class LogFilterBankFrontend(nn.Module):
 		with torch.no_grad():
 			self.mel.weight.copy_(basis.unsqueeze(-1))
 			self.mel.bias.fill_(eps)
+		# stft_mode = 'conv' (models.py:548-561): the reference evaluates the same STFT as a strided Conv1d with the windowed DFT basis (an
+		# ONNX-friendly formulation).  Here both modes run the fused FFT kernel -- the two are the same linear map -- and the basis is kept
+		# only as a parameter container, so that a checkpoint saved with the conv formulation ('frontend.stft.weight') loads unchanged.
 		self.stft = None
+		if self.stft_mode == 'conv':
+			basis_ri = torch.view_as_real(torch.fft.fft(torch.eye(self.nfft), dim = 1))[:self.freq_cutoff].permute(2, 0, 1).reshape(-1, 1, self.nfft)
+			left = (self.nfft - self.win_length) // 2
+			centred = torch.nn.functional.pad(self.window, (left, self.nfft - self.win_length - left))  # librosa.util.pad_center
+			self.stft = nn.Conv1d(1, basis_ri.shape[0], self.nfft, bias = False, stride = self.hop_length).requires_grad_(False)
+			with torch.no_grad():
+				self.stft.weight.copy_(basis_ri * centred)
 
 	def forward(self, signal, mask = None, xlen = None, **kwargs):
 		assert signal.ndim == 2
@@ -193,8 +203,9 @@ class ResidualActivation(nn.Module):
 
 	def __init__(self, nonlinearity, dropout = 0, invertible = False):
 		super().__init__()
-		if invertible:
-			raise _lib.ConvasrHipError('in-place invertible activations (the *Inplace configs) are a memory trick of the reference, not needed with 288 GB of HBM')
+		# invertible = True (the *Inplace configs, models.py:357-400): the reference recomputes the activation's input from its output to save
+		# memory; the VALUES are act(y + sum residuals) followed by dropout either way, which is what the fused kernels compute -- with
+		# 288 GB of HBM there is nothing to save, so the flag only records the configuration
 		self.nonlinearity, self.dropout, self.invertible = nonlinearity, dropout, invertible
 
 	def extra_repr(self):
@@ -206,8 +217,8 @@ class ConvBn1d(nn.Module):
 
 	def __init__(self, num_channels, kernel_size, stride = 1, dropout = 0, groups = 1, num_channels_residual: typing.List = [], repeat = 1, dilation = 1, separable = False, temporal_mask = True, nonlinearity = ('relu', ), nonlinearity_reference = True, batch_norm_momentum = 0.1, inplace = False):
 		super().__init__()
-		if inplace:
-			raise _lib.ConvasrHipError('inplace=True (InplaceBatchNorm1d) is a memory trick of the reference and is not implemented')
+		# inplace = True: the reference swaps in InplaceBatchNorm1d (models.py:402-433: the same statistics, affine map, parameters and
+		# state-dict keys, computed in place) and the invertible activation; same values, see ResidualActivation
 		self.conv = nn.ModuleList(ConvSamePadding(num_channels[0] if i == 0 else num_channels[1], num_channels[1], kernel_size = kernel_size, stride = stride, dilation = dilation, separable = separable, bias = False, groups = groups) for i in range(repeat))
 		self.bn = nn.ModuleList(nn.BatchNorm1d(num_channels[1], momentum = batch_norm_momentum) for i in range(repeat))
 		self.conv_residual = nn.ModuleList(nn.Identity() if c is None else nn.Conv1d(c, num_channels[1], kernel_size = 1) for c in num_channels_residual)
@@ -469,6 +480,21 @@ class JasperNetResidualBig(JasperNet):
 		super().__init__(*args, num_subblocks = 2, temporal_mask = False, residual = True, **kwargs)
 
 
+class JasperNetBigInplace(JasperNet):
+	"""models.py:1432-1442."""
+
+	def __init__(self, *args, **kwargs):
+		inplace = kwargs.pop('inplace', True)
+		super().__init__(*args, num_subblocks = 2, temporal_mask = False, inplace = inplace, nonlinearity = ('leaky_relu', 0.01), **kwargs)
+
+
+class Wav2LetterDenseNoDilationInplace(JasperNet):
+	"""models.py:1054-1094: dense residuals, leaky-relu, no dilation in the epilogue, 5 blocks, the in-place memory tricks."""
+
+	def __init__(self, num_input_features, num_classes, dropout = 0.2, base_width = 128, nonlinearity = ('leaky_relu', 0.01), kernel_size_prologue = 11, kernel_size_epilogue = 29, kernel_sizes = [11, 13, 17, 21, 25], dilation = 1, num_blocks = 5, decoder_type = None, normalize_features = True, frontend = None, **kwargs):
+		super().__init__(num_input_features, num_classes, base_width = base_width, inplace = True, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue, kernel_sizes = [kernel_size_prologue] * num_blocks, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], residual = 'dense', dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend, **kwargs)
+
+
 # ------------------------------------------------------------------------------------------------ wrappers (models.py:736-765)
 
 AMP_DTYPE = {'fp16': torch.float16, 'float16': torch.float16, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}[__import__('os').environ.get('CONVASR_AMP_DTYPE', 'fp16')]  # what apex's O1-O3 mean here
@@ -497,8 +523,10 @@ def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, op
 def distributed_data_parallel_and_autocast(model, local_rank, optimizer = None, opt_level = None, synchronize_bn = False, **kwargs):
 	"""models.py:755-765: one process per GPU; gradients are all-reduced over RCCL by convasr_amd.parallel.DataParallelEngine."""
 	from .parallel import DataParallelEngine
-	if synchronize_bn:
-		raise _lib.ConvasrHipError('synchronize_bn: the reference trains with per-GPU batch-norm statistics (train.py:704); SyncBatchNorm is not implemented')
+	if synchronize_bn and model.training:
+		# (the reference passes synchronize_bn on its evaluation path only, train.py:556-561, where SyncBatchNorm normalises with the
+		# running statistics exactly like BatchNorm1d: nothing to convert; its training path, train.py:704, does not pass it)
+		raise _lib.ConvasrHipError('synchronize_bn in training mode: the reference trains with per-GPU batch-norm statistics (train.py:704); cross-GPU batch statistics are not implemented')
 	model, optimizer = data_parallel_and_autocast(model, optimizer, opt_level = opt_level, **kwargs)
 	training = model.training
 	engine = DataParallelEngine(model, device = torch.device('cuda', local_rank))

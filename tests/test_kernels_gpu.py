@@ -782,7 +782,10 @@ def test_stored_gradient_gates_equal_the_rederived_ones(act):
 		s0, s1 = ops.ConvStats(C, B, T, d), ops.ConvStats(C, B, T, d)
 		dx0 = ops.conv1d_dgrad_bn_reduce(dyc, wd, C, K, 1, K - 1 - K // 2, y, scale, shift, mean, invstd, a, p_drop, 5, 11, xlen, s0)
 		dx1 = ops.conv1d_dgrad_bn_reduce(dyc, wd, C, K, 1, K - 1 - K // 2, y, scale, shift, mean, invstd, a, p_drop, 5, 11, xlen, s1, gate = gate)
-		assert dx0 is not None and torch.equal(dx0, dx1) and s0.rows == s1.rows and torch.equal(s0.totals(), s1.totals())
+		assert dx0 is not None and torch.equal(dx0, dx1) and s0.rows == s1.rows
+		# the two forms of the fused epilogue sum the same g (vector ALU, per-thread partial sums / matrix pipe, one fp32 chain per tile)
+		close(s1.totals()[:C], s0.totals()[:C], 1e-5, 1e-3, 'fused epilogue, sum g: matrix-pipe form vs vector-ALU form')
+		close(s1.totals()[C:], s0.totals()[C:], 1e-5, 3e-3, 'fused epilogue, sum g xhat: matrix-pipe form vs vector-ALU form')
 		# separate reduce pass (the unfused form): coefficients and parameter gradients from the bits against the re-derived ones
 		# (same g per element; the gated kernel sums g y and centres once per block, the other sums g xhat per element: fp32 rounding apart)
 		gamma = torch.rand(C, device = d) + 0.5
@@ -796,7 +799,11 @@ def test_stored_gradient_gates_equal_the_rederived_ones(act):
 
 
 @gpu
-def test_training_step_is_bitwise_the_same_with_and_without_stored_gates():
+def test_training_step_is_the_same_with_and_without_stored_gates():
+	"""Stored gates against re-derived ones over a whole bf16 training step.  The forward pass is bit-identical; in the backward pass the
+	fused dgrad epilogue sums g and g y on the matrix pipe when it has the gates (conv_v2s.hip, form 2) and on the vector ALU when it
+	re-derives them: the same per-element g (bitwise, test above), fp32 sums in a different order, so the batch-norm coefficients
+	agree to ~1e-6 and a few bf16 roundings of dy flip downstream: gradients agree to 2 % of their largest entry, cosine > 0.999."""
 	from convasr_amd import models, functional as Fn
 	d = dev()
 
@@ -818,7 +825,10 @@ def test_training_step_is_bitwise_the_same_with_and_without_stored_gates():
 
 	l1, g1 = run(True)
 	l0, g0 = run(False)
-	assert torch.equal(l1, l0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+	assert torch.equal(l1, l0)
+	for a, b in zip(g1, g0):
+		a, b = a.double().flatten(), b.double().flatten()
+		assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-12 and (float(b.norm()) == 0 or float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.999)
 
 
 @gpu

@@ -255,3 +255,57 @@ def test_prepacked_dgrad_weights_leave_training_bitwise_unchanged():
 		finally:
 			Fn.PREPACK = prev
 	assert torch.equal(finals[0], finals[1])
+
+
+def test_stft_conv_mode_frontend_matches_the_reference_and_loads_its_checkpoint():
+	"""LogFilterBankFrontend(stft_mode = 'conv') (models.py:548-561): the reference's state dict -- with the windowed DFT basis as
+	`stft.weight` -- loads with no missing or unexpected key, the basis built here equals the reference's, and the features of the
+	fused FFT kernel equal the reference's conv-formulation features (tests/golden/make_golden_r3.py) within the frontend tolerance."""
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'frontend_conv.npz'))
+	d = torch.device('cuda:0')
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window', stft_mode = 'conv')
+	ref_sd = {k[3:]: T_(g[k]) for k in g.files if k.startswith('sd/')}
+	assert set(ref_sd) == set(fe.state_dict()) and 'stft.weight' in ref_sd
+	close(fe.stft.weight, ref_sd['stft.weight'], 1e-6, 1e-6, 'windowed DFT basis')
+	res = fe.load_state_dict(ref_sd)
+	assert not res.missing_keys and not res.unexpected_keys
+	fe.to(d)
+	sig, lens = T_(g['signal']).to(d), T_(g['lens']).to(d)
+	feat = fe(sig, mask = ca.models.temporal_mask(sig, lens))
+	close(feat, g['feat'], 5e-4, 5e-4, 'features: FFT kernel vs the conv formulation')
+
+
+def test_inplace_configs_compute_the_plain_values():
+	"""inplace = True (InplaceBatchNorm1d + the invertible activation, models.py:357-433; the configs JasperNetBigInplace and
+	Wav2LetterDenseNoDilationInplace): a memory trick of the reference -- same statistics, same affine map, act(y + residuals) then
+	dropout.  A dense-residual leaky-relu net built with inplace = True against the oracle's plain restatement: logits, loss, gradients;
+	the state-dict keys equal those of the same net without the flag (InplaceBatchNorm1d subclasses nn.BatchNorm1d)."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	torch.manual_seed(5)
+	kw = dict(base_width = 32, kernel_sizes = [11, 13], out_width_factors = [2, 2], dropouts = [0.2, 0.2], out_width_factors_large = [2, 2], residual = 'dense', repeat = 2, num_subblocks = 1, check_time_dim_padded = False, nonlinearity = ('leaky_relu', 0.01), dropout = 0, temporal_mask = False)
+	model = ca.models.JasperNet(64, [38], inplace = True, **kw)
+	assert list(model.state_dict()) == list(ca.models.JasperNet(64, [38], **kw).state_dict()) and model.backbone[1].activation.invertible
+	sd = {k: v.clone() for k, v in model.state_dict().items()}
+	g = torch.Generator().manual_seed(3)
+	x = torch.randn(3, 64, 121, generator = g)
+	xlen = torch.tensor([1.0, 0.7, 0.85])
+	y = torch.randint(0, 37, (3, 1, 10), generator = g)
+	ylen = torch.tensor([[10], [6], [8]])
+	plan = O.jasper_plan(64, [38], **{k: v for k, v in kw.items() if k not in ('check_time_dim_padded', 'dropout', 'dropouts')})
+	ref = O.train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 0.0, momentum = 0.0, weight_decay = 0.0, max_norm = 1e30)
+	model.to(d).train()
+	flat = ca.train.FlatParameters(model)
+	out = model(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
+	(out['loss'] * ylen.to(d)[:, 0]).mean().backward()
+	flat.finalize_grads()
+	close(out['logits'][0], ref['logits'], 1e-3, 1e-4, 'logits')
+	close(out['loss'], ref['loss_vec'], 1e-4, 1e-5, 'loss')
+	params = dict(model.named_parameters())
+	for k in ['backbone.0.conv.0.0.weight', 'backbone.1.conv_residual.0.weight', 'backbone.2.bn.1.weight', 'decoder.0.bias']:
+		r = ref['grads'][k]
+		close(params[k].grad, r, 5e-3, 5e-3 * float(r.abs().max()) + 1e-7, 'grad ' + k)
+	assert ca.models.JasperNetBigInplace(64, [38]).backbone[3].activation.nonlinearity == ('leaky_relu', 0.01)
+	with pytest.raises(ca._lib.ConvasrHipError):
+		ca.models.distributed_data_parallel_and_autocast(model, 0, synchronize_bn = True)  # training mode: cross-GPU statistics are not implemented (the reference's training path does not ask for them)
