@@ -14,7 +14,7 @@ FE = dict(nfft = 512, hop_length = 160)
 STORAGE = dict(bf16 = torch.bfloat16, f16 = torch.float16)
 # per-layer bounds (relative L2 against the oracle's restatement with the same storage type, same inputs on both sides), measured numbers
 # in profiles/r03_*_per_layer.json: an output that flips a rounding moves by one ulp (2^-8 bf16, 2^-11 fp16)
-LAYER_BOUNDS = dict(bf16 = dict(z = 2e-4, dw = 1e-3, dbeta = 5e-4, dgamma = 5e-4, dx = 4e-3), f16 = dict(z = 2e-4, dw = 1e-3, dbeta = 5e-4, dgamma = 5e-4, dx = 4e-3))
+LAYER_BOUNDS = dict(bf16 = dict(z = 2e-4, dw = 1e-3, dbeta = 5e-4, dgamma = 5e-4, dx = 4e-3), f16 = dict(z = 8e-5, dw = 4e-4, dbeta = 1e-4, dgamma = 1e-4, dx = 1.5e-3))  # measured maxima: bf16 7.9e-5 / 4.8e-4 / 8.6e-5 / 5e-6 / 2.3e-3, fp16 2.9e-5 / 1.7e-4 / 2.7e-5 / 1.6e-6 / 7.4e-4
 
 
 def _dump(name, obj):
