@@ -34,6 +34,10 @@ _SIGNATURES = dict(
 	convasr_fold2_unfold_wgrad = (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_conv1d_fwd = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_p, c_p]),
 	convasr_conv_stats_max_rows = (c_int, [c_int, c_int]),
+	convasr_grouped_conv1d_fwd = (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_grouped_conv1d_dgrad = (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_grouped_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int]),
+	convasr_grouped_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_reduce_rows = (c_int, [c_p, c_int, c_int, c_p, c_p]),
 	convasr_debug_set_conv_v2 = (c_int, [c_int]),
 	convasr_conv1d_wgrad_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -570,6 +570,32 @@ class ConvBiasFunction(torch.autograd.Function):
 		return None, dx, dw, db
 
 
+class GroupedConvReluFunction(torch.autograd.Function):
+	"""The first half of the reference's separable block (models.py:50-64): nn.Conv1d(Cin, Cout, K, groups = G) with its bias, then ReLU;
+	the 1x1 conv that follows is an ordinary ConvBn1d repeat.  apply(cfg, x, weight, bias), cfg: dict(spec, groups, compute_dtype)."""
+
+	@staticmethod
+	def forward(ctx, cfg, x, weight, bias):
+		spec, dt = cfg['spec'], cfg['compute_dtype']
+		_take_link(x)  # (no cross-layer fusion through a grouped conv: a producer's link, if any, is dropped and that layer reduces on its own)
+		x = ops.as_cl(x, dt)
+		y = ops.grouped_conv1d(x, weight.detach(), None if bias is None else bias.detach(), cfg['groups'], spec.stride, spec.padding, relu = True)
+		ctx.cfg, ctx.params = cfg, (weight, bias)
+		ctx.save_for_backward(x, y)
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		cfg = ctx.cfg
+		spec, dt, groups = cfg['spec'], cfg['compute_dtype'], cfg['groups']
+		weight, bias = ctx.params
+		x, y = ctx.saved_tensors
+		dy = ops.as_cl(dy, dt)
+		dx = ops.grouped_conv1d_dgrad(dy, y, weight.detach(), x.shape[1], x.shape[2], groups, spec.stride, spec.padding) if ctx.needs_input_grad[1] else None
+		dw, db = _deliver([weight, bias], lambda outs, acc: ops.grouped_conv1d_wgrad(x, dy, y, outs[0], outs[1], groups, spec.stride, spec.padding, accumulate = acc))
+		return None, dx, dw, db
+
+
 class ConvBnActEvalFunction:
 	"""Inference path (BN folded into the conv epilogue's scale/shift, or a fused bias after fuse_conv_bn_eval): no graph."""
 

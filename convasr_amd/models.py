@@ -189,9 +189,19 @@ class ConvSamePadding(nn.Sequential):
 	"""models.py:47-77: parameter container; padding = dilation * kernel_size // 2."""
 
 	def __init__(self, in_channels, out_channels, kernel_size, stride, dilation, bias, groups, separable):
-		if separable or groups != 1:
-			raise _lib.ConvasrHipError('separable / grouped convolutions (JasperNetSeparable) are outside the hot path implemented here')
-		super().__init__(nn.Conv1d(in_channels, out_channels, kernel_size = kernel_size, stride = stride, padding = dilation * kernel_size // 2, dilation = dilation, groups = groups, bias = bias))
+		padding = dilation * kernel_size // 2
+		if separable:
+			# models.py:50-64: grouped conv (with its default bias) -> ReLU -> 1x1 conv; index 0 runs in csrc/grouped.hip, index 2 in the MFMA kernels
+			assert dilation == 1
+			super().__init__(nn.Conv1d(in_channels, out_channels, kernel_size = kernel_size, stride = stride, padding = padding, dilation = dilation, groups = groups), nn.ReLU(inplace = True), nn.Conv1d(out_channels, out_channels, kernel_size = 1, bias = bias))
+		elif groups != 1:
+			raise _lib.ConvasrHipError('grouped convolutions outside the separable block (models.py:50-64) are not implemented')
+		else:
+			super().__init__(nn.Conv1d(in_channels, out_channels, kernel_size = kernel_size, stride = stride, padding = padding, dilation = dilation, groups = groups, bias = bias))
+
+	@property
+	def separable(self):
+		return len(self) == 3
 
 
 def _spec_of(conv):
@@ -242,6 +252,9 @@ class ConvBn1d(nn.Module):
 				assert len(self.conv_residual) == len(self.bn_residual) == len(residual)
 			cfg = self._cfg(i, last)
 			conv, bn = self.conv[i][-1], self.bn[i]
+			if self.conv[i].separable:  # grouped conv + bias + ReLU first; what follows is this repeat with its 1x1 conv
+				g = self.conv[i][0]
+				x = Fn.GroupedConvReluFunction.apply(dict(spec = _spec_of(g), groups = g.groups, compute_dtype = self.compute_dtype), x, g.weight, g.bias)
 			bn_live = isinstance(bn, nn.BatchNorm1d)
 			if bn_live and bn.training:
 				flat = []
@@ -478,6 +491,13 @@ class JasperNetBigBpeOnly(JasperNet):
 class JasperNetResidualBig(JasperNet):
 	def __init__(self, *args, **kwargs):
 		super().__init__(*args, num_subblocks = 2, temporal_mask = False, residual = True, **kwargs)
+
+
+class JasperNetSeparable(JasperNet):
+	"""models.py:1372-1374."""
+
+	def __init__(self, *args, separable = True, groups = 128, **kwargs):
+		super().__init__(*args, separable = separable, groups = groups, **kwargs)
 
 
 class JasperNetBigInplace(JasperNet):

@@ -268,6 +268,37 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 	return dw
 
 
+# ------------------------------------------------------------------------------------------------ grouped conv (the separable block's first half)
+
+def grouped_conv1d(x, w, bias, groups, stride = 1, pad = 0, relu = True):
+	"""nn.Conv1d(Cin, Cout, K, groups = G) + bias (+ ReLU) on a channels-last activation; w: fp32 (Cout, Cin / G, K) of any strides."""
+	B, Cin, Tin = x.shape
+	Cout, cgi, K = w.shape
+	assert is_cl(x) and w.dtype == torch.float32 and cgi * groups == Cin
+	Tout = conv_out_len(Tin, K, stride, 1, pad)
+	y = empty_cl(B, Cout, Tout, x.dtype, x.device)
+	call('convasr_grouped_conv1d_fwd', ptr(x), ptr(w), w.stride(0), w.stride(1), w.stride(2), ptr(bias), ptr(y), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, pad, groups, int(relu), stream_ptr())
+	return y
+
+
+def grouped_conv1d_dgrad(dy, y_act, w, Cin, Tin, groups, stride = 1, pad = 0):
+	B, Cout, Tout = dy.shape
+	K = w.shape[2]
+	assert is_cl(dy) and (y_act is None or (is_cl(y_act) and y_act.dtype == dy.dtype))
+	dx = empty_cl(B, Cin, Tin, dy.dtype, dy.device)
+	call('convasr_grouped_conv1d_dgrad', ptr(dy), ptr(y_act), ptr(w), w.stride(0), w.stride(1), w.stride(2), ptr(dx), dtype_code(dy.dtype), B, Cin, Cout, Tin, Tout, K, stride, pad, groups, stream_ptr())
+	return dx
+
+
+def grouped_conv1d_wgrad(x, dy, y_act, dw, dbias, groups, stride = 1, pad = 0, accumulate = False):
+	B, Cin, Tin = x.shape
+	Cout, Tout, K = dy.shape[1], dy.shape[2], dw.shape[2]
+	assert is_cl(x) and is_cl(dy) and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin // groups, K)
+	ws = workspace(_lib.load().convasr_grouped_conv1d_wgrad_workspace_bytes(B, Cin, Cout, K, groups), x.device, 'grouped_wgrad')
+	call('convasr_grouped_conv1d_wgrad', ptr(x), ptr(dy), ptr(y_act), ptr(dw), dw.stride(0), dw.stride(1), dw.stride(2), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, pad, groups, int(accumulate), stream_ptr())
+	return dw
+
+
 # ------------------------------------------------------------------------------------------------ batch norm + activation
 
 def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked = None):

@@ -134,6 +134,24 @@ int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias,
                          int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil, int pad,
                          int accumulate, int dw_layout, void* stream);
 
+/* ---- grouped Conv1d: models.py:50-64 (ConvSamePadding(separable = True): nn.Conv1d(Cin, Cout, K, groups = G) -> ReLU -> 1x1 conv), ---------
+ * ---- JasperNetSeparable (models.py:1372-1374, G = 128).  The 1x1 half is convasr_conv1d_*; this is the grouped half. ------------------ */
+
+/* y[b,t,co] = act(bias[co] + sum_k sum_{j < Cin/G} x[b, t stride + k - pad, (co / (Cout/G)) Cin/G + j] w[co][j][k]); relu != 0: act = ReLU.
+ * x, y channels-last (B, T, C) of `dtype` (F32 / BF16 / F16); w the fp32 (Cout, Cin / G, K) parameter with element strides
+ * (w_sco, w_sj, w_sk) -- torch-contiguous or the training arena's tap-major view; at most 8 channels per group on either side. */
+int convasr_grouped_conv1d_fwd(const void* x, const float* w, int64_t w_sco, int64_t w_sj, int64_t w_sk, const float* bias, void* y, int dtype,
+                               int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int pad, int groups, int relu, void* stream);
+/* dx = input gradient (stride 1 only); y_act (may be NULL): the forward's post-ReLU output -- the gradient passes where it is > 0. */
+int convasr_grouped_conv1d_dgrad(const void* dy, const void* y_act, const float* w, int64_t w_sco, int64_t w_sj, int64_t w_sk, void* dx, int dtype,
+                                 int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int pad, int groups, void* stream);
+/* dw (+)= weight gradient (same strides as w), dbias (may be NULL) (+)= sum of the gated dy; per-utterance partial sums go through
+ * `workspace` and are added in a fixed order (no atomics). */
+int64_t convasr_grouped_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int K, int groups);
+int convasr_grouped_conv1d_wgrad(const void* x, const void* dy, const void* y_act, float* dw, int64_t w_sco, int64_t w_sj, int64_t w_sk, float* dbias,
+                                 void* workspace, int dtype, int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int pad, int groups,
+                                 int accumulate, void* stream);
+
 /* ---- BatchNorm1d + ResidualActivation + temporal mask: models.py:111-114, 127-139, 357-371, 436-443 ----------- */
 
 /* From the conv epilogue's stats (sum, sumsq over n = B*T values per channel): batch mean / biased var ->

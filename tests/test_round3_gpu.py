@@ -25,7 +25,7 @@ def _dump(name, obj):
 
 
 def close(a, b, rtol, atol, what = ''):
-	a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
+	a, b = a.detach().double().cpu(), (b.detach().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b))).double()
 	assert a.shape == b.shape, (what, a.shape, b.shape)
 	err = (a - b).abs()
 	tol = atol + rtol * b.abs()
@@ -309,3 +309,75 @@ def test_inplace_configs_compute_the_plain_values():
 	assert ca.models.JasperNetBigInplace(64, [38]).backbone[3].activation.nonlinearity == ('leaky_relu', 0.01)
 	with pytest.raises(ca._lib.ConvasrHipError):
 		ca.models.distributed_data_parallel_and_autocast(model, 0, synchronize_bn = True)  # training mode: cross-GPU statistics are not implemented (the reference's training path does not ask for them)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('case', [(3, 64, 64, 141, 11, 16, 1), (2, 256, 384, 97, 13, 128, 1), (2, 128, 128, 50, 25, 32, 1), (2, 64, 128, 61, 5, 16, 2)])
+def test_grouped_conv1d_kernels_vs_torch(case, dtype):
+	"""csrc/grouped.hip (the grouped half of the separable block, models.py:50-64): forward with bias + ReLU, input gradient through the
+	ReLU, weight / bias gradients against torch's grouped F.conv1d on the CPU, reference-layout and tap-major (training arena) weights."""
+	from convasr_amd import ops
+	B, Cin, Cout, T, K, G, stride = case
+	d = torch.device('cuda:0')
+	torch.manual_seed(sum(case))
+	dt = dict(f32 = torch.float32, bf16 = torch.bfloat16, f16 = torch.float16)[dtype]
+	x = torch.randn(B, Cin, T).to(dt).float().requires_grad_(True)
+	w = (torch.randn(Cout, Cin // G, K) / (Cin // G * K) ** 0.5).requires_grad_(True)
+	bias = torch.randn(Cout).requires_grad_(True)
+	pad = K // 2
+	y = torch.nn.functional.conv1d(x, w, bias, stride = stride, padding = pad, groups = G).relu()
+	dy = torch.randn_like(y).to(dt).float()
+	y.backward(dy)
+	rt, at = dict(f32 = (1e-4, 2e-5), bf16 = (4e-3, 5e-5), f16 = (6e-4, 5e-5))[dtype]
+	for kmajor in (False, True):
+		wd = w.detach().to(d)
+		if kmajor:  # (Cout, cgi, K) view of [K][Cout][cgi] memory, like FlatParameters keeps conv weights
+			wd = wd.permute(2, 0, 1).contiguous().permute(1, 2, 0)
+		xd, dyd = ops.as_cl(x.detach().to(d), dt), ops.as_cl(dy.to(d), dt)
+		yd = ops.grouped_conv1d(xd, wd, bias.detach().to(d), G, stride, pad, relu = True)
+		close(yd.float(), y, rt, at, 'forward')
+		dw = torch.full_like(wd, 7.0)
+		db = torch.full((Cout, ), 7.0, device = d)
+		ops.grouped_conv1d_wgrad(xd, dyd, yd, dw, db, G, stride, pad)
+		# (the ReLU gate comes from the stored 16-bit output: identical to the fp32 reference's except where |pre-activation| < one rounding)
+		close(dw, w.grad, 2e-3, 2e-3 * float(w.grad.abs().max()), 'wgrad')
+		close(db, bias.grad, 2e-3, 2e-3 * float(bias.grad.abs().max()), 'dbias')
+		ops.grouped_conv1d_wgrad(xd, dyd, yd, dw, db, G, stride, pad, accumulate = True)
+		close(dw, 2 * w.grad, 2e-3, 4e-3 * float(w.grad.abs().max()), 'wgrad accumulate')
+		if stride == 1:
+			dx = ops.grouped_conv1d_dgrad(dyd, yd, wd, Cin, T, G, stride, pad)
+			close(dx.float(), x.grad, max(rt, 2e-3), 2e-3 * float(x.grad.abs().max()), 'dgrad')
+
+
+def test_separable_jaspernet_matches_the_reference():
+	"""JasperNet(separable = True) (models.py:50-64; JasperNetSeparable is this with 128 groups) against vectors from the reference
+	(tests/golden/make_golden_r3.py): the reference's state dict (grouped weight + bias at index 0, 1x1 weight at index 2) loads
+	unchanged; train-mode logits / loss / gradients, running statistics, and eval logits after fuse_conv_bn_eval."""
+	import convasr_amd as ca
+	g = np.load(os.path.join(GOLDEN, 'separable.npz'))
+	d = torch.device('cuda:0')
+	kw = dict(base_width = 32, kernel_sizes = [11, 13], out_width_factors = [2, 3], dropouts = [0.2, 0.2], out_width_factors_large = [4, 4], residual = True, repeat = 2, num_subblocks = 1, check_time_dim_padded = False, dropout = 0, separable = True, groups = 16)
+	model = ca.models.JasperNet(64, [38], **kw)
+	sd = {k[3:]: T_(g[k]) for k in g.files if k.startswith('sd/')}
+	assert list(sd) == list(model.state_dict())
+	model.load_state_dict(sd)
+	model.to(d).train()
+	flat = ca.train.FlatParameters(model)
+	x, xlen, y, ylen = (T_(g[k]).to(d) for k in ('x', 'xlen', 'y', 'ylen'))
+	out = model(x, xlen, y = y, ylen = ylen)
+	close(out['logits'][0], g['logits'], 1e-3, 1e-4, 'logits')
+	close(out['loss'], g['loss'], 1e-4, 1e-5, 'loss')
+	(out['loss'] * ylen[:, 0]).mean().backward()
+	flat.finalize_grads()
+	params = dict(model.named_parameters())
+	for k in [n[5:] for n in g.files if n.startswith('grad/')]:
+		ref = g['grad/' + k]
+		close(params[k].grad, ref, 5e-3, 5e-3 * float(np.abs(ref).max()) + 1e-7, 'grad ' + k)
+	for k in [n[9:] for n in g.files if n.startswith('sd_after/')]:
+		close(model.state_dict()[k], g['sd_after/' + k], 1e-3, 1e-5, k)
+	model.eval()
+	model.fuse_conv_bn_eval()
+	with torch.no_grad():
+		ev = model(x, xlen)
+	close(ev['logits'][0], g['eval_logits'], 1e-3, 1e-3, 'eval logits after fuse_conv_bn_eval')
+	assert sum(p.numel() for p in ca.models.JasperNetSeparable(64, [38]).parameters()) > 0
