@@ -112,13 +112,28 @@ def throughput(model, device, B, secs, iters):
 			model(x, xlen)
 		torch.cuda.synchronize()
 	dt = (time.perf_counter() - t0) / iters
-	return dict(metric = 'offline inference throughput, fused eval path', unit = 'audio-seconds/sec', value = round(B * secs / dt, 1), ms_per_batch = round(dt * 1e3, 3), batch = [B, SAMPLE_RATE * secs])
+	# roofline of the dominant kernel, HIP events on the launching stream around every launch of it (a second pass of the same batches:
+	# an event pair costs ~5 us of stream time); FLOPs = 2 MAC of every forward conv it runs (6.67 GFLOP per audio-second
+	# for Wav2Letter full, of which the 38-class decoder's 3.75 GFLOP per batch are memory-bound and booked apart)
+	from convasr_amd import _lib
+	_lib.timer = _lib.KernelTimer(only = ['conv1d_igemm_v2s_kernel<bf16>'])
+	with torch.no_grad():
+		for _ in range(iters):
+			model(x, xlen)
+		torch.cuda.synchronize()
+	k = _lib.timer.summary().get('conv1d_igemm_v2s_kernel<bf16>')
+	_lib.timer = None
+	roof = None
+	if k is not None:
+		tf = k['work'] / (k['total_ms'] * 1e-3) / 1e12
+		roof = dict(bound = 'mfma', kernel = 'conv1d_igemm_v2s_kernel<H, H, 0> (the 18 forward convs per batch, BN folded: bias + activation + mask in the epilogue)', achieved = round(tf, 1), peak = 2500.0, unit = 'TFLOP/s', frac = round(tf / 2500.0, 4), launches_per_batch = k['launches'] // iters, ms_per_batch = round(k['total_ms'] / iters, 3), whole_batch_frac = round(6.67e9 * B * secs / dt / 2.5e15, 4), timing = f'HIP events around every launch of this kernel, {iters} batches right after the timed region')
+	return dict(metric = 'offline inference throughput, fused eval path', unit = 'audio-seconds/sec', value = round(B * secs / dt, 1), ms_per_batch = round(dt * 1e3, 3), batch = [B, SAMPLE_RATE * secs], roofline = roof)
 
 
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--model', default = 'Wav2Letter')
-	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f32'])
+	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f16', 'f32'])
 	ap.add_argument('-B', type = int, default = 1)
 	ap.add_argument('-T', type = float, default = 6.0)
 	ap.add_argument('--rps', type = float, default = 60)
@@ -130,7 +145,7 @@ def main():
 	device = torch.device('cuda', 0)
 	torch.cuda.set_device(device)
 	torch.manual_seed(1)
-	dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+	dtype = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32)[args.dtype]
 	model = build_model(args.model, device, dtype)
 	common = dict(model = args.model, dtype = args.dtype, data = 'synthetic', weights = 'random init')
 	if not args.no_throughput:

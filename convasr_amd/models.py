@@ -168,8 +168,10 @@ class MaskedInstanceNorm1d(nn.InstanceNorm1d):
 	def __init__(self, *args, temporal_mask = False, legacy = True, **kwargs):
 		super().__init__(*args, **kwargs)
 		self.temporal_mask, self.legacy = temporal_mask, legacy
-		if self.affine or self.track_running_stats or not legacy:
-			raise _lib.ConvasrHipError('MaskedInstanceNorm1d: only the affine=False, track_running_stats=False, legacy=True form (Wav2Letter / JasperNet* defaults) is implemented')
+		# legacy = False hands the unmasked case to nn.InstanceNorm1d.forward (models.py:711): (x - mean) / sqrt(biased var + eps), the same
+		# expression the legacy branch spells out (models.py:704-710) -- one kernel serves both
+		if self.affine or self.track_running_stats:
+			raise _lib.ConvasrHipError('MaskedInstanceNorm1d: only the affine=False, track_running_stats=False form (Wav2Letter / JasperNet* defaults) is implemented')
 
 	def forward(self, x, mask = None, xlen = None, out_dtype = None, pad_time_to = 1):
 		_lib.require_cuda(x)

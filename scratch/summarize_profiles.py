@@ -26,10 +26,10 @@ with open(f'profiles/{tag}_bench_hbm_traffic.csv', 'w') as f:
 		out[k] = dict(dispatches = n, fetch_kb = fs, write_kb = ws, hbm_bytes_per_launch = hb)
 conv = {k: v for k, v in out.items() if 'conv1d' in k or 'wgrad' in k}
 # both instantiations of the dominant kernel together (what bench.py's roofline.traffic reports)
-both = [v for k, v in conv.items() if 'conv1d_igemm_v2s_kernel<unsigned short' in k]
+both = [v for k, v in conv.items() if 'conv1d_igemm_v2s_kernel<unsigned short, unsigned short' in k or 'conv1d_igemm_v2s_kernel<unsigned short, false' in k or 'conv1d_igemm_v2s_kernel<unsigned short, true' in k]
 if both:
 	n = sum(v['dispatches'] for v in both)
-	conv['conv1d_igemm_v2s_kernel<unsigned short, false / true> (all launches)'] = dict(dispatches = n, fetch_kb = sum(v['fetch_kb'] * v['dispatches'] for v in both) / n, write_kb = sum(v['write_kb'] * v['dispatches'] for v in both) / n, hbm_bytes_per_launch = sum(v['hbm_bytes_per_launch'] * v['dispatches'] for v in both) / n)
+	conv['conv1d_igemm_v2s_kernel<bf16 in, bf16 out> (all launches of both instantiations, incl. the memory-bound decoder dgrad)'] = dict(dispatches = n, fetch_kb = sum(v['fetch_kb'] * v['dispatches'] for v in both) / n, write_kb = sum(v['write_kb'] * v['dispatches'] for v in both) / n, hbm_bytes_per_launch = sum(v['hbm_bytes_per_launch'] * v['dispatches'] for v in both) / n)
 json.dump(conv, open(f'profiles/{tag}_conv_traffic.json', 'w'), indent = 1)
 # SQ counters + clocks of the MFMA kernels
 def pmc(dirname):
@@ -55,7 +55,7 @@ for k in sq:
 		e['avg_duration_us_under_pmc'] = round(d / 1e3, 1); e['effective_clock_ghz'] = round(g / 8 / d, 3); e['mfma_busy_over_simd_cycles'] = round(mf / (1024 * g / 8), 4)
 	summary[k] = e
 json.dump(dict(note = 'rocprofv3 --kernel-trace --pmc (8 SQ counters in one pass; GRBM_GUI_ACTIVE + SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES in a second) over bench.py --steps 2 --warmup 1; means per dispatch.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles; effective clock = GRBM_GUI_ACTIVE / 8 / duration; mfma_busy_over_simd_cycles = MFMA busy cycles / (1024 SIMDs x kernel cycles)', kernels = summary), open(f'profiles/{tag}_pmc_sq.json', 'w'), indent = 1)
-for name in ('bench_line', 'launcher_n1', 'rccl_world1', 'plain_n1'):
+for name in ('bench_line', 'bench_line_f16', 'launcher_n1', 'plain_n1'):
 	src = f'{G}/{tag}_{name}.json'
 	if os.path.exists(src) and os.path.getsize(src) > 0: shutil.copy(src, f'profiles/{tag}_{name}.json')
 tot = sum(float(r['TotalDurationNs']) for r in rows)
