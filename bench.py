@@ -32,7 +32,7 @@ SAMPLE_RATE, SECS, BATCH, TARGET_LEN = 16000, 15, 64, 150
 FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # conv stack, 2*MAC, fwd + dgrad + wgrad
 PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-MAIN_KERNEL_SYMBOLS = dict(bf16 = 'conv1d_igemm_v2s_kernel<unsigned short, unsigned short', f16 = 'conv1d_igemm_v2s_kernel<_Float16, _Float16')  # <H, H, false> (plain) and <H, H, true> (dgrad + fused BN-backward epilogue); NOT <H, float, false>, the decoder head
+MAIN_KERNEL_SYMBOLS = dict(bf16 = ('conv1d_igemm_v2s_kernel<unsigned short, unsigned short', 'conv1d_igemm_v2s_kernelIttLi'), f16 = ('conv1d_igemm_v2s_kernel<_Float16, _Float16', 'conv1d_igemm_v2s_kernel<__half, __half', 'conv1d_igemm_v2s_kernelIDF16_DF16_Li'))  # demangled or (where the profiler's demangler does not know _Float16) mangled;  # <H, H, false> (plain) and <H, H, true> (dgrad + fused BN-backward epilogue); NOT <H, float, false>, the decoder head
 
 
 def parse_args(argv = None):
@@ -183,10 +183,10 @@ def measure_traffic(args, sequence, steps):
 			files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive = True)
 			if r.returncode != 0 or not files:
 				return None, f'rocprofv3 --pmc {counter} failed (rc {r.returncode})'
-			rows = [row for row in csv.DictReader(open(files[0])) if symbol in row['Kernel_Name'] and row['Counter_Name'] == counter]
+			rows = [row for row in csv.DictReader(open(files[0])) if any(sym in row['Kernel_Name'] for sym in symbol) and row['Counter_Name'] == counter]
 			rows.sort(key = lambda row: int(row.get('Dispatch_Id', 0)))
 			if not rows:
-				return None, f'no {symbol} dispatch in the {counter} pass'
+				return None, f'no {symbol[0]} dispatch in the {counter} pass'
 			if per_step and len(rows) % len(per_step) == 0:
 				vals = [float(row['Counter_Value']) for i, row in enumerate(rows) if counted[i % len(per_step)]]
 				how = f'{sum(counted)} of the {len(per_step)} dispatches of the symbol per step (the launches roofline.achieved covers)'

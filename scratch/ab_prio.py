@@ -1,5 +1,6 @@
 """A/B of static wave priorities in the LDS-DMA conv kernel (diagnostic build -DCONVASR_AB_PRIO=1, CONVASR_HIP_LIB=...prio.so):
-debug bit 512 = computing waves 4-7 at priority 1, 1024 = all computing waves, 2048 = the loader waves."""
+debug bit 512 = computing waves 4-7 at priority 1, 1024 = all computing waves, 2048 = the loader waves.
+(The three s_setprio lines sat in front of conv_v2s.hip's main loop; they were removed after this measurement showed nothing: DESIGN.md 9.3.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
