@@ -53,13 +53,16 @@ class DataParallelEngine(nn.Module):
 			Fn.bump_param_epoch()  # the arena changed behind torch's version counters: packed compute copies are stale
 
 	def _make_buckets(self, bucket_bytes, first_bucket_bytes):
-		"""Contiguous arena ranges.  Backward completes them from the END of the arena towards its start, so the bucket at the start
-		(the prologue layers) is the one whose all-reduce nothing overlaps: it is kept small (first_bucket_bytes)."""
+		"""Contiguous arena ranges.  Backward completes them from the END of the arena towards its start, so the buckets at the start
+		(the first layers) are the ones whose all-reduce little or nothing overlaps: sizes are graded -- first_bucket_bytes, then doubling
+		per bucket up to bucket_bytes (4, 8, 16, 32, 64, 64, ... MiB by default) -- so that the exposed tail of the exchange is a few MiB
+		while the bulk of the arena, which completes early in the backward pass, goes in a few large collectives (xGMI is point-to-point:
+		large messages per link)."""
 		flat = self.flat
 		buckets, cur = [], None
 		for p, off in zip(flat.params, flat.offsets):
 			end = off + p.numel()
-			limit = first_bucket_bytes if len(buckets) <= 1 else bucket_bytes
+			limit = min(bucket_bytes, first_bucket_bytes << max(len(buckets) - 1, 0))  # the limit of the bucket being filled
 			if cur is None or (end - cur['lo']) * 4 > limit and cur['params']:
 				cur = dict(lo = off, hi = end, params = [])
 				buckets.append(cur)
