@@ -1,0 +1,115 @@
+"""Host-side logic that needs no GPU: optimizer state in reference shapes, the fp16 / bf16 mapping of the apex opt levels, the
+loss scaler's host interface, graded gradient buckets, the stride-2 fold's padding rule, the accepted configuration flags."""
+import os
+
+import pytest
+import torch
+
+import convasr_amd as ca
+from convasr_amd import functional as Fn
+from convasr_amd.functional import ConvSpec
+
+
+def _small():
+	torch.manual_seed(0)
+	return torch.nn.Sequential(torch.nn.Conv1d(8, 16, 3), torch.nn.BatchNorm1d(16), torch.nn.Conv1d(16, 4, 1))
+
+
+def test_optimizer_state_dicts_are_per_parameter_in_reference_shapes():
+	"""SGD / NovoGrad state dicts (format 2): momentum as one tensor per parameter in the parameter's logical shape -- independent of the
+	arena's element order -- and a round trip restores it; a flat arena-ordered buffer (the untagged pre-format-2 layout) is rejected
+	with a message instead of being loaded into the wrong elements."""
+	m = _small()
+	flat = ca.train.FlatParameters(m)
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9)
+	opt.momentum_buffer.copy_(torch.arange(flat.numel, dtype = torch.float32))
+	sd = opt.state_dict()
+	assert sd['format'] == 2 and [tuple(t.shape) for t in sd['momentum_buffer']] == [tuple(p.shape) for p in flat.params]
+	opt2 = ca.train.SGD(ca.train.FlatParameters(_small()), lr = 1e-2, momentum = 0.9)
+	opt2.load_state_dict(sd)
+	for a, b in zip(opt2.flat.param_views(opt2.momentum_buffer), sd['momentum_buffer']):
+		assert torch.equal(a, b)
+	with pytest.raises(ValueError, match = 'layout tag'):
+		opt2.load_state_dict(dict(sd, momentum_buffer = torch.zeros(flat.numel)))
+	with pytest.raises(ValueError, match = 'shape'):
+		opt2.load_state_dict(dict(sd, momentum_buffer = [t.flatten() for t in sd['momentum_buffer']]))
+	ng = ca.optimizers.NovoGrad(ca.train.FlatParameters(_small()), lr = 1e-2)
+	ng.momentum_buffer.normal_()
+	ng.grads_ema[0, :ng.n_seg] = torch.arange(ng.n_seg, dtype = torch.float32)
+	ng.grads_ema[0, ng.n_seg] = 3.0
+	nsd = ng.state_dict()
+	assert nsd['steps_applied'] == 3 and nsd['grads_ema'].numel() == ng.n_seg
+	ng2 = ca.optimizers.NovoGrad(ca.train.FlatParameters(_small()), lr = 1e-2)
+	ng2.load_state_dict(nsd)
+	assert torch.equal(ng2.grads_ema[0, :ng2.n_seg], ng.grads_ema[0, :ng.n_seg]) and float(ng2.grads_ema[0, ng2.n_seg]) == 3.0
+	assert all(torch.equal(a, b) for a, b in zip(ng2.flat.param_views(ng2.momentum_buffer), ng.flat.param_views(ng.momentum_buffer)))  # (the alignment padding between parameters is not state)
+	views = ng2.state
+	assert all(tuple(views[p]['momentum_buffer'].shape) == tuple(p.shape) for p in ng2.flat.params)
+	ng2.load_state_dict(dict(nsd, grads_ema = torch.cat([nsd['grads_ema'], torch.tensor([5.0])])))  # the earlier layout: counter behind the EMAs
+	assert float(ng2.grads_ema[0, ng2.n_seg]) == 5.0
+
+
+def test_opt_levels_select_fp16_like_apex_and_attach_a_loss_scaler():
+	model = ca.models.JasperNet(64, [38], base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.2], out_width_factors_large = [2, 2], residual = False, repeat = 1, check_time_dim_padded = False)
+	flat = ca.train.FlatParameters(model)
+	opt = ca.train.SGD(flat)
+	assert ca.train.amp_state_dict(opt) == {}
+	for level, dtype, scaler in ((None, torch.float32, False), ('O0', torch.float32, False), ('O1', torch.float16, True), ('O2', torch.float16, True), ('O3', torch.float16, False)):
+		ca.models.data_parallel_and_autocast(model, opt, opt_level = level)
+		assert model.compute_dtype == dtype and (flat.loss_scaler is not None) == scaler, level
+	ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2', compute_dtype = torch.bfloat16)
+	assert model.compute_dtype == torch.bfloat16 and flat.loss_scaler is None
+	ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2', loss_scale = 128.0, keep_batchnorm_fp32 = True)
+	assert flat.loss_scaler.state_dict() == dict(loss_scale = 128.0, unskipped = 0) and float(flat.loss_scaler.current[3]) == 0.0  # static: no growth window
+	ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2')
+	assert ca.train.amp_state_dict(opt) == dict(loss_scaler0 = dict(loss_scale = 65536.0, unskipped = 0))
+	ca.train.amp_load_state_dict(opt, dict(loss_scaler0 = dict(loss_scale = 1024.0, unskipped = 17)))
+	assert ca.train.amp_state_dict(opt) == dict(loss_scaler0 = dict(loss_scale = 1024.0, unskipped = 17))
+	s = flat.loss_scaler
+	a, b = s.pair()
+	assert a.data_ptr() == s.current.data_ptr() and b.data_ptr() != a.data_ptr()
+	s.advance()
+	assert s.current.data_ptr() == b.data_ptr()
+
+
+def test_gradient_buckets_are_graded_and_cover_the_arena():
+	model = ca.models.Wav2Letter(64, [38])
+	flat = ca.train.FlatParameters(model)
+	engine = ca.parallel.DataParallelEngine(model, flat = flat)
+	sizes = [(b['hi'] - b['lo']) * 4 / 2 ** 20 for b in engine.buckets]
+	assert sizes[0] <= 4.5 and sizes[1] <= 8.5 and sizes[2] <= 16.5 and len(sizes) >= 6  # MiB: small where backward finishes last
+	assert engine.buckets[0]['lo'] == 0 and all(a['hi'] <= b['lo'] for a, b in zip(engine.buckets, engine.buckets[1:]))
+	assert sum(len(b['params']) for b in engine.buckets) == len(flat.params)
+	assert engine.buckets[-1]['hi'] == flat.offsets[-1] + flat.params[-1].numel()
+
+
+def test_fold2_pads_only_when_the_conv_output_is_unchanged():
+	"""The zero frame in front of the stride-2 prologue (functional.Fold2.wants_even_input): only for an odd frame count, an odd kernel
+	(the output length must not change) and channel counts inside the fold's envelope."""
+	want = Fn.Fold2.wants_even_input
+	assert want((256, 64, 11), ConvSpec(11, 2, 1, 5), 1501)
+	assert not want((256, 64, 11), ConvSpec(11, 2, 1, 5), 1502)   # already even
+	assert not want((256, 64, 12), ConvSpec(12, 2, 1, 6), 1501)   # even kernel: one more output frame with the padded input
+	assert not want((256, 40, 11), ConvSpec(11, 2, 1, 5), 1501)   # 2 * Cin not a multiple of 128
+	assert not want((200, 64, 11), ConvSpec(11, 2, 1, 5), 1501)   # Cout not a multiple of 128
+	assert not want((256, 64, 11), ConvSpec(11, 1, 1, 5), 1501)   # not strided
+
+
+def test_accepted_configuration_flags_build_the_reference_state_dict_layout():
+	kw = dict(base_width = 32, kernel_sizes = [11, 13], out_width_factors = [2, 2], dropouts = [0.2, 0.2], out_width_factors_large = [2, 2], repeat = 2, num_subblocks = 1)
+	plain = ca.models.JasperNet(64, [38], **kw)
+	assert list(ca.models.JasperNet(64, [38], inplace = True, **kw).state_dict()) == list(plain.state_dict())
+	sep = ca.models.JasperNet(64, [38], separable = True, groups = 16, **kw)
+	keys = list(sep.state_dict())
+	assert 'backbone.1.conv.0.0.bias' in keys and 'backbone.1.conv.0.2.weight' in keys and tuple(sep.state_dict()['backbone.1.conv.0.0.weight'].shape) == (64, 4, 11)
+	assert 'backbone.0.conv.0.0.bias' not in keys  # the prologue is not separable (models.py:200-211)
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window', stft_mode = 'conv')
+	assert tuple(fe.state_dict()['stft.weight'].shape) == (514, 1, 512)
+	with pytest.raises(ValueError):
+		ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window', stft_mode = 'fft2')
+	norm = ca.models.MaskedInstanceNorm1d(64, affine = False, track_running_stats = False, legacy = False)
+	assert norm.legacy is False
+	bpe = ca.models.JasperNet(64, [38, 48], decoder_type = 'bpe', **kw)
+	assert any(k.startswith('decoder.1.1.bn.0') for k in bpe.state_dict())
+	for name in ('JasperNetSeparable', 'JasperNetBigInplace', 'Wav2LetterDenseNoDilationInplace', 'JasperNetLarge', 'Wav2Letter'):
+		assert hasattr(ca.models, name)
