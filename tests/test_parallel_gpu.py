@@ -114,3 +114,58 @@ def test_two_ranks_side_stream_wgrad_equals_single_stream_bitwise():
 	assert torch.equal(side[0]['params'], side[1]['params']), 'replicas diverged with the side stream on'
 	assert torch.equal(side[0]['params'], plain[0]['params']), float((side[0]['params'] - plain[0]['params']).abs().max())
 	assert side[0]['losses'] == plain[0]['losses']
+
+
+def _worker_fp16(rank, world, port, out_dir):
+	os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+	dist.init_process_group('gloo', rank = rank, world_size = world)
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	torch.cuda.set_device(d)
+	model = _make(ca, d)
+	flat = ca.train.FlatParameters(model)
+	model._convasr_flat = flat
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	engine, opt = ca.models.distributed_data_parallel_and_autocast(model, 0, opt, opt_level = 'O2')
+	assert isinstance(engine, ca.parallel.DataParallelEngine) and model.compute_dtype == torch.float16 and flat.loss_scaler is not None
+	flat.loss_scaler = ca.train.LossScaler(d, init_scale = 2.0 ** 20)
+	x, xlen, y, ylen = _batch(rank, d)
+	history = []
+	poison = [False]
+	launch = engine._launch
+
+	def launch_with_private_overflow(bi, events = ()):
+		# rank 1, iteration 6: ITS local gradient holds an inf (as if its own backward had overflowed fp16) just before bucket 0 is
+		# all-reduced -- the verdict is read from the all-reduced gradient, so BOTH ranks must skip that step
+		if poison[0] and bi == 0:
+			comm = engine._comm(d)
+			for ev in events:
+				comm.wait_event(ev)
+			with torch.cuda.stream(comm):
+				flat.grad[engine.buckets[0]['lo']:engine.buckets[0]['lo'] + 1].fill_(float('inf'))
+		return launch(bi, events)
+	engine._launch = launch_with_private_overflow
+	for it in range(10):
+		poison[0] = it == 6 and rank == 1
+		res = ca.train.train_step(engine, opt, x, xlen, y, ylen, world_size = world, iteration = it, sync_metrics = True)
+		history.append((flat.loss_scaler.state_dict()['loss_scale'], bool(torch.isfinite(res['grad_norm']))))
+	torch.cuda.synchronize()
+	torch.save(dict(params = flat.data.cpu(), history = history, scaler = flat.loss_scaler.current.cpu()), os.path.join(out_dir, f'fp16_rank{rank}.pt'))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+def test_two_ranks_fp16_loss_scaler_skips_on_every_rank_or_on_none():
+	"""fp16 + dynamic loss scaling under the data-parallel engine (models.distributed_data_parallel_and_autocast(opt_level = 'O2')): the
+	overflow verdict is the non-finite norm of the ALL-REDUCED gradient, so it is the same on every rank: the start-up overflows (scale
+	2^20 here) and an overflow only rank 1's batch causes are skipped by both; replicas, scale and counters end identical."""
+	world = 2
+	with tempfile.TemporaryDirectory() as out_dir:
+		mp.spawn(_worker_fp16, args = (world, _free_port(), out_dir), nprocs = world, join = True)
+		got = [torch.load(os.path.join(out_dir, f'fp16_rank{r}.pt')) for r in range(world)]
+	assert torch.equal(got[0]['params'], got[1]['params']), 'replicas diverged'
+	assert got[0]['history'] == got[1]['history'] and torch.equal(got[0]['scaler'], got[1]['scaler'])
+	finite = [h[1] for h in got[0]['history']]
+	print('fp16 two ranks:', got[0]['history'])
+	assert not finite[0] and any(finite) and not finite[6], got[0]['history']  # start-up overflow, clean steps, and rank 1's private overflow skipped by both
+	assert bool(torch.isfinite(got[0]['params']).all())
