@@ -80,6 +80,7 @@ def prepack_dgrad_weights(weights, dtype):
 	if not PREPACK or not weights:
 		return
 	dev = weights[0].device
+	join_prepack(dev)  # (a previous step that never reached its backward pass -- a loss skipped on the host -- left its packs unjoined)
 	stale = []
 	for w in weights:
 		ent = _pack_cache.get((id(w), dtype))
