@@ -864,3 +864,36 @@ def test_stride2_fold_adjoint_identity_at_the_bench_size():
 	ya, yb_, ys = f(x), f(x2), f(xs.to(torch.bfloat16))
 	exact = (ops.as_cl(xs, torch.float32) - x.float() - x2.float()).abs().max()  # rounding of the bf16 sum
 	assert float((ys - ya - yb_).abs().max()) <= 64 * K * float(exact) * float(w.abs().max()) + 1e-3
+
+
+@gpu
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_fused_dgrad_epilogue_matrix_pipe_sums_at_the_bench_size(dtype):
+	"""The fused BN-backward epilogue with stored gates (conv_v2s.hip form 2: sums on the matrix pipe) at a size that runs BOTH tile
+	widths in one launch (64 x 751 frames, 256 channels: 384 tiles = 256 full + 128 cut into halves): dx bit-identical to the plain
+	dgrad launch, sum g and sum g xhat equal to the stand-alone gated reduce pass (fp32 sums in a different order) -- bf16 and fp16."""
+	from convasr_amd import ops, _lib
+	d = dev()
+	torch.manual_seed(5)
+	dt = HALF[dtype][0]
+	B, T, C, Cout, K = 64, 751, 256, 256, 5
+	dy = ops.as_cl(torch.randn(B, Cout, T, device = d), dt)
+	w = torch.randn(Cout, C, K, device = d) / (C * K) ** 0.5
+	_, wd = ops.pack_weight(w, dt, None)
+	y = ops.as_cl(torch.randn(B, C, T, device = d) * 4 + 2, dt)
+	scale, shift = torch.rand(C, device = d) + 0.5, torch.randn(C, device = d)
+	mean, invstd = torch.randn(C, device = d), torch.rand(C, device = d) + 0.5
+	xlen = torch.linspace(0.5, 1, B, device = d)
+	act = (_lib.ACT_HARDTANH, 0.0, 20.0)
+	gate = torch.zeros(B * T * C // 8, dtype = torch.uint8, device = d)
+	ops.bn_act(y, scale, shift, act, xlen = xlen, dropout_p = 0.2, seed = 3, offset = 5, gate = gate)
+	pad = K - 1 - K // 2
+	sums = ops.ConvStats(C, B, T, d)
+	dx = ops.conv1d_dgrad_bn_reduce(dy, wd, C, K, 1, pad, y, scale, shift, mean, invstd, act, 0.2, 3, 5, xlen, sums, gate = gate)
+	assert dx is not None and torch.equal(dx, ops.conv1d(dy, wd, C, K, 1, 1, pad))
+	ref = torch.zeros(2 * C, dtype = torch.float64, device = d)
+	ops.bn_act_bwd_reduce(dx, y, scale, shift, mean, invstd, act, xlen = xlen, dropout_p = 0.2, seed = 3, offset = 5, sums = ref, write_g = False, gate = gate)
+	got = sums.totals()
+	close(got[:C], ref[:C], 1e-5, 2e-2, 'sum g')  # sums of ~48 K terms of magnitude ~1: fp32 chains in different orders
+	close(got[C:], ref[C:], 1e-5, 1e-1, 'sum g xhat')
+	assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
