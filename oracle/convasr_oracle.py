@@ -18,8 +18,11 @@ Pinning: tests/golden/make_golden.py imports the reference itself in the authori
 container (stubbing its three missing imports) and writes input/output vectors under
 tests/golden/*.npz; tests/test_oracle_golden.py checks every function here against those
 vectors.  The mel filterbank has no in-container pin against real librosa (librosa is not
-installed and the reference does not vendor it): "parity unpinned" for that one matrix --
-it is pinned by its closed-form properties instead and by being committed as a fixture
+installed and the reference does not vendor it): "parity unpinned" against librosa itself
+for that one matrix.  It is pinned instead (a) against an independent third-party
+restatement of librosa.filters.mel -- transformers.audio_utils.mel_filter_bank, slaney /
+slaney, fixtures in tests/golden/mel_hf.npz, agreement to float32 rounding at five
+geometries -- (b) by its closed-form properties and (c) by being committed as a fixture
 that both the reference run and this oracle consumed.
 
 A second, independent restatement of CTC (float64 numpy alpha-beta recursion) lives in
