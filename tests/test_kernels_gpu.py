@@ -452,6 +452,66 @@ def test_ctc_against_oracle(shape):
 	close(grad.cpu()[fin], lp32.grad[fin], 1e-3, 3e-3 if T > 500 else 1e-4, 'grad vs float32 oracle')
 
 
+@gpu
+@pytest.mark.parametrize('S,T', [(64, 300), (128, 400), (200, 600), (300, 753), (383, 900), (447, 1000), (511, 1100)])
+def test_ctc_every_split_of_the_states_over_the_two_waves(S, T):
+	"""csrc/ctc.hip gives the two waves of a sweep NPH and NPL (blank, label) pairs per lane: (1,1) (2,1) (2,2) (3,2) (3,3) (4,3) (4,4) for
+	up to 511 labels.  One case per split, target lengths chosen so that the last two states of the extended target sit on the two sides of
+	the waves' common edge (S = 64, 128) or deep in the upper wave; T = 900 .. 1100 runs with the log-probs left in global memory."""
+	from convasr_amd import ops
+	B, C = 2, 38
+	torch.manual_seed(S)
+	lp = (torch.randn(B, C, T) * 2).log_softmax(dim = 1)
+	y = torch.randint(0, C - 1, (B, S))
+	y[1, : S // 3] = y[1, 0]   # repeats: no s-2 transitions there, and 2 S + 1 - (S // 3 - 1) more frames needed
+	olen = torch.tensor([T, T - 7])
+	ylen = torch.tensor([S, S])
+	lpr = lp.double().requires_grad_(True)
+	ref = O.ctc_loss(lpr, y, olen, ylen)
+	assert torch.isfinite(ref).all()
+	ref.sum().backward()
+	nll, grad = ops.ctc_loss(ops.as_cl(lp.to(dev())), y, olen, ylen, C - 1)
+	close(nll.cpu(), ref.detach().float(), 1e-5, 1e-4, 'nll')
+	close(grad.cpu(), lpr.grad.float(), 1e-4, 2e-4, 'grad vs float64 oracle')
+
+
+@gpu
+def test_ctc_infinite_and_nan_log_probs():
+	"""-inf log-probs are staged as the kernel's finite sentinel: a forbidden class off the target changes nothing, a forbidden class ON
+	the target makes the utterance infeasible (+inf, zero gradient -- F.ctc_loss: +inf).  A NaN must not hang the wave that polls the
+	other wave's edge states (their "not written yet" marker is a NaN pattern): the call returns and the loss is not finite."""
+	from convasr_amd import ops
+	B, C, T, S = 3, 38, 200, 150   # (2, 1) split: both waves of each sweep hold real states
+	torch.manual_seed(1)
+	lp = torch.randn(B, C, T).log_softmax(dim = 1)
+	y = torch.randint(0, C - 2, (B, S))   # class C - 2 never occurs in a target
+	lp[0, C - 2] = -float('inf')
+	lp[1, int(y[1, 140]), :] = -float('inf')
+	olen, ylen = torch.full((B, ), T), torch.full((B, ), S)
+	# consecutive equal labels need a blank between them: T = 200 frames hold 150 labels only if at most 50 repeats
+	for b in range(B):
+		for i in range(1, S):
+			if y[b, i] == y[b, i - 1]:
+				y[b, i] = (y[b, i] + 1) % (C - 2)
+	lp[1, :, :] = torch.randn(C, T).log_softmax(dim = 0)
+	lp[1, int(y[1, 140]), :] = -float('inf')
+	lpr = lp.double().requires_grad_(True)
+	ref = O.ctc_loss(lpr, y, olen, ylen)
+	assert torch.isfinite(ref[0]) and torch.isinf(ref[1]) and torch.isfinite(ref[2])
+	(ref[0] + ref[2]).backward()
+	nll, grad = ops.ctc_loss(ops.as_cl(lp.to(dev())), y, olen, ylen, C - 1)
+	assert torch.isinf(nll[1]) and nll[1] > 0 and float(grad[1].abs().max()) == 0.0
+	close(nll.cpu()[[0, 2]], ref.detach().float()[[0, 2]], 1e-5, 1e-4, 'nll')
+	g0 = grad.cpu()[0]
+	keep = torch.ones(C, dtype = torch.bool); keep[C - 2] = False
+	close(g0[keep], lpr.grad.float()[0][keep], 1e-4, 2e-4, 'grad beside a forbidden class')
+	close(grad.cpu()[2], lpr.grad.float()[2], 1e-4, 2e-4, 'grad')
+	lp[2, :, 100] = float('nan')   # what log_softmax makes of a frame with a NaN logit
+	nll, grad = ops.ctc_loss(ops.as_cl(lp.to(dev())), y, olen, ylen, C - 1)   # returns
+	torch.cuda.synchronize()
+	assert not torch.isfinite(nll[2]) and torch.isfinite(nll[0])
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 
 @gpu
