@@ -42,8 +42,9 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 	return m + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(md - m) + __builtin_amdgcn_exp2f(lo - m));
 }
 __device__ __forceinline__ float lse2(float a, float b) {
-	const float m = fmaxf(a, b);
-	return m + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(fminf(a, b) - m));
+	// max / min as v_med3_f32 with +-inf: fmaxf / fminf first canonicalise both operands (one v_max_f32 x, x each) under IEEE rules
+	const float m = __builtin_amdgcn_fmed3f(a, b, INFINITY);
+	return m + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(a, b, -INFINITY) - m));
 }
 
 // lane i <- lane i - 1 (lane 0 <- fill) / lane i <- lane i + 1 (lane 63 <- fill): one DPP move, no LDS round trip
