@@ -32,7 +32,7 @@
 #define CTC_RENORM 8
 #define CTC_RENORM_LOG2 3
 #define CTC_EMPTY 0xFFFFFFFFu    // "not written yet": a NaN bit pattern; published words are mapped away from it (ctc_word)
-#define CTC_SPIN_LIMIT (1 << 22) // a consumer never spins this long unless the producer died: give up (garbage out) rather than hang
+#define CTC_SPIN_LIMIT (1 << 22) // a consumer never spins this long unless the producer died: give up (the loss becomes NaN) rather than hang
 
 // base-2 log-sum-exp of three / two values >= the sentinel.  The largest term is exp2(0) = 1 exactly, so only the other terms go
 // through v_exp_f32 (max3 / med3 / min3 are single instructions): 3 transcendental instructions per label state, 2 per blank state.
@@ -92,6 +92,7 @@ struct CtcSweep {
 	uint32_t* edge;          // this sweep's edge slots [T] (alpha) / [T][2] (beta)
 	uint32_t* ecum;          // the edge producer's offsets [NB]
 	float *fin, *fcum;       // alpha only: the last column and this wave's final offset
+	float* gave_up;          // set when a consumer hit CTC_SPIN_LIMIT: the utterance's loss becomes NaN instead of a wrong number
 	int T, C, Tb, L, blank, cap, s_base, lane;
 };
 
@@ -170,6 +171,7 @@ __device__ __forceinline__ void ctc_sweep(const CtcSweep& q) {
 					x0 = slot_load(e);
 					if (!FWD) x1 = slot_load(e + 1);
 				} while ((x0 == CTC_EMPTY || x1 == CTC_EMPTY) && ++spins < CTC_SPIN_LIMIT);
+				if (spins >= CTC_SPIN_LIMIT) *q.gave_up = 1.f;
 				// the producer published its block's offset before that frame's states (LDS operations of a wave complete in order)
 				xc = slot_load(q.ecum + ((k - 1) >> CTC_RENORM_LOG2));
 			}
@@ -238,7 +240,7 @@ __device__ __forceinline__ void ctc_sweep(const CtcSweep& q) {
 // offs: [2][B][2][NB] integer-valued offsets, NB = T / CTC_RENORM + 1 (true log2 alpha(t, s) = lattice value + offs[0][b][wave of s][k / 8]
 // with k = t for alpha, olen - 1 - t for beta: offs[1]; wave of s = s >= 128 NPH for alpha, s >= 128 NPL for beta);
 // tot: [B][2] = {integer part, remainder} of the utterance's log2 likelihood.
-// Dynamic LDS (32-bit words): fin[cap] | fcum[4] | edge slots: alpha [T], beta [T][2], offsets [2][NB] | lp slab when LP_LDS.
+// Dynamic LDS (32-bit words): fin[cap] | fcum[2], gave-up flag, pad | edge slots: alpha [T], beta [T][2], offsets [2][NB] | lp slab when LP_LDS.
 template <int NPH, int NPL, bool LP_LDS>
 __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ olen,
                                                              const int64_t* __restrict__ ylen, float* __restrict__ nll, float* __restrict__ alpha,
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 		return;
 	}
 	for (int i = threadIdx.x; i < n_edge; i += blockDim.x) edge[i] = CTC_EMPTY;
+	if (threadIdx.x == 0) fcum[2] = 0.f;
 	if (LP_LDS) {
 		const int n = Tb * (C + 1);
 		for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 	q.off = offs + (((int64_t)(fwd ? 0 : 1) * B + b) * 2 + (wave & 1)) * NB;
 	q.edge = edge + (fwd ? 0 : T);
 	q.ecum = edge + 3 * T + (fwd ? 0 : NB);
-	q.fin = fin; q.fcum = fcum + (wave & 1);
+	q.fin = fin; q.fcum = fcum + (wave & 1); q.gave_up = fcum + 2;
 	q.T = T; q.C = C; q.Tb = Tb; q.L = L; q.blank = blank; q.cap = CAP; q.lane = threadIdx.x & 63;
 	// alpha: wave 0 = states [0, 128 NPH) produces the edge, wave 1 the rest; beta: wave 2 = states [0, 128 NPL) consumes, wave 3 produces
 	q.s_base = wave == 1 ? 128 * NPH : (wave == 3 ? 128 * NPL : 0);
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* __rest
 		const float l1 = fin[L - 1], l2 = L >= 2 ? fin[L - 2] + (fcum[L - 2 >= 128 * NPH] - c1) : CTC_NEG;
 		const float m = fmaxf(l1, l2);
 		const float rem = m + log2f(exp2f(l1 - m) + exp2f(l2 - m));
-		nll[b] = m > CTC_DEAD ? (float)(-CTC_LN2 * ((double)c1 + (double)rem)) : INFINITY;   // NaN log-probs: NaN (as the reference)
+		nll[b] = fcum[2] != 0.f ? NAN : (m > CTC_DEAD ? (float)(-CTC_LN2 * ((double)c1 + (double)rem)) : INFINITY);   // NaN log-probs: NaN (as the reference)
 		tot[2 * b] = c1;
 		tot[2 * b + 1] = rem;
 	}

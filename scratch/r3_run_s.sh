@@ -1,4 +1,2 @@
-timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/r03_s.log 2>&1; echo "tests rc $?"; grep -E "passed|failed|^E  |^FAILED" gpurun_out/r03_s.log | tail -12
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/r03_s.log 2>&1; echo "tests rc $?"; grep -E "passed|failed|^E  |^FAILED" gpurun_out/r03_s.log | tail -12
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic > gpurun_out/r03_s_bench.json 2> gpurun_out/r03_s_bench.err; echo "bench rc $?"; cut -c1-300 gpurun_out/r03_s_bench.json
-R=$GRAFT_REPO_ROOT; rm -rf $R/gpurun_out/r3q_prof; cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r3q_prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > /dev/null 2>&1
-cd $R; f=$(find gpurun_out/r3q_prof -name "*kernel_stats.csv" | head -1); grep -E "ctc" $f | awk -F'",' '{print substr($1,1,40), $2,$3,$4,$5,$6,$7}'
