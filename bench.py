@@ -1,38 +1,53 @@
 """bench.py -- BASELINE.json's headline metric on the MI355X-native path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wav2letter|jasper_large]
 
 N > 1 without WORLD_SIZE in the environment: this process touches no GPU and starts its own N ranks as a CHILD
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, the role of train.py:1057-1073's mp.spawn), relays rank 0's
-JSON line and exits with the child's return code.  Under torch.distributed.run (WORLD_SIZE set) it is one rank of that job.
+JSON line and exits with the child's return code (the child tree is killed and 124 returned when it outlives
+CONVASR_LAUNCH_TIMEOUT seconds).  Under torch.distributed.run (WORLD_SIZE set) it is one rank of that job.
 
 A step = one full training iteration of the hot path on one synthetic batch per GPU (train.py:745-783 of the reference):
-logmel frontend -> instance norm -> Wav2Letter full (18 x Conv1d+BN+hardtanh+dropout+mask, 1x1 decoder) -> log-softmax ->
-CTC loss -> backward (dgrad / wgrad / BN / CTC) -> gradient all-reduce (N > 1) -> clip_grad_norm_ -> SGD.  Workload =
-BASELINE configs[2]/[3]: 64 utterances x 15 s of 16 kHz audio per GPU, bf16 MFMA convolutions with fp32 accumulation and
-fp32 master weights, dropout 0.2 (--dtype f16: fp16 storage + MFMA under apex's dynamic loss scaling, the arithmetic BASELINE
-configs[4] names; --dtype f32: the exact-fp32 parity path).  Inputs are resident in HBM before the timed region.  Prints ONE JSON
-line on rank 0; its `parity` object is the second half of BASELINE's metric: the CTC loss of the GPU paths (fp32, bf16, fp16)
-relative to the CPU oracle on the sample the cpu_baseline leg runs anyway.
+logmel frontend -> instance norm -> conv stack -> 1x1 decoder -> log-softmax -> CTC loss -> backward (dgrad / wgrad / BN / CTC)
+-> gradient all-reduce (N > 1) -> clip_grad_norm_ -> optimizer.
+
+--workload wav2letter (the default, the HEADLINE): BASELINE configs[2] / [3] -- Wav2Letter full (18 x Conv1d+BN+hardtanh+dropout
++mask), 64 utterances x 15 s of 16 kHz audio per GPU, bf16 MFMA convolutions with fp32 accumulation and fp32 master weights,
+dropout 0.2, SGD (--dtype f16: fp16 storage + MFMA under apex's dynamic loss scaling; --dtype f32: the exact-fp32 parity path).
+--workload jasper_large (NOT the headline): BASELINE configs[4] -- JasperNetLarge ("Jasper 10x5", models.py:1407-1409, dense
+residuals), 32 utterances of 5-20 s per batch from BucketingBatchSampler -> collate_gpu (mixed lengths, bucketed as
+train.py:597-601), fp16 under apex O2 loss scaling, NovoGrad.
+
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0; its `parity` object is the second half of
+BASELINE's metric (CTC loss of the GPU paths relative to the CPU oracle on the sample the cpu_baseline leg runs anyway) plus, for
+a bf16 headline, a second short timed region of the same workload in fp16 -- the storage type that meets north_star's 1e-4.
 """
 import argparse
+import datetime
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
 import time
 
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL / cross-process GPU buffers need it on this driver (already exported on the pool)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL / cross-process GPU buffers need it on this driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SAMPLE_RATE, SECS, BATCH, TARGET_LEN = 16000, 15, 64, 150
-FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # conv stack, 2*MAC, fwd + dgrad + wgrad
-PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+SAMPLE_RATE, SECS, BATCH = 16000, 15, 64
+FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # Wav2Letter conv stack, 2*MAC, fwd + dgrad + wgrad
+PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
+PEAK_F32_MFMA = 157.3e12  # exact-fp32 MFMA
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-MAIN_KERNEL_SYMBOLS = dict(bf16 = ('conv1d_igemm_v2s_kernel<unsigned short, unsigned short', 'conv1d_igemm_v2s_kernelIttLi'), f16 = ('conv1d_igemm_v2s_kernel<_Float16, _Float16', 'conv1d_igemm_v2s_kernel<__half, __half', 'conv1d_igemm_v2s_kernelIDF16_DF16_Li'))  # demangled or (where the profiler's demangler does not know _Float16) mangled;  # <H, H, false> (plain) and <H, H, true> (dgrad + fused BN-backward epilogue); NOT <H, float, false>, the decoder head
+# demangled or (where the profiler's demangler does not know _Float16) mangled; <H, H, *> only -- NOT <H, float, 0>, the decoder head
+MAIN_KERNEL_SYMBOLS = dict(
+	bf16 = ('conv1d_igemm_v2s_kernel<unsigned short, unsigned short', 'conv1d_igemm_v2s_kernelIttLi'),
+	f16 = ('conv1d_igemm_v2s_kernel<_Float16, _Float16', 'conv1d_igemm_v2s_kernel<__half, __half', 'conv1d_igemm_v2s_kernelIDF16_DF16_Li'))
+MAIN_FAMILY = 'conv1d_igemm_v2s_kernel<bf16>'  # (family labels are shared by the two 16-bit types)
+HBM_DECODER = 'the 38-class decoder'
 
 
 def parse_args(argv = None):
@@ -40,15 +55,24 @@ def parse_args(argv = None):
 	ap.add_argument('--gpus', type = int, default = 1)
 	ap.add_argument('--steps', type = int, default = 10)
 	ap.add_argument('--warmup', type = int, default = 3)
-	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f16', 'f32'])
-	ap.add_argument('--dropout', type = float, default = 0.2, help = 'the reference Wav2Letter default is 0.2; other values are for experiments only')
+	ap.add_argument('--workload', default = 'wav2letter', choices = ['wav2letter', 'jasper_large'])
+	ap.add_argument('--dtype', default = None, choices = ['bf16', 'f16', 'f32'], help = 'default: bf16 (wav2letter), f16 (jasper_large)')
+	ap.add_argument('--dropout', type = float, default = 0.2, help = 'the reference default (train.py:1033) is 0.2; other values are for experiments only')
+	ap.add_argument('--batch', type = int, default = None, help = 'TEST ONLY: utterances per GPU (a line measured with it is not the headline)')
+	ap.add_argument('--secs', type = int, default = None, help = 'TEST ONLY: seconds per utterance (wav2letter)')
 	ap.add_argument('--no-cpu-baseline', action = 'store_true')
 	ap.add_argument('--no-kernel-timer', action = 'store_true')
+	ap.add_argument('--no-f16-leg', action = 'store_true', help = 'skip the second timed region in fp16 (parity.f16_value)')
 	ap.add_argument('--no-traffic', action = 'store_true', help = 'skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run')
-	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (+1.5-2 % step rate; off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
+	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
 	ap.add_argument('--launcher-dry-run', action = 'store_true', help = 'test hook: ranks only rendezvous (gloo, CPU tensors) and rank 0 prints a line; exercises the self-launch path without a GPU')
-	return ap.parse_args(argv)
+	args = ap.parse_args(argv)
+	if args.dtype is None:
+		args.dtype = 'f16' if args.workload == 'jasper_large' else 'bf16'
+	return args
 
+
+# ------------------------------------------------------------------------------------------------ launcher (parent side)
 
 def _free_port():
 	s = socket.socket()
@@ -73,24 +97,87 @@ def _last_json_line(text):
 
 def launch_ranks(args, argv):
 	"""Parent side of `python bench.py --gpus N`: no GPU call is made here (torch.cuda.device_count() does not initialise the
-	device on this image), the ranks run in a child process tree started by torch.distributed.run."""
+	device on this image); the ranks run in a child process tree started by torch.distributed.run, in a session of its own so
+	that a hung rendezvous / collective can be ended as a whole (a fresh child or an exit -- never a re-exec)."""
 	if not args.launcher_dry_run and os.environ.get('CONVASR_SHARE_GPU') != '1':
 		import torch
 		have = torch.cuda.device_count()
 		if have < args.gpus:
 			print(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible', file = sys.stderr)
 			return 2
-	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__), *argv]
-	proc = subprocess.run(cmd, stdout = subprocess.PIPE, text = True)  # stderr is inherited
-	line = _last_json_line(proc.stdout or '')
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+		'--master-port', str(_free_port()), os.path.abspath(__file__), *argv]
+	limit = float(os.environ.get('CONVASR_LAUNCH_TIMEOUT', 1500))
+	proc = subprocess.Popen(cmd, stdout = subprocess.PIPE, text = True, start_new_session = True)  # stderr is inherited
+	try:
+		out, _ = proc.communicate(timeout = limit)
+	except subprocess.TimeoutExpired:
+		print(f'bench.py: the {args.gpus} ranks did not finish within {limit:.0f} s (CONVASR_LAUNCH_TIMEOUT): ending the child tree', file = sys.stderr)
+		for sig in (signal.SIGTERM, signal.SIGKILL):
+			try:
+				os.killpg(proc.pid, sig)  # start_new_session: the child leads its own process group
+			except ProcessLookupError:
+				break
+			try:
+				proc.wait(timeout = 10)
+				break
+			except subprocess.TimeoutExpired:
+				continue
+		return 124
+	line = _last_json_line(out or '')
 	if line is not None:
 		print(line, flush = True)
-	elif proc.stdout:
-		sys.stderr.write(proc.stdout)
+	elif out:
+		sys.stderr.write(out)
 	if proc.returncode != 0:
 		return proc.returncode
 	return 0 if line is not None else 1
 
+
+# ------------------------------------------------------------------------------------------------ rank pre-flight (before any GPU call)
+
+def _kfd_gpu_nodes():
+	"""DRM render minors of the GPU nodes of the KFD topology, in node order (the order the HIP runtime enumerates devices in)."""
+	base = '/sys/class/kfd/kfd/topology/nodes'
+	out = []
+	for n in sorted((d for d in os.listdir(base) if d.isdigit()), key = int):
+		props = dict(ln.split(None, 1) for ln in open(os.path.join(base, n, 'properties')).read().splitlines() if ' ' in ln)
+		if int(props.get('simd_count', '0')) > 0:
+			out.append(int(props.get('drm_render_minor', '-1')))
+	return out
+
+
+def _cpulist(text):
+	cpus = set()
+	for part in text.strip().split(','):
+		if part:
+			lo, _, hi = part.partition('-')
+			cpus.update(range(int(lo), int(hi or lo) + 1))
+	return cpus
+
+
+def pin_to_gpu_numa_node(local_rank):
+	"""os.sched_setaffinity to the cores local to this rank's GPU (the NUMA node of its PCIe root, /sys/class/drm/renderD*/device/
+	{numa_node, local_cpulist}) -- host launch latency and the pinned staging buffers then stay on the socket the GPU hangs off.
+	Pure sysfs reads: runs before the first GPU call.  Best effort: returns a dict saying what was done (or why not)."""
+	try:
+		nodes = _kfd_gpu_nodes()
+		vis = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
+		if vis and all(v.strip().isdigit() for v in vis.split(',')):
+			nodes = [nodes[int(v)] for v in vis.split(',') if int(v) < len(nodes)]
+		minor = nodes[local_rank]
+		dev = f'/sys/class/drm/renderD{minor}/device'
+		node = int(open(os.path.join(dev, 'numa_node')).read())
+		cpus = _cpulist(open(os.path.join(dev, 'local_cpulist')).read()) & os.sched_getaffinity(0)
+		if not cpus:
+			return dict(pinned = False, reason = 'no local cpulist', numa_node = node)
+		os.sched_setaffinity(0, cpus)
+		return dict(pinned = True, numa_node = node, cpus = len(cpus), render_minor = minor)
+	except Exception as e:  # no sysfs topology (container), odd masks: the run goes on unpinned
+		return dict(pinned = False, reason = f'{type(e).__name__}: {e}')
+
+
+# ------------------------------------------------------------------------------------------------ workloads
 
 def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
 	import torch
@@ -100,6 +187,125 @@ def synthetic_batch(device, batch = BATCH, secs = SECS, seed = 1):
 	y = torch.randint(0, 37, (batch, 1, 10 * secs), generator = g)
 	ylen = torch.full((batch, 1), 10 * secs, dtype = torch.long)
 	return tuple(t.to(device) for t in (x, xlen, y, ylen))
+
+
+def conv_stack_flops(model, batch, samples):
+	"""Algorithmic FLOPs (2 x MAC) of one training step's convolutions on a (batch, samples) waveform batch: forward + weight gradient
+	for every conv (residual 1x1 convs and the decoder included), + input gradient for all but the prologue."""
+	import torch.nn as nn
+	t = 1 + samples // model.frontend.hop_length  # frames
+	first = model.backbone[0].conv[0][-1]
+	fwd = bwd = 0.0
+
+	def book(c, tin):
+		nonlocal fwd, bwd
+		tout = (tin + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // c.stride[0] + 1
+		f = 2.0 * batch * tout * c.out_channels * (c.in_channels // c.groups) * c.kernel_size[0]
+		fwd += f
+		bwd += f if c is first else 2 * f
+		return tout
+	for blk in model.backbone:
+		for seq in blk.conv:
+			for c in seq:
+				if isinstance(c, nn.Conv1d):
+					t = book(c, t)
+		for c in blk.conv_residual:  # 1x1 convs on earlier block outputs: same frame count (every block but the prologue keeps it)
+			if isinstance(c, nn.Conv1d):
+				book(c, t)
+	for c in model.decoder.modules():
+		if isinstance(c, nn.Conv1d):
+			book(c, t)
+	return fwd, bwd
+
+
+class Workload:
+	"""What one rank steps through: model, optimizer, the device-resident batches, and the audio / FLOPs each of them carries."""
+
+	def __init__(self, args, device, rank, world, dtype = None):
+		import torch
+		import convasr_amd as ca
+		self.args, self.device = args, device
+		dtype = dtype or args.dtype
+		self.dtype = dtype
+		compute = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32)[dtype]
+		fe = ca.models.LogFilterBankFrontend(64, SAMPLE_RATE, 0.02, 0.01, 'hann_window')
+		n_batches = args.warmup + args.steps + min(args.steps, 5)
+		if args.workload == 'wav2letter':
+			self.batch, self.secs = args.batch or BATCH, args.secs or SECS
+			model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = args.dropout, check_time_dim_padded = False, compute_dtype = compute)
+			self.model = model.to(device).train()
+			self.flat = ca.train.FlatParameters(self.model)
+			self.opt = ca.train.SGD(self.flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)  # train.py:879-884 defaults
+			b = synthetic_batch(device, batch = self.batch, secs = self.secs, seed = 1 + rank)
+			self.batches = [b]
+			self.audio = [(self.batch * self.secs, self.batch * self.secs)]  # (unpadded, padded) audio seconds per batch
+			self.name = f'Wav2Letter full (18 conv + decoder, 66.5M params), {self.batch}x{self.secs}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout {args.dropout:g}'
+		else:
+			self.batch = args.batch or 32
+			model = ca.models.JasperNetLarge(64, [38], frontend = fe, dropout = args.dropout, check_time_dim_padded = False, compute_dtype = compute)
+			self.model = model.to(device).train()
+			self.flat = ca.train.FlatParameters(self.model)
+			self.opt = ca.optimizers.NovoGrad(self.flat, lr = 1e-3, betas = (0.95, 0.5), weight_decay = 1e-3)
+			# mixed lengths, bucketed: every rank draws its own batches of one schedule (DistributedSamplerWrapper: the W ranks of an
+			# iteration get batches of the same bucket, i.e. equal padded length -- balanced steps)
+			ds = ca.datasets.SyntheticAudioTextDataset(self.batch * world * n_batches * 2, min_duration = 5.0, max_duration = 20.0, seed = 7)
+			sampler = ca.datasets.BucketingBatchSampler(ds, batch_size = self.batch, world_size = world)
+			sampler.set_epoch(0)
+			if world > 1:
+				sampler = ca.datasets.DistributedSamplerWrapper(sampler, num_replicas = world, rank = rank)
+			self.batches, self.audio = [], []
+			for meta, s, x, xlen, y, ylen in ca.datasets.gpu_batches(ds, sampler, device):
+				self.batches.append((x, xlen, y, ylen))
+				self.audio.append((sum(m['duration'] for m in meta), x.shape[0] * x.shape[1] / SAMPLE_RATE))
+				if len(self.batches) == n_batches:
+					break
+			self.name = f'JasperNetLarge (Jasper 10x5, dense residuals, {sum(p.numel() for p in model.parameters()) / 1e6:.0f}M params), {self.batch} utterances of 5-20 s per GPU and step (BucketingBatchSampler -> collate_gpu, mixed lengths), logmel+convstack+CTC fwd+bwd+clip+NovoGrad, dropout {args.dropout:g}'
+		self.model._convasr_flat = self.flat
+		if dtype == 'f16':  # apex O2: fp16 compute, fp32 masters, dynamic loss scaling from 2^16 (the start-up overflows fall into the warm-up steps)
+			ca.models.data_parallel_and_autocast(self.model, self.opt, opt_level = 'O2')
+			assert self.model.compute_dtype == torch.float16 and self.flat.loss_scaler is not None
+		self.flops = [conv_stack_flops(self.model, b[0].shape[0], b[0].shape[1]) for b in self.batches]
+
+	def batch_of(self, i):
+		return i % len(self.batches)
+
+	def release(self):
+		self.model = self.flat = self.opt = self.batches = None
+
+
+def run_timed(args, wl, engine, world, fence, time_main_kernel):
+	"""W warm-up steps, then K timed steps between two fences.  Returns (elapsed s, audio (unpadded, padded), flops (fwd, bwd), last
+	result, kernel-timer summary, launch sequence)."""
+	import convasr_amd as ca
+	from convasr_amd import _lib
+	last = None
+
+	def step(i):
+		x, xlen, y, ylen = wl.batches[wl.batch_of(i)]
+		return ca.train.train_step(engine, wl.opt, x, xlen, y, ylen, world_size = world, iteration = i, sync_metrics = engine is not wl.model)
+	for i in range(args.warmup):
+		last = step(i)
+	fence()
+	# HIP events (on the launching stream) bracket every launch of the DOMINANT kernel inside the timed region.  The other kernel
+	# families (wgrad, the HBM-bound passes, the small layers) are event-timed in a second, untimed pass of a few steps right after
+	# it: an event pair costs ~5 us of stream time, and bracketing all ~110 launches of a step slowed the headline by 3.4 %
+	# (18.06 vs 17.47 ms per step on one device; bracketing the dominant kernel only: ~1 %).
+	if time_main_kernel:
+		_lib.timer = _lib.KernelTimer(only = [MAIN_FAMILY, MAIN_FAMILY + '+bn_bwd'] if wl.dtype != 'f32' else ['conv1d_igemm (other variants)'])
+	if hasattr(engine, 'exposed_comm_events'):
+		engine.exposed_comm_events = []
+	t0 = time.perf_counter()
+	for i in range(args.steps):
+		last = step(args.warmup + i)
+	fence()
+	elapsed = time.perf_counter() - t0
+	kt = _lib.timer.summary() if _lib.timer is not None else {}
+	sequence = list(_lib.timer.sequence) if _lib.timer is not None else []
+	_lib.timer = None
+	idx = [wl.batch_of(args.warmup + i) for i in range(args.steps)]
+	audio = tuple(sum(wl.audio[j][k] for j in idx) for k in (0, 1))
+	flops = tuple(sum(wl.flops[j][k] for j in idx) for k in (0, 1))
+	return elapsed, audio, flops, last, kt, sequence, step
 
 
 def cpu_baseline(secs = SECS, batch = 4, iters = 3, keep = None):
@@ -131,7 +337,9 @@ def cpu_baseline(secs = SECS, batch = 4, iters = 3, keep = None):
 			keep.update(loss_vec = r['loss_vec'].clone(), loss = float(r['loss']))
 	timed = times[1:]
 	mean, best = sum(timed) / len(timed), min(timed)
-	return dict(value = round(batch * secs / mean, 2), best = round(batch * secs / best, 2), unit = 'audio-seconds/sec', cores = torch.get_num_threads(), host_cpus = os.cpu_count(), kind = 'port', sample = f'{batch}x{secs}s utterances, Wav2Letter full fp32, fwd+CTC+bwd+clip+SGD, mean of {iters} timed iterations after 1 warm-up ({mean:.2f} s/step mean, {best:.2f} s/step best)')
+	return dict(value = round(batch * secs / mean, 2), best = round(batch * secs / best, 2), unit = 'audio-seconds/sec', cores = torch.get_num_threads(),
+		host_cpus = os.cpu_count(), kind = 'port',
+		sample = f'{batch}x{secs}s utterances, Wav2Letter full fp32, fwd+CTC+bwd+clip+SGD, mean of {iters} timed iterations after 1 warm-up ({mean:.2f} s/step mean, {best:.2f} s/step best)')
 
 
 def gpu_parity(ref, device):
@@ -152,7 +360,11 @@ def gpu_parity(ref, device):
 			loss = model(x, xlen, y = y, ylen = ylen)['loss'].float().cpu()
 		out[name] = float(((loss - ref['loss_vec']).abs() / ref['loss_vec'].abs()).max())
 		del model
-	return dict(ctc_loss_rel_err = {k: float(f'{v:.3e}') for k, v in out.items()}, north_star_bound = 1e-4, reference = 'oracle (fp32 CPU restatement of the reference path, pinned to the reference by tests/golden)', sample = f'{x.shape[0]}x{x.shape[1] // SAMPLE_RATE}s utterances of the cpu_baseline leg, same initial parameters, train-mode forward, dropout 0; per-utterance CTC loss, max relative error', note = 'f32 is the parity path (within north_star\'s 1e-4); bf16 (8 significant bits of storage) and f16 (11) buy their throughput at the error shown: the deviation is the storage type\'s own (tests/test_round2_gpu.py: a CPU restatement with the same storage type deviates alike)')
+	return dict(ctc_loss_rel_err = {k: float(f'{v:.3e}') for k, v in out.items()}, north_star_bound = 1e-4,
+		reference = 'oracle (fp32 CPU restatement of the reference path, pinned to the reference by tests/golden)',
+		sample = f'{x.shape[0]}x{x.shape[1] // SAMPLE_RATE}s utterances of the cpu_baseline leg, same initial parameters, train-mode forward, dropout 0; per-utterance CTC loss, max relative error',
+		note = 'f32 is the parity path (within north_star\'s 1e-4); bf16 (8 significant bits of storage) and f16 (11) buy their throughput at the error shown: '
+			'the deviation is the storage type\'s own (tests/test_round2_gpu.py: a CPU restatement with the same storage type deviates alike)')
 
 
 def measure_traffic(args, sequence, steps):
@@ -178,7 +390,9 @@ def measure_traffic(args, sequence, steps):
 	for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
 		d = tempfile.mkdtemp(prefix = f'convasr_pmc_{counter}_', dir = '/tmp')
 		try:
-			cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--dtype', args.dtype, '--dropout', str(args.dropout), '--no-cpu-baseline', '--no-kernel-timer', '--no-traffic']
+			cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
+				'--steps', '1', '--warmup', '1', '--workload', args.workload, '--dtype', args.dtype, '--dropout', str(args.dropout),
+				'--no-cpu-baseline', '--no-kernel-timer', '--no-traffic', '--no-f16-leg']
 			r = subprocess.run(cmd, cwd = '/tmp', env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 600)
 			files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive = True)
 			if r.returncode != 0 or not files:
@@ -199,15 +413,19 @@ def measure_traffic(args, sequence, steps):
 		finally:
 			shutil.rmtree(d, ignore_errors = True)
 	mb = (2 * out['FETCH_SIZE'][0] + out['WRITE_SIZE'][0]) * 1024 / 1e6
-	return round(mb, 1), f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes over bench.py --steps 1 --warmup 1, mean of {out["FETCH_SIZE"][1]} dispatches = {out["FETCH_SIZE"][2]}, MB per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024'
+	src = (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes over bench.py --steps 1 --warmup 1, '
+		f'mean of {out["FETCH_SIZE"][1]} dispatches = {out["FETCH_SIZE"][2]}, MB per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024')
+	return round(mb, 1), src
 
 
 def dry_run_rank(args):
 	"""--launcher-dry-run: rendezvous + one all-reduce on CPU tensors (gloo); rank 0 prints the line the parent relays."""
 	import torch
 	import torch.distributed as dist
-	dist.init_process_group('gloo')
+	dist.init_process_group('gloo', timeout = datetime.timedelta(seconds = 120))
 	rank, world = dist.get_rank(), dist.get_world_size()
+	if int(os.environ.get('CONVASR_DRY_RUN_HANG_RANK', '-1')) == rank:
+		time.sleep(3600)  # test hook: the parent's CONVASR_LAUNCH_TIMEOUT must end the tree
 	t = torch.tensor([float(rank + 1)])
 	t0 = time.perf_counter()
 	dist.all_reduce(t)
@@ -220,8 +438,62 @@ def dry_run_rank(args):
 		return 3  # test hook: the parent must propagate a rank's failure
 	if rank == 0:
 		assert float(t) == world * (world + 1) / 2
-		print(json.dumps(dict(metric = 'launcher-dry-run', value = float(t), unit = 'sum of rank+1', n_gpus = world, steps = args.steps, warmup = args.warmup, dist = dict(backend = backend, world_size = world, launcher = os.environ.get('TORCHELASTIC_RUN_ID') is not None))), flush = True)
+		print(json.dumps(dict(metric = 'launcher-dry-run', value = float(t), unit = 'sum of rank+1', n_gpus = world, steps = args.steps, warmup = args.warmup,
+			dist = dict(backend = backend, world_size = world, launcher = os.environ.get('TORCHELASTIC_RUN_ID') is not None))), flush = True)
 	return 0
+
+
+def roofline_of(args, wl, kt, kt2, steps2, value, world):
+	"""The `roofline` object: the dominant kernel from the HIP events of the timed region (kt), every other family from the second
+	pass (kt2, steps2 steps), all from algorithmic FLOPs / bytes booked per launch by convasr_amd.ops."""
+	main_name, fused_name = MAIN_FAMILY, MAIN_FAMILY + '+bn_bwd'
+	half = wl.dtype in ('bf16', 'f16')
+	if not half:
+		main_name = 'conv1d_igemm (other variants)'
+	if main_name not in kt:
+		return None
+	scale = args.steps / max(steps2, 1)
+	for name, v in kt2.items():  # per-step figures of the second pass, rescaled to the timed region's step count
+		if name not in (main_name, fused_name):
+			kt[name] = dict(v, launches = int(v['launches'] * scale), total_ms = v['total_ms'] * scale, work = v['work'] * scale, bytes = v['bytes'] * scale)
+	plain = kt.get(main_name)
+	if fused_name in kt:
+		a, f = kt[main_name], kt.pop(fused_name)
+		n, ms = a['launches'] + f['launches'], a['total_ms'] + f['total_ms']
+		kt[main_name] = dict(launches = n, total_ms = ms, avg_us = 1e3 * ms / n, work = a['work'] + f['work'], bytes = a['bytes'] + f['bytes'])
+	peak = (PEAK_BF16_DENSE if half else PEAK_F32_MFMA) / 1e12  # (dense fp16 MFMA peak = the bf16 one)
+	tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
+	k = kt[main_name]
+	n_plain = 0 if plain is None or plain is k else plain['launches']
+	if half:
+		kernel = (f'conv1d_igemm_v2s_kernel<O, BNF> ({(plain["launches"] if plain else 0) // args.steps} forward / plain + {(k["launches"] - n_plain) // args.steps} fused dgrad launches per step; '
+			'the fused dgrads also run pass 1 of the BN backward of the layer below in their epilogue; the prologue conv runs here as its stride-2 fold)')
+	else:
+		kernel = 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)'
+	roof = dict(bound = 'mfma', kernel = kernel, achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None,
+		algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2),
+		ms_per_step = round(k['total_ms'] / args.steps, 3),
+		timing = f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it')
+	hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
+	kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
+	if plain is not None and plain is not k:
+		roof['plain_launches'] = dict(note = 'the launches of the same kernel without the fused BN-backward epilogue (forward, and the dgrads whose consumer is not fused): the epilogue adds work that is not counted as FLOPs',
+			achieved = round(tf(plain), 2), frac = round(tf(plain) / peak, 4), launches_per_step = plain['launches'] // args.steps, avg_launch_us = round(plain['avg_us'], 2))
+	if 'conv1d_wgrad' in kt and kt['conv1d_wgrad'] is not k:
+		w = kt['conv1d_wgrad']
+		roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel incl. its split-K combine (+ general wgrad kernel on small layers)', achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4),
+			launches_per_step = w['launches'] // args.steps, avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
+	allc = list(kt.values())
+	stack = sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12
+	roof['conv_stack'] = dict(achieved = round(stack, 2), ms_per_step = round(sum(v['total_ms'] for v in allc) / args.steps, 3), frac = round(stack / peak, 4))
+	roof['whole_step_frac'] = round(value / world / (peak * 1e12), 4)  # (value here: algorithmic conv FLOP/s of the whole job)
+	# the HBM-bound kernels of the path (frontend, BN + activation passes): algorithmic bytes / HIP-event time against 8 TB/s
+	gbs = lambda v: v['bytes'] / (v['total_ms'] * 1e-3) / 1e9
+	roof['hbm_kernels'] = {name: dict(achieved = round(gbs(v), 1), peak = PEAK_HBM_GBS, unit = 'GB/s', frac = round(gbs(v) / PEAK_HBM_GBS, 4),
+		launches_per_step = v['launches'] // args.steps, ms_per_step = round(v['total_ms'] / args.steps, 3)) for name, v in hbm.items()}
+	if 'logmel_kernel' in roof['hbm_kernels']:
+		roof['hbm_kernels']['logmel_kernel']['note'] = 'FFT-issue bound (three radix-8 Stockham passes through LDS per pair of frames), not HBM bound: under 1 % of the step'
+	return roof
 
 
 def main(argv = None):
@@ -232,6 +504,15 @@ def main(argv = None):
 	if args.launcher_dry_run:
 		return dry_run_rank(args)
 
+	world = int(os.environ.get('WORLD_SIZE', '1'))
+	rank = int(os.environ.get('RANK', '0'))
+	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	if args.gpus > 1 and world != args.gpus:
+		raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {world}')
+	use_dist = world > 1 or os.environ.get('CONVASR_FORCE_DIST') == '1'  # the latter: single-rank RCCL smoke test of the DP path
+	share_gpu = os.environ.get('CONVASR_SHARE_GPU') == '1'  # test hook for a 1-GPU box: every rank on cuda:0
+	affinity = pin_to_gpu_numa_node(0 if share_gpu else local_rank) if use_dist and os.environ.get('CONVASR_NO_PIN') != '1' else None  # before any GPU call
+
 	import torch
 
 	# stdout carries exactly one line, the JSON result of rank 0: native libraries (RCCL prints a version banner through C stdio,
@@ -240,15 +521,8 @@ def main(argv = None):
 	real_stdout = os.dup(1)
 	os.dup2(2, 1)
 
-	world = int(os.environ.get('WORLD_SIZE', '1'))
-	rank = int(os.environ.get('RANK', '0'))
-	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-	if args.gpus > 1 and world != args.gpus:
-		raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {world}')
-	# (test hooks for a 1-GPU box: CONVASR_SHARE_GPU=1 puts every rank on cuda:0, CONVASR_DIST_BACKEND=gloo replaces RCCL, which needs one GPU per rank)
-	device = torch.device('cuda', 0 if os.environ.get('CONVASR_SHARE_GPU') == '1' else local_rank)
+	device = torch.device('cuda', 0 if share_gpu else local_rank)
 	torch.cuda.set_device(device)
-	use_dist = world > 1 or os.environ.get('CONVASR_FORCE_DIST') == '1'  # the latter: single-rank RCCL smoke test of the DP path
 	dist_info = None
 	if use_dist:
 		import torch.distributed as dist
@@ -256,65 +530,47 @@ def main(argv = None):
 		os.environ.setdefault('MASTER_PORT', '29511')
 		os.environ.setdefault('RANK', '0')
 		os.environ.setdefault('WORLD_SIZE', '1')
-		backend = os.environ.get('CONVASR_DIST_BACKEND', 'nccl')
+		backend = os.environ.get('CONVASR_DIST_BACKEND', 'nccl')  # (test hook: gloo replaces RCCL, which needs one GPU per rank)
+		# a rendezvous or a collective that does not complete within 120 s ends the rank (torch's watchdog aborts the process), the
+		# launcher then reports the failure: a hang cannot outlive the driver's patience silently
+		limit = datetime.timedelta(seconds = float(os.environ.get('CONVASR_DIST_TIMEOUT', 120)))
 		if backend == 'nccl':
-			dist.init_process_group('nccl', device_id = device)
+			dist.init_process_group('nccl', device_id = device, timeout = limit)
 		else:
-			dist.init_process_group(backend)
-		dist_info = dict(backend = dist.get_backend() + (' (RCCL)' if backend == 'nccl' else ''), world_size = dist.get_world_size(), launcher = 'torch.distributed.run' if os.environ.get('TORCHELASTIC_RUN_ID') is not None else 'env')
+			dist.init_process_group(backend, timeout = limit)
+		rccl = None
+		try:
+			rccl = '.'.join(str(v) for v in torch.cuda.nccl.version()) if backend == 'nccl' else None
+		except Exception:
+			pass
+		dist_info = dict(backend = dist.get_backend() + (' (RCCL)' if backend == 'nccl' else ''), rccl_version = rccl, world_size = dist.get_world_size(),
+			launcher = 'torch.distributed.run' if os.environ.get('TORCHELASTIC_RUN_ID') is not None else 'env', timeout_s = limit.total_seconds(), affinity = affinity)
 
 	import convasr_amd as ca
 	from convasr_amd import _lib
 
 	torch.manual_seed(1)
 	ca.functional.manual_seed(int(os.environ.get('CONVASR_BENCH_DROPOUT_SEED', '1')) + rank)  # (the override: a measurement hook -- step time depends on the data through the chip's clock management)
-	compute = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32)[args.dtype]
-	fe = ca.models.LogFilterBankFrontend(64, SAMPLE_RATE, 0.02, 0.01, 'hann_window')
-	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = args.dropout, check_time_dim_padded = False, compute_dtype = compute).to(device).train()
-	flat = ca.train.FlatParameters(model)
-	model._convasr_flat = flat
-	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
-	if args.dtype == 'f16':  # apex O2: fp16 compute, fp32 masters, dynamic loss scaling from 2^16 (the start-up overflows fall into the warm-up steps)
-		ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2')
-		assert model.compute_dtype == torch.float16 and flat.loss_scaler is not None
-	engine = ca.parallel.DataParallelEngine(model, device = device, force_collectives = use_dist) if use_dist else model
-	x, xlen, y, ylen = synthetic_batch(device, seed = 1 + rank)
+	wl = Workload(args, device, rank, world)
+	flat = wl.flat
+	engine = ca.parallel.DataParallelEngine(wl.model, device = device, force_collectives = use_dist, measure_exposed_comm = True) if use_dist else wl.model
 	if args.side_stream:
 		ca.functional.enable_side_stream_wgrad(device)
-
-	def step(i):
-		return ca.train.train_step(engine, opt, x, xlen, y, ylen, world_size = world, iteration = i, sync_metrics = use_dist)
 
 	def fence():
 		if use_dist:
 			dist.barrier()
 		torch.cuda.synchronize()
 
-	last = None
-	for i in range(args.warmup):
-		last = step(i)
-	fence()
-	# HIP events (on the launching stream) bracket every launch of the DOMINANT kernel inside the timed region.  The other kernel
-	# families (wgrad, the HBM-bound passes, the small layers) are event-timed in a second, untimed pass of a few steps right after
-	# it: an event pair costs ~5 us of stream time, and bracketing all ~110 launches of a step slowed the headline by 3.4 %
-	# (18.06 vs 17.47 ms per step on one device; bracketing the dominant kernel only: ~1 %).
-	main_family = 'conv1d_igemm_v2s_kernel<bf16>' if args.dtype in ('bf16', 'f16') else 'conv1d_igemm (other variants)'  # (family labels are shared by the two 16-bit types)
 	overflows0 = float(flat.loss_scaler.current[7]) if flat.loss_scaler is not None else 0.0
-	if not args.no_kernel_timer and rank == 0:
-		_lib.timer = _lib.KernelTimer(only = [main_family, main_family + '+bn_bwd'])
-	t0 = time.perf_counter()
-	for i in range(args.steps):
-		last = step(args.warmup + i)
-	fence()
-	elapsed = time.perf_counter() - t0
-	kt = _lib.timer.summary() if _lib.timer is not None else {}
-	sequence = list(_lib.timer.sequence) if _lib.timer is not None else []
-	_lib.timer = None
+	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0)
+	exposed = engine.exposed_comm_ms() if use_dist else None
 	scaler_info = None
 	if flat.loss_scaler is not None:
 		st = flat.loss_scaler.current.tolist()
-		scaler_info = dict(loss_scale = st[0], clean_steps = int(st[1]), overflowed_steps_in_timed_region = int(st[7] - overflows0), overflowed_steps_total = int(st[7]), note = 'apex dynamic loss scaling (2^16, x2 per 2000 clean steps, /2 and skip on overflow); an overflowed step skips only the optimizer update')
-	steps2 = 0
+		scaler_info = dict(loss_scale = st[0], clean_steps = int(st[1]), overflowed_steps_in_timed_region = int(st[7] - overflows0), overflowed_steps_total = int(st[7]),
+			note = 'apex dynamic loss scaling (2^16, x2 per 2000 clean steps, /2 and skip on overflow); an overflowed step skips only the optimizer update')
+	steps2, kt2 = 0, {}
 	if not args.no_kernel_timer:
 		steps2 = min(args.steps, 5)
 		if rank == 0:
@@ -326,60 +582,65 @@ def main(argv = None):
 			kt2 = _lib.timer.summary()
 			_lib.timer = None
 	if use_dist:
-		t = torch.tensor([elapsed], dtype = torch.float64, device = device)
-		dist.all_reduce(t, op = dist.ReduceOp.MAX)
-		elapsed = float(t.item())
+		# (the parameter checksum: after K identical updates from identical initial replicas every rank must hold the same bits)
+		mine = torch.stack([torch.tensor(elapsed, dtype = torch.float64, device = device), torch.tensor(exposed if exposed is not None else float('nan'), dtype = torch.float64, device = device), wl.flat.data.double().sum(), wl.flat.data.double().abs().sum()])
+		every = [torch.zeros_like(mine) for _ in range(world)]
+		dist.all_gather(every, mine)
+		per_rank = [float(t[0]) * 1e3 / args.steps for t in every]
+		exposed_all = [float(t[1]) for t in every]
+		elapsed = max(float(t[0]) for t in every)  # MAX over ranks
+		dist_info.update(per_rank_ms = dict(min = round(min(per_rank), 3), max = round(max(per_rank), 3), mean = round(sum(per_rank) / world, 3), all = [round(v, 3) for v in per_rank]),
+			exposed_comm_ms = dict(mean = round(sum(exposed_all) / world, 4), max = round(max(exposed_all), 4),
+				how = 'HIP event pair on the main stream per step: backward fully enqueued -> communication stream joined (what the step waits for the gradient exchange beyond its own backward pass), mean over the timed steps'),
+			bucket_mib = [round((b['hi'] - b['lo']) * 4 / 2 ** 20, 1) for b in engine.buckets], comm_thread = engine._jobs is not None,
+			replicas_equal = all(bool(torch.equal(t[2:], every[0][2:])) for t in every))
 
+	line = None
 	if rank == 0:
-		audio_s = world * BATCH * SECS * args.steps
-		value = audio_s / elapsed
-		roof = None
-		main_name = main_family
-		fused_name = main_name + '+bn_bwd'  # the same kernel symbol launched as a dgrad with the fused BN-backward epilogue (functional._dgrad)
-		if kt:  # every other family comes from the second pass (per-step figures use its own step count)
-			for name, v in kt2.items():
-				if name not in (main_name, fused_name):
-					kt[name] = dict(v, launches = v['launches'] * args.steps // steps2, total_ms = v['total_ms'] * args.steps / steps2, work = v['work'] * args.steps / steps2, bytes = v['bytes'] * args.steps / steps2)
-		plain = kt.get(main_name)
-		if main_name in kt and fused_name in kt:
-			a, f = kt[main_name], kt.pop(fused_name)
-			kt[main_name] = dict(launches = a['launches'] + f['launches'], total_ms = a['total_ms'] + f['total_ms'], avg_us = 1e3 * (a['total_ms'] + f['total_ms']) / (a['launches'] + f['launches']), work = a['work'] + f['work'], bytes = a['bytes'] + f['bytes'])
-		if main_name in kt:
-			peak = PEAK_BF16_DENSE / 1e12 if args.dtype in ('bf16', 'f16') else 157.3  # (dense fp16 MFMA peak = the bf16 one)
-			tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
-			k = kt[main_name]
-			roof = dict(bound = 'mfma', kernel = f'conv1d_igemm_v2s_kernel<O, false / true> ({0 if plain is None else plain["launches"] // args.steps} forward + {(k["launches"] - (0 if plain is None or plain is k else plain["launches"])) // args.steps} dgrad launches per step; the dgrads, instantiation <.., true>, also run pass 1 of the BN backward of the layer below in their epilogue; the prologue conv runs here as its stride-2 fold)' if args.dtype in ('bf16', 'f16') else 'conv1d_igemm_kernel<float> (every forward + dgrad launch; exact-fp32 v_mfma_f32_32x32x2_f32)', achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None, algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2), ms_per_step = round(k['total_ms'] / args.steps, 3), timing = f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it')
-			hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
-			kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
-			if plain is not None and plain is not k:
-				roof['plain_launches'] = dict(note = 'the launches of the same kernel without the fused BN-backward epilogue (forward, and the dgrads whose consumer is not fused): the epilogue adds work that is not counted as FLOPs', achieved = round(tf(plain), 2), frac = round(tf(plain) / peak, 4), launches_per_step = plain['launches'] // args.steps, avg_launch_us = round(plain['avg_us'], 2))
-			others = {name: v for name, v in kt.items() if name != main_name}
-			if 'conv1d_wgrad' in others:
-				w = others['conv1d_wgrad']
-				roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel incl. its split-K combine (+ general wgrad kernel on 3 small layers)', achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4), launches_per_step = w['launches'] // args.steps, avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
-			allc = [v for v in kt.values()]
-			roof['conv_stack'] = dict(achieved = round(sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12, 2), ms_per_step = round(sum(v['total_ms'] for v in allc) / args.steps, 3))
-			roof['conv_stack']['frac'] = round(roof['conv_stack']['achieved'] / peak, 4)
-			roof['whole_step_frac'] = round(FLOP_PER_AUDIO_S_FWD_BWD * value / world / (peak * 1e12), 4)
-			# the HBM-bound kernels of the path (frontend, BN + activation passes): algorithmic bytes / HIP-event time against 8 TB/s
-			roof['hbm_kernels'] = {name: dict(achieved = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1), peak = PEAK_HBM_GBS, unit = 'GB/s', frac = round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), launches_per_step = v['launches'] // args.steps, ms_per_step = round(v['total_ms'] / args.steps, 3)) for name, v in hbm.items()}
-			if 'logmel_kernel' in roof['hbm_kernels']:
-				roof['hbm_kernels']['logmel_kernel']['note'] = 'FFT-issue bound (three radix-8 Stockham passes through LDS per pair of frames), not HBM bound: under 1 % of the step'
-		line = dict(metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s', value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup, ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic', config = dict(workload = f'Wav2Letter full (18 conv + decoder, 66.5M params), {BATCH}x{SECS}s 16kHz per GPU, logmel+convstack+CTC fwd+bwd+clip+SGD, dropout {args.dropout:g}', global_batch = BATCH * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), loss_scaler = scaler_info, dist = dist_info, roofline = roof, parity = None)
+		# whole-job figures: every rank steps through batches of the same padded size (one bucket per iteration), rank 0's own count x world
+		value = world * audio[0] / elapsed
+		headline = args.workload == 'wav2letter' and args.batch is None and args.secs is None
+		conv_flops_per_s = world * (flops[0] + flops[1]) / elapsed
+		roof = roofline_of(args, wl, kt, kt2, steps2, conv_flops_per_s, world) if kt else None
+		metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s' if headline else f'audio-seconds/sec/node (fwd+bwd+CTC), {args.workload}' + ('' if args.batch is None and args.secs is None else ' (TEST-ONLY size)')
+		line = dict(metric = metric, value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup,
+			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
+			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), loss_scaler = scaler_info,
+			dist = dist_info, roofline = roof, parity = None)
+		if args.workload == 'jasper_large':
+			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),
+				gflop_per_padded_audio_s_fwd = round(flops[0] / audio[1] / 1e9, 2), gflop_per_step_fwd_bwd = round((flops[0] + flops[1]) / args.steps / 1e9, 1),
+				note = 'value counts the utterances\' own durations; the kernels also compute the padded frames (temporal_mask = False, like the reference): whole_step_frac is over the padded FLOPs')
 	if use_dist:
 		dist.destroy_process_group()
 	if rank == 0:
 		# the legs below start child processes / use the host cores: model, optimizer state and workspaces are released first
-		del model, flat, opt, engine, x, xlen, y, ylen, last
+		del engine, last, flat, step
+		wl.release()
 		torch.cuda.empty_cache()
+		roof = line['roofline']
 		if world == 1 and roof is not None and args.dtype in ('bf16', 'f16') and not args.no_traffic:
-			traffic, src = measure_traffic(args, sequence, args.steps)
-			roof['traffic'], roof['traffic_source'] = traffic, src  # (None + the reason when the counters could not be collected: no stale fallback)
+			roof['traffic'], roof['traffic_source'] = measure_traffic(args, sequence, args.steps)  # (None + the reason when the counters could not be collected: no stale fallback)
+		f16_leg = None
+		if world == 1 and args.dtype == 'bf16' and not args.no_f16_leg and args.workload == 'wav2letter':
+			# the same workload in the storage type that meets north_star's 1e-4 CTC bound: its own model / arena / optimizer / loss scaler
+			wl16 = Workload(args, device, rank, world, dtype = 'f16')
+			ov0 = float(wl16.flat.loss_scaler.current[7])
+			el16, au16, fl16, last16, _, _, _ = run_timed(args, wl16, wl16.model, 1, lambda: torch.cuda.synchronize(), time_main_kernel = False)
+			st = wl16.flat.loss_scaler.current.tolist()
+			f16_leg = dict(f16_value = round(au16[0] / el16, 1), f16_ms_per_step = round(1e3 * el16 / args.steps, 3), f16_steps = args.steps, f16_warmup = args.warmup,
+				f16_whole_step_frac = round((fl16[0] + fl16[1]) / el16 / PEAK_BF16_DENSE, 4), f16_loss_scale = st[0], f16_overflowed_steps_in_timed_region = int(st[7] - ov0),
+				f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
+			del last16
+			wl16.release()
+			torch.cuda.empty_cache()
 		if world == 1 and not args.no_cpu_baseline:
 			ref = {}
 			line['cpu_baseline'] = cpu_baseline(keep = ref)
 			line['parity'] = gpu_parity(ref, device)
 			line['parity']['headline_dtype'] = args.dtype
+		if f16_leg is not None:
+			line['parity'] = dict(line['parity'] or {}, **f16_leg)
 		import ctypes
 		ctypes.CDLL(None).fflush(None)
 		sys.stdout.flush()

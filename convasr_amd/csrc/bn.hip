@@ -491,11 +491,11 @@ template <typename T> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_g
 					for (int k = 0; k < 8; ++k) {
 						const float g = ((q.gate >> k) & 1u) ? dz[k] * gate_scale : 0.f;
 						s1[k] += g;
-						s2[k] = fmaf(g, yv[k], s2[k]);
+						s2[k] = fmaf(g, yv[k] - mean[k], s2[k]);  // centred per element like the ungated kernel: sum(g y) - mean sum(g) cancels catastrophically for |mean| >> std
 					}
 				});
 #pragma unroll
-		for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][8 + k] = cok ? (s2[k] - mean[k] * s1[k]) * istd[k] : 0.f; }
+		for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][8 + k] = cok ? s2[k] * istd[k] : 0.f; }
 		__syncthreads();
 		if (rl == 0 && cok) {
 			float* dst = ws + (int64_t)blockIdx.x * 2 * p.C;

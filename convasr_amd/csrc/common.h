@@ -18,6 +18,15 @@ int convasr_fail(int code, const char* fmt, ...);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Kernels that ask for more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER DEVICE: `mask`
+// (one static per call site and kernel) keeps a bit per device ordinal, so a process that drives a second GPU sets it there too.
+static inline void convasr_allow_160k_lds(const void* kern, unsigned long long& mask) {
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	const unsigned long long bit = 1ull << (dev & 63);
+	if (!(mask & bit)) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); mask |= bit; }
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 // round-to-nearest-even; NaN stays NaN (a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

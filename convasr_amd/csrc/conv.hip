@@ -356,11 +356,8 @@ extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* 
 // ------------------------------------------------------------------------------------------------ forward / dgrad launcher
 template <typename T, typename O, int XI, bool AL> static int launch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
 	auto kern = conv1d_igemm_kernel<T, O, XI, AL>;
-	static bool attr_set = false;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
-	}
+	static unsigned long long attr_set = 0;
+	convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), attr_set);
 	hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(NTHREADS), smem, s, p);
 	return 0;
 }
@@ -699,11 +696,8 @@ extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout
 
 template <typename T, int XI, bool AX, bool AY> static void launch_wgrad(const WgradParams& p, size_t smem, hipStream_t s) {
 	auto kern = conv1d_wgrad_kernel<T, XI, AX, AY>;
-	static bool attr_set = false;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
-	}
+	static unsigned long long attr_set = 0;
+	convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), attr_set);
 	hipLaunchKernelGGL(kern, dim3(p.units * p.splits), dim3(NTHREADS), smem, s, p);
 }
 

@@ -419,13 +419,13 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 			}
 			}
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { bs1[k] += g[k]; bs2[k] = fmaf(g[k], yv[k], bs2[k]); }  // sum g*y; centred and scaled once per tile below
+			for (int k = 0; k < 8; ++k) { bs1[k] += g[k]; bs2[k] = fmaf(g[k], yv[k] - bmean[k], bs2[k]); }  // sum g * (y - mean): centred per element (no cancellation for |mean| >> std), scaled once per tile below
 		}
 	}
 	if (bnf) {
 		float* const bnred = reinterpret_cast<float*>(smem + BM_ * OPITCH + 8 * BN * sizeof(float));  // [V2_THREADS][17], past the output tile and `red`
 #pragma unroll
-		for (int k = 0; k < 8; ++k) { bnred[tid * 17 + k] = bs1[k]; bnred[tid * 17 + 8 + k] = (bs2[k] - bmean[k] * bs1[k]) * bistd[k]; }  // sum g * xhat of this thread's rows
+		for (int k = 0; k < 8; ++k) { bnred[tid * 17 + k] = bs1[k]; bnred[tid * 17 + 8 + k] = bs2[k] * bistd[k]; }  // sum g * xhat of this thread's rows
 		__syncthreads();
 		if (tid < BN_ && co0 + tid < p.Cout) {
 			const int chunk = tid >> 3, k = tid & 7;
@@ -547,8 +547,8 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 #else
 	const void* kern = f16 ? v2s_kernel<f16_t, V2_BM>(ki) : v2s_kernel<bf16_t, V2_BM>(ki);
 #endif
-	static bool attr_set[2][2][4] = {};
-	if (!attr_set[f16][bi][ki]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[f16][bi][ki] = true; }
+	static unsigned long long attr_set[2][2][4] = {};
+	convasr_allow_160k_lds(kern, attr_set[f16][bi][ki]);
 	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
 	p.full_tiles = p.total_tiles;
 	if (!(p.debug & 32)) {
@@ -557,7 +557,7 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 	}
 	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
 	void* args[] = {&p};
-	if (hipLaunchKernel(kern, dim3(grid), dim3(V2S_THREADS), args, smem, s) != hipSuccess) return 0;
+	if (hipLaunchKernel(kern, dim3(grid), dim3(V2S_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
 	if (m_tiles_out) *m_tiles_out = p.B * p.m_tiles_per_b;
 	return 1;
 }

@@ -386,8 +386,8 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
 	const bool in_lds = lds_fixed + lds_lp <= 159 * 1024;  // T = 753, C = 38: 117 KB + 12 KB of the 160 KiB of a CU
 #define CTC_LAUNCH(NPH, NPL, LDS) do { \
 		auto kern = ctc_alpha_beta_kernel<NPH, NPL, LDS>; \
-		static bool set = false; \
-		if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+		static unsigned long long set = 0; \
+		convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set); \
 		hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_fixed + (LDS ? lds_lp : 0), s, log_probs, targets, olen, ylen, nll, alpha, beta, offs, tot, B, T, C, S_max, blank); \
 	} while (0)
 #define CTC_CASE(NPH, NPL) case NPH + NPL: if (in_lds) CTC_LAUNCH(NPH, NPL, true); else CTC_LAUNCH(NPH, NPL, false); break;

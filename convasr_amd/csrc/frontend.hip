@@ -220,13 +220,13 @@ extern "C" int convasr_logmel_fwd(const void* signal, int signal_dtype, const fl
 	hipStream_t s = (hipStream_t)stream;
 	if (signal_dtype == CONVASR_F32) {
 		auto kern = logmel_kernel<float>;
-		static bool set = false;
-		if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+		static unsigned long long set = 0;
+		convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FE_WAVES), smem, s, (const float*)signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, F, hop, nmel, preemphasis, pairs_per_b, total_pairs);
 	} else if (signal_dtype == CONVASR_I16) {
 		auto kern = logmel_kernel<short>;
-		static bool set = false;
-		if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+		static unsigned long long set = 0;
+		convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FE_WAVES), smem, s, (const short*)signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, F, hop, nmel, preemphasis, pairs_per_b, total_pairs);
 	} else return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: signal dtype %d", signal_dtype);
 	CONVASR_CHECK_LAUNCH("logmel_fwd");

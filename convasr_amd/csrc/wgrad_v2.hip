@@ -298,10 +298,10 @@ int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
 	if (smem > 160 * 1024) return 0;
 	const bool f16 = dtype == CONVASR_F16;
 	const void* kern = f16 ? (const void*)conv1d_wgrad_v2_kernel<f16_t> : (const void*)conv1d_wgrad_v2_kernel<bf16_t>;
-	static bool set[2] = {false, false};
-	if (!set[f16]) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set[f16] = true; }
+	static unsigned long long set[2] = {0, 0};
+	convasr_allow_160k_lds(kern, set[f16]);
 	void* args[] = {&q};
-	if (hipLaunchKernel(kern, dim3(q.units * q.splits), dim3(W2_ALL_THREADS), args, smem, s) != hipSuccess) return 0;
+	if (hipLaunchKernel(kern, dim3(q.units * q.splits), dim3(W2_ALL_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
 	p = q;
 	return 1;
 }

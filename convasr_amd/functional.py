@@ -46,9 +46,10 @@ def packed_weight(w, dtype, mode):
 		if dtype == torch.float32:
 			ent['fwd'], ent['fwd_ver'] = flat.data[off:off + w.numel()].view(K, Cout, Cin), ver
 		else:
+			# the mirror segment is current only if the arena says so for THIS version: a mirror re-allocated in the other 16-bit type
+			# (FlatParameters.mirror) is zero-filled, and a cache entry left from before the switch must not vouch for it
 			ent['fwd'] = flat.mirror(dtype)[off:off + w.numel()].view(K, Cout, Cin)
-			if flat._mirror_ver.get(id(w)) == ver:
-				ent['fwd_ver'] = ver
+			ent['fwd_ver'] = ver if flat._mirror_ver.get(id(w)) == ver else None
 	if mode == _lib.PACK_FWD and ent['fwd_ver'] == ver:
 		return ent['fwd']
 	if mode == _lib.PACK_DGRAD and ent['dgr_ver'] == ver:

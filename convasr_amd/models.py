@@ -519,7 +519,17 @@ class Wav2LetterDenseNoDilationInplace(JasperNet):
 
 # ------------------------------------------------------------------------------------------------ wrappers (models.py:736-765)
 
-AMP_DTYPE = {'fp16': torch.float16, 'float16': torch.float16, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}[__import__('os').environ.get('CONVASR_AMP_DTYPE', 'fp16')]  # what apex's O1-O3 mean here
+def _amp_dtype_from_env():
+	"""What apex's O1-O3 mean here: fp16 (the reference's arithmetic) unless CONVASR_AMP_DTYPE says bf16."""
+	import os
+	names = {'fp16': torch.float16, 'float16': torch.float16, 'f16': torch.float16, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}
+	name = os.environ.get('CONVASR_AMP_DTYPE', 'fp16').strip().lower()
+	if name not in names:
+		raise _lib.ConvasrHipError(f'CONVASR_AMP_DTYPE={name!r}: expected one of {sorted(names)}')
+	return names[name]
+
+
+AMP_DTYPE = _amp_dtype_from_env()
 
 
 def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, opt_level = None, compute_dtype = None, loss_scale = None, **kwargs):
@@ -539,6 +549,12 @@ def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, op
 		if loss_scale is None:
 			loss_scale = 'dynamic' if (dtype == torch.float16 and opt_level in ('O1', 'O2')) else None
 		flat.loss_scaler = None if loss_scale in (None, 1, 1.0) else LossScaler(flat.data.device, loss_scale = loss_scale)
+	elif dtype == torch.float16 and master_module(model).training and opt_level in ('O1', 'O2'):
+		# apex would scale the loss here; without an arena optimizer (convasr_amd.train.SGD / optimizers.NovoGrad / AdamW) there is nothing
+		# to attach the scaler to, and unscaled fp16 gradients of this network underflow
+		import warnings
+		warnings.warn(f'data_parallel_and_autocast(opt_level = {opt_level!r}): fp16 training WITHOUT loss scaling -- pass a convasr_amd arena optimizer '
+			'(its .flat carries the LossScaler), or compute_dtype = torch.bfloat16', RuntimeWarning, stacklevel = 2)
 	return model, optimizer
 
 

@@ -4,12 +4,17 @@ One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm
 cut into contiguous buckets; backward kernels report each parameter the moment its gradient is final, and as soon as every
 parameter of a bucket has reported, that bucket's sum-all-reduce is enqueued asynchronously (RCCL runs it on its own HIP
 stream, ordered after the producing kernels by an event) -- so communication overlaps the rest of the backward conv stack.
-xGMI is point-to-point, so a few large buckets (default 32 MiB) beat many small ones; only the bucket that completes last (the
-first layers, nothing left to overlap it with) is kept small.  Batch-norm statistics stay per GPU,
-exactly as in the reference's training path (train.py:704 does not pass synchronize_bn)."""
+xGMI is point-to-point, so a few large buckets (default 64 MiB, CONVASR_BUCKET_MIB) beat many small ones; only the buckets that
+complete last (the first layers, nothing left to overlap them with) are kept small: 4, 8, 16, 32 MiB.  Batch-norm statistics stay
+per GPU, exactly as in the reference's training path (train.py:704 does not pass synchronize_bn).
+
+CONVASR_COMM_THREAD=1 moves the host side of every collective (20-50 us each inside torch.distributed / RCCL) to a helper thread.
+It is OFF by default: it has only ever run with one RCCL rank and with two gloo ranks sharing a GPU (+0.3 % there), and a first
+multi-GPU run should not depend on a second thread issuing collectives."""
 import os
 import queue
 import threading
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -19,7 +24,7 @@ from .train import FlatParameters
 
 
 class DataParallelEngine(nn.Module):
-	def __init__(self, module, device = None, bucket_bytes = int(os.environ.get('CONVASR_BUCKET_MIB', 64)) << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True, comm_thread = os.environ.get('CONVASR_COMM_THREAD', '1') == '1'):
+	def __init__(self, module, device = None, bucket_bytes = int(os.environ.get('CONVASR_BUCKET_MIB', 64)) << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True, comm_thread = os.environ.get('CONVASR_COMM_THREAD', '0') == '1', measure_exposed_comm = False):
 		super().__init__()
 		self.module = module
 		self.group = process_group
@@ -43,14 +48,49 @@ class DataParallelEngine(nn.Module):
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
 				p._convasr_ready = self._make_hook(bi)
+		# measurement hook (bench.py): per step a HIP event pair on the main stream around the wait for the communication stream in
+		# finish_gradient_sync -- the part of the gradient exchange the backward pass did not cover
+		self.measure_exposed_comm = measure_exposed_comm
+		self.exposed_comm_events = []
 		from . import functional as Fn
-		Fn.after_long_launch_hooks[id(self)] = self.poll  # the backward pass calls poll() right after it has enqueued a long kernel
+		# the backward pass calls poll() right after it has enqueued a long kernel.  The registry holds the engine weakly: an engine
+		# that is dropped un-registers itself (close() does it eagerly and stops the helper thread)
+		ref, key = weakref.ref(self), id(self)
+		def hook():
+			eng = ref()
+			if eng is None:
+				Fn.after_long_launch_hooks.pop(key, None)
+			else:
+				eng.poll()
+		Fn.after_long_launch_hooks[key] = hook
+		self._hook_key = key
 		if self.collectives:
 			dist.broadcast(self.flat.data, src = 0, group = self.group)  # identical initial replicas
 			for buf in module.buffers():
 				dist.broadcast(buf, src = 0, group = self.group)
 			from . import functional as Fn
 			Fn.bump_param_epoch()  # the arena changed behind torch's version counters: packed compute copies are stale
+
+	def close(self):
+		"""Un-register from the backward pass's hook list and stop the helper thread (idempotent; also runs when the engine is collected)."""
+		from . import functional as Fn
+		Fn.after_long_launch_hooks.pop(getattr(self, '_hook_key', None), None)
+		worker, self._worker = getattr(self, '_worker', None), None
+		if worker is not None and self._jobs is not None:
+			self._jobs.put(None)  # the sentinel: run() returns
+			worker.join(timeout = 5)
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:
+			pass
+
+	def exposed_comm_ms(self):
+		"""Mean over the recorded steps of the time the main stream spent waiting for the communication stream (call after a device
+		synchronisation); None when nothing was recorded."""
+		ms = [a.elapsed_time(b) for a, b in self.exposed_comm_events]
+		return sum(ms) / len(ms) if ms else None
 
 	def _make_buckets(self, bucket_bytes, first_bucket_bytes):
 		"""Contiguous arena ranges.  Backward completes them from the END of the arena towards its start, so the buckets at the start
@@ -113,19 +153,20 @@ class DataParallelEngine(nn.Module):
 
 	def _submit(self, job):
 		if self._worker is None:
+			jobs, device, errors = self._jobs, self.flat.data.device, []  # (no reference to the engine: the thread must not keep it alive)
 			def run():
-				torch.cuda.set_device(self.flat.data.device)
+				torch.cuda.set_device(device)
 				while True:
-					job = self._jobs.get()
+					job = jobs.get()
 					try:
 						if job is None:
 							return
 						job()
 					except BaseException as e:  # surfaced by _drain() on the training thread
-						self._worker_error = e
+						errors.append(e)
 					finally:
-						self._jobs.task_done()
-			self._worker_error = None
+						jobs.task_done()
+			self._worker_errors = errors
 			self._worker = threading.Thread(target = run, name = 'convasr-comm', daemon = True)
 			self._worker.start()
 		self._jobs.put(job)
@@ -134,8 +175,9 @@ class DataParallelEngine(nn.Module):
 		"""Wait until the helper thread has enqueued everything handed to it (host-side only: nothing here waits for the GPU)."""
 		if self._jobs is not None and self._worker is not None:
 			self._jobs.join()
-			if self._worker_error is not None:
-				e, self._worker_error = self._worker_error, None
+			if self._worker_errors:
+				e = self._worker_errors.pop(0)
+				del self._worker_errors[:]
 				raise e
 
 	def _launch(self, bi, events):
@@ -206,9 +248,17 @@ class DataParallelEngine(nn.Module):
 				self._mark_ready(bi)
 		self.poll()
 		self._drain()
+		timed = self.measure_exposed_comm and self.flat.data.is_cuda
+		if timed:
+			ev0 = torch.cuda.Event(enable_timing = True)
+			ev0.record()
 		for work, view in self._pending:
 			work.wait()  # RCCL: orders the CURRENT stream behind the collective (it ran on the backend's own stream), no host block; gloo: host wait
 		self.join_comm_stream()
+		if timed:
+			ev1 = torch.cuda.Event(enable_timing = True)
+			ev1.record()
+			self.exposed_comm_events.append((ev0, ev1))
 		if self.world_size > 1:
 			if self.fold_mean:
 				self.flat.grad_scale = 1.0 / self.world_size  # flat.grad holds the SUM over ranks until the optimizer consumes it

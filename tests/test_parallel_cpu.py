@@ -1,5 +1,6 @@
 """World-size-2 gloo tests (CPU) of the data-parallel engine's host logic: flat arenas, bucketing, readiness-ordered launches,
 mean-reduction, broadcast of the initial replica.  The kernels themselves are covered by the -m gpu tests."""
+import json
 import os
 import socket
 
@@ -83,17 +84,47 @@ def _worker(rank, world, port, out):
 	out.put((rank, 'ok'))
 
 
-def test_data_parallel_engine_gloo_world2():
+@pytest.mark.parametrize('world', [2, 8])
+def test_data_parallel_engine_gloo(world):
 	ctx = mp.get_context('spawn')
 	out = ctx.Queue()
 	port = _free_port()
-	procs = [ctx.Process(target = _worker, args = (r, 2, port, out)) for r in range(2)]
+	procs = [ctx.Process(target = _worker, args = (r, world, port, out)) for r in range(world)]
 	for p in procs:
 		p.start()
 	for p in procs:
-		p.join(120)
+		p.join(180)
 	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-	assert sorted(out.get(timeout = 5)[0] for _ in range(2)) == [0, 1]
+	assert sorted(out.get(timeout = 5)[0] for _ in range(world)) == list(range(world))
+
+
+def test_bucket_grading_and_hook_lifetime():
+	"""Buckets are contiguous arena ranges in parameter order, graded 4, 8, 16, ... up to the limit from the START of the arena (the
+	part of the exchange nothing overlaps), and an engine that is closed or dropped leaves nothing behind in the backward pass's hook
+	registry."""
+	import gc
+	from convasr_amd.parallel import DataParallelEngine
+	from convasr_amd import functional as Fn
+
+	class Wide(nn.Module):
+		def __init__(self):
+			super().__init__()
+			self.layers = nn.ModuleList(nn.Conv1d(64, 64, 1, bias = False) for _ in range(40))  # 16 KiB each
+	before = set(Fn.after_long_launch_hooks)
+	eng = DataParallelEngine(Wide(), bucket_bytes = 128 << 10, first_bucket_bytes = 16 << 10)
+	sizes = [(b['hi'] - b['lo']) * 4 for b in eng.buckets]
+	assert sizes[:4] == [16 << 10, 32 << 10, 64 << 10, 128 << 10] and max(sizes) == 128 << 10, sizes
+	assert all(a['hi'] <= b['lo'] for a, b in zip(eng.buckets, eng.buckets[1:])) and eng.buckets[0]['lo'] == 0
+	assert sum(len(b['params']) for b in eng.buckets) == 40
+	assert len(set(Fn.after_long_launch_hooks) - before) == 1
+	eng.close()
+	assert set(Fn.after_long_launch_hooks) == before
+	eng2 = DataParallelEngine(Wide())
+	assert len(set(Fn.after_long_launch_hooks) - before) == 1
+	del eng2
+	gc.collect()
+	Fn._after_long_launch()  # a stale entry, had one survived, removes itself here
+	assert set(Fn.after_long_launch_hooks) == before
 
 
 def test_flat_parameters_views_and_state_dict_roundtrip():
@@ -171,6 +202,41 @@ def test_bench_launches_its_own_ranks_world2():
 def test_bench_launcher_propagates_a_rank_failure():
 	r = _run_bench(dict(CONVASR_DRY_RUN_FAIL_RANK = '1'), '--gpus', '2', '--launcher-dry-run')
 	assert r.returncode != 0
+
+
+def test_bench_launcher_world8_dry_run():
+	r = _run_bench({}, '--gpus', '8', '--launcher-dry-run')
+	assert r.returncode == 0, r.stderr[-2000:]
+	line = json.loads(r.stdout.strip().splitlines()[-1])
+	assert line['n_gpus'] == 8 and line['value'] == 36.0 and line['dist']['world_size'] == 8
+
+
+def test_bench_launcher_ends_a_hung_child_tree():
+	"""A rank that never reaches its collective: the parent gives up after CONVASR_LAUNCH_TIMEOUT, ends the whole child tree
+	(its own session) and exits 124 -- no orphan keeps the port or a GPU."""
+	import subprocess, time
+	t0 = time.time()
+	r = _run_bench(dict(CONVASR_DRY_RUN_HANG_RANK = '1', CONVASR_LAUNCH_TIMEOUT = '20'), '--gpus', '2', '--launcher-dry-run')
+	assert r.returncode == 124 and 'ending the child tree' in r.stderr, (r.returncode, r.stderr[-1500:])
+	assert time.time() - t0 < 90
+	time.sleep(1.0)
+	left = subprocess.run(['pgrep', '-f', 'launcher-dry-run'], stdout = subprocess.PIPE, text = True).stdout.split()
+	assert not left, left
+
+
+def test_bench_rank_preflight_and_flop_count():
+	"""pin_to_gpu_numa_node is best effort (no KFD topology in the CPU container: it must say so, not raise); conv_stack_flops
+	reproduces SURVEY 8(d)'s figures from the module tree."""
+	import bench
+	import convasr_amd as ca
+	info = bench.pin_to_gpu_numa_node(0)
+	assert isinstance(info, dict) and 'pinned' in info and (info['pinned'] or 'reason' in info)
+	assert bench._cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	fwd, bwd = bench.conv_stack_flops(ca.models.Wav2Letter(64, [38], frontend = fe), 64, 15 * 16000)
+	assert abs(fwd / 1e9 - 6399) < 2 and abs((fwd + bwd) / (64 * 15) / 1e9 - 19.98) < 0.01, (fwd, bwd)
+	fwd, bwd = bench.conv_stack_flops(ca.models.JasperNetLarge(64, [38], frontend = fe), 32, 20 * 16000)
+	assert abs(fwd / 1e9 - 17751) < 20, fwd
 
 
 def test_bench_launcher_refuses_more_ranks_than_gpus():
