@@ -61,6 +61,7 @@ _SIGNATURES = dict(
 	convasr_sumsq_workspace_bytes = (c_i64, []),
 	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_f32, c_p, c_p]),
 	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
+	convasr_adamw_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_p, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
 	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p]),
 	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
 	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
@@ -94,7 +95,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 5:
+		if lib.convasr_abi_version() != 6:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib

@@ -417,3 +417,70 @@ extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* gra
 	CONVASR_CHECK_LAUNCH("sgd_step");
 	return 0;
 }
+
+// torch.optim.AdamW (train.py:663-668) over the flat arena, with clip_grad_norm_ (train.py:777), the device-side loss gate, the
+// gradient-mean scale, the 16-bit mirror and the dynamic loss scaler folded in exactly as in sgd_step_kernel.  The number of steps
+// APPLIED so far lives on the device (step_in[0] -> step_out[0], two buffers the host swaps): a gated or overflowed launch does not
+// advance the bias corrections, like a reference run that never reached optimizer.step().
+template <typename H> __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                         int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                                                         const float* __restrict__ step_in, float* __restrict__ step_out, const float* __restrict__ loss_gate, float grad_scale,
+                                                         H* __restrict__ p16, const float* __restrict__ scaler_in, float* __restrict__ scaler_out) {
+	const bool gated = loss_gate && !(fabsf(*loss_gate) < INFINITY);
+	const LossScale ls = loss_scale_read(scaler_in, (scaler_in && sumsq) ? *sumsq : 0.0);
+	const float t0 = *step_in;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		if (scaler_in) loss_scale_advance(scaler_in, scaler_out, ls.overflow, gated);
+		*step_out = (gated || ls.overflow) ? t0 : t0 + 1.f;
+	}
+	if (gated || ls.overflow) return;
+	grad_scale *= ls.inv;
+	float clip = 1.f;
+	if (sumsq && max_norm > 0.f) {
+		const float total = (float)sqrt(*sumsq) * grad_scale;
+		const float c = max_norm / (total + 1e-6f);
+		clip = c < 1.f ? c : 1.f;
+	}
+	clip *= grad_scale;
+	// torch/optim/adamw.py (single-tensor path): p *= 1 - lr wd; m, v EMAs; p -= (lr / (1 - beta1^t)) m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+	const double t = (double)t0 + 1.0;
+	const float bc1 = (float)(1.0 - pow((double)beta1, t)), bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+	const float step_size = lr / bc1, decay = 1.f - lr * wd, omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+	auto update = [&](float gi, float pv, float& mv, float& vv) {
+		const float gc = gi * clip;
+		mv = beta1 * mv + omb1 * gc;
+		vv = beta2 * vv + omb2 * gc * gc;
+		return pv * decay - step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+	};
+	const int64_t n4 = n >> 2;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+		const float4 g4 = reinterpret_cast<const float4*>(g)[i], p4 = reinterpret_cast<const float4*>(p)[i];
+		float4 m4 = reinterpret_cast<const float4*>(m)[i], v4 = reinterpret_cast<const float4*>(v)[i], r;
+		r.x = update(g4.x, p4.x, m4.x, v4.x); r.y = update(g4.y, p4.y, m4.y, v4.y); r.z = update(g4.z, p4.z, m4.z, v4.z); r.w = update(g4.w, p4.w, m4.w, v4.w);
+		reinterpret_cast<float4*>(p)[i] = r;
+		reinterpret_cast<float4*>(m)[i] = m4;
+		reinterpret_cast<float4*>(v)[i] = v4;
+		if (p16) reinterpret_cast<uint2*>(p16)[i] = make_uint2(pack16<H>(r.x, r.y), pack16<H>(r.z, r.w));
+	}
+	if (blockIdx.x == 0 && (int64_t)threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		float mv = m[i], vv = v[i];
+		const float r = update(g[i], p[i], mv, vv);
+		p[i] = r; m[i] = mv; v[i] = vv;
+		if (p16) Elem<H>::store(p16 + i, r);
+	}
+}
+
+extern "C" int convasr_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const double* sumsq, float max_norm, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, const float* step_in, float* step_out, const float* loss_gate,
+                                  float grad_scale, void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream) {
+	CONVASR_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step_in && step_out && step_in != step_out, "adamw_step: bad arguments");
+	CONVASR_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adamw_step: betas in [0, 1), eps >= 0");
+	CONVASR_CHECK_ARG(!p16 || convasr_is_half(p16_dtype), "adamw_step: the mirror's dtype must be CONVASR_BF16 or CONVASR_F16");
+	CONVASR_CHECK_ARG((scaler_in == nullptr) == (scaler_out == nullptr) && (!scaler_in || (scaler_in != scaler_out && sumsq)), "adamw_step: the loss scaler needs distinct in / out states and the gradient's sum of squares (its overflow check)");
+	int64_t blocks = ceil_div64(n, 256);
+	if (blocks > 4096) blocks = 4096;
+	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((adamw_step_kernel<H>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step_in, step_out, loss_gate, grad_scale, (H*)p16, scaler_in, scaler_out));
+	CONVASR_CHECK_LAUNCH("adamw_step");
+	return 0;
+}

@@ -615,7 +615,10 @@ class ConvBnActEvalFunction:
 		else:
 			wp = packed_weight(weight, dt, _lib.PACK_FWD)
 			conv = lambda **epilogue: ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, **epilogue)
-		if not res_list:
+		# dropout > 0 here means a FROZEN block (JasperNet.freeze, models.py:328-339): its batch norms run on their running statistics
+		# but the block is still in training mode, and the reference's ResidualActivation applies dropout by self.training (models.py:365-369)
+		p_drop = float(cfg.get('dropout_p', 0.0))
+		if not res_list and p_drop == 0:
 			return conv(scale = scale, shift = shift, act = act, xlen = xl)
 		y = conv()
 		res_y, rscale, rshift = [], [], []
@@ -627,7 +630,8 @@ class ConvBnActEvalFunction:
 				res_y.append(ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb))
 				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])
 		# rscale None (identity residual, or a residual conv already fused with its BN) means "add as is"
-		return ops.bn_act(y, scale, shift, act, xlen = xl, res = res_y, rscale = rscale, rshift = rshift)
+		seed, offset = _DropoutState.next(y.numel()) if p_drop > 0 else (0, 0)
+		return ops.bn_act(y, scale, shift, act, xlen = xl, res = res_y, rscale = rscale, rshift = rshift, dropout_p = p_drop, seed = seed, offset = offset)
 
 
 class LogSoftmaxFunction(torch.autograd.Function):

@@ -496,6 +496,15 @@ def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nest
 	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
 
 
+def adamw_step(p, g, exp_avg, exp_avg_sq, n, sumsq_buf, max_norm, lr, beta1, beta2, eps, weight_decay, step_in, step_out, loss_gate = None, grad_scale = 1.0, p16 = None, scaler = None):
+	"""One fused torch.optim.AdamW step (+ clip_grad_norm_) over the flat arena; step_in / step_out: 1-element fp32 device tensors (applied-step counter)."""
+	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
+	assert p16 is None or (p16.dtype in HALF_DTYPES and p16.numel() == n)
+	assert step_in.dtype == step_out.dtype == torch.float32 and step_in.data_ptr() != step_out.data_ptr()
+	s_in, s_out = _scaler_pair(scaler)
+	call('convasr_adamw_step', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), n, ptr(sumsq_buf), float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), ptr(step_in), ptr(step_out), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
+
+
 def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None, gate = None):
 	"""dx = dgrad(dy) with pass 1 of the consumer layer's batch-norm backward fused into the epilogue (bn_sums += per-channel sums).
 	Returns dx, or None when the shape is outside the fused kernel's envelope (nothing was launched)."""

@@ -73,6 +73,64 @@ class NovoGrad:
 			g.update(s)
 
 
+class AdamW:
+	"""torch.optim.AdamW (train.py:663-668: lr, betas, weight_decay from the command line; eps 1e-8, no amsgrad) as ONE fused launch over
+	FlatParameters, with clip_grad_norm_, the device-side loss gate, the data-parallel mean and the fp16 loss scaler folded in like
+	convasr_amd.train.SGD.  The count of APPLIED steps (what the bias corrections use) lives on the device: a gated / overflowed step
+	does not advance it, as in a reference run that skipped optimizer.step()."""
+
+	def __init__(self, flat, lr = 1e-3, betas = (0.9, 0.999), eps = 1e-8, weight_decay = 1e-2, amsgrad = False):
+		if amsgrad:
+			raise ValueError('AdamW(amsgrad = True) is not implemented (the reference never passes it)')
+		self.flat = flat
+		self.defaults = dict(lr = lr, betas = tuple(betas), eps = eps, weight_decay = weight_decay)
+		self.param_groups = [dict(params = flat.params, **self.defaults)]
+		self.exp_avg = torch.zeros_like(flat.data)
+		self.exp_avg_sq = torch.zeros_like(flat.data)
+		self.applied = torch.zeros(2, 1, dtype = torch.float32, device = flat.data.device)  # [steps & 1] is current
+		self.steps = 0
+
+	def zero_grad(self, set_to_none = False):
+		self.flat.zero_grad()
+
+	def step(self, loss_gate = None):
+		g = self.param_groups[0]
+		flat = self.flat
+		if flat.clip is None:
+			flat.finalize_grads()
+		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
+		scaler = getattr(flat, 'loss_scaler', None)
+		if scaler is not None and sumsq is None:  # the overflow check reads the gradient's sum of squares
+			sumsq = ops.sumsq(flat.grad, flat._sumsq)
+		cur = self.steps & 1
+		grad_scale = flat.grad_scale
+		flat.mirror_carried_over(lambda p16: ops.adamw_step(flat.data, flat.grad, self.exp_avg, self.exp_avg_sq, flat.numel, sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.applied[cur], self.applied[1 - cur], loss_gate = loss_gate, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair()))
+		if scaler is not None:
+			scaler.advance()
+		self.steps += 1
+		flat.clip, flat.grad_scale = None, 1.0
+
+	@property
+	def state(self):
+		"""torch's vocabulary: {param: dict(step, exp_avg, exp_avg_sq)} with the moments viewed in the parameters' logical shapes."""
+		m, v = self.flat.param_views(self.exp_avg), self.flat.param_views(self.exp_avg_sq)
+		step = self.applied[self.steps & 1, 0]
+		return {p: dict(step = step, exp_avg = m[i], exp_avg_sq = v[i]) for i, p in enumerate(self.flat.params)}
+
+	def state_dict(self):
+		"""format 2 (like SGD / NovoGrad here): moments per parameter in the reference's shapes, independent of the arena's element order."""
+		return dict(format = 2, steps = self.steps, steps_applied = int(self.applied[self.steps & 1, 0].item()), exp_avg = self.flat.export_state(self.exp_avg), exp_avg_sq = self.flat.export_state(self.exp_avg_sq),
+			param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+
+	def load_state_dict(self, sd):
+		self.steps = sd['steps']
+		self.flat.import_state(self.exp_avg, sd['exp_avg'], 'AdamW.load_state_dict(exp_avg)')
+		self.flat.import_state(self.exp_avg_sq, sd['exp_avg_sq'], 'AdamW.load_state_dict(exp_avg_sq)')
+		self.applied[self.steps & 1, 0] = float(sd.get('steps_applied', sd['steps']))
+		for g, s in zip(self.param_groups, sd['param_groups']):
+			g.update(s)
+
+
 def reset_options(optimizer):
 	for group in optimizer.param_groups:
 		group.update(optimizer.defaults)

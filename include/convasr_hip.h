@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 5
+#define CONVASR_ABI_VERSION 6
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2, CONVASR_F16 = 3 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -283,6 +283,15 @@ int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, flo
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale,
                      void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream);
+/* torch.optim.AdamW step (train.py:663-668; decoupled weight decay, no amsgrad) with the same folded-in pieces as convasr_sgd_step:
+ * g' = c*grad_scale*g (c from sumsq / max_norm as above); p *= 1 - lr*wd; m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2;
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = step_in[0] + 1.  step_in / step_out: one device float each, distinct
+ * buffers the caller swaps per call: the number of steps APPLIED so far (a launch gated by loss_gate or skipped by the loss scaler
+ * writes step_out[0] = step_in[0] and changes nothing else, so the bias corrections follow the applied steps like torch's state['step']).
+ * loss_gate, grad_scale, p16 / p16_dtype, scaler_in / scaler_out: as in convasr_sgd_step. */
+int convasr_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const double* sumsq, float max_norm, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, const float* step_in, float* step_out, const float* loss_gate,
+                       float grad_scale, void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream);
 
 /* Fused backward step (bf16 / fp16 storage `dtype`, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
  * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:

@@ -372,12 +372,15 @@ def fuse_conv_bn_eval(sd, eps = 1e-5):
 	return out
 
 
-def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None):
+def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None, frozen = None):
 	"""JasperNet.forward (models.py:282-326).  sd: state dict (tensors, BN buffers are updated in place when
 	training), plan: jasper_plan(...), frontend: dict(window, nfft, hop_length) or None (x is features).
 	storage = torch.bfloat16 restates the same algorithm with the MI355X throughput path's storage precision: activations, conv
 	outputs, packed weights and the gradients flowing between layers rounded to bf16 where the HIP kernels store them in bf16,
-	every sum accumulated in fp32 (see _conv_bn_stored); storage = None is the reference's fp32 arithmetic."""
+	every sum accumulated in fp32 (see _conv_bn_stored); storage = None is the reference's fp32 arithmetic.
+	frozen = dict(backbone = k, decoder0 = bool): JasperNet.freeze (models.py:328-339) -- the batch norms of the first k blocks run on
+	their running statistics (module.eval(), models.py:333) while everything else stays in training mode."""
+	n_frozen = (frozen or {}).get('backbone', 0) or 0
 	if frontend is not None:
 		x = logmel_frontend(x, xlen, sd['frontend.window'], sd['frontend.mel.weight'], sd['frontend.mel.bias'], frontend['nfft'], frontend['hop_length'])
 	assert x.ndim == 3
@@ -388,7 +391,7 @@ def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = N
 	residual = []
 	L = len(plan['layers'])
 	for i, layer in enumerate(plan['layers']):
-		x = conv_block(x, sd, f'backbone.{i}', layer, xlen, residual, plan['nonlinearity'], plan['temporal_mask'], training, storage = storage)
+		x = conv_block(x, sd, f'backbone.{i}', layer, xlen, residual, plan['nonlinearity'], plan['temporal_mask'], training and i >= n_frozen, storage = storage)
 		if i >= L - 2 - 1:
 			residual = []
 		elif plan['residual'] == 'dense':
@@ -678,15 +681,18 @@ def novograd_step(params, grads, state, lr = 1.0, betas = (0.95, 0.98), eps = 1e
 	return total
 
 
-def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, max_norm = 100.0, momentum_buffers = None, nesterov = False, storage = None):
+def train_step(sd, plan, x, xlen, y, ylen, frontend = None, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3, max_norm = 100.0, momentum_buffers = None, nesterov = False, storage = None, frozen = None):
 	"""One iteration of the reference loop with accumulate=1: forward (748), loss = mean(loss * ylen) (755),
 	backward (774), clip_grad_norm_ (777), SGD step (780).  Returns dict(loss, loss_cur, entropy, grad_norm, grads);
-	sd parameters and momentum_buffers are updated in place."""
-	names = [k for k, v in sd.items() if v.is_floating_point() and not k.startswith('frontend.') and 'running_' not in k]
+	sd parameters and momentum_buffers are updated in place.  frozen: see jasper_forward; frozen parameters get no gradient and
+	no update (models.py:337-338: requires_grad = False; torch.optim.SGD skips parameters without a gradient, weight decay included)."""
+	fz = frozen or {}
+	frozen_prefixes = tuple(f'backbone.{i}.' for i in range(fz.get('backbone', 0) or 0)) + (('decoder.0.', ) if fz.get('decoder0') else ())
+	names = [k for k, v in sd.items() if v.is_floating_point() and not k.startswith('frontend.') and 'running_' not in k and not k.startswith(frozen_prefixes)]
 	for k in names:
 		sd[k].requires_grad_(True)
 		sd[k].grad = None
-	out = jasper_forward(sd, plan, x, xlen, y, ylen, frontend = frontend, training = True, storage = storage)
+	out = jasper_forward(sd, plan, x, xlen, y, ylen, frontend = frontend, training = True, storage = storage, frozen = frozen)
 	loss_vec = out['loss']
 	loss = (loss_vec * ylen[:, 0]).mean()
 	loss_cur = loss_vec.mean()
