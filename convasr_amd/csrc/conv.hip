@@ -391,6 +391,14 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	// a caller may ask for the first Tout < expect frames only (the stride-2 fold below needs one frame less than its even folded kernel yields)
 	CONVASR_CHECK_ARG(Tout <= expect, "conv1d_fwd: Tout %d inconsistent with Tin %d K %d stride %d dil %d pad %d (at most %lld)", Tout, Tin, K, stride, dil, pad, (long long)expect);
 	CONVASR_CHECK_ARG(x_dtype == CONVASR_F32 || convasr_is_half(x_dtype), "conv1d_fwd: x dtype %d", x_dtype);
+	// A one-tap, stride-1, unpadded conv has no temporal coupling: without per-utterance length masks the batch is ONE sequence of
+	// B * T frames, and the tiles need not stop at utterance ends (32 utterances of 626 frames: 79 tiles of 256 rows instead of 96).
+	// Same k order per element; the BN partial rows are grouped by the new tiles.  (debug bit 512: off, A/B runs)
+	if (K == 1 && stride == 1 && pad == 0 && Tin == Tout && B > 1 && !xlen && !(bn_fusion && bn_fusion->bn_xlen) && !(g_conv_debug & 512) &&
+	    (int64_t)B * Tin * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31)) {
+		Tin = Tout = B * Tin;
+		B = 1;
+	}
 	ConvParams p = {};
 	if (bn_fusion) p = *bn_fusion;  // only the bn_* fields are set in it
 	p.x = x; p.w = wp; p.y = y; p.bias = bias; p.stats = stats; p.scale = scale; p.shift = shift; p.xlen = xlen;

@@ -27,6 +27,7 @@ struct ConvParams {
 	int m_tiles_per_b, n_tiles, total_tiles;
 	int full_tiles;  // conv_v2s only: tiles [0, full_tiles) are 256 x 128; each later one is computed as two 256 x 64 halves by two workgroups
 	int x_rows;  // LDS rows of one X tile (even)
+	int tail128;  // conv_v2s only: the last m tile of every utterance covers at most 128 frames and runs as a 128-row tile (half the MFMA work of a padded 256-row one)
 	// conv_v2s only, optional (bn_y != NULL): this launch is the dgrad that produces dz of a Conv+BN+activation layer, and its
 	// epilogue also runs pass 1 of that layer's batch-norm backward on the tile it just produced (see convasr_conv1d_dgrad_bn_reduce)
 	const void* bn_y; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; const float* bn_xlen; double* bn_sums;

@@ -54,7 +54,7 @@ template <> struct HalfOnes<bf16_t> { static constexpr unsigned pair = 0x3F803F8
 template <> struct HalfOnes<f16_t> { static constexpr unsigned pair = 0x3C003C00u; };
 template <> struct HalfOnes<float> { static constexpr unsigned pair = 0u; };  // (never used: the fused epilogues exist for 16-bit outputs only)
 
-template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int v, const int half) {
+template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int mtile, const int ntile, const int half, const int bm_full) {
 	constexpr int BN_ = 32 * NB, MI = BM_ / 64, WROWS = 16 * MI;  // MI 16-row blocks = WROWS rows per wave
 	// LDS map of the epilogue (everything the main loop used is dead by then): output tile, BN-statistics scratch, and for BNF == 2 the
 	// consumer layer's y tile (row-major, BN_ * 2 bytes per row, brought in by the loader waves) and the 256-entry gate -> mask table
@@ -64,13 +64,13 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
 
-	int ntile, mtile;
-	tile_coords(v, p.B * p.m_tiles_per_b, p.n_tiles, mtile, ntile);
-	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * BM_;
+	// (bm_full: the launch's regular tile height -- m tiles are bm_full frames apart; BM_ < bm_full only for the short last tile of an utterance)
+	const int b = mtile / p.m_tiles_per_b, t0 = (mtile % p.m_tiles_per_b) * bm_full;
 	const int co0 = ntile * BN + half * BN_;
 	const int tin0 = t0 - p.pad;
 
-	const int xbytes = p.x_rows * ROW_BYTES;
+	const int x_rows = p.x_rows - (bm_full - BM_);  // (a multiple of 16 either way)
+	const int xbytes = x_rows * ROW_BYTES;
 	// X slab buffers: two (the slab being read + the next one landing); K = 1 has ONE interval per slab, so reading the next interval's first
 	// fragments ahead of the barrier needs the next slab resident one interval earlier: three buffers (and only the 3-slot weight ring)
 	const bool k1 = p.K == 1;
@@ -81,7 +81,7 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 	const v4i32 wsrc = make_srd(p.w, (unsigned)(p.K * p.CoutPad * row_bytes));
 	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 	const int n_cib = p.Cin >> 6;
-	const int x_units = p.x_rows >> 3;
+	const int x_units = x_rows >> 3;
 
 	// Waves 0-7 compute; waves 8-11 (one per SIMD) only issue the LDS-DMA pieces.  A piece costs its issuing wave ~100 cycles
 	// (M0 hand-over, address math, the buffer_load itself) during which an in-order wave issues no MFMA: with the 38 pieces of an
@@ -144,7 +144,7 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 			__builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
 			__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
 		}
-		__builtin_amdgcn_sched_group_barrier(0x008, MI * NB - (MI + NB), 0);
+		if (MI * NB > MI + NB) __builtin_amdgcn_sched_group_barrier(0x008, MI * NB - (MI + NB), 0);
 	};
 	auto mma_frag = [&](const Frag& f) {
 #pragma unroll
@@ -492,11 +492,26 @@ template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__
 
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
-	if (bid < p.full_tiles) {
-		v2s_tile<I, O, 4, BNF, BM_>(p, smem, xcd_remap(bid, p.full_tiles), 0);
-	} else {  // full_tiles is a multiple of 8, so (bid - full_tiles) keeps the workgroup's XCD; the two halves of a tile share an XCD (and its X tile in L2)
+	int v, half = 0;
+	const bool narrow = bid >= p.full_tiles;
+	if (!narrow) v = xcd_remap(bid, p.full_tiles);
+	else {  // full_tiles is a multiple of 8, so (bid - full_tiles) keeps the workgroup's XCD; the two halves of a tile share an XCD (and its X tile in L2)
 		const int h = xcd_remap(bid - p.full_tiles, 2 * (p.total_tiles - p.full_tiles));
-		v2s_tile<I, O, 2, BNF, BM_>(p, smem, p.full_tiles + (h >> 1), h & 1);
+		v = p.full_tiles + (h >> 1);
+		half = h & 1;
+	}
+	int ntile, mtile;
+	tile_coords(v, p.B * p.m_tiles_per_b, p.n_tiles, mtile, ntile);
+	// Short last tile: an utterance of 626 frames is 2 x 256 + 114 -- run as a third 256-row tile the tail costs a full tile of MFMAs for
+	// 114 useful rows (mixed-length batches, BASELINE configs[4]: ~8 % of the forward / dgrad time on average); as a 128-row tile (two
+	// 16-row blocks per wave instead of four, same k order per element: bit-identical values) it costs half.
+	const bool tail = p.tail128 && (mtile % p.m_tiles_per_b) == p.m_tiles_per_b - 1;
+	if (!tail) {
+		if (!narrow) v2s_tile<I, O, 4, BNF, BM_>(p, smem, mtile, ntile, 0, BM_);
+		else v2s_tile<I, O, 2, BNF, BM_>(p, smem, mtile, ntile, half, BM_);
+	} else {
+		if (!narrow) v2s_tile<I, O, 4, BNF, 128>(p, smem, mtile, ntile, 0, BM_);
+		else v2s_tile<I, O, 2, BNF, 128>(p, smem, mtile, ntile, half, BM_);
 	}
 }
 
@@ -539,6 +554,8 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.K * p.CoutPad * p.Cin * 2 >= (1ll << 31) || (int64_t)(p.Tout + bm) * p.Cout * 2 >= (1ll << 31)) return 0;
 	p.m_tiles_per_b = (p.Tout + bm - 1) / bm;
 	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
+	const int tail_rows = p.Tout - (p.m_tiles_per_b - 1) * bm;
+	p.tail128 = (bm == V2_BM && tail_rows <= 128 && !(p.debug & 128)) ? 1 : 0;  // (debug bit 128: off, A/B runs)
 	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
 	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
 	const int ki = wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0), bi = bm == 192 ? 1 : 0;

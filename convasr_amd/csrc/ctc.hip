@@ -32,7 +32,12 @@
 #define CTC_RENORM 8
 #define CTC_RENORM_LOG2 3
 #define CTC_EMPTY 0xFFFFFFFFu    // "not written yet": a NaN bit pattern; published words are mapped away from it (ctc_word)
+#ifndef CTC_SPIN_LIMIT
 #define CTC_SPIN_LIMIT (1 << 22) // a consumer never spins this long unless the producer died: give up (the loss becomes NaN) rather than hang
+#endif
+// Diagnostic build only (python -m convasr_amd.build --variant ctcskip -DCONVASR_CTC_SKIP_PUBLISH=100 -DCTC_SPIN_LIMIT=65536;
+// tests/test_round4_gpu.py): the producing wave of every sweep "dies" at that frame -- it never publishes the frame's edge states -- so that
+// the consumer's give-up path runs: the loss of every utterance long enough must come out NaN, and the launch must end.
 
 // base-2 log-sum-exp of three / two values >= the sentinel.  The largest term is exp2(0) = 1 exactly, so only the other terms go
 // through v_exp_f32 (max3 / med3 / min3 are single instructions): 3 transcendental instructions per label state, 2 per blank state.
@@ -135,6 +140,9 @@ __device__ __forceinline__ void ctc_sweep(const CtcSweep& q) {
 	float a[NS], cur[NS], nxt[NS];
 	const int t0 = FWD ? 0 : Tb - 1, dt = FWD ? 1 : -1;
 	auto publish = [&](int t) {
+#ifdef CONVASR_CTC_SKIP_PUBLISH
+		if (t == CONVASR_CTC_SKIP_PUBLISH) return;
+#endif
 		if (!consumes && edge_lane) {
 			if (FWD) slot_store(q.edge + t, ctc_word(a[NS - 1]));
 			else { slot_store(q.edge + 2 * t, ctc_word(a[0])); slot_store(q.edge + 2 * t + 1, ctc_word(a[1])); }

@@ -39,7 +39,7 @@ def packed_weight(w, dtype, mode):
 	arena = getattr(w, '_convasr_arena', None)
 	# (the address test: p.data may have been replaced since FlatParameters re-homed it -- model.to(), load_state_dict(assign = True) --
 	# with the strides preserved; such a parameter no longer aliases the arena and is packed like any other)
-	in_place = arena is not None and ops.weight_layout(w) == _lib.W_KMAJOR and ops.cout_pad(w.shape[0]) == w.shape[0] and dtype in (torch.float32, ) + ops.HALF_DTYPES and w.device == arena[0].data.device and w.data_ptr() == arena[0].data.data_ptr() + 4 * arena[1]
+	in_place = arena is not None and (ops.weight_layout(w) == _lib.W_KMAJOR or (w.shape[2] == 1 and w.is_contiguous())) and ops.cout_pad(w.shape[0]) == w.shape[0] and dtype in (torch.float32, ) + ops.HALF_DTYPES and w.device == arena[0].data.device and w.data_ptr() == arena[0].data.data_ptr() + 4 * arena[1]
 	if in_place:
 		flat, off = arena
 		Cout, Cin, K = w.shape
@@ -469,10 +469,13 @@ class ConvBnActFunction(torch.autograd.Function):
 			# The bias of a conv that feeds a train-mode batch norm has an identically zero gradient: dry sums to zero over (b, t) for
 			# every channel (sum of g minus N times its mean, minus mean(g xhat) times sum of xhat = 0).  The reference's autograd
 			# gets rounding noise around 0 from the column sum of dry; here the entry is set to exact zero and the pass is skipped.
-			def res_wgrad(outs, acc, rx = rx, dry = dry):
+			def res_wgrad(outs, acc, rx = rx, dry = dry, rb = rb):
 				ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], accumulate = acc)
-				if outs[1] is not None and not acc:
+				if outs[1] is not None and not acc and not (outs[1] is getattr(rb, '_convasr_grad', None) and getattr(rb, '_convasr_grad_is_zero', False)):
 					outs[1].zero_()
+					# the arena segment of this bias gradient is written by nobody else (zero at allocation, zero again now, sums of zeros
+					# under data parallelism): later steps skip the fill -- dense blocks carry up to ten such biases
+					rb._convasr_grad_is_zero = outs[1] is getattr(rb, '_convasr_grad', None)
 			drw, drb = _deliver([rw, rb], res_wgrad)
 			res_grads += [drx, drw, drb, drg, drbeta]
 		return (None, dx, dw, dgamma, dbeta, None, *res_grads)

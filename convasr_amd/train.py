@@ -48,7 +48,10 @@ class FlatParameters:
 			p.data = view
 			p._convasr_grad = as_param(self.grad)
 			p._convasr_fresh = True
-			p._convasr_arena = (self, o) if kmajor else None
+			# (a one-tap conv weight, (Cout, Cin, 1) contiguous, IS its own tap-major form: its mirror segment serves as the packed forward
+			# operand just the same -- the dense-residual models carry ~55 such 1x1 convs, one packing launch each per step otherwise)
+			one_tap = p.ndim == 3 and p.shape[2] == 1 and (p.shape[0] * p.shape[1]) % 8 == 0 and dev.type == 'cuda'
+			p._convasr_arena = (self, o) if (kmajor or one_tap) else None
 			p.grad = p._convasr_grad
 		self._by_id = {id(p): p for p in params}
 		self.clip = None  # (sumsq double buffer, max_norm) set by clip_grad_norm_

@@ -102,7 +102,7 @@ def test_trained_wav2letter_32x10s_greedy_strings_identical_to_the_oracle():
 		assert same == B, (mode, [(a, b) for a, b in zip(got, want) if a != b][:2])
 		close(out['logits'][0], ref['logits'], 1e-3, 1e-4 * max(scale, 1.0), 'logits ' + mode)
 		assert rel <= 1e-4, (mode, rel)
-		assert all(len(w) > 5 for w in want) and len(set(want)) >= B0
+		assert sum(map(len, want)) / B > 10 and len(set(want)) >= B0  # (non-trivial transcripts: the comparison above is not between empty strings)
 
 
 FREEZE_CFG = dict(base_width = 32, kernel_sizes = [11, 13], out_width_factors = [2, 3], dropouts = [0.2, 0.2], out_width_factors_large = [4, 4], residual = 'dense', repeat = 2, num_subblocks = 1,
@@ -137,9 +137,10 @@ def test_freeze_two_sgd_steps_match_the_reference():
 	close(seen['loss'], g['loss0'], 1e-4, 1e-5, 'loss, first iteration')
 	close(r0['grad_norm'], g['grad_norm0'], 1e-3, 0, 'gradient norm')
 	params = dict(model.named_parameters())
+	clip = min(1.0, 100.0 / (float(g['grad_norm0']) + 1e-6))  # the golden gradients were saved after clip_grad_norm_ scaled them in place (norm 131 > 100)
 	for k in [n[5:] for n in g.files if n.startswith('grad/')]:
-		ref = g['grad/' + k]  # (the arena still holds the raw gradients: clipping rides in the optimizer kernel)
-		close(params[k]._convasr_grad, ref, 2e-3, 2e-3 * float(np.abs(ref).max()) + 1e-8, 'grad ' + k)
+		ref = g['grad/' + k]  # (the arena still holds the raw gradients: here the clipping rides in the optimizer kernel)
+		close(params[k]._convasr_grad * clip, ref, 2e-3, 2e-3 * float(np.abs(ref).max()) + 1e-8, 'grad ' + k)
 	r1 = ca.train.train_step(model, opt, x, xlen, y, ylen, iteration = 1)
 	close(seen['loss'], g['loss1'], 5e-4, 1e-5, 'loss, second iteration')
 	close(r1['grad_norm'], g['grad_norm1'], 2e-3, 0, 'gradient norm, second iteration')
@@ -275,3 +276,85 @@ def test_fused_adamw_matches_torch_adamw():
 	one(opt2, 5, gated = False)
 	for k, rp in zip(names, ref_params):
 		close(params[k], rp, 2e-6, 1e-7, 'parameter after reload ' + k)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('T', [626, 100, 128, 129, 385, 897])
+def test_short_last_tile_is_bit_identical_to_the_padded_one(T, dtype):
+	"""conv_v2s.hip runs the last m tile of an utterance as a 128-row tile when it covers at most 128 frames (mixed-length batches:
+	626 frames = 2 x 256 + 114).  Same k order per element: the forward output, its BN statistics, the plain dgrad and the fused
+	dgrad's dx and BN-backward sums are bit-identical to the launch with the short tile switched off (debug bit 128: every tile 256
+	rows), for sizes with a short tail (626, 100, 128, 385, 897) and one without (129: tail of 129 rows stays a full tile)."""
+	from convasr_amd import ops, _lib
+	d = torch.device('cuda:0')
+	torch.manual_seed(T)
+	B, C, Cout, K = 5, 128, 256, 7
+	x = ops.as_cl(torch.randn(B, C, T, device = d).clamp_(0, 20), dtype)
+	w = torch.randn(Cout, C, K, device = d) / (C * K) ** 0.5
+	wf, wd = ops.pack_weight(w, dtype, None)
+	dy = ops.as_cl(torch.randn(B, Cout, T, device = d), dtype)
+	scale, shift = torch.rand(C, device = d) + 0.5, torch.randn(C, device = d)
+	mean, invstd = torch.randn(C, device = d), torch.rand(C, device = d) + 0.5
+	xlen = torch.linspace(0.6, 1, B, device = d)
+	act = (_lib.ACT_RELU, 0.0, 0.0)
+	ybn = ops.as_cl(torch.randn(B, C, T, device = d) * 3 + 1, dtype)
+	gate = torch.zeros(B * T * C // 8, dtype = torch.uint8, device = d)
+	ops.bn_act(ybn, scale, shift, act, xlen = xlen, dropout_p = 0.3, seed = 9, offset = 2, gate = gate)
+
+	def run():
+		st = ops.ConvStats(Cout, B, T, d)
+		y = ops.conv1d(x, wf, Cout, K, 1, 1, K // 2, stats = st)
+		dx = ops.conv1d(dy, wd, C, K, 1, 1, K - 1 - K // 2)
+		sums = ops.ConvStats(C, B, T, d)
+		dxf = ops.conv1d_dgrad_bn_reduce(dy, wd, C, K, 1, K - 1 - K // 2, ybn, scale, shift, mean, invstd, act, 0.3, 9, 2, xlen, sums, gate = gate)
+		return y, st.totals(), dx, dxf, sums.totals()
+	lib = _lib.load()
+	short = run()
+	prev = lib.convasr_debug_set_conv_v2(1 | (128 << 8))
+	try:
+		full = run()
+	finally:
+		lib.convasr_debug_set_conv_v2(prev)
+	for a, b, what in zip(short, full, ('y', 'BN statistics', 'dx', 'fused dx', 'fused BN-backward sums')):
+		assert a is not None and torch.equal(a, b), (what, T)
+	ref = torch.nn.functional.conv1d(x.float().cpu().contiguous(), wf.float().cpu().permute(1, 2, 0).contiguous(), padding = K // 2)
+	assert float((short[0].float().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+CTC_SKIP_DEFINES = ['-DCONVASR_CTC_SKIP_PUBLISH=100', '-DCTC_SPIN_LIMIT=65536']
+
+
+def test_ctc_give_up_path_turns_a_stalled_hand_over_into_nan_not_a_hang():
+	"""csrc/ctc.hip's sweeps are two-wave pipelines whose consumer polls an LDS slot per frame; CTC_SPIN_LIMIT bounds the poll.  In a
+	diagnostic build of the library (convasr_amd.build variant 'ctcskip': the producing wave never publishes frame 100) the launch
+	must END, utterances that reach frame 100 must report NaN -- never a finite wrong number --, and an utterance that ends before
+	frame 100 is untouched.  Runs in a child process (the variant is a second copy of the library)."""
+	from convasr_amd import build
+	lib = build.build(verbose = False, variant = 'ctcskip', defines = CTC_SKIP_DEFINES)
+	code = '''
+import json, torch
+import convasr_amd as ca
+from convasr_amd import ops
+d = torch.device('cuda:0')
+torch.manual_seed(0)
+B, T, C, S = 4, 400, 38, 60
+lp = torch.log_softmax(torch.randn(B, T, C, device = d), dim = -1).permute(0, 2, 1)
+y = torch.randint(0, C - 1, (B, S), device = d)
+olen = torch.tensor([400, 300, 90, 101], device = d)
+ylen = torch.tensor([60, 50, 20, 30], device = d)
+nll, grad = ops.ctc_loss(ops.as_cl(lp, torch.float32), y, olen, ylen, C - 1, need_grad = True)
+torch.cuda.synchronize()
+print(json.dumps(dict(nll = [float(v) for v in nll.cpu()], lib = ca._lib.LIB_PATH)))
+'''
+	env = dict(os.environ, CONVASR_HIP_LIB = lib, PYTHONPATH = ROOT)
+	r = subprocess.run([sys.executable, '-c', code], env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 300)
+	assert r.returncode == 0, r.stderr[-2000:]
+	out = json.loads(r.stdout.strip().splitlines()[-1])
+	assert out['lib'].endswith('libconvasr_hip.ctcskip.so')
+	nll = out['nll']
+	assert all(np.isnan(nll[i]) for i in (0, 1, 3)), nll  # 400, 300 and 101 frames: frame 100 is inside the sweep
+	assert np.isfinite(nll[2]) and nll[2] > 0, nll  # 90 frames: never reaches it
+	env['CONVASR_HIP_LIB'] = os.path.join(ROOT, 'convasr_amd', 'libconvasr_hip.so')
+	r = subprocess.run([sys.executable, '-c', code], env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 300)
+	ok = json.loads(r.stdout.strip().splitlines()[-1])['nll']
+	assert all(np.isfinite(v) for v in ok) and abs(ok[2] - nll[2]) <= 1e-6 * abs(ok[2]), (ok, nll)
