@@ -257,12 +257,13 @@ extern "C" int convasr_argmax(const float* log_probs, int64_t* idx, int64_t rows
 
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ sc, const int64_t* __restrict__ div, int64_t div_stride, float* __restrict__ out, int64_t per_b) {
 	const int b = blockIdx.y;
-	const float s = div ? sc[b] / (float)div[b * div_stride] : sc[b];
+	const float s0 = sc ? sc[b] : 1.f;  // (gscale NULL: a plain division by gdiv -- the "/ ylen[:, 0]" of models.py:323 in the forward direction)
+	const float s = div ? s0 / (float)div[b * div_stride] : s0;
 	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_b; i += (int64_t)gridDim.x * 256) out[b * per_b + i] = g[b * per_b + i] * s;
 }
 
 extern "C" int convasr_scale_rows(const float* grad, const float* gscale, const int64_t* gdiv, int64_t gdiv_stride, float* out, int B, int64_t per_b, void* stream) {
-	CONVASR_CHECK_ARG(grad && gscale && out && B > 0 && per_b > 0, "scale_rows: bad arguments");
+	CONVASR_CHECK_ARG(grad && (gscale || gdiv) && out && B > 0 && per_b > 0, "scale_rows: bad arguments");
 	unsigned gx = (unsigned)(ceil_div64(per_b, 256) > 64 ? 64 : ceil_div64(per_b, 256));
 	hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, grad, gscale, gdiv, gdiv_stride, out, per_b);
 	CONVASR_CHECK_LAUNCH("scale_rows");

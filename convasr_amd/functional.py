@@ -523,10 +523,20 @@ class _HeadPad:
 			ent['ver'] = ver
 		return ent['wd']
 
-	@staticmethod
-	def pad_grad(dy, dt):
+	_pad_bufs = {}
+
+	@classmethod
+	def pad_grad(cls, dy, dt):
 		B, Cout, T = dy.shape
-		out = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)
+		# the padded buffer is kept per (shape, type, stream): channels >= Cout are zero from its allocation on and never written, so a step
+		# only rewrites the Cout live channels (no fill launch); its readers of the previous step are ordered before this write on the same
+		# stream (train_step joins the weight-gradient side stream before the optimizer)
+		key = (B, T, Cout, dt, dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
+		out = cls._pad_bufs.get(key)
+		if out is None:
+			if len(cls._pad_bufs) >= 64:
+				cls._pad_bufs.clear()  # mixed-length training: one entry per padded length; bounded
+			out = cls._pad_bufs[key] = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)
 		_lib.call('convasr_convert_layout', _lib.ptr(dy), _lib.dtype_code(dy.dtype), dy.stride(0), dy.stride(1), dy.stride(2), _lib.ptr(out), _lib.dtype_code(dt), out.stride(0), out.stride(1), out.stride(2), B, Cout, T, _lib.stream_ptr())
 		return out
 
@@ -560,9 +570,14 @@ class ConvBiasFunction(torch.autograd.Function):
 				dwp = torch.empty(HEAD_PAD, x.shape[1], 1, dtype = torch.float32, device = x.device)
 				dbp = torch.empty(HEAD_PAD, dtype = torch.float32, device = x.device) if outs[1] is not None else None
 				ops.conv1d_wgrad(x, dyp, HEAD_PAD, 1, 1, 1, 0, dwp, dbias = dbp)
-				for o, v in ((outs[0], dwp[:Cout]), (outs[1], None if dbp is None else dbp[:Cout])):
-					if o is not None:
-						o.add_(v) if acc else o.copy_(v)
+				for o, v in ((outs[0], dwp[:Cout]), (outs[1], None if dbp is None else dbp[:Cout].view(Cout, 1, 1))):
+					if o is None:
+						continue
+					if acc:
+						o.add_(v.view(o.shape))
+					else:  # rows < Cout of the padded result into the gradient (arena) view: our own strided copy kernel, element (c, t) = (co, ci)
+						ov = o.view(Cout, -1, 1) if o.ndim == 1 else o
+						_lib.call('convasr_convert_layout', _lib.ptr(v), _lib.F32, 0, v.stride(0), v.stride(1), _lib.ptr(ov), _lib.F32, 0, ov.stride(0), ov.stride(1), 1, Cout, v.shape[1], _lib.stream_ptr())
 			dw, db = _deliver([weight, bias], wgrad)
 			return None, dx, dw, db
 		dy = ops.as_cl(dy, dt)
@@ -666,7 +681,11 @@ class CtcLossFunction(torch.autograd.Function):
 		ctx.norm = norm
 		if need:
 			ctx.save_for_backward(grad)
-		return nll if norm is None else nll / norm
+		if norm is None:
+			return nll
+		if norm.dtype == torch.int64 and norm.ndim == 1 and norm.device == nll.device:
+			return ops.scale_rows(nll, None, norm)  # nll / norm in one small launch of our own (an ATen true-divide of fp32 by int64 otherwise)
+		return nll / norm
 
 	@staticmethod
 	def backward(ctx, g):

@@ -417,7 +417,8 @@ class JasperNet(nn.Module):
 		aux = {}
 		if y is not None and ylen is not None:
 			loss = [Fn.ctc_loss(lp, y[:, i], olen[i], ylen[:, i], lp.shape[1] - 1, norm = ylen[:, 0]) for i, lp in enumerate(log_probs)]
-			aux = dict(loss = sum(loss) if not self.bpe_only else sum(loss[1:]))
+			heads = loss if not self.bpe_only else loss[1:]
+			aux = dict(loss = heads[0] if len(heads) == 1 else sum(heads[1:], heads[0]))  # (Python's sum() would start from 0 + tensor: an ATen launch per step)
 		return self.dict(logits = logits, log_probs = log_probs, olen = olen, **aux)
 
 	def freeze(self, backbone = 0, decoder0 = False, frontend = False):

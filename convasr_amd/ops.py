@@ -402,11 +402,11 @@ def ctc_loss(log_probs, targets, olen, ylen, blank, need_grad = True):
 
 
 def scale_rows(grad, gscale, gdiv = None):
-	"""out[b] = grad[b] * gscale[b] (/ gdiv[b] if given: an int64 (B,) vector, possibly a strided column)."""
+	"""out[b] = grad[b] * gscale[b] (/ gdiv[b] if given: an int64 (B,) vector, possibly a strided column); gscale None: grad[b] / gdiv[b]."""
 	B = grad.shape[0]
 	out = torch.empty_like(grad)  # preserves strides (channels-last stays channels-last)
 	assert gdiv is None or (gdiv.dtype == torch.int64 and gdiv.ndim == 1 and gdiv.shape[0] == B and gdiv.device == grad.device)
-	call('convasr_scale_rows', ptr(grad), ptr(gscale.to(torch.float32).contiguous()), ptr(gdiv), 0 if gdiv is None else gdiv.stride(0), ptr(out), B, grad.numel() // B, stream_ptr())
+	call('convasr_scale_rows', ptr(grad), None if gscale is None else ptr(gscale.to(torch.float32).contiguous()), ptr(gdiv), 0 if gdiv is None else gdiv.stride(0), ptr(out), B, grad.numel() // B, stream_ptr())
 	return out
 
 

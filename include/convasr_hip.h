@@ -229,7 +229,8 @@ int64_t convasr_ctc_workspace_bytes(int B, int T, int S_max);
 int convasr_ctc_loss(const float* log_probs, const int64_t* targets, const int64_t* olen, const int64_t* ylen,
                      float* nll, float* grad, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);
 /* out[b,t,c] = grad[b,t,c] * gscale[b]   (chain rule for reduction='none'); with gdiv != NULL the factor is
- * gscale[b] / (float)gdiv[b * gdiv_stride]: the "/ ylen[:, 0]" of models.py:323 folded into the same pass. */
+ * gscale[b] / (float)gdiv[b * gdiv_stride]: the "/ ylen[:, 0]" of models.py:323 folded into the same pass.  gscale NULL (gdiv given):
+ * the factor is 1 / gdiv -- the same division in the forward direction (per_b = 1: nll[b] / ylen[b, 0]). */
 int convasr_scale_rows(const float* grad, const float* gscale, const int64_t* gdiv, int64_t gdiv_stride, float* out, int B, int64_t per_b, void* stream);
 
 /* The scalar bookkeeping of one training iteration (train.py:754-756, 769) in one launch: loss_vec[b] = per-utterance loss

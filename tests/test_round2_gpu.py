@@ -332,9 +332,15 @@ def test_jaspernet_large_dense_residual_gradients_vs_oracle_2x5s():
 	# 55 batch-normed conv layers deep, two fp32 implementations with different summation orders agree to 0.4-1.5 % in these gradients
 	# (logits to 1e-3 of their range): the random-init network amplifies rounding differences layer by layer.  Against the same
 	# oracle run in float64 the MI355X fp32 path is 0.26-1.9 % off and the fp32 CPU oracle 0.31-1.1 % (profiles/r02_fp64_reference.json)
-	for k in names:
-		cos, rel = _cos_rel(params[k].grad, ref['grads'][k])
-		assert cos >= 0.9995 and rel <= 3e-2, (k, cos, rel)
+	measured = {k: _cos_rel(params[k].grad, ref['grads'][k]) for k in names}
+	print('JasperNetLarge 2x5s fp32 gradients vs oracle (cos, rel):', {k: (round(c, 7), float(f'{r:.3e}')) for k, (c, r) in measured.items()}, 'logits err', err, 'of', scale, 'loss rel', loss_rel)
+	_dump('r04_jasper_large_grad_parity.json', dict(logits_max_abs_err = err, logits_range = scale, ctc_rel_err = loss_rel, gradients = {k: dict(cos = c, rel = r) for k, (c, r) in measured.items()}))
+	# round 4, on the fp32 kernel with two-level accumulation (conv.hip TWO_LEVEL, 7.9e-8 from float64 per conv): cos 0.99993 .. 0.999995,
+	# rel 3.1e-3 (the last block's convs) .. 1.2e-2 (the prologue, 55 layers of amplification below the loss); the bars leave a
+	# factor ~1.6 over the measured worst case -- the fp32 CPU oracle itself sits 0.31-1.1 % from its float64 run in these gradients
+	for k, (cos, rel) in measured.items():
+		assert cos >= 0.9999 and rel <= 2e-2, (k, cos, rel)
+	assert measured['backbone.10.conv.4.0.weight'][1] <= 6e-3 and measured['backbone.10.conv_residual.0.weight'][1] <= 6e-3, measured
 
 
 def _residual_model(ca, d):

@@ -140,6 +140,11 @@ def test_freeze_two_sgd_steps_match_the_reference():
 	clip = min(1.0, 100.0 / (float(g['grad_norm0']) + 1e-6))  # the golden gradients were saved after clip_grad_norm_ scaled them in place (norm 131 > 100)
 	for k in [n[5:] for n in g.files if n.startswith('grad/')]:
 		ref = g['grad/' + k]  # (the arena still holds the raw gradients: here the clipping rides in the optimizer kernel)
+		if 'conv_residual' in k and k.endswith('.bias'):
+			# the bias of a conv that feeds a train-mode batch norm has an identically zero gradient: the reference's autograd leaves rounding
+			# noise around 0 (1e-6 here), this path writes exact zeros (known deviation (ii))
+			assert float(np.abs(ref).max()) < 1e-5 and float(params[k]._convasr_grad.abs().max()) == 0.0, k
+			continue
 		close(params[k]._convasr_grad * clip, ref, 2e-3, 2e-3 * float(np.abs(ref).max()) + 1e-8, 'grad ' + k)
 	r1 = ca.train.train_step(model, opt, x, xlen, y, ylen, iteration = 1)
 	close(seen['loss'], g['loss1'], 5e-4, 1e-5, 'loss, second iteration')
