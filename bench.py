@@ -273,7 +273,7 @@ class Workload:
 		self.model = self.flat = self.opt = self.batches = None
 
 
-def run_timed(args, wl, engine, world, fence, time_main_kernel):
+def run_timed(args, wl, engine, world, fence, time_main_kernel, on_warm = None):
 	"""W warm-up steps, then K timed steps between two fences.  Returns (elapsed s, audio (unpadded, padded), flops (fwd, bwd), last
 	result, kernel-timer summary, launch sequence)."""
 	import convasr_amd as ca
@@ -286,6 +286,7 @@ def run_timed(args, wl, engine, world, fence, time_main_kernel):
 	for i in range(args.warmup):
 		last = step(i)
 	fence()
+	run_timed.warm_value = on_warm() if on_warm is not None else None  # (a host read between warm-up and timed region, e.g. the loss scaler's overflow count)
 	# HIP events (on the launching stream) bracket every launch of the DOMINANT kernel inside the timed region.  The other kernel
 	# families (wgrad, the HBM-bound passes, the small layers) are event-timed in a second, untimed pass of a few steps right after
 	# it: an event pair costs ~5 us of stream time, and bracketing all ~110 launches of a step slowed the headline by 3.4 %
@@ -562,8 +563,9 @@ def main(argv = None):
 			dist.barrier()
 		torch.cuda.synchronize()
 
-	overflows0 = float(flat.loss_scaler.current[7]) if flat.loss_scaler is not None else 0.0
-	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0)
+	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0,
+		on_warm = (lambda: flat.loss_scaler.current[7].item()) if flat.loss_scaler is not None else None)
+	overflows0 = run_timed.warm_value or 0.0  # the scaler's overflow count when the timed region starts (warm-up overflows are not the timed region's)
 	exposed = engine.exposed_comm_ms() if use_dist else None
 	scaler_info = None
 	if flat.loss_scaler is not None:
@@ -624,11 +626,15 @@ def main(argv = None):
 		f16_leg = None
 		if world == 1 and args.dtype == 'bf16' and not args.no_f16_leg and args.workload == 'wav2letter':
 			# the same workload in the storage type that meets north_star's 1e-4 CTC bound: its own model / arena / optimizer / loss scaler
-			wl16 = Workload(args, device, rank, world, dtype = 'f16')
-			ov0 = float(wl16.flat.loss_scaler.current[7])
-			el16, au16, fl16, last16, _, _, _ = run_timed(args, wl16, wl16.model, 1, lambda: torch.cuda.synchronize(), time_main_kernel = False)
+			# (at least 8 warm-up steps here: apex's dynamic scale starts at 2^16 and halves once per overflowed step until the gradients
+			# of this random-data workload fit -- that search belongs to the warm-up, not to the timed region)
+			args16 = argparse.Namespace(**dict(vars(args), warmup = max(args.warmup, 8)))
+			wl16 = Workload(args16, device, rank, world, dtype = 'f16')
+			ov0 = None
+			el16, au16, fl16, last16, _, _, _ = run_timed(args16, wl16, wl16.model, 1, lambda: torch.cuda.synchronize(), time_main_kernel = False, on_warm = lambda: wl16.flat.loss_scaler.current[7].item())
 			st = wl16.flat.loss_scaler.current.tolist()
-			f16_leg = dict(f16_value = round(au16[0] / el16, 1), f16_ms_per_step = round(1e3 * el16 / args.steps, 3), f16_steps = args.steps, f16_warmup = args.warmup,
+			ov0 = run_timed.warm_value
+			f16_leg = dict(f16_value = round(au16[0] / el16, 1), f16_ms_per_step = round(1e3 * el16 / args.steps, 3), f16_steps = args.steps, f16_warmup = args16.warmup,
 				f16_whole_step_frac = round((fl16[0] + fl16[1]) / el16 / PEAK_BF16_DENSE, 4), f16_loss_scale = st[0], f16_overflowed_steps_in_timed_region = int(st[7] - ov0),
 				f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
 			del last16
