@@ -61,6 +61,21 @@ __device__ __forceinline__ void tile_coords(int v, int M, int N, int& m, int& n)
 	n = ng * NT + w2 % width;
 }
 
+#ifdef CONVASR_AB_BLOCK
+// Diagnostic build only (python -m convasr_amd.build --variant abblock -DCONVASR_AB_BLOCK=1; scratch/ab_block.py): the same walk with the
+// block shape chosen at run time (ConvParams::debug bits 10-12), to measure what the L2-missing operand bytes of each shape cost.
+__device__ __forceinline__ void tile_coords_rt(int v, int M, int N, int MB, int NT, int& m, int& n) {
+	const int mb = v / (MB * N);
+	const int rows = min(MB, M - mb * MB);
+	const int w = v - mb * MB * N;
+	const int ng = w / (rows * NT);
+	const int width = min(NT, N - ng * NT);
+	const int w2 = w - ng * rows * NT;
+	m = mb * MB + w2 / width;
+	n = ng * NT + w2 % width;
+}
+#endif
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
 	static constexpr int EPC = 8;  // elements per 16-byte chunk

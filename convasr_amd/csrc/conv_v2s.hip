@@ -501,7 +501,15 @@ template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__
 		half = h & 1;
 	}
 	int ntile, mtile;
+#ifdef CONVASR_AB_BLOCK
+	{
+		const int sel = (p.debug >> 10) & 7;  // m x n tiles an XCD's ~32 resident workgroups cover: 16x2 (shipped), 8x4, 32x1, 11x3, 16x3, 4x8, 16x6, 6x6
+		const int MBs[8] = {16, 8, 32, 11, 16, 4, 16, 6}, NTs[8] = {2, 4, 1, 3, 3, 8, 6, 6};
+		tile_coords_rt(v, p.B * p.m_tiles_per_b, p.n_tiles, MBs[sel], NTs[sel], mtile, ntile);
+	}
+#else
 	tile_coords(v, p.B * p.m_tiles_per_b, p.n_tiles, mtile, ntile);
+#endif
 	// Short last tile: an utterance of 626 frames is 2 x 256 + 114 -- run as a third 256-row tile the tail costs a full tile of MFMAs for
 	// 114 useful rows (mixed-length batches, BASELINE configs[4]: ~8 % of the forward / dgrad time on average); as a 128-row tile (two
 	// 16-row blocks per wave instead of four, same k order per element: bit-identical values) it costs half.

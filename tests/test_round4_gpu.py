@@ -287,9 +287,10 @@ def test_fused_adamw_matches_torch_adamw():
 @pytest.mark.parametrize('T', [626, 100, 128, 129, 385, 897])
 def test_short_last_tile_is_bit_identical_to_the_padded_one(T, dtype):
 	"""conv_v2s.hip runs the last m tile of an utterance as a 128-row tile when it covers at most 128 frames (mixed-length batches:
-	626 frames = 2 x 256 + 114).  Same k order per element: the forward output, its BN statistics, the plain dgrad and the fused
-	dgrad's dx and BN-backward sums are bit-identical to the launch with the short tile switched off (debug bit 128: every tile 256
-	rows), for sizes with a short tail (626, 100, 128, 385, 897) and one without (129: tail of 129 rows stays a full tile)."""
+	626 frames = 2 x 256 + 114).  Same k order per element: the forward output, the plain dgrad and the fused dgrad's dx and
+	BN-backward sums are bit-identical to the launch with the short tile switched off (debug bit 128: every tile 256 rows); the BN
+	statistics group the same fp32 values by 32 rows per wave instead of 64 and agree to fp32 rounding.  Sizes with a short tail (626,
+	100, 128, 385, 897) and one without (129: a tail of 129 rows stays a full tile)."""
 	from convasr_amd import ops, _lib
 	d = torch.device('cuda:0')
 	torch.manual_seed(T)
@@ -321,7 +322,11 @@ def test_short_last_tile_is_bit_identical_to_the_padded_one(T, dtype):
 	finally:
 		lib.convasr_debug_set_conv_v2(prev)
 	for a, b, what in zip(short, full, ('y', 'BN statistics', 'dx', 'fused dx', 'fused BN-backward sums')):
-		assert a is not None and torch.equal(a, b), (what, T)
+		assert a is not None and b is not None, what
+		if what == 'BN statistics':  # the same fp32 values summed per wave over 32 rows instead of 64: equal to fp32 rounding of the partial sums, not bit for bit
+			assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (what, T, float((a - b).abs().max()), float(b.abs().max()))
+		else:
+			assert torch.equal(a, b), (what, T)
 	ref = torch.nn.functional.conv1d(x.float().cpu().contiguous(), wf.float().cpu().permute(1, 2, 0).contiguous(), padding = K // 2)
 	assert float((short[0].float().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
