@@ -55,10 +55,32 @@ for k in sq:
 		e['avg_duration_us_under_pmc'] = round(d / 1e3, 1); e['effective_clock_ghz'] = round(g / 8 / d, 3); e['mfma_busy_over_simd_cycles'] = round(mf / (1024 * g / 8), 4)
 	summary[k] = e
 json.dump(dict(note = 'rocprofv3 --kernel-trace --pmc (8 SQ counters in one pass; GRBM_GUI_ACTIVE + SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES in a second) over bench.py --steps 2 --warmup 1; means per dispatch.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles; effective clock = GRBM_GUI_ACTIVE / 8 / duration; mfma_busy_over_simd_cycles = MFMA busy cycles / (1024 SIMDs x kernel cycles)', kernels = summary), open(f'profiles/{tag}_pmc_sq.json', 'w'), indent = 1)
-for name in ('bench_line', 'bench_line_f16', 'launcher_n1', 'plain_n1'):
+for name in ('bench_line', 'bench_line_f16', 'launcher_n1', 'plain_n1', 'rccl_world1', 'config4_line', 'bench_infer'):
 	src = f'{G}/{tag}_{name}.json'
 	if os.path.exists(src) and os.path.getsize(src) > 0: shutil.copy(src, f'profiles/{tag}_{name}.json')
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:14]: print('%-80s %6s calls  avg %8.1f us  %5.1f%%' % (r['Name'][:80], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
 for k, v in conv.items(): print(k[:75], round(v['hbm_bytes_per_launch'] / 1e6, 1), 'MB/launch')
 for k, v in summary.items(): print(k[:60], {a: b for a, b in v.items() if 'over' in a or 'clock' in a})
+
+# ---------------------------------------------------------------- BASELINE configs[4] (bench.py --workload jasper_large), round 4 on
+c4 = glob.glob(f'{G}/{tag}_config4_stats/**/*kernel_stats.csv', recursive = True)
+if c4:
+	rows4 = list(csv.DictReader(open(c4[0])))
+	with open(f'profiles/{tag}_config4_kernel_stats.csv', 'w') as f:
+		f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload jasper_large --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-kernel-timer   (7 training steps of JasperNetLarge, fp16, 32 utterances of 5-20 s per step)\n')
+		w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+		for r in rows4: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+	tr = {}
+	for c in ['FETCH_SIZE', 'WRITE_SIZE']:
+		ff = glob.glob(f'{G}/{tag}_config4_pmc_{c}/**/*counter_collection.csv', recursive = True)
+		if not ff: continue
+		agg = collections.defaultdict(list)
+		for r in csv.DictReader(open(ff[0])): agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+		for k, v in agg.items(): tr.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+	out4 = {k: dict(dispatches = v.get('FETCH_SIZE', (0, 0))[1], fetch_kb = v.get('FETCH_SIZE', (0, 0))[0], write_kb = v.get('WRITE_SIZE', (0, 0))[0], hbm_bytes_per_launch = (2 * v.get('FETCH_SIZE', (0, 0))[0] + v.get('WRITE_SIZE', (0, 0))[0]) * 1024) for k, v in tr.items() if any(t in k for t in ('conv1d', 'wgrad', 'bn_act'))}
+	json.dump(out4, open(f'profiles/{tag}_config4_traffic.json', 'w'), indent = 1)
+	tot4 = sum(float(r['TotalDurationNs']) for r in rows4)
+	print('--- configs[4]')
+	for r in rows4[:12]: print('%-80s %6s calls  avg %8.1f us  %5.1f%%' % (r['Name'][:80], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot4))
+if os.path.exists(f'{G}/{tag}_c4_layers.log'): shutil.copy(f'{G}/{tag}_c4_layers.log', f'profiles/{tag}_config4_layers.txt')
