@@ -160,21 +160,24 @@ def pin_to_gpu_numa_node(local_rank):
 	"""os.sched_setaffinity to the cores local to this rank's GPU (the NUMA node of its PCIe root, /sys/class/drm/renderD*/device/
 	{numa_node, local_cpulist}) -- host launch latency and the pinned staging buffers then stay on the socket the GPU hangs off.
 	Pure sysfs reads: runs before the first GPU call.  Best effort: returns a dict saying what was done (or why not)."""
+	step = 'reading the KFD topology'
 	try:
 		nodes = _kfd_gpu_nodes()
 		vis = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
 		if vis and all(v.strip().isdigit() for v in vis.split(',')):
 			nodes = [nodes[int(v)] for v in vis.split(',') if int(v) < len(nodes)]
 		minor = nodes[local_rank]
+		step = 'reading the render node\'s numa_node / local_cpulist'
 		dev = f'/sys/class/drm/renderD{minor}/device'
 		node = int(open(os.path.join(dev, 'numa_node')).read())
 		cpus = _cpulist(open(os.path.join(dev, 'local_cpulist')).read()) & os.sched_getaffinity(0)
 		if not cpus:
 			return dict(pinned = False, reason = 'no local cpulist', numa_node = node)
+		step = f'sched_setaffinity to {len(cpus)} cpus of node {node}'
 		os.sched_setaffinity(0, cpus)
 		return dict(pinned = True, numa_node = node, cpus = len(cpus), render_minor = minor)
-	except Exception as e:  # no sysfs topology (container), odd masks: the run goes on unpinned
-		return dict(pinned = False, reason = f'{type(e).__name__}: {e}')
+	except Exception as e:  # no sysfs topology (container), odd masks, a sandbox that forbids the call: the run goes on unpinned
+		return dict(pinned = False, reason = f'{step}: {type(e).__name__}: {e}')
 
 
 # ------------------------------------------------------------------------------------------------ workloads

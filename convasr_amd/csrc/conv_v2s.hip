@@ -127,11 +127,23 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 	auto load_frag = [&](unsigned xs_off, unsigned ws_off, int tap_, int ks, Frag& f) {
 		const unsigned xa = (lds_base + xs_off + lane_off(wm * WROWS + r16 + tap_ * p.dil)) ^ (ks << 6);
 		const unsigned wa = (w0 + ws_off) ^ (ks << 6);
+#ifdef CONVASR_AB_FRAGREADS
+		// Diagnostic builds only (results are garbage, timing only; scratch/ab_fragreads.py): what would fewer LDS fragment reads per MFMA buy?
+		// 1: only the first half of the X fragments is read (the others keep their values of the first load); 2: the same for the W
+		// fragments; 3: both -- i.e. 6 / 6 / 4 ds_read_b128 per 16 MFMAs instead of 8.
+		constexpr int RA = (CONVASR_AB_FRAGREADS & 1) ? MI / 2 : MI, RB = (CONVASR_AB_FRAGREADS & 2) ? NB / 2 : NB;
+#pragma unroll
+		for (int i = 0; i < (MI > NB ? MI : NB); ++i) {
+			if (i < RA) f.a[i] = *(lds_u4)(size_t)(xa + i * 2048);
+			if (i < RB) f.b[i] = *(lds_u4)(size_t)(wa + i * 2048);
+		}
+#else
 #pragma unroll
 		for (int i = 0; i < (MI > NB ? MI : NB); ++i) {
 			if (i < MI) f.a[i] = *(lds_u4)(size_t)(xa + i * 2048);
 			if (i < NB) f.b[i] = *(lds_u4)(size_t)(wa + i * 2048);
 		}
+#endif
 	};
 	// Scheduling hint placed after a (load_frag, mma_frag) pair: the MI + NB ds_read_b128 of the NEXT fragment go out one per MFMA
 	// from the first MFMA of the current group on.  Left alone, hipcc sinks them behind the 12th-14th MFMA of the group, and the
@@ -208,6 +220,16 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 		}
 		__builtin_amdgcn_s_barrier();
 		Frag f0, f1;
+#ifdef CONVASR_AB_FRAGREADS
+		{  // every fragment register gets a defined (stale) value once: the loop then re-reads only part of them
+			const unsigned xa = lds_base + lane_off(wm * WROWS + r16), wa = w0 + e_slot(0);
+#pragma unroll
+			for (int i = 0; i < (MI > NB ? MI : NB); ++i) {
+				if (i < MI) f0.a[i] = f1.a[i] = *(lds_u4)(size_t)(xa + i * 2048);
+				if (i < NB) f0.b[i] = f1.b[i] = *(lds_u4)(size_t)(wa + i * 2048);
+			}
+		}
+#endif
 		load_frag(0, e_slot(0), 0, 0, f0);
 		STAMPI(t_loop0)
 		// The loop is instantiated per `pre` so that the read-ahead is unconditional inside it: a conditional LDS load makes hipcc
