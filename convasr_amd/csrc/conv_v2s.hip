@@ -535,13 +535,17 @@ template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__
 	// Short last tile: an utterance of 626 frames is 2 x 256 + 114 -- run as a third 256-row tile the tail costs a full tile of MFMAs for
 	// 114 useful rows (mixed-length batches, BASELINE configs[4]: ~8 % of the forward / dgrad time on average); as a 128-row tile (two
 	// 16-row blocks per wave instead of four, same k order per element: bit-identical values) it costs half.
-	const bool tail = p.tail128 && (mtile % p.m_tiles_per_b) == p.m_tiles_per_b - 1;
+	// tail128 == 2: EVERY m tile is 128 rows (m tiles 128 frames apart): launches that would put less than about a round of 256-row tiles on
+	// the chip (32 utterances of 376 frames x 2-3 n tiles) get twice the workgroups to spread over the CUs and lose no rows to padding.
+	const bool all_short = p.tail128 == 2;
+	const bool tail = all_short || (p.tail128 && (mtile % p.m_tiles_per_b) == p.m_tiles_per_b - 1);
+	const int bm_full = all_short ? 128 : BM_;
 	if (!tail) {
 		if (!narrow) v2s_tile<I, O, 4, BNF, BM_>(p, smem, mtile, ntile, 0, BM_);
 		else v2s_tile<I, O, 2, BNF, BM_>(p, smem, mtile, ntile, half, BM_);
 	} else {
-		if (!narrow) v2s_tile<I, O, 4, BNF, 128>(p, smem, mtile, ntile, 0, BM_);
-		else v2s_tile<I, O, 2, BNF, 128>(p, smem, mtile, ntile, half, BM_);
+		if (!narrow) v2s_tile<I, O, 4, BNF, 128>(p, smem, mtile, ntile, 0, bm_full);
+		else v2s_tile<I, O, 2, BNF, 128>(p, smem, mtile, ntile, half, bm_full);
 	}
 }
 
@@ -568,10 +572,18 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 	// instantiations exist only in a diagnostic build (python -m convasr_amd.build --variant tile192 -DCONVASR_AB_TILE192=1), where
 	// debug bit 64 selects them.
 #ifdef CONVASR_AB_TILE192
-	const int bm = (p.debug & 64) ? 192 : V2_BM;
+	int bm = (p.debug & 64) ? 192 : V2_BM;
 #else
-	const int bm = V2_BM;
+	int bm = V2_BM;
 #endif
+	// 128-row tiles for the whole launch (ConvParams::tail128 == 2, see the kernel): when 256-row tiles would not even fill the chip once.
+	// debug bit 1024 forces it, bit 2048 forbids it (A/B runs).
+	bool all_short = false;
+	if (bm == V2_BM && !(p.debug & 2048)) {
+		const int tiles256 = p.B * ((p.Tout + V2_BM - 1) / V2_BM) * p.n_tiles;
+		all_short = (p.debug & 1024) || tiles256 * 4 <= n_cu * 3;
+	}
+	if (all_short) bm = 128;
 	const int xr = (bm - 1) + (p.K - 1) * p.dil + 1;
 	p.x_rows = (xr + 15) & ~15;  // whole 1-KiB pieces and an even number of them per 16-row swizzle period
 	const size_t osz = y_dtype == CONVASR_F32 ? 4 : 2;
@@ -585,10 +597,10 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 	p.m_tiles_per_b = (p.Tout + bm - 1) / bm;
 	p.total_tiles = p.B * p.m_tiles_per_b * p.n_tiles;
 	const int tail_rows = p.Tout - (p.m_tiles_per_b - 1) * bm;
-	p.tail128 = (bm == V2_BM && tail_rows <= 128 && !(p.debug & 128)) ? 1 : 0;  // (debug bit 128: off, A/B runs)
+	p.tail128 = all_short ? 2 : ((bm == V2_BM && tail_rows <= 128 && !(p.debug & 128)) ? 1 : 0);  // (debug bit 128: short tails off, A/B runs)
 	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
 	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
-	const int ki = wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0), bi = bm == 192 ? 1 : 0;
+	const int ki = wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0), bi = bm == 192 ? 1 : 0;  // (bm == 128 runs the 256-row kernel's 128-row instantiation)
 #ifdef CONVASR_AB_TILE192
 	const void* kern = f16 ? (bi ? v2s_kernel<f16_t, 192>(ki) : v2s_kernel<f16_t, V2_BM>(ki)) : (bi ? v2s_kernel<bf16_t, 192>(ki) : v2s_kernel<bf16_t, V2_BM>(ki));
 #else
