@@ -535,8 +535,8 @@ template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__
 	// Short last tile: an utterance of 626 frames is 2 x 256 + 114 -- run as a third 256-row tile the tail costs a full tile of MFMAs for
 	// 114 useful rows (mixed-length batches, BASELINE configs[4]: ~8 % of the forward / dgrad time on average); as a 128-row tile (two
 	// 16-row blocks per wave instead of four, same k order per element: bit-identical values) it costs half.
-	// tail128 == 2: EVERY m tile is 128 rows (m tiles 128 frames apart): launches that would put less than about a round of 256-row tiles on
-	// the chip (32 utterances of 376 frames x 2-3 n tiles) get twice the workgroups to spread over the CUs and lose no rows to padding.
+	// tail128 == 2: EVERY m tile is 128 rows (m tiles 128 frames apart): launches whose 256-row tiles would occupy at most a quarter of the
+	// CUs get twice the workgroups (the dispatcher says when, with the measurement behind it).
 	const bool all_short = p.tail128 == 2;
 	const bool tail = all_short || (p.tail128 && (mtile % p.m_tiles_per_b) == p.m_tiles_per_b - 1);
 	const int bm_full = all_short ? 128 : BM_;
@@ -576,12 +576,15 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 #else
 	int bm = V2_BM;
 #endif
-	// 128-row tiles for the whole launch (ConvParams::tail128 == 2, see the kernel): when 256-row tiles would not even fill the chip once.
+	// 128-row tiles for the whole launch (ConvParams::tail128 == 2, see the kernel): only when 256-row tiles would occupy at most a quarter
+	// of the CUs.  Measured on JasperNetLarge's shapes at 32 x 251-876 frames (profiles/r04_ab_short_tiles.json, scratch/ab_short_tiles.py):
+	// a 128-row tile costs 1.2-1.4x per FLOP (twice the weight bytes into LDS per row, 6 fragment reads per 8 MFMAs), so even launches
+	// of 96-192 tiles on 256 CUs are faster with 256-row tiles; 64 tiles (32 x 251 frames, 256 channels) are not: 0.83x.
 	// debug bit 1024 forces it, bit 2048 forbids it (A/B runs).
 	bool all_short = false;
 	if (bm == V2_BM && !(p.debug & 2048)) {
 		const int tiles256 = p.B * ((p.Tout + V2_BM - 1) / V2_BM) * p.n_tiles;
-		all_short = (p.debug & 1024) || tiles256 * 4 <= n_cu * 3;
+		all_short = (p.debug & 1024) || tiles256 * 4 <= n_cu;
 	}
 	if (all_short) bm = 128;
 	const int xr = (bm - 1) + (p.K - 1) * p.dil + 1;
