@@ -686,6 +686,7 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 
 extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil) {
 	WgradParams p;
+	p.debug = 0;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil;
 	p.pad = 0;
 	// the largest split count any of the kernels' plans would pick for this shape (bf16 LDS-DMA kernel, bf16 / fp32 general kernel)
@@ -728,6 +729,7 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 	CONVASR_CHECK_ARG(dw_layout == CONVASR_W_REFERENCE || (((int64_t)Cout * Cin) & 3) == 0, "conv1d_wgrad: K-major dw needs Cout * Cin %% 4 == 0");
 	CONVASR_CHECK_ARG(K <= 64, "conv1d_wgrad: K %d > 64", K);
 	WgradParams p;
+	p.debug = g_conv_debug;
 	p.x = x; p.dy = dy; p.slab = (float*)workspace;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
 	hipStream_t s = (hipStream_t)stream;

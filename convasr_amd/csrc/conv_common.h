@@ -122,6 +122,7 @@ struct WgradParams {
 	int co_tiles, ci_tiles, tap_groups, units, splits;
 	int chunks_per_b, total_chunks, chunks_per_split;
 	int x_rows;
+	int debug;  // experiment flags (diagnostic builds only)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));

@@ -71,7 +71,31 @@ template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1
 
 	const int v = xcd_remap(blockIdx.x, p.units * p.splits);
 	const int unit = v % p.units, split = v / p.units;
+#ifdef CONVASR_AB_WGRAD_ORDER
+	// Diagnostic build only (scratch/ab_wgrad_order.py): which (co tile, ci tile, tap group) units run side by side on an XCD decides how
+	// often a split's dY / X rows are fetched from beyond L2.  Order 0 = shipped (tap group fastest, then ci, then co: ~32 resident units =
+	// 2 co x all ci x all tap groups); 1 = co fastest, then ci, then tap group; 2 = 3 x 3 (co x ci) blocks with all tap groups inside.
+	int tg, ci_t, co_t;
+	{
+		const int order = (p.debug >> 13) & 3;
+		if (order == 1) { co_t = unit % p.co_tiles; ci_t = (unit / p.co_tiles) % p.ci_tiles; tg = unit / (p.co_tiles * p.ci_tiles); }
+		else if (order == 2) {
+			const int BS = 3, cb = (p.co_tiles + BS - 1) / BS, ib = (p.ci_tiles + BS - 1) / BS;
+			// walk blocks of up to 3 x 3 (co, ci) pairs; inside a block the tap groups are fastest.  Units beyond the ragged edge are
+			// remapped by a linear search over the block list (few hundred units at most).
+			int u = unit, found = 0; tg = ci_t = co_t = 0;
+			for (int b0 = 0; b0 < cb * ib && !found; ++b0) {
+				const int c0 = (b0 / ib) * BS, i0 = (b0 % ib) * BS;
+				const int nc = min(BS, p.co_tiles - c0), ni = min(BS, p.ci_tiles - i0), n = nc * ni * p.tap_groups;
+				if (u < n) { tg = u % p.tap_groups; const int r = u / p.tap_groups; ci_t = i0 + r % ni; co_t = c0 + r / ni; found = 1; }
+				else u -= n;
+			}
+		}
+		else { tg = unit % p.tap_groups; ci_t = (unit / p.tap_groups) % p.ci_tiles; co_t = unit / (p.tap_groups * p.ci_tiles); }
+	}
+#else
 	const int tg = unit % p.tap_groups, ci_t = (unit / p.tap_groups) % p.ci_tiles, co_t = unit / (p.tap_groups * p.ci_tiles);
+#endif
 	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * WG_TG;
 	const int c_begin = split * p.chunks_per_split, c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
 	// slot A / slot B of this wave: tap index, mask of the k-substeps (of 4 per chunk) it covers, shared with the other wave half?
