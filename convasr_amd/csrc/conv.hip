@@ -376,6 +376,7 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 }
 
 int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out);  // conv_v2s.hip
+int convasr_conv1x1_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* rows_out);        // conv1x1.hip
 int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s);      // wgrad_v2.hip
 static int g_conv_use_v2 = 1;
 static int g_conv_debug = 0;
@@ -416,6 +417,11 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	CONVASR_CHECK_ARG(smem <= 160 * 1024, "conv1d_fwd: tile needs %zu B of LDS", smem);
 	hipStream_t s = (hipStream_t)stream;
 	int v2_rows = 0;
+	if (convasr_is_half(x_dtype) && g_conv_use_v2 && convasr_conv1x1_try(p, x_dtype, y_dtype, s, &v2_rows)) {  // one-tap training launches with short reductions
+		CONVASR_CHECK_LAUNCH("conv1d_fwd (1x1)");
+		if (rows_out) *rows_out = v2_rows;
+		return 0;
+	}
 	if (convasr_is_half(x_dtype) && g_conv_use_v2 && convasr_conv1d_v2_try(p, x_dtype, y_dtype, s, &v2_rows)) {
 		CONVASR_CHECK_LAUNCH("conv1d_fwd (v2)");
 		if (rows_out) *rows_out = v2_rows;

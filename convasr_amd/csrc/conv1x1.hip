@@ -1,0 +1,155 @@
+// One-tap (K = 1) Conv1d of 16-bit activations as a plain GEMM over the flattened batch:  Y[m][co] = sum_ci X[m][ci] * W[co][ci] (+ bias[co]),
+// m = (b, t) over all B * T frames.  Reference arithmetic: nn.Conv1d(kernel_size = 1), the residual branches of models.py:107-110 / 129-131
+// (up to ten per dense block, 55 per JasperNetLarge step) and their input gradients.
+//
+// Why its own kernel: conv_v2s.hip's 256 x 128 tile owns a CU (150 KB of LDS, 12 waves of 168 registers) and spends ~9.6 K cycles per tile
+// in prologue + epilogue whatever the reduction length; a one-tap tile over 256-640 input channels has only 4-10 barrier intervals of
+// ~870 cycles to put beside them -- the launches ran at 20-30 % of the HBM rate they are bound by (profiles/r04_config4_layers.txt).
+// Here a workgroup is small (128 x 128 tile, 4 waves of 64 x 64, 64 KB of LDS) so that several are resident per CU: one workgroup's
+// output staging and stores overlap another's DMA and MFMAs by occupancy, with nothing to schedule by hand.
+//   * both operands come in by LDS-DMA (buffer_load_dwordx4 ... lds), two stages of (X 128 rows + W 128 rows) x 128 B, one barrier per
+//     64-channel slab: barrier -> issue the next slab into the other stage -> 2 x (8 ds_read_b128 + 16 v_mfma_f32_16x16x32) per wave ->
+//     wait for the own pieces;
+//   * the LDS image, its XOR swizzle and the fragment addressing are conv_v2s.hip's (conflict-free ds_read_b128 for every row base);
+//   * rows past B * T and (for padded weights) rows past Cout read zeros through the buffer descriptors' range checks;
+//   * epilogue: (+ bias) -> BN statistics of that value (per-tile fp64 partial rows, summed in a fixed order by bn_finalize) -> 16-bit
+//     store through an LDS tile, 16 bytes per lane.  Same k order per element as conv_v2s.hip: bit-identical outputs.
+// Envelope: K = 1, stride 1, no padding, Cin % 64 == 0, Cout % 128 == 0, output type = input type, no folded scale / activation / length
+// mask (the training launches; everything else stays in conv_v2s.hip).
+#include "conv_v2_common.h"
+
+#define C11_THREADS 256
+#define C11_BM 128
+#define C11_STAGE (2 * C11_BM * ROW_BYTES)  // X tile + W tile of one 64-channel slab: 32 KiB
+
+template <typename I> __global__ __launch_bounds__(C11_THREADS, 2) void conv1x1_kernel(ConvParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	constexpr int MI = 4, NB = 4;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
+
+	// consecutive workgroups of an XCD walk the n tiles of one m tile first: its X rows are fetched from beyond L2 once
+	const int v = xcd_remap(blockIdx.x, p.total_tiles);
+	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
+	const int m0 = mtile * C11_BM, co0 = ntile * BN;
+	const int64_t M = (int64_t)p.B * p.Tout;
+
+	const int row_bytes = p.Cin * 2;
+	const v4i32 xsrc = make_srd(p.x, (unsigned)(M * row_bytes));
+	const v4i32 wsrc = make_srd(p.w, (unsigned)(p.CoutPad * row_bytes));
+	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+	const int n_cib = p.Cin >> 6;
+
+	// 16 X pieces + 16 W pieces of 1 KiB per slab; wave w issues pieces w, w + 4, ... of each (a piece = 8 rows x 128 B, swizzled per lane)
+	const int plane = v2s_src_offset(lane, row_bytes);
+	auto issue = [&](int cib, int stage) {
+		const unsigned dst = lds_base + stage * C11_STAGE;
+		const int xbase = m0 * row_bytes + cib * 128, wbase = co0 * row_bytes + cib * 128;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int u = wave + 4 * j;
+			dma16(xsrc, __builtin_amdgcn_readfirstlane(dst + u * 1024), xbase + u * 8 * row_bytes + plane);
+			dma16(wsrc, __builtin_amdgcn_readfirstlane(dst + C11_BM * ROW_BYTES + u * 1024), wbase + u * 8 * row_bytes + plane);
+		}
+	};
+
+	f32x4 acc[MI][NB];
+#pragma unroll
+	for (int i = 0; i < MI; ++i)
+#pragma unroll
+		for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+	typedef const __attribute__((address_space(3))) u32x4* lds_u4;
+	const int kb4 = kb << 4;
+	auto lane_off = [&](int row) { return (unsigned)((row << 7) + (kb4 ^ ((row << 4) & 0x60))); };
+	const unsigned xa0 = lds_base + lane_off(wm * 64 + r16), wa0 = lds_base + C11_BM * ROW_BYTES + lane_off(wn * 64 + r16);
+
+	issue(0, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	for (int cib = 0; cib < n_cib; ++cib) {
+		__builtin_amdgcn_s_barrier();  // slab cib has landed for everyone; everyone is done reading the other stage
+		if (cib + 1 < n_cib) issue(cib + 1, (cib + 1) & 1);
+		const unsigned so = (cib & 1) * C11_STAGE;
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks) {
+			u32x4 a[MI], b[NB];
+			const unsigned xa = (xa0 + so) ^ (ks << 6), wa = (wa0 + so) ^ (ks << 6);
+#pragma unroll
+			for (int i = 0; i < MI; ++i) { a[i] = *(lds_u4)(size_t)(xa + i * 2048); b[i] = *(lds_u4)(size_t)(wa + i * 2048); }
+#pragma unroll
+			for (int i = 0; i < MI; ++i)
+#pragma unroll
+				for (int j = 0; j < NB; ++j) acc[i][j] = Mma16<I>::run(a[i], b[j], acc[i][j]);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the own pieces of slab cib + 1
+	}
+	__syncthreads();  // the stages are dead: the output tile takes their place
+
+	// ---------------- epilogue: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg
+	constexpr int OPITCH = BN * 2 + 16;
+	char* const otile = smem;
+	float* const red = reinterpret_cast<float*>(smem + C11_BM * OPITCH);  // [2][2 (wm)][BN]
+	const bool full = m0 + C11_BM <= M;
+#pragma unroll
+	for (int ni = 0; ni < NB; ++ni) {
+		const int col = wn * 64 + ni * 16 + r16, co = co0 + col;
+		const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const int row = wm * 64 + mi * 16 + kb * 4 + g;
+				const float val = acc[mi][ni][g] + bias;
+				if (p.stats && (full || m0 + row < M)) { s1 += val; s2 += val * val; }
+				Elem<I>::store(reinterpret_cast<I*>(otile + row * OPITCH) + col, val);
+			}
+		}
+		if (p.stats) {
+			s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+			s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+			if (kb == 0) { red[(0 * 2 + wm) * BN + col] = s1; red[(1 * 2 + wm) * BN + col] = s2; }
+		}
+	}
+	__syncthreads();
+	if (p.stats && tid < BN && co0 + tid < p.Cout) {
+		double* const prow = p.stats + (int64_t)mtile * 2 * p.Cout;  // per-(m tile) partial row, summed in a fixed order by bn_finalize
+		prow[co0 + tid] = (double)red[(0 * 2 + 0) * BN + tid] + (double)red[(0 * 2 + 1) * BN + tid];
+		prow[p.Cout + co0 + tid] = (double)red[(1 * 2 + 0) * BN + tid] + (double)red[(1 * 2 + 1) * BN + tid];
+	}
+	I* const yb = reinterpret_cast<I*>(p.y);
+	constexpr int OCH = BN / 8;  // 16-byte chunks per tile row
+#pragma unroll
+	for (int it = 0; it < C11_BM * OCH / C11_THREADS; ++it) {
+		const int e = tid + it * C11_THREADS, row = e / OCH, ch = e % OCH;
+		const int64_t m = (int64_t)m0 + row;
+		if (m < M) *reinterpret_cast<uint4*>(yb + m * p.Cout + co0 + ch * 8) = *reinterpret_cast<const uint4*>(otile + row * OPITCH + ch * 16);
+	}
+}
+
+// Returns 1 if this kernel took the launch (rows_out = partial statistics rows written), 0 if the shape is outside its envelope.
+int convasr_conv1x1_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* rows_out) {
+	if (p.K != 1 || p.stride != 1 || p.pad != 0 || p.Tin != p.Tout || (p.Cin & 63) != 0 || (p.Cout & 127) != 0 || p.CoutPad != p.Cout) return 0;
+	if (!convasr_is_half(x_dtype) || y_dtype != x_dtype || p.scale || p.act != CONVASR_ACT_NONE || p.xlen || p.bn_y) return 0;
+	// Measured against conv_v2s.hip on every one-tap shape of the two bench workloads (profiles/r04_ab_conv1x1.json, scratch/ab_conv1x1.py:
+	// 32 x 376-1001 frames, 256-768 channels; 64 x 753, 896 <-> 1024): bit-identical outputs, 15-25 % less time throughout (2-3.5 TB/s
+	// of algorithmic bytes; the L2 -> LDS fills, ~5x those bytes at a 128 x 128 tile, are what it runs into).  debug bit 8192 forbids
+	// this kernel (A/B runs)
+	if (p.debug & 8192) return 0;
+	const int64_t M = (int64_t)p.B * p.Tout;
+	if (M * p.Cin * 2 >= (1ll << 31) || M * p.Cout * 2 >= (1ll << 31) || (int64_t)p.CoutPad * p.Cin * 2 >= (1ll << 31)) return 0;
+	p.n_tiles = p.Cout / BN;
+	const int m_tiles = (int)((M + C11_BM - 1) / C11_BM);
+	p.total_tiles = m_tiles * p.n_tiles;
+	const size_t smem = 2 * C11_STAGE;  // 64 KiB (the epilogue's 34.8 KB output tile + 1 KB of sums fit inside)
+	const bool f16 = x_dtype == CONVASR_F16;
+	const void* kern = f16 ? (const void*)conv1x1_kernel<f16_t> : (const void*)conv1x1_kernel<bf16_t>;
+	static unsigned long long set[2] = {0, 0};
+	convasr_allow_160k_lds(kern, set[f16]);
+	void* args[] = {&p};
+	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(C11_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	if (rows_out) *rows_out = m_tiles;
+	return 1;
+}

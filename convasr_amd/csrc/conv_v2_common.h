@@ -30,3 +30,15 @@ __device__ __forceinline__ void dma16(const v4i32& srd, unsigned lds_addr, int v
 	             : "memory");
 }
 
+// LDS image of a tile: 256-byte lines of two 128-byte rows (row = 2 * pair + s), a row's 16-byte chunk c at position
+// s * 8 + (c ^ swz(pair)) of its line.  A ds_read_b128 fragment read serves lanes {0-3, 12-15, 20-27} (and the three like groups) in
+// one LDS cycle each: 16 rows base + r16, k-block kb for eight of them and kb ^ 1 for the other eight, and it is conflict-free iff
+// the 16 positions are distinct.  With swz = pair & 7 (conv_v2.hip's image, made for its own read pattern) that holds only for
+// base = 0 mod 16, and the X fragments of tap t start at row t * dilation: SQ_LDS_BANK_CONFLICT was 24.5 % of SQ_LDS_IDX_ACTIVE.
+// swz = (pair & 3) << 1 is conflict-free for EVERY base (exhaustive check over bases, groups and k sub-steps: scratch/swizzle_search.py).
+__device__ __forceinline__ int v2s_swz(int pair) { return (pair & 3) << 1; }
+// LDS slot p (16-byte units) of the tile <- global (row, chunk): byte offset of that lane's 16 bytes relative to row 0 / chunk 0
+__device__ __forceinline__ int v2s_src_offset(int p, int row_bytes) {
+	const int pair = p >> 4, s = p & 15;
+	return (2 * pair + (s >> 3)) * row_bytes + (((s & 7) ^ v2s_swz(pair)) << 4);
+}

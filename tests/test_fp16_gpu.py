@@ -161,7 +161,9 @@ def test_fp16_training_step_scaled_equals_unscaled_and_overflow_is_skipped():
 	rel = float((upd_a - upd_b).norm() / upd_a.norm())
 	print('fp16 scaled vs unscaled: update rel L2', rel, 'losses', runs['plain'][1], runs['static'][1], 'norms', runs['plain'][2], runs['static'][2])
 	assert rel <= 5e-2 and abs(runs['plain'][2][0] - runs['static'][2][0]) <= 1e-5 * runs['plain'][2][0]
-	assert all(abs(a - b) <= 3e-4 * abs(a) for a, b in zip(runs['plain'][1], runs['static'][1]))
+	# losses: the first two agree to rounding (2e-6); the third follows two updates that already differ by 2.4 % in L2 (fp16 rounding of
+	# the scaled intermediates, see above) and moves with them: 1e-4 .. 4e-4 depending on the kernels' summation order
+	assert all(abs(a - b) <= tol * abs(a) for a, b, tol in zip(runs['plain'][1], runs['static'][1], (1e-4, 1e-4, 1e-3)))
 	# (c) overflow
 	model = _tiny(ca, torch.float16).to(d).train()
 	flat = ca.train.FlatParameters(model)
