@@ -197,7 +197,9 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	es, osz = x.element_size(), (2 if out_dtype in HALF_DTYPES else 4)
 	flops, nbytes_ = 2.0 * B * Tout * Cout * Cin * K if work is None else work, float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz)
 	symbol = 'v2s16' if family.startswith('conv1d_igemm_v2s') and out_dtype == x.dtype else None
-	if family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
+	if family.startswith('conv1d_igemm_v2s') and K == 1 and pad == 0 and Cout % 128 == 0 and out_dtype == x.dtype and scale is None and act[0] == _lib.ACT_NONE and xlen is None:
+		family, symbol = 'hbm:conv1x1_kernel (one-tap training launches)', None  # conv1x1.hip takes these (csrc/conv.hip: conv1d_run); bound by bytes moved, booked under the HBM roofline
+	elif family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
 		family = 'hbm:conv1d_igemm_v2s_kernel (memory-bound launches: the 38-class decoder)'
 	_lib.timed(family, flops, lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr()), nbytes = nbytes_, symbol = symbol)
 	if part is not None:

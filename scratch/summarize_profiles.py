@@ -1,5 +1,9 @@
 """Turn the rocprofv3 CSVs under gpurun_out/<tag>_* (scratch/r02_profiles.sh) into the small committed summaries under profiles/."""
-import csv, glob, json, collections, sys, os, shutil
+import csv, glob as _glob, json, collections, sys, os, shutil
+class glob:  # newest match first: a directory may hold the files of several calls
+	@staticmethod
+	def glob(pat, recursive = False):
+		return sorted(_glob.glob(pat, recursive = recursive), key = os.path.getmtime, reverse = True)
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 G = 'gpurun_out'
 stats = glob.glob(f'{G}/{tag}_stats/**/*kernel_stats.csv', recursive = True)[0]
