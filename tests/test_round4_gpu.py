@@ -384,3 +384,39 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
 	assert out['n_gpus'] == 2 and dist['backend'].startswith('nccl') and dist['world_size'] == 2 and dist['replicas_equal'] is True
 	assert len(dist['per_rank_ms']['all']) == 2 and dist['exposed_comm_ms']['mean'] >= 0
 	print('2 GPUs over RCCL:', out['value'], 'audio-s/s', dist['per_rank_ms'], dist['exposed_comm_ms']['mean'], dist['rccl_version'])
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(5, 333, 128, 256), (3, 128, 256, 128), (1, 77, 64, 384), (7, 200, 640, 768)])
+def test_one_tap_kernel_against_torch_and_the_big_tile_kernel(shape, dtype):
+	"""conv1x1.hip (every K = 1 training launch with 16-bit output) on sizes whose frame count is no multiple of its 128-row tile, with and
+	without bias / BN statistics: bit-identical to conv_v2s.hip (debug bit 8192 routes the same call there), close to torch's fp32 conv of
+	the same 16-bit operands, statistics equal to the sums of the output it stored (fp32 values before rounding: to 2^-8 / 2^-11)."""
+	from convasr_amd import ops, _lib
+	B, T, cin, cout = shape
+	d = torch.device('cuda:0')
+	torch.manual_seed(B * T + cin)
+	x = ops.as_cl(torch.randn(B, cin, T, device = d), dtype)
+	w = torch.randn(cout, cin, 1, device = d) / cin ** 0.5
+	bias = torch.randn(cout, device = d)
+	wp = ops.pack_weight(w, dtype, _lib.PACK_FWD)
+	lib = _lib.load()
+	outs = {}
+	for name, bits in (('1x1', 0), ('v2s', 8192)):
+		prev = lib.convasr_debug_set_conv_v2(1 | (bits << 8))
+		try:
+			st = ops.ConvStats(cout, B, T, d)
+			y = ops.conv1d(x, wp, cout, 1, 1, 1, 0, bias = bias, stats = st)
+			y0 = ops.conv1d(x, wp, cout, 1, 1, 1, 0)
+			outs[name] = (y, st.totals(), y0)
+		finally:
+			lib.convasr_debug_set_conv_v2(prev)
+	assert torch.equal(outs['1x1'][0], outs['v2s'][0]) and torch.equal(outs['1x1'][2], outs['v2s'][2])
+	assert float((outs['1x1'][1] - outs['v2s'][1]).abs().max()) <= 2e-6 * float(outs['v2s'][1].abs().max())
+	ref = torch.nn.functional.conv1d(x.float().contiguous(), wp[0, :cout].float().unsqueeze(-1), bias)
+	eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+	y = outs['1x1'][0].float()
+	assert float((y - ref).abs().max()) <= eps * float(ref.abs().max()) + 1e-4
+	tot = outs['1x1'][1]
+	s1, s2 = ref.double().sum(dim = (0, 2)), ref.double().square().sum(dim = (0, 2))
+	assert float((tot[:cout] - s1).abs().max()) <= 1e-4 * float(s1.abs().max() + B * T) and float((tot[cout:] - s2).abs().max()) <= 1e-4 * float(s2.abs().max())
