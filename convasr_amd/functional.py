@@ -652,6 +652,124 @@ class ConvBnActEvalFunction:
 		return ops.bn_act(y, scale, shift, act, xlen = xl, res = res_y, rscale = rscale, rshift = rshift, dropout_p = p_drop, seed = seed, offset = offset)
 
 
+class ConvBnActFrozenStatsFunction(torch.autograd.Function):
+	"""One repeat of ConvBn1d whose batch norms normalise with their RUNNING statistics (`bn.eval()`: a block frozen by JasperNet.freeze
+	whose input still carries a gradient, or a fine-tuning recipe that freezes the statistics only) while gradients are wanted --
+	for the conv weights, gamma / beta, the input, the residual branches, or any subset.  Eval-mode batch norm is a per-channel affine map
+	u = y * scale + shift with scale = gamma / sqrt(running_var + eps), so backward is g = dz * act'(.) * dropout * mask, dy = g * scale,
+	dgamma = sum g * (y - running_mean) / sqrt(running_var + eps), dbeta = sum g: the training path's kernels with the batch-statistics
+	terms of the coefficients set to zero (the reference gets the same from autograd through F.batch_norm(training = False)).
+
+	apply(cfg, x, weight, bias, gamma, beta, xlen, *flat_res) with flat_res per residual (res_x, res_weight, res_bias, res_gamma, res_beta),
+	the last four None for an identity residual -- ConvBnActFunction's argument list plus the conv bias (a fused conv carries one).
+	cfg['bn'] / cfg['res_bn'][r]: the BatchNorm1d modules (running statistics, eps), or None / nn.Identity where fuse_conv_bn_eval removed them."""
+
+	@staticmethod
+	def _affine(bn, gamma, beta):
+		if bn is None or not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
+			return None, None, None, None
+		ss = ops.bn_eval_scale_shift(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
+		return ss[0], ss[1], bn.running_mean.detach().float(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+
+	@staticmethod
+	def forward(ctx, cfg, x, weight, bias, gamma, beta, xlen, *flat_res):
+		spec, dt, act = cfg['spec'], cfg['compute_dtype'], cfg['act']
+		ctx.producer_link = _take_link(x)
+		x = ops.as_cl(x, dt)
+		dev = x.device
+		Cout = weight.shape[0]
+		xl = ops.xlen_f32(xlen, dev) if (cfg['temporal_mask'] and xlen is not None) else None
+		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias)
+		aff = ConvBnActFrozenStatsFunction._affine(cfg['bn'], gamma, beta)
+		n_res = len(flat_res) // 5
+		res_x, res_y, res_aff = [], [], []
+		for r in range(n_res):
+			rx, rw, rb, rg, rbeta = flat_res[5 * r:5 * r + 5]
+			rx = ops.as_cl(rx, dt)
+			res_x.append(rx)
+			if rw is None:
+				res_y.append(rx); res_aff.append((None, None, None, None))
+			else:
+				res_y.append(ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb))
+				res_aff.append(ConvBnActFrozenStatsFunction._affine(cfg['res_bn'][r], rg, rbeta))
+		p_drop = cfg['dropout_p']
+		seed, offset = _DropoutState.next(y.numel()) if p_drop > 0 else (0, 0)
+		z = ops.bn_act(y, aff[0], aff[1], act, xlen = xl, res = res_y, rscale = [a[0] for a in res_aff], rshift = [a[1] for a in res_aff], dropout_p = p_drop, seed = seed, offset = offset)
+		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset)
+		ctx.params = (weight, bias, gamma, beta) + tuple(flat_res[5 * r + k] for r in range(n_res) for k in range(1, 5))
+		ctx.aff, ctx.res_aff = aff, res_aff
+		ctx.x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
+		ctx.save_for_backward(x, y, xl, *res_x, *res_y)
+		return z
+
+	@staticmethod
+	def _coef(scale, C, dev):
+		coef = torch.zeros(3 * C, dtype = torch.float32, device = dev)  # dy = A * g + Bc * y + D with Bc = D = 0: no batch-statistics terms
+		coef[:C] = 1.0 if scale is None else scale
+		return coef
+
+	@staticmethod
+	def backward(ctx, dz):
+		cfg, n_res = ctx.cfg, ctx.n_res
+		spec, dt, act = cfg['spec'], cfg['compute_dtype'], cfg['act']
+		saved = ctx.saved_tensors
+		x, y, xl = saved[:3]
+		res_x, res_y = list(saved[3:3 + n_res]), list(saved[3 + n_res:3 + 2 * n_res])
+		weight, bias, gamma, beta = ctx.params[:4]
+		scale, shift, rmean, rinv = ctx.aff
+		p_drop, seed, offset = ctx.drop
+		B, Cout, Tout = y.shape
+		dev = y.device
+		dz = ops.as_cl(dz, dt)
+		live = lambda p: p is not None and p.requires_grad
+		common = dict(xlen = xl, res = res_y, rscale = [a[0] for a in ctx.res_aff], rshift = [a[1] for a in ctx.res_aff], dropout_p = p_drop, seed = seed, offset = offset)
+		# g = dz * act' * dropout * mask, materialised (the residual branches and the weight gradients read it); with trainable gamma / beta the
+		# same pass also sums g and g * (y - running_mean) * rinv per channel.  (The finalize kernel's coefficients are not used: they carry
+		# the batch-statistics terms of a TRAINING batch norm.)
+		dgamma = dbeta = None
+		if scale is not None and (live(gamma) or live(beta)):
+			sums = torch.empty(2 * Cout, dtype = torch.float64, device = dev)
+			scratch = torch.empty(3 * Cout, dtype = torch.float32, device = dev)
+			holder = {}
+			def reduce(outs, acc):
+				holder['g'] = ops.bn_act_bwd_reduce(dz, y, scale, shift, rmean, rinv, act, sums = sums, write_g = True, gamma = gamma, coef = scratch, dgamma = outs[0], dbeta = outs[1], accumulate = acc, **common)
+			dgamma, dbeta = _deliver([gamma, beta], reduce)
+			g = holder['g']
+		else:
+			g = ops.bn_act_bwd_reduce(dz, y, scale, shift, None, None, act, write_g = True, **common)
+		dy = g if scale is None else ops.bn_act_bwd_apply(g, y, ConvBnActFrozenStatsFunction._coef(scale, Cout, dev), False)
+		dw, db = _deliver([weight, bias], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], dbias = outs[1], accumulate = acc))
+		dx = None
+		if ctx.x_needs_grad:
+			if spec.stride != 1:
+				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
+			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link)
+		res_grads = []
+		for r in range(n_res):
+			rw, rb, rg, rbeta = ctx.params[4 + 4 * r:4 + 4 * r + 4]
+			need_rx = ctx.needs_input_grad[7 + 5 * r]
+			if rw is None:
+				res_grads += [g if need_rx else None, None, None, None, None]
+				continue
+			rscale, rshift, rrm, rri = ctx.res_aff[r]
+			drg = drbeta = None
+			if rscale is not None and (live(rg) or live(rbeta)):
+				# sum g and sum g * xhat of this branch: the reduce kernel on (g, g) with an identity activation and ONE "residual" = the branch
+				rs = torch.empty(2 * Cout, dtype = torch.float64, device = dev)
+				ops.bn_act_bwd_reduce(g, g, None, None, None, None, (_lib.ACT_NONE, 0.0, 0.0), res = [res_y[r]], rscale = [None], rshift = [None], rmean = [rrm], rinvstd = [rri], rsums = [rs], write_g = False)
+				def put(outs, acc, rs = rs):
+					for o, v in ((outs[0], rs[Cout:]), (outs[1], rs[:Cout])):
+						if o is not None:
+							o.add_(v.float()) if acc else o.copy_(v.float())
+				drg, drbeta = _deliver([rg, rbeta], put)
+			dry = g if rscale is None else ops.bn_act_bwd_apply(g, res_y[r], ConvBnActFrozenStatsFunction._coef(rscale, Cout, dev), False)
+			join_prepack(dev)
+			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), res_x[r].shape[1], 1, 1, 1, 0) if need_rx else None
+			drw, drb = _deliver([rw, rb], lambda outs, acc, rx = res_x[r], dry = dry: ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], dbias = outs[1], accumulate = acc))
+			res_grads += [drx, drw, drb, drg, drbeta]
+		return (None, dx, dw, db, dgamma, dbeta, None, *res_grads)
+
+
 class LogSoftmaxFunction(torch.autograd.Function):
 	"""F.log_softmax(logits, dim=1).float() (models.py:316) on channels-last fp32 logits."""
 

@@ -269,8 +269,23 @@ class ConvBn1d(nn.Module):
 						flat += [rx, rc.weight, rc.bias, rbn.weight, rbn.bias]
 				x = Fn.ConvBnActFunction.apply(cfg, x, conv.weight, bn.weight, bn.bias, lengths_fraction, *flat)
 			else:
-				if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
-					raise _lib.ConvasrHipError('backward through eval-mode / fused batch norm is not implemented: call the model under torch.no_grad() for inference')
+				res_live = lambda rc, rbn, rx: rx.requires_grad or (not isinstance(rc, nn.Identity) and any(p.requires_grad for p in list(rc.parameters()) + list(rbn.parameters())))
+				wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in list(conv.parameters()) + list(bn.parameters())) or any(res_live(rc, rbn, rx) for rc, rbn, rx in zip(self.conv_residual, self.bn_residual, res)))
+				if wants_grad:
+					# batch norms on their running statistics (bn.eval(): JasperNet.freeze with a gradient still flowing through, or statistics frozen
+					# for fine-tuning) under autograd: backward through the per-channel affine map (functional.ConvBnActFrozenStatsFunction)
+					flat = []
+					for rc, rbn, rx in zip(self.conv_residual, self.bn_residual, res):
+						if isinstance(rc, nn.Identity):
+							flat += [rx, None, None, None, None]
+						elif isinstance(rbn, nn.BatchNorm1d) and rbn.training:
+							raise _lib.ConvasrHipError('mixed train/eval batch norms inside one ConvBn1d are not supported')
+						else:
+							live_bn = isinstance(rbn, nn.BatchNorm1d)
+							flat += [rx, rc.weight, rc.bias, rbn.weight if live_bn else None, rbn.bias if live_bn else None]
+					fcfg = dict(cfg, bn = bn if bn_live else None, res_bn = list(self.bn_residual) if last else [])
+					x = Fn.ConvBnActFrozenStatsFunction.apply(fcfg, x, conv.weight, conv.bias, bn.weight if bn_live else None, bn.bias if bn_live else None, lengths_fraction, *flat)
+					continue
 				ss = ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps) if bn_live else None
 				res_list = []
 				for rc, rbn, rx in zip(self.conv_residual, self.bn_residual, res):

@@ -380,7 +380,7 @@ def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = N
 	every sum accumulated in fp32 (see _conv_bn_stored); storage = None is the reference's fp32 arithmetic.
 	frozen = dict(backbone = k, decoder0 = bool): JasperNet.freeze (models.py:328-339) -- the batch norms of the first k blocks run on
 	their running statistics (module.eval(), models.py:333) while everything else stays in training mode."""
-	n_frozen = (frozen or {}).get('backbone', 0) or 0
+	n_frozen = max((frozen or {}).get('backbone', 0) or 0, (frozen or {}).get('bn_stats', 0) or 0)  # bn_stats = k: the batch norms of the first k blocks in eval mode (`bn.eval()`), their parameters still trainable
 	if frontend is not None:
 		x = logmel_frontend(x, xlen, sd['frontend.window'], sd['frontend.mel.weight'], sd['frontend.mel.bias'], frontend['nfft'], frontend['hop_length'])
 	assert x.ndim == 3
