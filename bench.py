@@ -137,14 +137,31 @@ def launch_ranks(args, argv):
 # ------------------------------------------------------------------------------------------------ rank pre-flight (before any GPU call)
 
 def _kfd_gpu_nodes():
-	"""DRM render minors of the GPU nodes of the KFD topology, in node order (the order the HIP runtime enumerates devices in)."""
+	"""DRM render minors of the GPUs in the order the HIP runtime enumerates them: the GPU nodes of the KFD topology in node order; where an
+	unprivileged process may not read the topology (the pool's containers), the AMD render nodes in PCI-address order, which is the same
+	order on a single-root node."""
 	base = '/sys/class/kfd/kfd/topology/nodes'
-	out = []
-	for n in sorted((d for d in os.listdir(base) if d.isdigit()), key = int):
-		props = dict(ln.split(None, 1) for ln in open(os.path.join(base, n, 'properties')).read().splitlines() if ' ' in ln)
-		if int(props.get('simd_count', '0')) > 0:
-			out.append(int(props.get('drm_render_minor', '-1')))
-	return out
+	try:
+		out = []
+		for n in sorted((d for d in os.listdir(base) if d.isdigit()), key = int):
+			props = dict(ln.split(None, 1) for ln in open(os.path.join(base, n, 'properties')).read().splitlines() if ' ' in ln)
+			if int(props.get('simd_count', '0')) > 0:
+				out.append(int(props.get('drm_render_minor', '-1')))
+		if out:
+			return out
+	except OSError:
+		pass
+	import glob
+	nodes = []
+	for r in glob.glob('/sys/class/drm/renderD*'):
+		try:
+			if open(os.path.join(r, 'device', 'vendor')).read().strip() == '0x1002':
+				nodes.append((os.path.basename(os.path.realpath(os.path.join(r, 'device'))), int(os.path.basename(r)[7:])))
+		except OSError:
+			continue
+	if not nodes:
+		raise FileNotFoundError('no KFD topology and no AMD render node under /sys/class/drm')
+	return [minor for _, minor in sorted(nodes)]
 
 
 def _cpulist(text):
