@@ -161,6 +161,10 @@ def _kfd_gpu_nodes():
 			continue
 	if not nodes:
 		raise FileNotFoundError('no KFD topology and no AMD render node under /sys/class/drm')
+	import torch
+	visible = torch.cuda.device_count()  # (does not initialise the GPU on this image)
+	if visible != len(nodes):  # a container that is handed some of the host's GPUs still sees all of them in sysfs: which render node is device i?
+		raise LookupError(f'{len(nodes)} AMD render nodes in sysfs for {visible} visible device(s): the mapping is ambiguous')
 	return [minor for _, minor in sorted(nodes)]
 
 
