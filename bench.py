@@ -161,10 +161,6 @@ def _kfd_gpu_nodes():
 			continue
 	if not nodes:
 		raise FileNotFoundError('no KFD topology and no AMD render node under /sys/class/drm')
-	import torch
-	visible = torch.cuda.device_count()  # (does not initialise the GPU on this image)
-	if visible != len(nodes):  # a container that is handed some of the host's GPUs still sees all of them in sysfs: which render node is device i?
-		raise LookupError(f'{len(nodes)} AMD render nodes in sysfs for {visible} visible device(s): the mapping is ambiguous')
 	return [minor for _, minor in sorted(nodes)]
 
 
@@ -187,6 +183,10 @@ def pin_to_gpu_numa_node(local_rank):
 		vis = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
 		if vis and all(v.strip().isdigit() for v in vis.split(',')):
 			nodes = [nodes[int(v)] for v in vis.split(',') if int(v) < len(nodes)]
+		import torch
+		visible = torch.cuda.device_count()  # (does not initialise the GPU on this image)
+		if visible != len(nodes):  # a container that is handed some of the host's GPUs still sees all of them in sysfs: which one is device i?
+			return dict(pinned = False, reason = f'{len(nodes)} GPU render nodes in sysfs for {visible} visible device(s): the mapping is ambiguous')
 		minor = nodes[local_rank]
 		step = 'reading the render node\'s numa_node / local_cpulist'
 		dev = f'/sys/class/drm/renderD{minor}/device'
