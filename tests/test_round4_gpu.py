@@ -315,18 +315,25 @@ def test_short_last_tile_is_bit_identical_to_the_padded_one(T, dtype):
 		dxf = ops.conv1d_dgrad_bn_reduce(dy, wd, C, K, 1, K - 1 - K // 2, ybn, scale, shift, mean, invstd, act, 0.3, 9, 2, xlen, sums, gate = gate)
 		return y, st.totals(), dx, dxf, sums.totals()
 	lib = _lib.load()
+
+	def with_bits(bits):
+		prev = lib.convasr_debug_set_conv_v2(1 | (bits << 8))
+		try:
+			return run()
+		finally:
+			lib.convasr_debug_set_conv_v2(prev)
+	full = with_bits(128 | 2048)  # every tile 256 rows
+	for name, got in (('short last tile (shipped choice)', run()), ('128-row tiles for the whole launch', with_bits(1024))):
+		for a, b, what in zip(got, full, ('y', 'BN statistics', 'dx', 'fused dx', 'fused BN-backward sums')):
+			assert a is not None and b is not None, (name, what)
+			if what in ('BN statistics', 'fused BN-backward sums'):
+				# the same fp32 values summed per wave over 32 rows instead of 64 (statistics), per 128-row instead of 256-row tile (the
+				# matrix-pipe sums when the launch is tiled in 128 rows throughout -- which the shipped heuristic also picks for shapes as
+				# small as this test's): equal to fp32 rounding of the partial sums, not bit for bit
+				assert float((a - b).abs().max()) <= 4e-6 * float(b.abs().max()) + 1e-9, (name, what, T, float((a - b).abs().max()), float(b.abs().max()))
+			else:
+				assert torch.equal(a, b), (name, what, T)
 	short = run()
-	prev = lib.convasr_debug_set_conv_v2(1 | (128 << 8))
-	try:
-		full = run()
-	finally:
-		lib.convasr_debug_set_conv_v2(prev)
-	for a, b, what in zip(short, full, ('y', 'BN statistics', 'dx', 'fused dx', 'fused BN-backward sums')):
-		assert a is not None and b is not None, what
-		if what == 'BN statistics':  # the same fp32 values summed per wave over 32 rows instead of 64: equal to fp32 rounding of the partial sums, not bit for bit
-			assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (what, T, float((a - b).abs().max()), float(b.abs().max()))
-		else:
-			assert torch.equal(a, b), (what, T)
 	ref = torch.nn.functional.conv1d(x.float().cpu().contiguous(), wf.float().cpu().permute(1, 2, 0).contiguous(), padding = K // 2)
 	assert float((short[0].float().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
