@@ -5,11 +5,12 @@
 // Why its own kernel: conv_v2s.hip's 256 x 128 tile owns a CU (150 KB of LDS, 12 waves of 168 registers) and spends ~9.6 K cycles per tile
 // in prologue + epilogue whatever the reduction length; a one-tap tile over 256-640 input channels has only 4-10 barrier intervals of
 // ~870 cycles to put beside them -- the launches ran at 20-30 % of the HBM rate they are bound by (profiles/r04_config4_layers.txt).
-// Here a workgroup is small (128 x 128 tile, 4 waves of 64 x 64, 64 KB of LDS) so that several are resident per CU: one workgroup's
-// output staging and stores overlap another's DMA and MFMAs by occupancy, with nothing to schedule by hand.
-//   * both operands come in by LDS-DMA (buffer_load_dwordx4 ... lds), two stages of (X 128 rows + W 128 rows) x 128 B, one barrier per
-//     64-channel slab: barrier -> issue the next slab into the other stage -> 2 x (8 ds_read_b128 + 16 v_mfma_f32_16x16x32) per wave ->
-//     wait for the own pieces;
+// Here a workgroup is small (128 x 128 tile, 4 waves of 64 x 64, 37 or 64 KB of LDS, 104 registers) so that several are resident per CU:
+// one workgroup's output staging and stores overlap another's DMA and MFMAs by occupancy, with nothing to schedule by hand.
+//   * both operands come in by LDS-DMA (buffer_load_dwordx4 ... lds), stages of (X 128 rows + W 128 rows) x 128 B.  One stage (the default:
+//     four workgroups per CU): issue the slab -> wait for the own pieces -> barrier -> 2 x (8 ds_read_b128 + 16 v_mfma_f32_16x16x32) per
+//     wave -> barrier.  Two stages (two workgroups per CU; long reductions into few output channels): barrier -> issue the next slab into
+//     the other stage -> the MFMAs of this one -> wait for the own pieces;
 //   * the LDS image, its XOR swizzle and the fragment addressing are conv_v2s.hip's (conflict-free ds_read_b128 for every row base);
 //   * rows past B * T and (for padded weights) rows past Cout read zeros through the buffer descriptors' range checks;
 //   * epilogue: (+ bias) -> BN statistics of that value (per-tile fp64 partial rows, summed in a fixed order by bn_finalize) -> 16-bit
@@ -22,7 +23,9 @@
 #define C11_BM 128
 #define C11_STAGE (2 * C11_BM * ROW_BYTES)  // X tile + W tile of one 64-channel slab: 32 KiB
 
-template <typename I> __global__ __launch_bounds__(C11_THREADS, 2) void conv1x1_kernel(ConvParams p) {
+// NS = LDS stages: 2 = the next slab's DMA is in flight while this one is computed (64 KiB: two workgroups per CU); 1 = issue, wait, compute
+// (36.9 KiB incl. the epilogue's tile: four workgroups per CU, twice the bytes in flight per CU, the overlap left to occupancy alone).
+template <typename I, int NS> __global__ __launch_bounds__(C11_THREADS, NS == 1 ? 4 : 2) void conv1x1_kernel(ConvParams p) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int MI = 4, NB = 4;
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -66,12 +69,19 @@ template <typename I> __global__ __launch_bounds__(C11_THREADS, 2) void conv1x1_
 	auto lane_off = [&](int row) { return (unsigned)((row << 7) + (kb4 ^ ((row << 4) & 0x60))); };
 	const unsigned xa0 = lds_base + lane_off(wm * 64 + r16), wa0 = lds_base + C11_BM * ROW_BYTES + lane_off(wn * 64 + r16);
 
-	issue(0, 0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (NS == 2) {
+		issue(0, 0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
 	for (int cib = 0; cib < n_cib; ++cib) {
-		__builtin_amdgcn_s_barrier();  // slab cib has landed for everyone; everyone is done reading the other stage
-		if (cib + 1 < n_cib) issue(cib + 1, (cib + 1) & 1);
-		const unsigned so = (cib & 1) * C11_STAGE;
+		if (NS == 1) {
+			if (cib) __builtin_amdgcn_s_barrier();  // everyone is done reading the stage
+			issue(cib, 0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__builtin_amdgcn_s_barrier();  // slab cib has landed for everyone (NS == 2: and everyone is done reading the other stage)
+		if (NS == 2 && cib + 1 < n_cib) issue(cib + 1, (cib + 1) & 1);
+		const unsigned so = NS == 2 ? (cib & 1) * C11_STAGE : 0u;
 #pragma unroll
 		for (int ks = 0; ks < 2; ++ks) {
 			u32x4 a[MI], b[NB];
@@ -83,7 +93,7 @@ template <typename I> __global__ __launch_bounds__(C11_THREADS, 2) void conv1x1_
 #pragma unroll
 				for (int j = 0; j < NB; ++j) acc[i][j] = Mma16<I>::run(a[i], b[j], acc[i][j]);
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the own pieces of slab cib + 1
+		if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the own pieces of slab cib + 1
 	}
 	__syncthreads();  // the stages are dead: the output tile takes their place
 
@@ -143,11 +153,16 @@ int convasr_conv1x1_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, i
 	p.n_tiles = p.Cout / BN;
 	const int m_tiles = (int)((M + C11_BM - 1) / C11_BM);
 	p.total_tiles = m_tiles * p.n_tiles;
-	const size_t smem = 2 * C11_STAGE;  // 64 KiB (the epilogue's 34.8 KB output tile + 1 KB of sums fit inside)
+	// Stages: one (four workgroups per CU) unless the reduction is long against the output width (Cin >= 3 Cout: 768 -> 256), where the
+	// two-stage form's prefetch wins by 7-10 %; everywhere else on profiles/r04_ab_conv1x1.json's shapes the single stage is 0-25 % faster
+	// (640 -> 768 at 32 x 376: 27.3 -> 20.9 us; 896 -> 1024 at 64 x 753: 114.6 -> 97.5 us).  debug bit 16384 inverts the choice (A/B runs).
+	const bool one_stage = (p.Cin < 3 * p.Cout) != ((p.debug & 16384) != 0);
+	const size_t epi = (size_t)C11_BM * (BN * 2 + 16) + 4 * BN * sizeof(float);  // the epilogue's output tile + sums: 36.9 KB
+	const size_t smem = one_stage ? (epi > C11_STAGE ? epi : C11_STAGE) : 2 * (size_t)C11_STAGE;
 	const bool f16 = x_dtype == CONVASR_F16;
-	const void* kern = f16 ? (const void*)conv1x1_kernel<f16_t> : (const void*)conv1x1_kernel<bf16_t>;
-	static unsigned long long set[2] = {0, 0};
-	convasr_allow_160k_lds(kern, set[f16]);
+	const void* kern = one_stage ? (f16 ? (const void*)conv1x1_kernel<f16_t, 1> : (const void*)conv1x1_kernel<bf16_t, 1>) : (f16 ? (const void*)conv1x1_kernel<f16_t, 2> : (const void*)conv1x1_kernel<bf16_t, 2>);
+	static unsigned long long set[2][2] = {};
+	convasr_allow_160k_lds(kern, set[one_stage][f16]);
 	void* args[] = {&p};
 	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(C11_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	if (rows_out) *rows_out = m_tiles;

@@ -27,7 +27,7 @@ for (B, T, cin, cout, dt) in CASES:
 		stats = ops.ConvStats(cout, B, T, d) if with_stats else None
 		run = lambda: ops.conv1d(x, wp, cout, 1, 1, 1, 0, bias = bias if with_stats else None, stats = stats)
 		for rnd in range(2):
-			for name, bits in (('v2s', 8192), ('1x1', 4096)):
+			for name, bits in (('v2s', 8192), ('1x1', 0), ('1x1s1', 16384)):
 				lib.convasr_debug_set_conv_v2(1 | (bits << 8))
 				y = run()
 				key = (name, with_stats)
@@ -35,12 +35,12 @@ for (B, T, cin, cout, dt) in CASES:
 				res.setdefault(key, []).append(timeit(run))
 		lib.convasr_debug_set_conv_v2(1)
 		a, b = ys[('v2s', with_stats)], ys[('1x1', with_stats)]
-		assert torch.equal(a[0], b[0]), ('output differs', B, T, cin, cout, with_stats)
+		assert torch.equal(a[0], b[0]) and torch.equal(a[0], ys[('1x1s1', with_stats)][0]), ('output differs', B, T, cin, cout, with_stats)
 		if with_stats:
 			assert float((a[1] - b[1]).abs().max()) <= 2e-6 * float(a[1].abs().max()), ('stats', B, T, cin, cout)
 	best = {k: min(v) for k, v in res.items()}
 	nbytes = B * T * (cin + cout) * 2
-	row = dict(fwd_v2s = round(best[('v2s', True)], 1), fwd_1x1 = round(best[('1x1', True)], 1), plain_v2s = round(best[('v2s', False)], 1), plain_1x1 = round(best[('1x1', False)], 1), tbps_1x1 = round(nbytes / best[('1x1', False)] / 1e6, 2))
+	row = dict(fwd_v2s = round(best[('v2s', True)], 1), fwd_1x1 = round(best[('1x1', True)], 1), fwd_1x1_one_stage = round(best[('1x1s1', True)], 1), plain_v2s = round(best[('v2s', False)], 1), plain_1x1 = round(best[('1x1', False)], 1), plain_1x1_one_stage = round(best[('1x1s1', False)], 1), tbps_1x1 = round(nbytes / best[('1x1', False)] / 1e6, 2))
 	out[f'{B}x{T} {cin}->{cout} {str(dt)[6:]}'] = row
 	print(f'{B}x{T} {cin}->{cout}', row, flush = True)
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'r04_ab_conv1x1.json'), 'w'), indent = 1)
