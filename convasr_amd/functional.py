@@ -33,6 +33,16 @@ def packed_weight(w, dtype, mode):
 	kernels keep current -- only the transposed dgrad copy is still built by a packing launch."""
 	ver = param_version(w)
 	ent = _pack_cache.get((id(w), dtype))
+	if ent is not None:
+		# fast path (most calls of a step): the copy asked for is current.  For a weight served from the arena's 16-bit mirror that
+		# also means: the mirror object is still the one the entry points into, and the arena vouches for this version of the segment
+		if mode == _lib.PACK_DGRAD:
+			if ent['dgr_ver'] == ver:
+				return ent['dgr']
+		elif ent['fwd_ver'] == ver:
+			flat = ent.get('flat')
+			if flat is None or (flat.data16 is ent.get('mirror') and flat._mirror_ver.get(id(w)) == ver):
+				return ent['fwd']
 	both = w.requires_grad  # (grad mode is off inside autograd.Function.forward, so it cannot be consulted here)
 	if ent is None:
 		ent = _pack_cache[(id(w), dtype)] = dict(w = w, fwd = None, dgr = None, fwd_ver = None, dgr_ver = None)  # holds `w`: id() stays unique
@@ -50,6 +60,7 @@ def packed_weight(w, dtype, mode):
 			# (FlatParameters.mirror) is zero-filled, and a cache entry left from before the switch must not vouch for it
 			ent['fwd'] = flat.mirror(dtype)[off:off + w.numel()].view(K, Cout, Cin)
 			ent['fwd_ver'] = ver if flat._mirror_ver.get(id(w)) == ver else None
+			ent['flat'], ent['mirror'] = flat, flat.data16  # (what the fast path above re-checks)
 	if mode == _lib.PACK_FWD and ent['fwd_ver'] == ver:
 		return ent['fwd']
 	if mode == _lib.PACK_DGRAD and ent['dgr_ver'] == ver:

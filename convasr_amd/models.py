@@ -425,8 +425,11 @@ class JasperNet(nn.Module):
 		logits = self.decoder(x)
 		if y is not None and ylen is not None and self.training and torch.is_grad_enabled():
 			# the backward pass's transposed weight copies, on a side stream under the CTC recursion that follows (functional.prepack_dgrad_weights)
-			convs = [c[-1] for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv] + [c for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv_residual if isinstance(c, nn.Conv1d)]
-			Fn.prepack_dgrad_weights([c.weight for c in convs[1:] if c.stride[0] == 1], self.compute_dtype)
+			weights = getattr(self, '_dgrad_weights', None)
+			if weights is None:  # (the module tree is walked once, not per step: fuse_conv_bn_eval, which replaces conv modules, drops the list)
+				convs = [c[-1] for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv] + [c for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv_residual if isinstance(c, nn.Conv1d)]
+				weights = self._dgrad_weights = [c.weight for c in convs[1:] if c.stride[0] == 1]
+			Fn.prepack_dgrad_weights(weights, self.compute_dtype)
 		log_probs = [Fn.LogSoftmaxFunction.apply(l) for l in logits]
 		olen = [ops.output_lengths(xlen, l.shape[0], l.shape[-1], l.device) for l in logits]  # compute_output_lengths (models.py:611-614) as one launch
 		aux = {}
@@ -447,6 +450,7 @@ class JasperNet(nn.Module):
 				p.requires_grad = False
 
 	def fuse_conv_bn_eval(self, K = None):
+		self._dgrad_weights = None
 		for block in self.backbone[:K]:
 			block.fuse_conv_bn_eval()
 
