@@ -596,6 +596,16 @@ def main(argv = None):
 		st = flat.loss_scaler.current.tolist()
 		scaler_info = dict(loss_scale = st[0], clean_steps = int(st[1]), overflowed_steps_in_timed_region = int(st[7] - overflows0), overflowed_steps_total = int(st[7]),
 			note = 'apex dynamic loss scaling (2^16, x2 per 2000 clean steps, /2 and skip on overflow); an overflowed step skips only the optimizer update')
+	# host time of a step with the GPU drained first (the enqueue never waits for queue space): how far ahead of the GPU the Python side
+	# can run.  The Wav2Letter step needs ~4 ms of it for 16 ms of GPU work; a JasperNetLarge step ~20 ms for ~44 (1,200 launches): on a
+	# host that is busy with other tenants that step turns host-bound (seen: 48 ms), and this number says so.
+	host_ms = []
+	for i in range(3):
+		torch.cuda.synchronize()
+		h0 = time.perf_counter()
+		step(args.warmup + args.steps + i)
+		host_ms.append((time.perf_counter() - h0) * 1e3)
+	fence()
 	steps2, kt2 = 0, {}
 	if not args.no_kernel_timer:
 		steps2 = min(args.steps, 5)
@@ -631,7 +641,7 @@ def main(argv = None):
 		metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s' if headline else f'audio-seconds/sec/node (fwd+bwd+CTC), {args.workload}' + ('' if args.batch is None and args.secs is None else ' (TEST-ONLY size)')
 		line = dict(metric = metric, value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup,
 			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
-			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}'), loss = round(float(last['loss']), 4), loss_scaler = scaler_info,
+			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2)), loss = round(float(last['loss']), 4), loss_scaler = scaler_info,
 			dist = dist_info, roofline = roof, parity = None)
 		if args.workload == 'jasper_large':
 			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),

@@ -216,7 +216,13 @@ def test_bench_data_parallel_path_with_eight_ranks_sharing_the_gpu():
 	diagnostic fields a bad scaling curve would be read from -- per-rank step times, exposed communication, bucket sizes, replica
 	equality after the timed steps."""
 	env = dict(os.environ, CONVASR_SHARE_GPU = '1', CONVASR_DIST_BACKEND = 'gloo', HSA_ENABLE_IPC_MODE_LEGACY = '0')
-	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--batch', '4', '--secs', '2', '--steps', '3', '--warmup', '1', '--no-kernel-timer'], env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 900)
+	for attempt in range(2):
+		# (one retry: eight processes rendezvous over TCP on a host shared with other tenants; one abort of a gloo rank at start-up was seen in
+		# a dozen runs of this test.  A second failure in a row is a real one.)
+		r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--batch', '4', '--secs', '2', '--steps', '3', '--warmup', '1', '--no-kernel-timer'], env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 900)
+		if r.returncode == 0:
+			break
+		print('attempt', attempt, 'failed with', r.returncode, r.stderr[-1500:])
 	assert r.returncode == 0, r.stderr[-3000:]
 	lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
 	assert len(lines) == 1, lines
