@@ -9,7 +9,7 @@ G = 'gpurun_out'
 stats = glob.glob(f'{G}/{tag}_stats/**/*kernel_stats.csv', recursive = True)[0]
 rows = list(csv.DictReader(open(stats)))
 with open(f'profiles/{tag}_bench_kernel_stats.csv', 'w') as f:
-	f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic   (7 steps of the headline region incl. warm-up + 5 steps of the second event pass = 12 training steps)\n')
+	f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic   (warm-up + timed region + host-probe steps + the second event pass: the number of training steps = Calls of sgd_step_kernel)\n')
 	w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
 	for r in rows: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 traffic = {}
@@ -72,7 +72,7 @@ c4 = glob.glob(f'{G}/{tag}_config4_stats/**/*kernel_stats.csv', recursive = True
 if c4:
 	rows4 = list(csv.DictReader(open(c4[0])))
 	with open(f'profiles/{tag}_config4_kernel_stats.csv', 'w') as f:
-		f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload jasper_large --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-kernel-timer   (7 training steps of JasperNetLarge, fp16, 32 utterances of 5-20 s per step)\n')
+		f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload jasper_large --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-kernel-timer   (JasperNetLarge, fp16, 32 utterances of 5-20 s per step; the number of training steps = Calls of ng_step_kernel)\n')
 		w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
 		for r in rows4: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 	tr = {}
