@@ -38,7 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SAMPLE_RATE, SECS, BATCH = 16000, 15, 64
-FLOP_PER_AUDIO_S_FWD_BWD = 19.98e9  # Wav2Letter conv stack, 2*MAC, fwd + dgrad + wgrad
+# (the Wav2Letter conv stack is 19.98 GFLOP per audio-second, 2 * MAC, fwd + dgrad + wgrad; conv_stack_flops() below
+# derives the same figure -- and configs[4]'s 27.7 GFLOP per audio-second forward -- from the module tree, tests/test_parallel_cpu.py)
 PEAK_BF16_DENSE = 2.5e15  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak
 PEAK_F32_MFMA = 157.3e12  # exact-fp32 MFMA
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -47,7 +48,6 @@ MAIN_KERNEL_SYMBOLS = dict(
 	bf16 = ('conv1d_igemm_v2s_kernel<unsigned short, unsigned short', 'conv1d_igemm_v2s_kernelIttLi'),
 	f16 = ('conv1d_igemm_v2s_kernel<_Float16, _Float16', 'conv1d_igemm_v2s_kernel<__half, __half', 'conv1d_igemm_v2s_kernelIDF16_DF16_Li'))
 MAIN_FAMILY = 'conv1d_igemm_v2s_kernel<bf16>'  # (family labels are shared by the two 16-bit types)
-HBM_DECODER = 'the 38-class decoder'
 
 
 def parse_args(argv = None):
