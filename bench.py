@@ -64,11 +64,15 @@ def parse_args(argv = None):
 	ap.add_argument('--no-kernel-timer', action = 'store_true')
 	ap.add_argument('--no-f16-leg', action = 'store_true', help = 'skip the second timed region in fp16 (parity.f16_value)')
 	ap.add_argument('--no-traffic', action = 'store_true', help = 'skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run')
-	ap.add_argument('--side-stream', action = 'store_true', help = 'run wgrad on a second HIP stream (off by default so that the per-kernel HIP-event durations of the roofline leg are not inflated by overlap)')
+	ap.add_argument('--side-stream', default = 'auto', choices = ['auto', 'on', 'off'], nargs = '?', const = 'on',
+		help = 'run wgrad on a second HIP stream beside the dgrad of the same layer.  auto: on for jasper_large (launches of 0.5-3 rounds leave CUs idle: +2 % measured), '
+			'off for wav2letter (launches fill the chip: -1 %).  With the side stream on, every per-kernel HIP-event duration (the dominant kernel included) is measured in the '
+			'second pass, where the side stream is switched off again: overlapped launches would inflate each other')
 	ap.add_argument('--launcher-dry-run', action = 'store_true', help = 'test hook: ranks only rendezvous (gloo, CPU tensors) and rank 0 prints a line; exercises the self-launch path without a GPU')
 	args = ap.parse_args(argv)
 	if args.dtype is None:
 		args.dtype = 'f16' if args.workload == 'jasper_large' else 'bf16'
+	args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.workload == 'jasper_large')
 	return args
 
 
@@ -475,9 +479,16 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world):
 	half = wl.dtype in ('bf16', 'f16')
 	if not half:
 		main_name = 'conv1d_igemm (other variants)'
+	scale = args.steps / max(steps2, 1)
+	second_pass_main = main_name not in kt and main_name in kt2  # (side stream on: nothing was event-timed inside the timed region)
+	if second_pass_main:
+		kt = dict(kt)
+		for name in (main_name, fused_name):
+			if name in kt2:
+				v = kt2[name]
+				kt[name] = dict(v, launches = int(v['launches'] * scale), total_ms = v['total_ms'] * scale, work = v['work'] * scale, bytes = v['bytes'] * scale)
 	if main_name not in kt:
 		return None
-	scale = args.steps / max(steps2, 1)
 	for name, v in kt2.items():  # per-step figures of the second pass, rescaled to the timed region's step count
 		if name not in (main_name, fused_name):
 			kt[name] = dict(v, launches = int(v['launches'] * scale), total_ms = v['total_ms'] * scale, work = v['work'] * scale, bytes = v['bytes'] * scale)
@@ -498,7 +509,8 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world):
 	roof = dict(bound = 'mfma', kernel = kernel, achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None,
 		algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2),
 		ms_per_step = round(k['total_ms'] / args.steps, 3),
-		timing = f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it')
+		timing = (f'HIP events on the launching stream around every launch, in a second pass of {steps2} steps right after the timed region (the timed region runs wgrad on a side stream: overlapped launches would inflate each other\'s durations; the second pass runs without it)'
+			if second_pass_main else f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it'))
 	hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
 	kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
 	if plain is not None and plain is not k:
@@ -587,7 +599,7 @@ def main(argv = None):
 			dist.barrier()
 		torch.cuda.synchronize()
 
-	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0,
+	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0 and not args.side_stream,
 		on_warm = (lambda: flat.loss_scaler.current[7].item()) if flat.loss_scaler is not None else None)
 	overflows0 = run_timed.warm_value or 0.0  # the scaler's overflow count when the timed region starts (warm-up overflows are not the timed region's)
 	exposed = engine.exposed_comm_ms() if use_dist else None
@@ -607,6 +619,9 @@ def main(argv = None):
 		host_ms.append((time.perf_counter() - h0) * 1e3)
 	fence()
 	steps2, kt2 = 0, {}
+	if args.side_stream:
+		ca.functional.join_side_streams()
+		ca.functional.enable_side_stream_wgrad(device, False)  # the event-timed pass below runs every kernel alone on the main stream
 	if not args.no_kernel_timer:
 		steps2 = min(args.steps, 5)
 		if rank == 0:
@@ -637,11 +652,11 @@ def main(argv = None):
 		value = world * audio[0] / elapsed
 		headline = args.workload == 'wav2letter' and args.batch is None and args.secs is None
 		conv_flops_per_s = world * (flops[0] + flops[1]) / elapsed
-		roof = roofline_of(args, wl, kt, kt2, steps2, conv_flops_per_s, world) if kt else None
+		roof = roofline_of(args, wl, kt, kt2, steps2, conv_flops_per_s, world) if (kt or kt2) else None
 		metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s' if headline else f'audio-seconds/sec/node (fwd+bwd+CTC), {args.workload}' + ('' if args.batch is None and args.secs is None else ' (TEST-ONLY size)')
 		line = dict(metric = metric, value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup,
 			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
-			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2)), loss = round(float(last['loss']), 4), loss_scaler = scaler_info,
+			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', side_stream_wgrad = bool(args.side_stream), host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2)), loss = round(float(last['loss']), 4), loss_scaler = scaler_info,
 			dist = dist_info, roofline = roof, parity = None)
 		if args.workload == 'jasper_large':
 			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),
