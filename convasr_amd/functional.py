@@ -163,6 +163,7 @@ def _deliver(params, compute):
 	return outs
 
 
+RES_WGRAD_SIDE = os.environ.get('CONVASR_NO_RES_WGRAD_SIDE') != '1'  # A/B hook: the residual branches' weight gradients on the wgrad side stream too
 after_long_launch_hooks = {}  # id -> callable, run right after the backward pass has enqueued a long kernel (a dgrad): the data-parallel engine enqueues its ready collectives there, where their host cost hides behind queued GPU work
 _side_streams = {}  # device -> torch.cuda.Stream running the weight-gradient kernels (None entry = disabled)
 
@@ -487,7 +488,12 @@ class ConvBnActFunction(torch.autograd.Function):
 					# the arena segment of this bias gradient is written by nobody else (zero at allocation, zero again now, sums of zeros
 					# under data parallelism): later steps skip the fill -- dense blocks carry up to ten such biases
 					rb._convasr_grad_is_zero = outs[1] is getattr(rb, '_convasr_grad', None)
-			drw, drb = _deliver([rw, rb], res_wgrad)
+			if RES_WGRAD_SIDE and getattr(rw, '_convasr_grad', None) is not None and getattr(rb, '_convasr_grad', rw._convasr_grad) is not None:
+				# gradient arenas: the weight gradient of the branch goes to the wgrad side stream like the main conv's (it only reads rx and dry
+				# and writes the arena: the consumers of the arena join that stream, functional.join_side_streams / the data-parallel engine)
+				drw, drb = _run_wgrad(dry.device, (rx, dry), lambda: _deliver([rw, rb], res_wgrad))
+			else:
+				drw, drb = _deliver([rw, rb], res_wgrad)
 			res_grads += [drx, drw, drb, drg, drbeta]
 		return (None, dx, dw, dgamma, dbeta, None, *res_grads)
 
