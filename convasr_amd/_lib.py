@@ -44,10 +44,10 @@ _SIGNATURES = dict(
 	convasr_conv1d_wgrad = (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_bn_finalize = (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p, c_p, c_p, c_int, c_p, c_p]),
 	convasr_bn_eval_scale_shift = (c_int, [c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_int, c_p]),
-	convasr_bn_act_fwd = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p, c_p]),
+	convasr_bn_act_fwd = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_bwd_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
-	convasr_bn_act_bwd_reduce = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
-	convasr_bn_act_bwd_apply = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_int, c_int, c_int, c_p, c_p]),
+	convasr_bn_act_bwd_reduce = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
+	convasr_bn_act_bwd_apply = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_bwd_apply = (c_int, [c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_log_softmax_fwd = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_log_softmax_bwd = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
@@ -60,11 +60,13 @@ _SIGNATURES = dict(
 	convasr_argmax = (c_int, [c_p, c_p, c_i64, c_int, c_p]),
 	convasr_sumsq_workspace_bytes = (c_i64, []),
 	convasr_sumsq = (c_int, [c_p, c_i64, c_p, c_p, c_p, c_f32, c_p, c_p]),
-	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
-	convasr_adamw_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_p, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
-	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p]),
+	convasr_sgd_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_f32, c_p, c_int, c_p, c_p, c_p, c_p]),
+	convasr_adamw_step = (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_p, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p, c_p]),
+	convasr_conv1d_dgrad_bn_reduce = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p, c_p]),
 	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
-	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p]),
+	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p, c_p]),
+	convasr_step_begin = (c_int, [c_p, c_p]),
+	convasr_copy = (c_int, [c_p, c_p, c_i64, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int]),
@@ -95,7 +97,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 6:
+		if lib.convasr_abi_version() != 7:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib

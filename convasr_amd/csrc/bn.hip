@@ -135,12 +135,13 @@ struct BnActParams {
 	unsigned drop_thr;  // an element is dropped when its 16 random bits are < drop_thr (= round(p * 65536))
 	float keep_scale;   // 65536 / (65536 - drop_thr): E[keep] = 1 exactly
 	uint64_t seed, offset;
+	const uint64_t* step_key;  // optional device word XORed into the seed: the per-step dropout key (convasr_step_begin), so that a captured step graph draws new masks at every replay
 	int B, T, C;
 	int cgroups, rlanes, rows_per_block;  // thread tid -> channel group tid % cgroups (8 channels), row-lane tid / cgroups
 };
 
-static void set_dropout(BnActParams& p, float dropout_p, uint64_t seed, uint64_t offset) {
-	p.p_drop = dropout_p; p.seed = convasr_mix_seed(seed); p.offset = offset;
+static void set_dropout(BnActParams& p, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key) {
+	p.p_drop = dropout_p; p.seed = convasr_mix_seed(seed); p.offset = offset; p.step_key = step_key;
 	p.drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
 	if (p.drop_thr > 65535u) p.drop_thr = 65535u;
 	p.keep_scale = 65536.f / (float)(65536u - p.drop_thr);
@@ -269,6 +270,8 @@ template <typename L, typename U> __device__ __forceinline__ void walk_rows4(con
 }
 
 __device__ __forceinline__ void dropout_keep8(const BnActParams& p, int64_t idx, float (&keep)[8]) { dropout_mask8(p.seed, p.offset, p.drop_thr, p.keep_scale, idx, keep); }
+// once per kernel (p is the kernel's own copy of the parameter block): fold the device-resident step key into the seed -- a uniform scalar load
+__device__ __forceinline__ void fold_step_key(BnActParams& p) { if (p.drop_thr && p.step_key) p.seed ^= *p.step_key; }
 
 // MODE bit 0: residual inputs present, bit 1: dropout on, bit 2: gate bits wanted, bit 3: BN scale / shift present, bit 4: the
 // activation may be leaky-relu (else a clamp: one v_med3_f32 per element) -- compile-time, so
@@ -278,6 +281,7 @@ template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fw
 	constexpr bool RES = MODE & 1, DROP = (MODE & 2) != 0, GATE = (MODE & 4) != 0, AFFINE = (MODE & 8) != 0, LEAKY = (MODE & 16) != 0;
 	ResArgs ra = ra_;
 	if (!RES) ra.n = 0;
+	if (DROP) fold_step_key(p);
 	if (!AFFINE) p.scale = nullptr;
 	else __builtin_assume(p.scale != nullptr);
 	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
@@ -346,14 +350,14 @@ static unsigned ew_grid(int64_t total) {
 
 extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
                                   const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
-                                  uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, uint8_t* gate, void* stream) {
+                                  uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C, uint8_t* gate, void* stream) {
 	CONVASR_CHECK_ARG(y && z && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_fwd: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG(!gate || act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE, "bn_act_fwd: the one-bit gate needs an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr) && dropout_p >= 0.f && dropout_p < 1.f, "bn_act_fwd: bad scale/shift/dropout");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_fwd: B * T must fit in 31 bits");
 	BnActParams p = {};
 	p.y = y; p.out = z; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.gate_out = gate;
-	set_dropout(p, dropout_p, seed, offset);
+	set_dropout(p, dropout_p, seed, offset, step_key);
 	p.B = B; p.T = T; p.C = C;
 	ResArgs ra;
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, nullptr, nullptr, nullptr)) return rc;
@@ -381,6 +385,7 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 // workspace [set][block][2C]; bn_bwd_finalize_kernel sums the blocks in fp64: deterministic, and no contended fp64 atomics
 // (4096 blocks x 2C atomics per call cost 4x the streaming time).
 template <typename T, bool RES> __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnActParams p, ResArgs ra, float* __restrict__ ws) {
+	fold_step_key(p);
 	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	__shared__ float red[256][17];
 	const int c8 = p.C >> 3;
@@ -602,7 +607,7 @@ extern "C" int64_t convasr_bn_bwd_workspace_bytes(int B, int T, int C) {
 extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype, const float* scale, const float* shift, const float* mean,
                                          const float* invstd, int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                                          const float* const* rmean, const float* const* rinvstd, double* const* rsums, int act, float act_lo, float act_hi,
-                                         float dropout_p, uint64_t seed, uint64_t offset, const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
+                                         float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
                                          int accumulate, int B, int T, int C, const uint8_t* gate, void* stream) {
 	CONVASR_CHECK_ARG(!gate || (n_res == 0 && !g && mean && (act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE)), "bn_act_bwd_reduce: the one-bit gate form takes no residuals, writes no g, needs mean / invstd and an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG(dz && y && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_reduce: bad arguments (C must be a multiple of 8)");
@@ -611,7 +616,7 @@ extern "C" int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g,
 	BnActParams p = {};
 	p.y = y; p.dz = dz; p.out = g; p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.xlen = xlen; p.sums = sums;
 	p.act = act; p.lo = act_lo; p.hi = act_hi; p.B = B; p.T = T; p.C = C;
-	set_dropout(p, dropout_p, seed, offset);
+	set_dropout(p, dropout_p, seed, offset, step_key);
 	ResArgs ra;
 	if (int rc = fill_res(ra, n_res, res, rscale, rshift, rmean, rinvstd, rsums)) return rc;
 	for (int r = 2; r < n_res; ++r) if (ra.rsums[r]) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_reduce: batch-normed residuals beyond the first two must be reduced by separate calls");
@@ -675,6 +680,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // the gated form carries none of the re-derivation's registers -- 95 -> ~50 VGPRs -- or code)
 template <typename T, int SRC> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
 	constexpr bool FROM_DZ = SRC != 0, GATED = SRC == 2;
+	if (FROM_DZ && !GATED) fold_step_key(p);
 	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
 	const int c8 = p.C >> 3;
 	const int cg = threadIdx.x % p.cgroups, rl = threadIdx.x / p.cgroups;
@@ -733,13 +739,13 @@ template <typename T, int SRC> __global__ __launch_bounds__(256) void bn_act_bwd
 
 extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
                                         const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                                        const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
+                                        const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
 	CONVASR_CHECK_ARG(dz_or_g && y && dy && coef && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_apply: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG(!gate || (from_dz && (act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE)), "bn_act_bwd_apply: the one-bit gate needs from_dz and an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_apply: B * T must fit in 31 bits");
 	BnActParams p = {};
 	p.y = y; p.dz = dz_or_g; p.scale = scale; p.shift = shift; p.xlen = xlen; p.act = act; p.lo = act_lo; p.hi = act_hi; p.gate_in = gate;
-	set_dropout(p, dropout_p, seed, offset);
+	set_dropout(p, dropout_p, seed, offset, step_key);
 	p.B = B; p.T = T; p.C = C;
 	dim3 grid, block;
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);

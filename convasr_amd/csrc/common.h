@@ -218,7 +218,7 @@ __device__ __forceinline__ unsigned lowbias32_keyed(unsigned x, unsigned key) {
 }
 // host side of the dropout generator: the caller's seed is whitened once per launch (splitmix64), so that seeds 1, 2, 3 ... give
 // unrelated keys; the kernels receive the whitened value
-static inline uint64_t convasr_mix_seed(uint64_t z) {
+__host__ __device__ static inline uint64_t convasr_mix_seed(uint64_t z) {
 	z += 0x9E3779B97F4A7C15ull;
 	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;

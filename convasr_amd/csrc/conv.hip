@@ -452,13 +452,13 @@ extern "C" int convasr_conv_stats_max_rows(int B, int Tout) { return B * ((Tout 
 
 extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad,
                                               const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
-                                              int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                              int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key,
                                               const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream) {
 	CONVASR_CHECK_ARG(!bn_gate || bn_act == CONVASR_ACT_RELU || bn_act == CONVASR_ACT_HARDTANH || bn_act == CONVASR_ACT_NONE, "conv1d_dgrad_bn_reduce: the one-bit gate needs an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG(bn_y && bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && bn_rows && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0 && convasr_is_half(dtype), "conv1d_dgrad_bn_reduce: bad arguments (dtype must be CONVASR_BF16 or CONVASR_F16)");
 	ConvParams f = {};
 	f.bn_y = bn_y; f.bn_scale = bn_scale; f.bn_shift = bn_shift; f.bn_mean = bn_mean; f.bn_invstd = bn_invstd; f.bn_xlen = bn_xlen; f.bn_sums = bn_sums;
-	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = convasr_mix_seed(seed); f.bn_offset = offset; f.bn_gate = bn_gate;
+	f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = convasr_mix_seed(seed); f.bn_offset = offset; f.bn_step_key = step_key; f.bn_gate = bn_gate;
 	f.bn_drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
 	if (f.bn_drop_thr > 65535u) f.bn_drop_thr = 65535u;
 	f.bn_keep_scale = 65536.f / (float)(65536u - f.bn_drop_thr);

@@ -31,7 +31,7 @@ struct ConvParams {
 	// conv_v2s only, optional (bn_y != NULL): this launch is the dgrad that produces dz of a Conv+BN+activation layer, and its
 	// epilogue also runs pass 1 of that layer's batch-norm backward on the tile it just produced (see convasr_conv1d_dgrad_bn_reduce)
 	const void* bn_y; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; const float* bn_xlen; double* bn_sums;
-	int bn_act; float bn_lo, bn_hi; unsigned bn_drop_thr; float bn_keep_scale; uint64_t bn_seed, bn_offset;
+	int bn_act; float bn_lo, bn_hi; unsigned bn_drop_thr; float bn_keep_scale; uint64_t bn_seed, bn_offset; const uint64_t* bn_step_key;  // (bn_step_key, optional: device word XORed into bn_seed, see convasr_step_begin)
 	const uint8_t* bn_gate;  // optional: the one-bit gradient gates convasr_bn_act_fwd stored (instead of re-deriving act' / dropout / mask from bn_y)
 	int debug;   // experiment flags (scratch/ only): 1 = skip DMA issue in the main loop, 2 = skip MFMAs, 4 = skip epilogue stores
 };

@@ -424,7 +424,7 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 			for (int k = 0; k < 8; ++k) g[k] = dz[k] * act_grad(fmaf(yv[k], bsc[k], bsh[k]), bn_ac);
 			if (p.bn_drop_thr) {
 				float keep[8];
-				dropout_mask8(p.bn_seed, p.bn_offset, p.bn_drop_thr, p.bn_keep_scale, idx, keep);
+				dropout_mask8(p.bn_seed ^ (p.bn_step_key ? *p.bn_step_key : 0ull), p.bn_offset, p.bn_drop_thr, p.bn_keep_scale, idx, keep);
 #pragma unroll
 				for (int k = 0; k < 8; ++k) g[k] *= keep[k];
 			}

@@ -307,6 +307,30 @@ __global__ __launch_bounds__(256) void loss_head_kernel(const float* __restrict_
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ per-step device state
+// state[0] = the caller's dropout seed, state[1] = steps begun so far, state[2] = the key of the current step (what the dropout kernels
+// XOR into their seed through `step_key`), state[3] reserved.  One thread: a step that is replayed from a captured graph advances the
+// same words as an eagerly launched one, so the two draw identical masks.
+__global__ void step_begin_kernel(uint64_t* __restrict__ st) {
+	const uint64_t step = st[1] + 1;
+	st[1] = step;
+	st[2] = convasr_mix_seed(st[0] ^ convasr_mix_seed(step));
+}
+
+extern "C" int convasr_step_begin(uint64_t* state, void* stream) {
+	CONVASR_CHECK_ARG(state, "step_begin: state is NULL");
+	hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+	CONVASR_CHECK_LAUNCH("step_begin");
+	return 0;
+}
+
+extern "C" int convasr_copy(const void* src, void* dst, int64_t nbytes, void* stream) {
+	CONVASR_CHECK_ARG(src && dst && nbytes >= 0, "copy: bad arguments");
+	if (nbytes == 0) return 0;
+	if (hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "copy: hipMemcpyAsync failed");
+	return 0;
+}
+
 extern "C" int convasr_loss_head(const float* loss_vec, const int64_t* ylen, int64_t ylen_stride, const float* entropy, int B, float accumulate_iterations, float* out3,
                                  float* grad_loss_vec, unsigned char* skipped, const float* loss_scaler, float metric_scale, void* stream) {
 	CONVASR_CHECK_ARG(loss_vec && ylen && out3 && B > 0 && accumulate_iterations > 0.f, "loss_head: bad arguments");
@@ -359,7 +383,8 @@ extern "C" int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* wor
 
 template <typename H> __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, float* __restrict__ gout,
                                                        int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float mom, float wd, int nesterov, int first,
-                                                       const float* __restrict__ loss_gate, float grad_scale, H* __restrict__ p16, const float* __restrict__ scaler_in, float* __restrict__ scaler_out) {
+                                                       const float* __restrict__ loss_gate, float grad_scale, H* __restrict__ p16, const float* __restrict__ scaler_in, float* __restrict__ scaler_out, const float* __restrict__ lr_dev) {
+	if (lr_dev) lr = *lr_dev;  // the learning rate from device memory (a captured step graph follows the host's scheduler through it)
 	const bool gated = loss_gate && !(fabsf(*loss_gate) < INFINITY);  // inf or NaN loss: the step is skipped (train.py:769-772)
 	const LossScale ls = loss_scale_read(scaler_in, (scaler_in && sumsq) ? *sumsq : 0.0);
 	if (scaler_in && blockIdx.x == 0 && threadIdx.x == 0) loss_scale_advance(scaler_in, scaler_out, ls.overflow, gated);
@@ -408,13 +433,13 @@ template <typename H> __global__ __launch_bounds__(256) void sgd_step_kernel(flo
 
 extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm, float lr,
                                 float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale, void* p16, int p16_dtype,
-                                const float* scaler_in, float* scaler_out, void* stream) {
+                                const float* scaler_in, float* scaler_out, const float* lr_dev, void* stream) {
 	CONVASR_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || buf), "sgd_step: bad arguments");
 	CONVASR_CHECK_ARG(!p16 || convasr_is_half(p16_dtype), "sgd_step: the mirror's dtype must be CONVASR_BF16 or CONVASR_F16");
 	CONVASR_CHECK_ARG((scaler_in == nullptr) == (scaler_out == nullptr) && (!scaler_in || (scaler_in != scaler_out && sumsq)), "sgd_step: the loss scaler needs distinct in / out states and the gradient's sum of squares (its overflow check)");
 	int64_t blocks = ceil_div64(n, 256);
 	if (blocks > 4096) blocks = 4096;
-	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((sgd_step_kernel<H>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale, (H*)p16, scaler_in, scaler_out));
+	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((sgd_step_kernel<H>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, grad_out, n, sumsq, max_norm, lr, momentum, weight_decay, nesterov, first, loss_gate, grad_scale, (H*)p16, scaler_in, scaler_out, lr_dev));
 	CONVASR_CHECK_LAUNCH("sgd_step");
 	return 0;
 }
@@ -426,7 +451,8 @@ extern "C" int convasr_sgd_step(float* p, const float* g, float* buf, float* gra
 template <typename H> __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                          int64_t n, const double* __restrict__ sumsq, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                                                          const float* __restrict__ step_in, float* __restrict__ step_out, const float* __restrict__ loss_gate, float grad_scale,
-                                                         H* __restrict__ p16, const float* __restrict__ scaler_in, float* __restrict__ scaler_out) {
+                                                         H* __restrict__ p16, const float* __restrict__ scaler_in, float* __restrict__ scaler_out, const float* __restrict__ lr_dev) {
+	if (lr_dev) lr = *lr_dev;
 	const bool gated = loss_gate && !(fabsf(*loss_gate) < INFINITY);
 	const LossScale ls = loss_scale_read(scaler_in, (scaler_in && sumsq) ? *sumsq : 0.0);
 	const float t0 = *step_in;
@@ -474,14 +500,14 @@ template <typename H> __global__ __launch_bounds__(256) void adamw_step_kernel(f
 
 extern "C" int convasr_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const double* sumsq, float max_norm, float lr,
                                   float beta1, float beta2, float eps, float weight_decay, const float* step_in, float* step_out, const float* loss_gate,
-                                  float grad_scale, void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream) {
+                                  float grad_scale, void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, const float* lr_dev, void* stream) {
 	CONVASR_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step_in && step_out && step_in != step_out, "adamw_step: bad arguments");
 	CONVASR_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adamw_step: betas in [0, 1), eps >= 0");
 	CONVASR_CHECK_ARG(!p16 || convasr_is_half(p16_dtype), "adamw_step: the mirror's dtype must be CONVASR_BF16 or CONVASR_F16");
 	CONVASR_CHECK_ARG((scaler_in == nullptr) == (scaler_out == nullptr) && (!scaler_in || (scaler_in != scaler_out && sumsq)), "adamw_step: the loss scaler needs distinct in / out states and the gradient's sum of squares (its overflow check)");
 	int64_t blocks = ceil_div64(n, 256);
 	if (blocks > 4096) blocks = 4096;
-	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((adamw_step_kernel<H>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step_in, step_out, loss_gate, grad_scale, (H*)p16, scaler_in, scaler_out));
+	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((adamw_step_kernel<H>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step_in, step_out, loss_gate, grad_scale, (H*)p16, scaler_in, scaler_out, lr_dev));
 	CONVASR_CHECK_LAUNCH("adamw_step");
 	return 0;
 }

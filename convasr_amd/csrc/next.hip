@@ -64,6 +64,7 @@ struct NgParams {
 	int dampening, first;
 	const float* loss_gate; float* norm_out; float grad_scale;
 	void* p16;
+	const float* lr_dev;  // optional: the learning rate read from device memory instead of `lr`
 	const float* scaler_in; float* scaler_out;  // optional dynamic loss scaler (common.h): gradients are multiplied by 1 / scale, a non-finite gradient norm skips the step
 };
 
@@ -74,6 +75,7 @@ template <typename H> __global__ __launch_bounds__(256) void ng_step_kernel(NgPa
 	// first < 0: the EMA buffers carry one extra element, the count of steps APPLIED so far (a gated step does not count: the
 	// reference creates no optimizer state on an iteration it skips, optimizers.py:76-80 / train.py:769-772)
 	const int n_carry = q.n_seg + (q.first < 0 ? 1 : 0);
+	if (q.lr_dev) q.lr = *q.lr_dev;
 	const bool gated = q.loss_gate && !(fabsf(*q.loss_gate) < INFINITY);
 	q.offsets = ng_stage_offsets(q.offsets, q.n_seg, tab);
 	double tot = 0;
@@ -136,7 +138,7 @@ template <typename H> __global__ __launch_bounds__(256) void ng_step_kernel(NgPa
 extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema_in, float* ema_out, double* g2, const int64_t* offsets, int n_seg,
                                      int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part, float max_norm, float lr, float beta1,
                                      float beta2, float eps, float weight_decay, int dampening, int first, const float* loss_gate, float* total_norm, float grad_scale,
-                                     void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream) {
+                                     void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, const float* lr_dev, void* stream) {
 	CONVASR_CHECK_ARG(!p16 || convasr_is_half(p16_dtype), "novograd_step: the mirror's dtype must be CONVASR_BF16 or CONVASR_F16");
 	CONVASR_CHECK_ARG((scaler_in == nullptr) == (scaler_out == nullptr) && (!scaler_in || scaler_in != scaler_out), "novograd_step: the loss scaler needs distinct in / out states");
 	CONVASR_CHECK_ARG(p && g && mom && ema_in && ema_out && ema_in != ema_out && g2 && offsets && items && seg_first && item_part && n_seg > 0 && n_items >= n_seg && n > 0, "novograd_step: bad arguments");
@@ -146,7 +148,7 @@ extern "C" int convasr_novograd_step(float* p, const float* g, float* mom, const
 	NgParams q;
 	q.p = p; q.g = g; q.mom = mom; q.ema_in = ema_in; q.ema_out = ema_out; q.g2 = g2; q.offsets = offsets; q.n_seg = n_seg; q.n = n;
 	q.max_norm = max_norm; q.lr = lr; q.b1 = beta1; q.b2 = beta2; q.eps = eps; q.wd = weight_decay; q.dampening = dampening; q.first = first;
-	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale; q.p16 = p16; q.scaler_in = scaler_in; q.scaler_out = scaler_out;
+	q.loss_gate = loss_gate; q.norm_out = total_norm; q.grad_scale = grad_scale; q.p16 = p16; q.scaler_in = scaler_in; q.scaler_out = scaler_out; q.lr_dev = lr_dev;
 	CONVASR_DISPATCH_HALF(p16_dtype, H, hipLaunchKernelGGL((ng_step_kernel<H>), dim3((unsigned)ceil_div64(n, NG_CHUNK)), dim3(256), 0, s, q));
 	CONVASR_CHECK_LAUNCH("novograd_step");
 	return 0;

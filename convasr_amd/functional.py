@@ -76,8 +76,18 @@ def packed_weight(w, dtype, mode):
 	return ent['fwd'] if mode == _lib.PACK_FWD else ent['dgr']
 
 
+_structure_epoch = [0]
+
+
 def invalidate_pack_cache():
+	"""Called when conv modules were replaced (fuse_conv_bn_eval): packed copies are dropped and everything derived from the module tree
+	(JasperNet's list of dgrad weights, captured step graphs) is rebuilt on next use."""
 	_pack_cache.clear()
+	_structure_epoch[0] += 1
+
+
+def structure_epoch():
+	return _structure_epoch[0]
 
 
 # The transposed, tap-flipped dgrad copies of the weights (one ~8 us memory-bound launch per layer and step) depend on nothing but the
@@ -120,9 +130,21 @@ def join_prepack(device):
 		st[1] = False
 
 
+CAPTURING = ops._capturing  # [False]; set by train.GraphedTrainStep while a training step is being captured into a HIP graph: every buffer a captured kernel touches must then be persistent or allocated inside the capture (no module-level / per-stream caches), and double-buffered device state is handed back instead of swapped
+
+
+def capturing():
+	return CAPTURING[0]
+
+
 class _DropoutState:
+	"""The dropout generator's host side.  A mask is a function of (seed, offset, element index) XOR a per-step key word that lives on
+	the device (include/convasr_hip.h, convasr_step_begin): `offset` numbers the layers of ONE step (begin_step resets it), the key
+	numbers the steps -- so a step replayed from a captured graph, whose seed / offset arguments are frozen, still draws fresh masks,
+	and draws the same ones as the eager step it was captured from."""
 	seed = 0x5EEDC0DE
 	offset = 0
+	dev = {}  # device -> dict(state = int64 (4,) device tensor {seed, steps begun, key of the current step, reserved}, seed = the seed it was initialised from)
 
 	@classmethod
 	def next(cls, numel):
@@ -130,9 +152,40 @@ class _DropoutState:
 		cls.offset += (numel + 3) // 4 + 1
 		return cls.seed, off
 
+	@classmethod
+	def key(cls, device):
+		"""Device address of the current step's key word (what the kernels take as `step_key`), or None before the first begin_step()."""
+		st = cls.dev.get(device)
+		return None if st is None else st['state'].data_ptr() + 16
+
+	@classmethod
+	def upload(cls, device):
+		signed = cls.seed - (1 << 64) if cls.seed >= (1 << 63) else cls.seed
+		st = cls.dev.get(device)
+		if st is None:
+			st = cls.dev[device] = dict(state = torch.zeros(4, dtype = torch.int64, device = device), seed = None)
+		st['state'].copy_(torch.tensor([signed, 0, 0, 0], dtype = torch.int64))
+		st['seed'] = cls.seed
+		return st
+
 
 def manual_seed(seed):
 	_DropoutState.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+	_DropoutState.offset = 0
+	for device in list(_DropoutState.dev):
+		_DropoutState.upload(device)  # (eagerly: a captured step graph reads the words, the host cannot patch them at the next begin_step)
+
+
+def begin_step(device):
+	"""First call of a training step (train.train_step): advances the device-resident step key (one single-thread launch) and restarts
+	the per-layer offsets, so that step s, layer l draws the same mask whether the step is launched kernel by kernel or replayed."""
+	device = torch.device(device)
+	st = _DropoutState.dev.get(device)
+	if st is None or st['seed'] != _DropoutState.seed:
+		if CAPTURING[0]:
+			raise _lib.ConvasrHipError('begin_step: the dropout state of this device must exist before a step is captured (run one eager step first)')
+		st = _DropoutState.upload(device)
+	_lib.call('convasr_step_begin', st['state'].data_ptr(), _lib.stream_ptr())
 	_DropoutState.offset = 0
 
 
@@ -309,7 +362,7 @@ def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
 	join_prepack(dy.device)
 	wd = packed_weight(weight, dt, _lib.PACK_DGRAD) if wd is None else wd
 	if link is not None and dt in ops.HALF_DTYPES and spec.stride == 1:
-		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'], gate = link.get('gate'))
+		dx = ops.conv1d_dgrad_bn_reduce(dy, wd, Cin, spec.K, spec.dilation, pad, link['y'], link['bnp'][2], link['bnp'][3], link['bnp'][0], link['bnp'][1], link['act'], link['drop'][0], link['drop'][1], link['drop'][2], link['xl'], link['sums'], gate = link.get('gate'), step_key = link['drop'][3])
 		if dx is not None:
 			link['dz'] = dx  # held until the producer's backward has looked at it: the address cannot be recycled meanwhile
 			_after_long_launch()
@@ -369,22 +422,23 @@ class ConvBnActFunction(torch.autograd.Function):
 
 		p_drop = cfg['dropout_p']
 		seed, offset = _DropoutState.next(B * Cout * Tout) if p_drop > 0 else (0, 0)
+		skey = _DropoutState.key(dev) if p_drop > 0 else None
 		# one bit per element: does the gradient pass it (activation range, dropout, frame mask)?  The backward kernels of a residual-free
 		# layer take the bits back in instead of re-deriving the pre-activation, re-hashing the dropout mask and redoing the frame arithmetic
 		gate = None
 		if GATE_BITS and n_res == 0 and act[0] in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_HARDTANH) and Cout % 8 == 0 and (weight.requires_grad or x_needs_grad or gamma.requires_grad):
 			gate = torch.empty(B * Tout * Cout // 8, dtype = torch.uint8, device = dev)
-		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, gate = gate)
+		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, gate = gate, step_key = skey)
 		ctx.gate = gate
 
-		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset)
+		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset, skey)
 		ctx.params = (weight, gamma, beta) + tuple(flat_res[5 * r + k] for r in range(n_res) for k in range(1, 5))
 		ctx.x_needs_grad = x_needs_grad
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
 		ctx.bwd_link = None
 		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt in ops.HALF_DTYPES and Cout % 8 == 0:
-			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None, gate = gate)
+			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset, skey), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None, gate = gate)
 			setattr(z, _LINK_ATTR, ctx.bwd_link)
 		return z
 
@@ -399,7 +453,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		it = iter(saved[4 + 2 * n_res:])
 		res_bnp = [next(it) if has else None for has in ctx.res_has_bn]
 		weight, gamma, beta = ctx.params[:3]
-		p_drop, seed, offset = ctx.drop
+		p_drop, seed, offset, skey = ctx.drop
 		B, Cout, Tout = y.shape
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
@@ -418,25 +472,25 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				finalize([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey)
 			g = rsum_of = None
 		elif n_res == 0:
 			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
 			# per-channel coefficients, pass 2 recomputes g from dz on the fly: dy = A*g + Bc*y + D
 			coef = torch.empty(3 * Cout, dtype = torch.float32, device = dev)
-			reduce = lambda outs, acc: ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, write_g = False, gamma = gamma, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc, gate = ctx.gate)
+			reduce = lambda outs, acc: ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, write_g = False, gamma = gamma, coef = coef, dgamma = outs[0], dbeta = outs[1], accumulate = acc, gate = ctx.gate, step_key = skey)
 			if gamma.requires_grad or beta.requires_grad:
 				dgamma, dbeta = _deliver([gamma, beta], reduce)
 			else:
 				reduce([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey)
 			g = rsum_of = None
 		else:
 			bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
 			sums = torch.empty(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)  # written by the reduce kernels
 			rsum_of = {r: sums[2 * Cout * (1 + i):2 * Cout * (2 + i)] for i, r in enumerate(bn_idx)}
-			common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset)
+			common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, step_key = skey)
 			# the kernel reduces the main BN plus the first two batch-normed residuals per pass; dense blocks with more take extra passes
 			first = [r for r in bn_idx if r < 2]
 			g = ops.bn_act_bwd_reduce(dz, y, bnp[2], bnp[3], bnp[0], bnp[1], act, rsums = [rsum_of.get(r) if r in first else None for r in range(n_res)], sums = sums[:2 * Cout], **common)
@@ -500,6 +554,8 @@ class ConvBnActFunction(torch.autograd.Function):
 
 def _momentum(bn):
 	if bn.momentum is None:  # cumulative moving average (reset_bn_running_stats_, models.py:731)
+		if CAPTURING[0]:
+			raise _lib.ConvasrHipError('a batch norm with momentum = None (cumulative average: its factor is read from the device every step) cannot be captured into a step graph')
 		return 1.0 / float(int(bn.num_batches_tracked.item()) + 1)
 	return bn.momentum
 
@@ -507,6 +563,8 @@ def _momentum(bn):
 def _stats_buffer(bn, C, dev, B, Tout, slot = '_convasr_stats'):
 	"""Persistent per-BatchNorm partial-sum buffer (ops.ConvStats) for the conv epilogue's statistics; `slot` picks the forward
 	one or the one the fused backward epilogue fills.  Nothing to zero: every launch overwrites the rows it reports."""
+	if CAPTURING[0]:
+		return ops.ConvStats(C, B, Tout, dev)  # allocated inside the capture (the graph's own pool): a buffer cached on the module could be replaced -- and freed -- by a later, larger batch
 	st = getattr(bn, slot, None)
 	if st is None or not st.fits(C, B, Tout, dev):
 		st = ops.ConvStats(C, B, Tout, dev)
@@ -549,8 +607,10 @@ class _HeadPad:
 		# only rewrites the Cout live channels (no fill launch); its readers of the previous step are ordered before this write on the same
 		# stream (train_step joins the weight-gradient side stream before the optimizer)
 		key = (B, T, Cout, dt, dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
-		out = cls._pad_bufs.get(key)
-		if out is None:
+		out = None if CAPTURING[0] else cls._pad_bufs.get(key)
+		if CAPTURING[0]:
+			out = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)  # (inside a capture: the graph's own buffer, zero-filled by a memset node at every replay)
+		elif out is None:
 			if len(cls._pad_bufs) >= 64:
 				cls._pad_bufs.clear()  # mixed-length training: one entry per padded length; bounded
 			out = cls._pad_bufs[key] = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)
@@ -666,7 +726,7 @@ class ConvBnActEvalFunction:
 				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])
 		# rscale None (identity residual, or a residual conv already fused with its BN) means "add as is"
 		seed, offset = _DropoutState.next(y.numel()) if p_drop > 0 else (0, 0)
-		return ops.bn_act(y, scale, shift, act, xlen = xl, res = res_y, rscale = rscale, rshift = rshift, dropout_p = p_drop, seed = seed, offset = offset)
+		return ops.bn_act(y, scale, shift, act, xlen = xl, res = res_y, rscale = rscale, rshift = rshift, dropout_p = p_drop, seed = seed, offset = offset, step_key = _DropoutState.key(y.device) if p_drop > 0 else None)
 
 
 class ConvBnActFrozenStatsFunction(torch.autograd.Function):
@@ -711,8 +771,9 @@ class ConvBnActFrozenStatsFunction(torch.autograd.Function):
 				res_aff.append(ConvBnActFrozenStatsFunction._affine(cfg['res_bn'][r], rg, rbeta))
 		p_drop = cfg['dropout_p']
 		seed, offset = _DropoutState.next(y.numel()) if p_drop > 0 else (0, 0)
-		z = ops.bn_act(y, aff[0], aff[1], act, xlen = xl, res = res_y, rscale = [a[0] for a in res_aff], rshift = [a[1] for a in res_aff], dropout_p = p_drop, seed = seed, offset = offset)
-		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset)
+		skey = _DropoutState.key(dev) if p_drop > 0 else None
+		z = ops.bn_act(y, aff[0], aff[1], act, xlen = xl, res = res_y, rscale = [a[0] for a in res_aff], rshift = [a[1] for a in res_aff], dropout_p = p_drop, seed = seed, offset = offset, step_key = skey)
+		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset, skey)
 		ctx.params = (weight, bias, gamma, beta) + tuple(flat_res[5 * r + k] for r in range(n_res) for k in range(1, 5))
 		ctx.aff, ctx.res_aff = aff, res_aff
 		ctx.x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
@@ -734,12 +795,12 @@ class ConvBnActFrozenStatsFunction(torch.autograd.Function):
 		res_x, res_y = list(saved[3:3 + n_res]), list(saved[3 + n_res:3 + 2 * n_res])
 		weight, bias, gamma, beta = ctx.params[:4]
 		scale, shift, rmean, rinv = ctx.aff
-		p_drop, seed, offset = ctx.drop
+		p_drop, seed, offset, skey = ctx.drop
 		B, Cout, Tout = y.shape
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
 		live = lambda p: p is not None and p.requires_grad
-		common = dict(xlen = xl, res = res_y, rscale = [a[0] for a in ctx.res_aff], rshift = [a[1] for a in ctx.res_aff], dropout_p = p_drop, seed = seed, offset = offset)
+		common = dict(xlen = xl, res = res_y, rscale = [a[0] for a in ctx.res_aff], rshift = [a[1] for a in ctx.res_aff], dropout_p = p_drop, seed = seed, offset = offset, step_key = skey)
 		# g = dz * act' * dropout * mask, materialised (the residual branches and the weight gradients read it); with trainable gamma / beta the
 		# same pass also sums g and g * (y - running_mean) * rinv per channel.  (The finalize kernel's coefficients are not used: they carry
 		# the batch-statistics terms of a TRAINING batch norm.)
@@ -782,6 +843,8 @@ class ConvBnActFrozenStatsFunction(torch.autograd.Function):
 			dry = g if rscale is None else ops.bn_act_bwd_apply(g, res_y[r], ConvBnActFrozenStatsFunction._coef(rscale, Cout, dev), False)
 			join_prepack(dev)
 			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), res_x[r].shape[1], 1, 1, 1, 0) if need_rx else None
+			if rb is not None:
+				rb._convasr_grad_is_zero = False  # a real bias gradient lands in the arena segment: the train-mode path (ConvBnActFunction) must zero it again
 			drw, drb = _deliver([rw, rb], lambda outs, acc, rx = res_x[r], dry = dry: ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], dbias = outs[1], accumulate = acc))
 			res_grads += [drx, drw, drb, drg, drbeta]
 		return (None, dx, dw, db, dgamma, dbeta, None, *res_grads)

@@ -425,18 +425,21 @@ class JasperNet(nn.Module):
 		logits = self.decoder(x)
 		if y is not None and ylen is not None and self.training and torch.is_grad_enabled():
 			# the backward pass's transposed weight copies, on a side stream under the CTC recursion that follows (functional.prepack_dgrad_weights)
-			weights = getattr(self, '_dgrad_weights', None)
-			if weights is None:  # (the module tree is walked once, not per step: fuse_conv_bn_eval, which replaces conv modules, drops the list)
+			cached = getattr(self, '_dgrad_weights', None)
+			if cached is None or cached[0] != Fn.structure_epoch():  # (the module tree is walked once, not per step: any fuse_conv_bn_eval -- the network's or a single block's -- replaces conv modules and bumps the epoch)
 				convs = [c[-1] for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv] + [c for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv_residual if isinstance(c, nn.Conv1d)]
-				weights = self._dgrad_weights = [c.weight for c in convs[1:] if c.stride[0] == 1]
-			Fn.prepack_dgrad_weights(weights, self.compute_dtype)
+				cached = self._dgrad_weights = (Fn.structure_epoch(), [c.weight for c in convs[1:] if c.stride[0] == 1])
+			Fn.prepack_dgrad_weights(cached[1], self.compute_dtype)
 		log_probs = [Fn.LogSoftmaxFunction.apply(l) for l in logits]
 		olen = [ops.output_lengths(xlen, l.shape[0], l.shape[-1], l.device) for l in logits]  # compute_output_lengths (models.py:611-614) as one launch
 		aux = {}
 		if y is not None and ylen is not None:
 			loss = [Fn.ctc_loss(lp, y[:, i], olen[i], ylen[:, i], lp.shape[1] - 1, norm = ylen[:, 0]) for i, lp in enumerate(log_probs)]
 			heads = loss if not self.bpe_only else loss[1:]
-			aux = dict(loss = heads[0] if len(heads) == 1 else sum(heads[1:], heads[0]))  # (Python's sum() would start from 0 + tensor: an ATen launch per step)
+			if not heads:  # bpe_only with a single head: the reference's sum(loss[1:]) over nothing is 0 (models.py:325)
+				aux = dict(loss = torch.zeros_like(loss[0]))
+			else:
+				aux = dict(loss = heads[0] if len(heads) == 1 else sum(heads[1:], heads[0]))  # (Python's sum() would start from 0 + tensor: an ATen launch per step)
 		return self.dict(logits = logits, log_probs = log_probs, olen = olen, **aux)
 
 	def freeze(self, backbone = 0, decoder0 = False, frontend = False):

@@ -229,12 +229,15 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 
 
 _workspaces = {}
+_capturing = [False]  # functional.CAPTURING (the same list object, installed by functional at import)
 
 
 def workspace(nbytes, device, tag = 'default'):
 	"""Grow-only scratch buffer per (device, tag, current stream): kernels that share one are ordered by that stream, and a
 	buffer replaced by a bigger one is released by the caching allocator in the order of the stream it was allocated on (the
 	side-stream wgrad and a main-stream wgrad of the same backward never share or free each other's slabs)."""
+	if _capturing[0]:
+		return torch.empty(max(int(nbytes), 256), dtype = torch.uint8, device = device)  # inside a graph capture: from the graph's own pool, never a cached buffer a later eager step could replace
 	key = (device, tag, _lib.stream_ptr() if device.type == 'cuda' else 0)  # (the current device's current stream: kernels are launched there)
 	buf = _workspaces.get(key)
 	if buf is None or buf.numel() < nbytes:
@@ -355,20 +358,21 @@ def _ptr_array(items):
 	return arr
 
 
-def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None):
-	"""gate (optional uint8 (B*T*C/8,)): receives one bit per element, set iff the gradient passes it (include/convasr_hip.h)."""
+def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None):
+	"""gate (optional uint8 (B*T*C/8,)): receives one bit per element, set iff the gradient passes it (include/convasr_hip.h).
+	step_key (optional, here and in the backward passes): device address (int) of the per-step dropout key word (functional.begin_step)."""
 	B, C, T = y.shape
 	assert gate is None or (gate.dtype == torch.uint8 and gate.numel() * 8 == B * C * T and gate.is_contiguous())
 	assert is_cl(y) and all(is_cl(r) and r.dtype == y.dtype for r in res)
 	z = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
-	_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res))))
+	_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res))))
 	return z
 
 
 _bn_bwd_ws_bytes = {}
 
 
-def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None, write_g = True, gamma = None, coef = None, dgamma = None, dbeta = None, accumulate = False, gate = None):
+def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res = (), rscale = (), rshift = (), rmean = (), rinvstd = (), rsums = (), dropout_p = 0.0, seed = 0, offset = 0, sums = None, write_g = True, gamma = None, coef = None, dgamma = None, dbeta = None, accumulate = False, gate = None, step_key = None):
 	"""gate: the forward pass's one-bit gradient gates (bn_act(..., gate = ...)); needs write_g = False and no residuals."""
 	B, C, T = y.shape
 	assert is_cl(y) and is_cl(dz) and dz.dtype == y.dtype and (gate is None or (not write_g and not res))
@@ -377,14 +381,14 @@ def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res =
 	if nb is None:
 		nb = _bn_bwd_ws_bytes[(B, T, C)] = _lib.load().convasr_bn_bwd_workspace_bytes(B, T, C)
 	ws = workspace(nb, y.device, 'bn_bwd')
-	_lib.timed('hbm:bn_act_bwd_reduce_kernel', 0.0, lambda: call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res) + (1 if write_g else 0))))
+	_lib.timed('hbm:bn_act_bwd_reduce_kernel', 0.0, lambda: call('convasr_bn_act_bwd_reduce', ptr(dz), ptr(y), ptr(g), dtype_code(y.dtype), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, _ptr_array(rmean) if rmean else None, _ptr_array(rinvstd) if rinvstd else None, _ptr_array(rsums) if rsums else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), ptr(sums), ptr(ws), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), int(accumulate), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res) + (1 if write_g else 0))))
 	return g
 
 
-def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None):
+def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None):
 	B, C, T = y.shape
 	dy = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
-	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * 3))
+	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * 3))
 	return dy
 
 
@@ -522,24 +526,24 @@ def _scaler_pair(scaler):
 	return s_in, s_out
 
 
-def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0, p16 = None, scaler = None):
-	"""p16: optional 16-bit mirror of the parameters (bf16 or fp16, n elements); scaler: optional (state_in, state_out) of a dynamic loss scaler."""
+def sgd_step(p, g, buf, n, sumsq_buf, max_norm, lr, momentum, weight_decay, nesterov, first, grad_out = None, loss_gate = None, grad_scale = 1.0, p16 = None, scaler = None, lr_dev = None):
+	"""lr_dev: optional 1-element fp32 device tensor that replaces `lr` when the kernel runs (captured step graphs); p16: optional 16-bit mirror of the parameters (bf16 or fp16, n elements); scaler: optional (state_in, state_out) of a dynamic loss scaler."""
 	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
 	assert p16 is None or (p16.dtype in HALF_DTYPES and p16.numel() == n)
 	s_in, s_out = _scaler_pair(scaler)
-	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
+	call('convasr_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(grad_out), n, ptr(sumsq_buf), float(max_norm), float(lr), float(momentum), float(weight_decay), int(nesterov), int(first), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), ptr(lr_dev), stream_ptr())
 
 
-def adamw_step(p, g, exp_avg, exp_avg_sq, n, sumsq_buf, max_norm, lr, beta1, beta2, eps, weight_decay, step_in, step_out, loss_gate = None, grad_scale = 1.0, p16 = None, scaler = None):
+def adamw_step(p, g, exp_avg, exp_avg_sq, n, sumsq_buf, max_norm, lr, beta1, beta2, eps, weight_decay, step_in, step_out, loss_gate = None, grad_scale = 1.0, p16 = None, scaler = None, lr_dev = None):
 	"""One fused torch.optim.AdamW step (+ clip_grad_norm_) over the flat arena; step_in / step_out: 1-element fp32 device tensors (applied-step counter)."""
 	assert loss_gate is None or (loss_gate.dtype == torch.float32 and loss_gate.numel() == 1)
 	assert p16 is None or (p16.dtype in HALF_DTYPES and p16.numel() == n)
 	assert step_in.dtype == step_out.dtype == torch.float32 and step_in.data_ptr() != step_out.data_ptr()
 	s_in, s_out = _scaler_pair(scaler)
-	call('convasr_adamw_step', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), n, ptr(sumsq_buf), float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), ptr(step_in), ptr(step_out), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
+	call('convasr_adamw_step', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), n, ptr(sumsq_buf), float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), ptr(step_in), ptr(step_out), ptr(loss_gate), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), ptr(lr_dev), stream_ptr())
 
 
-def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None, gate = None):
+def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, bn_shift, bn_mean, bn_invstd, act, dropout_p, seed, offset, xlen, bn_sums, work = None, gate = None, step_key = None):
 	"""dx = dgrad(dy) with pass 1 of the consumer layer's batch-norm backward fused into the epilogue (bn_sums += per-channel sums).
 	Returns dx, or None when the shape is outside the fused kernel's envelope (nothing was launched)."""
 	import ctypes
@@ -550,7 +554,7 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 	dx = empty_cl(B, Cin, T, dy.dtype, dy.device)
 	rc = [0]
 	def run():
-		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), dtype_code(dy.dtype), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), ptr(gate), stream_ptr())
+		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_bn_reduce', ptr(dy), ptr(packed_dgrad), ptr(dx), dtype_code(dy.dtype), B, Cout, Cin, Tdy, T, K, dil, pad, ptr(bn_y), ptr(bn_scale), ptr(bn_shift), ptr(bn_mean), ptr(bn_invstd), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), ptr(bn_sums.buf), ctypes.byref(rows), ptr(gate), stream_ptr())
 	family = 'conv1d_igemm_v2s_kernel<bf16>+bn_bwd' if Cout % 64 == 0 else 'conv1d_igemm (other variants)'
 	flops, nbytes_ = 2.0 * B * T * Cout * Cin * K if work is None else work, float(B * Tdy * Cout * 2 + K * Cout * Cin * 2 + 2 * B * T * Cin * 2)
 	symbol = 'v2s16' if family.startswith('conv1d_igemm_v2s') else None
@@ -581,7 +585,7 @@ def novograd_work_table(offsets_host, device):
 	return (torch.tensor(items, dtype = torch.int64, device = device), torch.tensor(seg_first, dtype = torch.int64, device = device), torch.empty(len(items), dtype = torch.float64, device = device))
 
 
-def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0, p16 = None, scaler = None):
+def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, lr, beta1, beta2, eps, weight_decay, dampening, first, loss_gate = None, total_norm = None, grad_scale = 1.0, p16 = None, scaler = None, lr_dev = None):
 	"""One fused NovoGrad step (+ clip_grad_norm_) over the flat arena; offsets: device int64 [n_seg + 1]; table: novograd_work_table(...)."""
 	items, seg_first, item_part = table
 	assert offsets.dtype == torch.int64 and ema_in.data_ptr() != ema_out.data_ptr() and g2.dtype == torch.float64
@@ -589,7 +593,7 @@ def novograd_step(p, g, mom, ema_in, ema_out, g2, offsets, n, table, max_norm, l
 	s_in, s_out = _scaler_pair(scaler)
 	assert p16 is None or (p16.dtype in HALF_DTYPES and p16.numel() == n)
 	assert int(first) >= 0 or (ema_in.numel() == n_seg + 1 and ema_out.numel() == n_seg + 1), 'first = -1 (device-side first-step detection) needs the applied-step counter behind the EMAs'
-	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), stream_ptr())
+	call('convasr_novograd_step', ptr(p), ptr(g), ptr(mom), ptr(ema_in), ptr(ema_out), ptr(g2), ptr(offsets), n_seg, n, ptr(items), items.shape[0], ptr(seg_first), ptr(item_part), float(max_norm or 0.0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(bool(dampening)), int(first), ptr(loss_gate), ptr(total_norm), float(grad_scale), ptr(p16), _lib.BF16 if p16 is None else dtype_code(p16.dtype), ptr(s_in), ptr(s_out), ptr(lr_dev), stream_ptr())
 
 
 def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):

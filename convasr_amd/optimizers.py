@@ -6,8 +6,17 @@ tensor; it replaces both the reference's Python loop and apex's FusedNovoGrad (t
 are host arithmetic and keep the reference's class names and arguments."""
 import torch
 
-from . import ops
+from . import ops, _lib
 from . import functional as Fn
+
+
+def _advance(opt, pair):
+	"""The fused launch read pair[opt._cur] and wrote the other row: make that one current -- by swapping, or, while a step graph is
+	being captured (its kernels read the same row at every replay), by enqueueing the copy that hands the new values back."""
+	if Fn.capturing():
+		_lib.call('convasr_copy', _lib.ptr(pair[1 - opt._cur]), _lib.ptr(pair[opt._cur]), pair[0].numel() * pair.element_size(), _lib.stream_ptr())
+	else:
+		opt._cur = 1 - opt._cur
 
 
 class NovoGrad:
@@ -22,10 +31,12 @@ class NovoGrad:
 		self._table = ops.novograd_work_table(host_offsets, dev)
 		self.momentum_buffer = torch.zeros_like(flat.data)
 		self.n_seg = n_seg
-		self.grads_ema = torch.zeros(2, n_seg + 1, dtype = torch.float32, device = dev)  # [steps & 1] is current; last element = number of steps applied so far (a gated step does not count), kept on the device
+		self.grads_ema = torch.zeros(2, n_seg + 1, dtype = torch.float32, device = dev)  # [_cur] is current; last element = number of steps applied so far (a gated step does not count), kept on the device
 		self._g2 = torch.zeros(n_seg, dtype = torch.float64, device = dev)
 		self.total_norm = torch.zeros(1, dtype = torch.float32, device = dev)
 		self.steps = 0
+		self._cur = 0  # which row of grads_ema is current (the fused launch reads it and writes the other one)
+		self.lr_dev = None  # see train.SGD
 
 	def zero_grad(self, set_to_none = False):
 		self.flat.zero_grad()
@@ -36,32 +47,33 @@ class NovoGrad:
 		if flat.clip is None:
 			flat.finalize_grads()
 		max_norm = flat.clip[1] if flat.clip is not None else 0.0
-		cur = self.steps & 1
+		cur = self._cur
 		grad_scale = flat.grad_scale
 		scaler = getattr(flat, 'loss_scaler', None)
-		flat.mirror_carried_over(lambda p16: ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair()))
+		flat.mirror_carried_over(lambda p16: ops.novograd_step(flat.data, flat.grad, self.momentum_buffer, self.grads_ema[cur], self.grads_ema[1 - cur], self._g2, self.offsets, flat.numel, self._table, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], g['dampening'], -1, loss_gate = loss_gate, total_norm = self.total_norm, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair(), lr_dev = self.lr_dev if Fn.capturing() else None))
 		if scaler is not None:
 			scaler.advance()
+		_advance(self, self.grads_ema)
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 
 	@property
 	def state(self):
 		"""Per-parameter view in the reference's vocabulary: {'_grads_ema': 0-d tensor, 'momentum_buffer': tensor}."""
-		ema = self.grads_ema[self.steps & 1, :self.n_seg]
+		ema = self.grads_ema[self._cur, :self.n_seg]
 		views = self.flat.param_views(self.momentum_buffer)  # the parameters' logical shapes: conv segments of the arena are tap-major
 		return {p: dict(_grads_ema = ema[i], momentum_buffer = views[i]) for i, p in enumerate(self.flat.params)}
 
 	def state_dict(self):
 		"""format 2: momentum per parameter in the reference's shapes; grads_ema = one value per parameter, steps_applied = how many
 		steps were not skipped by the device-side gates (what decides 'first step' on the device)."""
-		ema = self.grads_ema[self.steps & 1]
+		ema = self.grads_ema[self._cur]
 		return dict(format = 2, steps = self.steps, steps_applied = int(ema[self.n_seg].item()), momentum_buffer = self.flat.export_state(self.momentum_buffer), grads_ema = ema[:self.n_seg].clone(), param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
 
 	def load_state_dict(self, sd):
 		self.steps = sd['steps']
 		self.flat.import_state(self.momentum_buffer, sd['momentum_buffer'], 'NovoGrad.load_state_dict(momentum_buffer)')
-		ema, cur = sd['grads_ema'], self.grads_ema[self.steps & 1]
+		ema, cur = sd['grads_ema'], self.grads_ema[self._cur]
 		if ema.numel() == self.n_seg + 1:  # (an earlier layout carried the applied-step counter behind the EMAs)
 			cur.copy_(ema)
 		elif ema.numel() == self.n_seg:
@@ -87,8 +99,10 @@ class AdamW:
 		self.param_groups = [dict(params = flat.params, **self.defaults)]
 		self.exp_avg = torch.zeros_like(flat.data)
 		self.exp_avg_sq = torch.zeros_like(flat.data)
-		self.applied = torch.zeros(2, 1, dtype = torch.float32, device = flat.data.device)  # [steps & 1] is current
+		self.applied = torch.zeros(2, 1, dtype = torch.float32, device = flat.data.device)  # [_cur] is current
 		self.steps = 0
+		self._cur = 0
+		self.lr_dev = None  # see train.SGD
 
 	def zero_grad(self, set_to_none = False):
 		self.flat.zero_grad()
@@ -102,11 +116,12 @@ class AdamW:
 		scaler = getattr(flat, 'loss_scaler', None)
 		if scaler is not None and sumsq is None:  # the overflow check reads the gradient's sum of squares
 			sumsq = ops.sumsq(flat.grad, flat._sumsq)
-		cur = self.steps & 1
+		cur = self._cur
 		grad_scale = flat.grad_scale
-		flat.mirror_carried_over(lambda p16: ops.adamw_step(flat.data, flat.grad, self.exp_avg, self.exp_avg_sq, flat.numel, sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.applied[cur], self.applied[1 - cur], loss_gate = loss_gate, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair()))
+		flat.mirror_carried_over(lambda p16: ops.adamw_step(flat.data, flat.grad, self.exp_avg, self.exp_avg_sq, flat.numel, sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.applied[cur], self.applied[1 - cur], loss_gate = loss_gate, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair(), lr_dev = self.lr_dev if Fn.capturing() else None))
 		if scaler is not None:
 			scaler.advance()
+		_advance(self, self.applied)
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 
@@ -114,19 +129,35 @@ class AdamW:
 	def state(self):
 		"""torch's vocabulary: {param: dict(step, exp_avg, exp_avg_sq)} with the moments viewed in the parameters' logical shapes."""
 		m, v = self.flat.param_views(self.exp_avg), self.flat.param_views(self.exp_avg_sq)
-		step = self.applied[self.steps & 1, 0]
+		step = self.applied[self._cur, 0]
 		return {p: dict(step = step, exp_avg = m[i], exp_avg_sq = v[i]) for i, p in enumerate(self.flat.params)}
 
 	def state_dict(self):
 		"""format 2 (like SGD / NovoGrad here): moments per parameter in the reference's shapes, independent of the arena's element order."""
-		return dict(format = 2, steps = self.steps, steps_applied = int(self.applied[self.steps & 1, 0].item()), exp_avg = self.flat.export_state(self.exp_avg), exp_avg_sq = self.flat.export_state(self.exp_avg_sq),
+		return dict(format = 2, steps = self.steps, steps_applied = int(self.applied[self._cur, 0].item()), exp_avg = self.flat.export_state(self.exp_avg), exp_avg_sq = self.flat.export_state(self.exp_avg_sq),
 			param_groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
 
 	def load_state_dict(self, sd):
+		if 'state' in sd and 'steps' not in sd:
+			# torch.optim.AdamW.state_dict() as the reference saves it (train.py:331) and reloads it (train.py:681-682): state[i] = dict(step,
+			# exp_avg, exp_avg_sq) in parameter order, param_groups[0] carrying the hyper-parameters
+			order = [i for g in sd['param_groups'] for i in g['params']]
+			if len(order) != len(self.flat.params) or any(i not in sd['state'] for i in order):
+				raise ValueError(f'AdamW.load_state_dict: a torch.optim.AdamW state for {len(order)} parameters ({len(sd["state"])} with moments) does not match the {len(self.flat.params)} trainable parameters of this arena')
+			steps = {int(sd['state'][i]['step']) for i in order}
+			if len(steps) != 1:
+				raise ValueError(f'AdamW.load_state_dict: parameters with different step counts {sorted(steps)} (the fused kernel keeps one applied-step counter)')
+			self.steps = steps.pop()
+			self.flat.import_state(self.exp_avg, [sd['state'][i]['exp_avg'] for i in order], 'AdamW.load_state_dict(state[i].exp_avg)')
+			self.flat.import_state(self.exp_avg_sq, [sd['state'][i]['exp_avg_sq'] for i in order], 'AdamW.load_state_dict(state[i].exp_avg_sq)')
+			self.applied[self._cur, 0] = float(self.steps)
+			for g, s in zip(self.param_groups, sd['param_groups']):
+				g.update({k: (tuple(v) if k == 'betas' else v) for k, v in s.items() if k in ('lr', 'betas', 'eps', 'weight_decay')})
+			return
 		self.steps = sd['steps']
 		self.flat.import_state(self.exp_avg, sd['exp_avg'], 'AdamW.load_state_dict(exp_avg)')
 		self.flat.import_state(self.exp_avg_sq, sd['exp_avg_sq'], 'AdamW.load_state_dict(exp_avg_sq)')
-		self.applied[self.steps & 1, 0] = float(sd.get('steps_applied', sd['steps']))
+		self.applied[self._cur, 0] = float(sd.get('steps_applied', sd['steps']))
 		for g, s in zip(self.param_groups, sd['param_groups']):
 			g.update(s)
 

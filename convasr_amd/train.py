@@ -103,6 +103,14 @@ class FlatParameters:
 			p.grad = p._convasr_grad
 		self.clip = None
 
+	def grads_written_externally(self):
+		"""Call after anything other than this package's backward kernels wrote into `.grad` / `p._convasr_grad` (an optimizer that keeps its
+		clipped gradients there, a test, a hand-rolled gradient edit): drops the "this segment is known to be zero" notes the train-mode
+		residual branches keep for their conv biases (functional.ConvBnActFunction), so that the next backward zeroes them again."""
+		for p in self.params:
+			if getattr(p, '_convasr_grad_is_zero', False):
+				p._convasr_grad_is_zero = False
+
 	def finalize_grads(self):
 		"""Parameters that received no gradient this step count as zero."""
 		for p in self.params:
@@ -142,7 +150,12 @@ class LossScaler:
 		return self.state[self.cur], self.state[1 - self.cur]
 
 	def advance(self):
-		self.cur = 1 - self.cur
+		"""After an optimizer launch wrote the next state into the other buffer: swap the two -- or, while a step graph is being captured
+		(its kernels will read THIS buffer at every replay), enqueue the copy that hands the new state back to it."""
+		if Fn.capturing():
+			_lib.call('convasr_copy', _lib.ptr(self.state[1 - self.cur]), _lib.ptr(self.state[self.cur]), 4 * _lib.LOSS_SCALER_FLOATS, _lib.stream_ptr())
+		else:
+			self.cur = 1 - self.cur
 
 	def loss_scale(self):
 		"""Host read (synchronises): apex's `_amp_state.loss_scalers[0].loss_scale()`."""
@@ -181,6 +194,7 @@ class SGD:
 		self.momentum_buffer = torch.zeros_like(flat.data) if momentum != 0 else None
 		self.steps = 0
 		self.keep_clipped_grads = keep_clipped_grads
+		self.lr_dev = None  # 1-element fp32 device tensor the captured step graphs read the learning rate from (GraphedTrainStep keeps it equal to param_groups[0]['lr'])
 
 	def zero_grad(self, set_to_none = False):
 		self.flat.zero_grad()
@@ -193,12 +207,16 @@ class SGD:
 			flat.finalize_grads()
 		sumsq, max_norm = flat.clip if flat.clip is not None else (None, 0.0)
 		first, grad_scale = self.steps == 0, flat.grad_scale
+		if first and Fn.capturing():
+			raise _lib.ConvasrHipError('SGD: the first step (which initialises the momentum buffer) cannot be the one captured into a step graph')
 		scaler = flat.loss_scaler
 		if scaler is not None and sumsq is None:  # the overflow check reads the gradient's sum of squares
 			sumsq = ops.sumsq(flat.grad, flat._sumsq)
-		flat.mirror_carried_over(lambda p16: ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], first, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair()))
+		flat.mirror_carried_over(lambda p16: ops.sgd_step(flat.data, flat.grad, self.momentum_buffer, flat.numel, sumsq, max_norm, g['lr'], g['momentum'], g['weight_decay'], g['nesterov'], first, grad_out = flat.grad if self.keep_clipped_grads else None, loss_gate = loss_gate, grad_scale = grad_scale, p16 = p16, scaler = None if scaler is None else scaler.pair(), lr_dev = self.lr_dev if Fn.capturing() else None))
 		if scaler is not None:
 			scaler.advance()
+		if self.keep_clipped_grads:
+			flat.grads_written_externally()  # (zero times a NaN clip factor is not zero)
 		self.steps += 1
 		flat.clip, flat.grad_scale = None, 1.0
 
@@ -235,6 +253,7 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	(all-reduced) loss and leaves parameters and momentum untouched when it is not finite -- the same parameters as the
 	reference after the iteration, without draining the GPU in the middle of every step.  With accumulation (or
 	device_gate = False) the gate is the reference's host-side check."""
+	Fn.begin_step(x.device)  # the device-resident dropout key of this step (one single-thread launch; the same whether the step is launched eagerly or replayed from a graph)
 	out = model(x, xlen, y = y, ylen = ylen)
 	log_probs, olen, loss_vec = out['log_probs'], out['olen'], out['loss']
 	# train.py:754-756 in one launch (ops.loss_head): loss = mean(loss_vec * ylen[:, 0]) / accum, loss_cur = mean(loss_vec), the mean
@@ -287,14 +306,113 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	return res
 
 
-def train_epoch(model, optimizer, batches, sampler = None, scheduler = None, iteration = 0, world_size = 1, max_norm = 100.0, accumulate_iterations = 1, max_iterations = None, on_step = None):
+class GraphedTrainStep:
+	"""train_step(model, optimizer, x, xlen, y, ylen) with accumulate_iterations = 1, replayed from a HIP graph: one graph per batch shape
+	(x.shape, y.shape -- a bucketed loader that pads every batch of a bucket to the bucket's ceiling, datasets.bucket_ceiling, produces
+	about a dozen), captured after `warmup` eager steps of that shape.  A JasperNetLarge step is ~1,000 kernel launches and ~20 ms of
+	Python for ~40 ms of GPU work; a replay is one call.
+
+	What makes the captured step a faithful replay (tests/test_graph_gpu.py compares 20 steps bit for bit with the eager path):
+	* everything that changes from step to step is read from device memory when the kernels RUN -- the dropout step key
+	  (functional.begin_step), the loss scaler, the optimizer's step counters / EMAs, the learning rate (`optimizer.lr_dev`, refreshed here
+	  whenever the host's scheduler changed param_groups[0]['lr']), the device-side skip gates;
+	* double-buffered device state is handed back to the buffer the graph reads (LossScaler.advance, optimizers._advance);
+	* every buffer a captured kernel touches is either persistent (parameters, arenas, optimizer state, packed weights) or was allocated
+	  inside the capture, from a memory pool all graphs of this object share (they never run concurrently): functional.CAPTURING turns the
+	  per-module / per-stream caches off;
+	* the weight-gradient side stream and the dgrad-weight prepack stream are forked and joined inside the capture.
+
+	Inputs are copied into the graph's static buffers (one device-to-device copy each; pass the static buffers themselves -- .inputs(key)
+	-- to skip it).  Returned metrics are the graph's static output tensors: read them before the next call with the same shape.
+	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step."""
+
+	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True):
+		self.model, self.optimizer, self.max_norm, self.warmup = model, optimizer, max_norm, max(int(warmup), 1)
+		engine = model if hasattr(model, 'finish_gradient_sync') else None
+		self.enabled = bool(enabled) and not (engine is not None and engine.collectives)
+		self.graphs, self.seen = {}, {}
+		self.pool = None
+		self.epoch = Fn.structure_epoch()
+		self.replays = self.captures = self.eager_steps = 0
+		self._lr = None
+
+	@staticmethod
+	def key_of(x, xlen, y, ylen):
+		return (tuple(x.shape), x.dtype, tuple(xlen.shape), tuple(y.shape), y.dtype, tuple(ylen.shape))
+
+	def inputs(self, key):
+		g = self.graphs.get(key)
+		return None if g is None else g['static']
+
+	def _eager(self, x, xlen, y, ylen, iteration):
+		self.eager_steps += 1
+		return train_step(self.model, self.optimizer, x, xlen, y, ylen, max_norm = self.max_norm, iteration = iteration)
+
+	def _sync_lr(self):
+		lr = float(self.optimizer.param_groups[0]['lr'])
+		if self.optimizer.lr_dev is None:
+			self.optimizer.lr_dev = torch.empty(1, dtype = torch.float32, device = self.optimizer.flat.data.device)
+			self._lr = None
+		if lr != self._lr:
+			self.optimizer.lr_dev.fill_(lr)  # (outside the graph, only when the scheduler moved: one tiny launch)
+			self._lr = lr
+
+	def _capture(self, key, x, xlen, y, ylen, iteration):
+		dev = x.device
+		static = tuple(t.clone() for t in (x, xlen, y, ylen))
+		if self.pool is None:
+			self.pool = torch.cuda.graph_pool_handle()
+		graph = torch.cuda.CUDAGraph()
+		opt = self.optimizer
+		steps0 = opt.steps
+		self._sync_lr()
+		torch.cuda.synchronize(dev)
+		Fn.CAPTURING[0] = True
+		try:
+			with torch.cuda.graph(graph, pool = self.pool):
+				res = train_step(self.model, opt, *static, max_norm = self.max_norm, iteration = iteration)
+		finally:
+			Fn.CAPTURING[0] = False
+		opt.steps = steps0  # (nothing ran: the replay below is this step)
+		self.graphs[key] = dict(graph = graph, static = static, res = res)
+		self.captures += 1
+
+	def __call__(self, x, xlen, y, ylen, iteration = 0):
+		if not self.enabled:
+			return self._eager(x, xlen, y, ylen, iteration)
+		if self.epoch != Fn.structure_epoch():  # conv modules were replaced (fuse_conv_bn_eval): the captured pointers are stale
+			self.graphs, self.seen, self.epoch = {}, {}, Fn.structure_epoch()
+		key = self.key_of(x, xlen, y, ylen)
+		g = self.graphs.get(key)
+		if g is None:
+			n = self.seen.get(key, 0)
+			if n < self.warmup or self.optimizer.steps == 0:
+				self.seen[key] = n + 1
+				return self._eager(x, xlen, y, ylen, iteration)
+			self._capture(key, x, xlen, y, ylen, iteration)
+			g = self.graphs[key]
+		for dst, src in zip(g['static'], (x, xlen, y, ylen)):
+			if dst.data_ptr() != src.data_ptr():
+				_lib.call('convasr_copy', _lib.ptr(src if src.is_contiguous() else src.contiguous()), _lib.ptr(dst), dst.numel() * dst.element_size(), _lib.stream_ptr())
+		self._sync_lr()
+		opt = self.optimizer
+		opt.flat.mirror_carried_over(lambda p16: g['graph'].replay())  # (the same version bookkeeping an eager optimizer launch gets: the 16-bit mirror stays current, other packed copies go stale)
+		opt.steps += 1
+		self.replays += 1
+		return g['res']
+
+
+def train_epoch(model, optimizer, batches, sampler = None, scheduler = None, iteration = 0, world_size = 1, max_norm = 100.0, accumulate_iterations = 1, max_iterations = None, on_step = None, graphs = None):
 	"""The body of the reference's epoch loop (train.py:739-808) over an iterable of (meta, s, x, xlen, y, ylen) batches whose
 	tensors are already on the device (convasr_amd.datasets.gpu_batches): train_step, scheduler.step(iteration) after every
 	optimizer step (train.py:783), iteration += 1, sampler.batch_idx += world_size (train.py:807-808, what makes a resumed
 	epoch start where it stopped).  Metrics stay on the device; on_step(iteration, batch, result) may read them.
 	Returns the next iteration number."""
 	for meta, s, x, xlen, y, ylen in batches:
-		res = train_step(model, optimizer, x, xlen, y, ylen, max_norm = max_norm, accumulate_iterations = accumulate_iterations, iteration = iteration, world_size = world_size, sync_metrics = world_size > 1)
+		if graphs is not None and accumulate_iterations == 1 and world_size == 1:
+			res = graphs(x, xlen, y, ylen, iteration = iteration)  # a GraphedTrainStep(model, optimizer, max_norm): replayed per batch shape
+		else:
+			res = train_step(model, optimizer, x, xlen, y, ylen, max_norm = max_norm, accumulate_iterations = accumulate_iterations, iteration = iteration, world_size = world_size, sync_metrics = world_size > 1)
 		# train.py:769-783: the scheduler steps only inside the not-skipped branch.  Where the host knows the verdict (a host-side gate
 		# returned skipped = True) the reference's behaviour is reproduced exactly; with the device-side gate the host does not wait
 		# for it, and after a skipped iteration the next step's lr is one scheduler tick ahead of the reference's

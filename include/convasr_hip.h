@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 6
+#define CONVASR_ABI_VERSION 7
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2, CONVASR_F16 = 3 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -173,13 +173,16 @@ int convasr_bn_eval_scale_shift(const float* gamma, const float* beta, const flo
 /* z = mask_t( dropout( act( y * scale[c] + shift[c] + sum_r (res_r * rscale_r[c] + rshift_r[c]) ) ) ).
  * y, z, res_r channels-last (B, T, C) of `dtype`.  n_res <= 12; rscale_r NULL means the residual is added as is.
  * dropout_p == 0 disables dropout; otherwise a counter-based hash of (seed, offset, element index) decides.
+ * step_key (may be NULL; here and in the three backward entry points that re-derive the mask): one device word XORed into the
+ * whitened seed when the kernel runs -- the per-step key convasr_step_begin() advances -- so that a training step captured into a
+ * HIP graph (whose by-value arguments are frozen) draws fresh masks at every replay, the same ones an eager step draws.
  * gate (may be NULL; B*T*C/8 bytes; activations with derivative 0 or 1 only: none / relu / hardtanh): bit (e & 7) of byte (e >> 3) for
  * element e = (b*T + t)*C + c is set iff the gradient passes the element -- inside the activation's linear range, kept by dropout,
  * frame not masked.  The backward passes below take it back in: g = dz * (1 / (1 - p)) or 0, with no re-derivation of the
  * pre-activation, no hash and no frame arithmetic (bit-identical to the re-derived g). */
 int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift,
                        int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
-                       int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                       int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key,
                        const float* xlen, int B, int T, int C, uint8_t* gate, void* stream);
 
 /* Backward of the above, pass 1.  g = dz * mask * dropout * act'(pre), pre recomputed from y (and residuals).
@@ -196,7 +199,7 @@ int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype,
                               const float* mean, const float* invstd,
                               int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
                               const float* const* rmean, const float* const* rinvstd, double* const* rsums,
-                              int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                              int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key,
                               const float* xlen, double* sums, void* workspace, const float* gamma, float* coef, float* dgamma, float* dbeta,
                               int accumulate, int B, int T, int C, const uint8_t* gate, void* stream);
 
@@ -205,7 +208,7 @@ int convasr_bn_act_bwd_reduce(const void* dz, const void* y, void* g, int dtype,
  * one-bit gates convasr_bn_act_fwd stored, used instead of the re-derivation (dropout_p still supplies the 1 / (1 - p)). */
 int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz,
                              const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
-                             uint64_t seed, uint64_t offset, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream);
+                             uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream);
 
 /* Backward pass 2: dy = gamma * invstd * (g - sum_g / n - xhat * sum_gxhat / n)  (batch-norm training backward);
  * dgamma = sum_gxhat, dbeta = sum_g (written, or added when accumulate).  In place allowed (dy == g). */
@@ -280,10 +283,12 @@ int convasr_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, flo
  * reference's "skip the step on a non-finite loss" (train.py:769-772) without a host round trip in the middle of the step.
  * p16 (may be NULL): n values of p16_dtype (CONVASR_BF16 or CONVASR_F16), receives the updated parameters rounded to that type -- with
  * K-major masters that mirror IS the packed forward weight of every conv whose Cout is a multiple of the kernel's N tile (no
- * per-step packing launches).  scaler_in / scaler_out (both or neither): the dynamic loss scaler above; needs sumsq. */
+ * per-step packing launches).  scaler_in / scaler_out (both or neither): the dynamic loss scaler above; needs sumsq.
+ * lr_dev (may be NULL; likewise in the two optimizers below): one device float that replaces `lr` when the kernel runs -- a captured
+ * step graph follows the host's learning-rate schedule (optimizers.py:13-63, train.py:783) through it. */
 int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int64_t n, const double* sumsq, float max_norm,
                      float lr, float momentum, float weight_decay, int nesterov, int first, const float* loss_gate, float grad_scale,
-                     void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream);
+                     void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, const float* lr_dev, void* stream);
 /* torch.optim.AdamW step (train.py:663-668; decoupled weight decay, no amsgrad) with the same folded-in pieces as convasr_sgd_step:
  * g' = c*grad_scale*g (c from sumsq / max_norm as above); p *= 1 - lr*wd; m = b1*m + (1-b1)*g'; v = b2*v + (1-b2)*g'^2;
  * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = step_in[0] + 1.  step_in / step_out: one device float each, distinct
@@ -292,7 +297,7 @@ int convasr_sgd_step(float* p, const float* g, float* buf, float* grad_out, int6
  * loss_gate, grad_scale, p16 / p16_dtype, scaler_in / scaler_out: as in convasr_sgd_step. */
 int convasr_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const double* sumsq, float max_norm, float lr,
                        float beta1, float beta2, float eps, float weight_decay, const float* step_in, float* step_out, const float* loss_gate,
-                       float grad_scale, void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, void* stream);
+                       float grad_scale, void* p16, int p16_dtype, const float* scaler_in, float* scaler_out, const float* lr_dev, void* stream);
 
 /* Fused backward step (bf16 / fp16 storage `dtype`, stride 1): dx = dgrad(dy) of one Conv1d -- i.e. dz of the Conv+BN+activation layer that produced
  * this conv's input -- plus pass 1 of THAT layer's batch-norm backward in the epilogue, on the tile just produced:
@@ -306,10 +311,20 @@ int convasr_adamw_step(float* p, const float* g, float* exp_avg, float* exp_avg_
 int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K,
                                    int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                    const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
-                                   uint64_t offset, const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream);
+                                   uint64_t offset, const uint64_t* step_key, const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream);
 /* coef / dgamma / dbeta from those partial rows (the second half of convasr_bn_act_bwd_reduce), added in a fixed order; n = B*T. */
 int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamma, const float* mean, const float* invstd, float* coef,
                             float* dgamma, float* dbeta, int accumulate, int64_t n, int C, void* stream);
+
+/* ---- per-step device state: what lets train.py:745-783 replay from a HIP graph ------------------------------------- */
+
+/* state: four device words {dropout seed (the caller's, models.py:365-369 draws from torch's generator), steps begun, key of the
+ * current step, reserved}.  Enqueues state[1] += 1; state[2] = mix(state[0] ^ mix(state[1])) -- one thread.  The training step calls it
+ * first; &state[2] is the `step_key` of the dropout entry points above.  Eager and graph-replayed steps advance the same words. */
+int convasr_step_begin(uint64_t* state, void* stream);
+/* dst[0..nbytes) = src[0..nbytes), device to device, on `stream` (a memcpy node under capture): hands a double-buffered device state
+ * (loss scaler, NovoGrad EMAs, AdamW step count) back to the buffer a captured graph reads. */
+int convasr_copy(const void* src, void* dst, int64_t nbytes, void* stream);
 
 /* ---- SURVEY 8(f) "next" rows ------------------------------------------------------------------------------------ */
 
@@ -330,7 +345,7 @@ int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema
                           int n_seg, int64_t n, const int64_t* items, int n_items, const int64_t* seg_first, double* item_part,
                           float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int dampening, int first,
                           const float* loss_gate, float* total_norm, float grad_scale, void* p16, int p16_dtype, const float* scaler_in,
-                          float* scaler_out, void* stream);
+                          float* scaler_out, const float* lr_dev, void* stream);
 /* largest item the table may hold (elements) */
 int64_t convasr_novograd_item_elems(void);
 

@@ -400,7 +400,7 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('shape', [(5, 333, 128, 256), (3, 128, 256, 128), (1, 77, 64, 384), (7, 200, 640, 768)])
+@pytest.mark.parametrize('shape', [(5, 333, 128, 256), (3, 128, 256, 128), (1, 77, 64, 384), (7, 200, 640, 768), (3, 333, 768, 256), (2, 500, 1024, 256)])  # (the last two: Cin >= 3 Cout, the two-stage instantiation)
 def test_one_tap_kernel_against_torch_and_the_big_tile_kernel(shape, dtype):
 	"""conv1x1.hip (every K = 1 training launch with 16-bit output) on sizes whose frame count is no multiple of its 128-row tile, with and
 	without bias / BN statistics: bit-identical to conv_v2s.hip (debug bit 8192 routes the same call there), close to torch's fp32 conv of

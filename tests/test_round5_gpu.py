@@ -1,0 +1,227 @@
+"""Round-5 cases on the MI355X: BASELINE configs[2]'s own configuration (Wav2Letter full, 64 x 15 s) against the CPU oracle at FULL size;
+the training step replayed from HIP graphs (train.GraphedTrainStep) bit for bit against the eager step -- SGD / bf16 with dropout and a
+moving learning rate, NovoGrad / fp16 under the dynamic loss scaler on a dense-residual network with the weight gradients on a side
+stream; the stale "this bias gradient is zero" note."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import convasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FE = dict(nfft = 512, hop_length = 160)
+
+
+def _dump(name, obj):
+	out = os.path.join(ROOT, 'gpurun_out')
+	if os.path.isdir(out):
+		with open(os.path.join(out, name), 'w') as f:
+			json.dump(obj, f, indent = 1)
+
+
+def _cos_rel(a, b):
+	a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+	return float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm())
+
+
+# ------------------------------------------------------------------------------------------------ configs[2] at its own size
+
+def test_full_wav2letter_64x15s_fp32_vs_oracle_and_16bit_losses():
+	"""BASELINE configs[2] / the metric's own configuration -- Wav2Letter full, 64 utterances x 15 s, lengths linspace(0.5, 1) -- forward,
+	CTC and backward on the MI355X fp32 path against the CPU oracle (models.py:282-326, train.py:745-783) at FULL size (the 4 x 10 s and
+	32 x 10 s cases elsewhere are reduced batches).  Bars: per-utterance CTC loss 1e-4 relative (north_star), logits rtol 1e-3 / atol
+	1e-4 x range, olen equal, gradient norm 1e-3, gradients of the decoder / an upper / the first conv and one BN gamma by cosine and
+	relative L2 (the deviation of a deep gradient between two exact-fp32 implementations of this random-init network is summation-order
+	noise amplified ~1.2x per layer: DESIGN section 2 -- 1.4e-2 in the first layer at 4 x 10 s); the bf16 / fp16 paths' losses of the same
+	batch within 2e-3 / 2e-4."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	B, secs = 64, 15
+	g = torch.Generator().manual_seed(11)
+	x = torch.rand(B, 16000 * secs, generator = g) * 2 - 1
+	xlen = torch.linspace(0.5, 1, B)
+	y = torch.randint(0, 37, (B, 1, 10 * secs), generator = g)
+	ylen = (xlen * 8 * secs).long().clamp(min = 1).view(B, 1)  # ~8 labels per valid second: feasible for every utterance
+	plan = O.jasper_plan(64, [38], **O.WAV2LETTER)
+	sd0 = O.init_state_dict(plan, seed = 1, frontend = O.frontend_config())
+	torch.set_num_threads(min(os.cpu_count() or 1, 16))
+	sd = {k: v.clone() for k, v in sd0.items()}
+	ref = O.train_step(sd, plan, x, xlen, y, ylen, frontend = FE, max_norm = 1e30, momentum_buffers = {})  # (max_norm: the gradients as backward left them)
+
+	def gpu(dt):
+		fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+		model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0.0, check_time_dim_padded = False, compute_dtype = dt)
+		assert not model.load_state_dict(sd0, strict = False).missing_keys
+		return model.to(d).train()
+
+	model = gpu(torch.float32)
+	out = model(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
+	loss_vec = out['loss']
+	loss = (loss_vec * ylen[:, 0].to(d)).mean()
+	loss.backward()
+	rel_loss = float(((loss_vec.detach().cpu() - ref['loss_vec']).abs() / ref['loss_vec'].abs()).max())
+	scale = float(ref['logits'].abs().max())
+	logit_err = float((out['logits'][0].detach().cpu() - ref['logits']).abs().max())
+	assert torch.equal(out['olen'][0].cpu(), ref['olen'])
+	params = dict(model.named_parameters())
+	names = ['decoder.0.weight', 'backbone.17.conv.0.0.weight', 'backbone.6.conv.0.0.weight', 'backbone.0.conv.0.0.weight', 'backbone.6.bn.0.weight']
+	grads = {k: _cos_rel(params[k].grad, ref['grads'][k]) for k in names}
+	gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+	gn_ref = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ref['grads'].values())))
+	report = dict(ctc_loss_rel_err_max = rel_loss, logits_max_abs_err = logit_err, logits_range = scale, grad_norm = gn, grad_norm_oracle = gn_ref, grads_cos_rel = grads)
+	del model, out, loss, loss_vec, params
+	for name, dt in (('bf16', torch.bfloat16), ('f16', torch.float16)):
+		m16 = gpu(dt)
+		with torch.no_grad():
+			l16 = m16(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))['loss'].float().cpu()
+		report[f'ctc_loss_rel_err_max_{name}'] = float(((l16 - ref['loss_vec']).abs() / ref['loss_vec'].abs()).max())
+		del m16
+	_dump('r05_config2_64x15s_parity.json', report)
+	assert rel_loss <= 1e-4, report
+	assert logit_err <= 1e-3 * scale + 1e-4 * max(scale, 1.0), report
+	assert abs(gn - gn_ref) / gn_ref <= 1e-3, report
+	assert grads['decoder.0.weight'][0] >= 0.999999 and grads['decoder.0.weight'][1] <= 1e-3, report
+	assert grads['backbone.17.conv.0.0.weight'][0] >= 0.99999 and grads['backbone.17.conv.0.0.weight'][1] <= 5e-3, report
+	assert grads['backbone.6.conv.0.0.weight'][0] >= 0.9999 and grads['backbone.6.conv.0.0.weight'][1] <= 1.5e-2, report
+	assert grads['backbone.0.conv.0.0.weight'][0] >= 0.9995 and grads['backbone.0.conv.0.0.weight'][1] <= 3e-2, report
+	assert grads['backbone.6.bn.0.weight'][0] >= 0.9999 and grads['backbone.6.bn.0.weight'][1] <= 1.5e-2, report
+	assert report['ctc_loss_rel_err_max_bf16'] <= 2e-3 and report['ctc_loss_rel_err_max_f16'] <= 2e-4, report
+
+
+# ------------------------------------------------------------------------------------------------ step graphs
+
+def _wav2letter_small(ca, d, dt, dropout):
+	torch.manual_seed(3)
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	return ca.models.Wav2Letter(64, [38], frontend = fe, dropout = dropout, base_width = 64, check_time_dim_padded = False, compute_dtype = dt).to(d).train()
+
+
+def _dense_small(ca, d, dt, dropout):
+	torch.manual_seed(4)
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	return ca.models.JasperNet(64, [38], frontend = fe, base_width = 64, kernel_sizes = [11, 13, 17], out_width_factors = [2, 3, 4], dropouts = [0.2, 0.2, 0.2], out_width_factors_large = [4, 4], residual = 'dense', repeat = 2, num_subblocks = 2, dropout = dropout, check_time_dim_padded = False, temporal_mask = False, compute_dtype = dt).to(d).train()
+
+
+def _batches(d, n, shapes):
+	g = torch.Generator().manual_seed(5)
+	out = []
+	for i in range(n):
+		B, secs = shapes[i % len(shapes)]
+		x = torch.rand(B, 16000 * secs, generator = g) * 2 - 1
+		xlen = torch.linspace(0.6, 1, B)
+		y = torch.randint(0, 37, (B, 1, 128), generator = g)
+		ylen = torch.randint(10, 5 * secs, (B, 1), generator = g)
+		out.append(tuple(t.to(d) for t in (x, xlen, y, ylen)))
+	return out
+
+
+def _run(ca, build, make_opt, batches, graphed, side_stream = False, lr_of = None, opt_level = None):
+	d = torch.device('cuda:0')
+	ca.functional.manual_seed(17)
+	model = build()
+	flat = ca.train.FlatParameters(model)
+	opt = make_opt(flat)
+	if opt_level is not None:
+		ca.models.data_parallel_and_autocast(model, opt, opt_level = opt_level)
+	ca.functional.enable_side_stream_wgrad(d, side_stream)
+	stepper = ca.train.GraphedTrainStep(model, opt, max_norm = 100.0, warmup = 1, enabled = graphed)
+	trace = []
+	try:
+		for it, (x, xlen, y, ylen) in enumerate(batches):
+			if lr_of is not None:
+				opt.param_groups[0]['lr'] = lr_of(it)
+			r = stepper(x, xlen, y, ylen, iteration = it)
+			trace.append((float(r['loss']), float(r['loss_cur']), float(r['grad_norm']), bool(r['skipped'])))
+	finally:
+		ca.functional.enable_side_stream_wgrad(d, False)
+	torch.cuda.synchronize()
+	scaler = None if flat.loss_scaler is None else flat.loss_scaler.current.tolist()
+	return trace, flat.data.clone(), {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}, stepper, scaler
+
+
+def test_step_graphs_sgd_bf16_dropout_moving_lr_bitwise_equal_to_eager():
+	"""20 steps over two alternating batch shapes (two graphs sharing one memory pool), dropout 0.2 (the masks of a replayed step come from
+	the device-resident step key: the same as the eager step's), a learning rate that changes every step (read from device memory by the
+	captured optimizer kernel): loss / grad-norm trajectory, parameters and running statistics equal bit for bit; 16 of the 20 steps replayed."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	batches = _batches(d, 20, [(6, 4), (4, 6)])
+	build = lambda: _wav2letter_small(ca, d, torch.bfloat16, 0.2)
+	make_opt = lambda flat: ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	lr_of = lambda it: 1e-2 * (0.9 ** it)
+	eager = _run(ca, build, make_opt, batches, False, lr_of = lr_of)
+	graph = _run(ca, build, make_opt, batches, True, lr_of = lr_of)
+	assert graph[3].captures == 2 and graph[3].replays >= 16, (graph[3].captures, graph[3].replays, graph[3].eager_steps)
+	assert eager[0] == graph[0], list(zip(eager[0], graph[0]))
+	assert torch.equal(eager[1], graph[1])
+	assert all(torch.equal(eager[2][k], graph[2][k]) for k in eager[2])
+	assert eager[0][0][0] != eager[0][2][0]  # (the same batch shape at steps 0 and 2 with different data: not a frozen replay)
+
+
+def test_step_graphs_novograd_fp16_dense_residuals_side_stream_bitwise_equal_to_eager():
+	"""BASELINE configs[4]'s ingredients at test size: dense-residual JasperNet (1x1 residual branches with their own batch norms), fp16
+	under apex's dynamic loss scaler (its start-up overflows fall into the replayed steps: the scaler's double-buffered device state is
+	handed back inside the graph), NovoGrad (device-side first-step detection, EMAs double-buffered), weight gradients on the side stream
+	(forked and joined inside the capture), three batch shapes."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	batches = _batches(d, 24, [(4, 5), (3, 7), (5, 4)])
+	build = lambda: _dense_small(ca, d, torch.float16, 0.2)
+	make_opt = lambda flat: ca.optimizers.NovoGrad(flat, lr = 1e-3, betas = (0.95, 0.5), weight_decay = 1e-3)
+	eager = _run(ca, build, make_opt, batches, False, side_stream = True, opt_level = 'O2')
+	graph = _run(ca, build, make_opt, batches, True, side_stream = True, opt_level = 'O2')
+	assert graph[3].captures == 3 and graph[3].replays >= 18
+	assert eager[0] == graph[0], list(zip(eager[0], graph[0]))
+	assert torch.equal(eager[1], graph[1])
+	assert all(torch.equal(eager[2][k], graph[2][k]) for k in eager[2])
+	assert eager[4] == graph[4], (eager[4], graph[4])  # the scaler went through the same overflows
+	print('loss scaler state after 24 steps:', eager[4])
+
+
+def test_step_graphs_replayed_masks_change_from_step_to_step():
+	"""The same batch replayed three times from one graph with dropout 0.5 and lr 0: the losses differ (fresh masks per replay)."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	b = _batches(d, 1, [(4, 4)])[0]
+	ca.functional.manual_seed(3)
+	model = _wav2letter_small(ca, d, torch.bfloat16, 0.5)
+	flat = ca.train.FlatParameters(model)
+	opt = ca.train.SGD(flat, lr = 0.0, momentum = 0.0, weight_decay = 0.0)
+	stepper = ca.train.GraphedTrainStep(model, opt, warmup = 1)
+	losses = [float(stepper(*b, iteration = it)['loss']) for it in range(6)]
+	assert stepper.replays == 4 and len(set(losses)) == 6, losses
+
+
+def test_residual_bias_gradient_is_zero_again_after_a_pass_through_eval_mode_batch_norm():
+	"""train -> bn.eval() backward (which writes a real bias gradient into the arena segment) -> train must leave the
+	residual conv's bias gradient at exactly zero again."""
+	import convasr_amd as ca
+	import torch.nn as nn
+	d = torch.device('cuda:0')
+	model = _dense_small(ca, d, torch.float32, 0.0)
+	flat = ca.train.FlatParameters(model)
+	x, xlen, y, ylen = _batches(d, 1, [(3, 4)])[0]
+	blk = model.backbone[2]
+	rb = blk.conv_residual[0].bias
+
+	def fwd_bwd():
+		flat.zero_grad()
+		out = model(x, xlen, y = y, ylen = ylen)
+		out['loss'].sum().backward()
+		flat.finalize_grads()
+		torch.cuda.synchronize()
+	fwd_bwd()
+	assert float(rb._convasr_grad.abs().max()) == 0.0
+	bns = [m for m in blk.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+	for m in bns:
+		m.eval()
+	fwd_bwd()
+	assert float(rb._convasr_grad.abs().max()) > 0.0  # through the frozen statistics the bias has a real gradient
+	for m in bns:
+		m.train()
+	fwd_bwd()
+	assert float(rb._convasr_grad.abs().max()) == 0.0
