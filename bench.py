@@ -68,11 +68,17 @@ def parse_args(argv = None):
 		help = 'run wgrad on a second HIP stream beside the dgrad of the same layer.  auto: on for jasper_large (launches of 0.5-3 rounds leave CUs idle: +2 % measured), '
 			'off for wav2letter (launches fill the chip: -1 %).  With the side stream on, every per-kernel HIP-event duration (the dominant kernel included) is measured in the '
 			'second pass, where the side stream is switched off again: overlapped launches would inflate each other')
+	ap.add_argument('--graph', default = 'auto', choices = ['auto', 'on', 'off'], nargs = '?', const = 'on',
+		help = 'replay the training step from HIP graphs, one per batch shape (convasr_amd.train.GraphedTrainStep); jasper_large batches are then padded to their bucket\'s '
+			'ceiling (one shape per bucket).  auto: on with one rank (N > 1 stays eager: RCCL has not run under capture on this pool).  With graphs on, per-kernel HIP-event '
+			'durations come from the second, eager pass')
+	ap.add_argument('--no-jasper-leg', action = 'store_true', help = 'skip the bounded BASELINE configs[4] leg (extra.jasper_large) of the default line')
 	ap.add_argument('--launcher-dry-run', action = 'store_true', help = 'test hook: ranks only rendezvous (gloo, CPU tensors) and rank 0 prints a line; exercises the self-launch path without a GPU')
 	args = ap.parse_args(argv)
 	if args.dtype is None:
 		args.dtype = 'f16' if args.workload == 'jasper_large' else 'bf16'
 	args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.workload == 'jasper_large')
+	args.graph = args.graph == 'on' or (args.graph == 'auto' and args.gpus == 1 and os.environ.get('CONVASR_FORCE_DIST') != '1')
 	return args
 
 
@@ -282,7 +288,7 @@ class Workload:
 			if world > 1:
 				sampler = ca.datasets.DistributedSamplerWrapper(sampler, num_replicas = world, rank = rank)
 			self.batches, self.audio = [], []
-			for meta, s, x, xlen, y, ylen in ca.datasets.gpu_batches(ds, sampler, device):
+			for meta, s, x, xlen, y, ylen in ca.datasets.gpu_batches(ds, sampler, device, pad_to_bucket = bool(args.graph)):
 				self.batches.append((x, xlen, y, ylen))
 				self.audio.append((sum(m['duration'] for m in meta), x.shape[0] * x.shape[1] / SAMPLE_RATE))
 				if len(self.batches) == n_batches:
@@ -293,26 +299,53 @@ class Workload:
 			ca.models.data_parallel_and_autocast(self.model, self.opt, opt_level = 'O2')
 			assert self.model.compute_dtype == torch.float16 and self.flat.loss_scaler is not None
 		self.flops = [conv_stack_flops(self.model, b[0].shape[0], b[0].shape[1]) for b in self.batches]
+		self.stepper = None
+
+	def make_stepper(self, engine, world):
+		"""What a step is: train_step on the engine (N > 1, or --graph off), or the same step replayed from one HIP graph per batch shape."""
+		import convasr_amd as ca
+		graphed = bool(self.args.graph) and engine is self.model
+		self.stepper = ca.train.GraphedTrainStep(self.model, self.opt, max_norm = 100.0, warmup = 1, enabled = graphed)
+
+		def step(i):
+			x, xlen, y, ylen = self.batches[self.batch_of(i)]
+			if self.stepper.enabled:
+				return self.stepper(x, xlen, y, ylen, iteration = i)
+			return ca.train.train_step(engine, self.opt, x, xlen, y, ylen, world_size = world, iteration = i, sync_metrics = engine is not self.model)
+		return step
+
+	def prime_graphs(self, step, indices):
+		"""Extra untimed warm-up: every batch shape the steps `indices` will use gets its eager warm-up step(s) and its capture now."""
+		if self.stepper is None or not self.stepper.enabled:
+			return 0
+		extra, seen = 0, set()
+		for i in indices:
+			key = self.stepper.key_of(*self.batches[self.batch_of(i)])
+			if key in seen:
+				continue
+			seen.add(key)
+			while self.stepper.inputs(key) is None:
+				step(i)
+				extra += 1
+		return extra
 
 	def batch_of(self, i):
 		return i % len(self.batches)
 
 	def release(self):
-		self.model = self.flat = self.opt = self.batches = None
+		self.model = self.flat = self.opt = self.batches = self.stepper = None
 
 
-def run_timed(args, wl, engine, world, fence, time_main_kernel, on_warm = None):
+def run_timed(args, wl, engine, world, fence, time_main_kernel, on_warm = None, probe = None):
 	"""W warm-up steps, then K timed steps between two fences.  Returns (elapsed s, audio (unpadded, padded), flops (fwd, bwd), last
 	result, kernel-timer summary, launch sequence)."""
 	import convasr_amd as ca
 	from convasr_amd import _lib
 	last = None
-
-	def step(i):
-		x, xlen, y, ylen = wl.batches[wl.batch_of(i)]
-		return ca.train.train_step(engine, wl.opt, x, xlen, y, ylen, world_size = world, iteration = i, sync_metrics = engine is not wl.model)
+	step = wl.make_stepper(engine, world)
 	for i in range(args.warmup):
 		last = step(i)
+	run_timed.extra_warmup = wl.prime_graphs(step, range(args.warmup, args.warmup + args.steps + min(args.steps, 5)))
 	fence()
 	run_timed.warm_value = on_warm() if on_warm is not None else None  # (a host read between warm-up and timed region, e.g. the loss scaler's overflow count)
 	# HIP events (on the launching stream) bracket every launch of the DOMINANT kernel inside the timed region.  The other kernel
@@ -323,11 +356,15 @@ def run_timed(args, wl, engine, world, fence, time_main_kernel, on_warm = None):
 		_lib.timer = _lib.KernelTimer(only = [MAIN_FAMILY, MAIN_FAMILY + '+bn_bwd'] if wl.dtype != 'f32' else ['conv1d_igemm (other variants)'])
 	if hasattr(engine, 'exposed_comm_events'):
 		engine.exposed_comm_events = []
+	if probe is not None:
+		probe.start()
 	t0 = time.perf_counter()
 	for i in range(args.steps):
 		last = step(args.warmup + i)
 	fence()
 	elapsed = time.perf_counter() - t0
+	if probe is not None:
+		probe.stop()
 	kt = _lib.timer.summary() if _lib.timer is not None else {}
 	sequence = list(_lib.timer.sequence) if _lib.timer is not None else []
 	_lib.timer = None
@@ -421,7 +458,7 @@ def measure_traffic(args, sequence, steps):
 		try:
 			cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
 				'--steps', '1', '--warmup', '1', '--workload', args.workload, '--dtype', args.dtype, '--dropout', str(args.dropout),
-				'--no-cpu-baseline', '--no-kernel-timer', '--no-traffic', '--no-f16-leg']
+				'--no-cpu-baseline', '--no-kernel-timer', '--no-traffic', '--no-f16-leg', '--no-jasper-leg', '--graph', 'off', '--side-stream', 'off']
 			r = subprocess.run(cmd, cwd = '/tmp', env = env, stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 600)
 			files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive = True)
 			if r.returncode != 0 or not files:
@@ -472,7 +509,7 @@ def dry_run_rank(args):
 	return 0
 
 
-def roofline_of(args, wl, kt, kt2, steps2, value, world):
+def roofline_of(args, wl, kt, kt2, steps2, value, world, graphed = False):
 	"""The `roofline` object: the dominant kernel from the HIP events of the timed region (kt), every other family from the second
 	pass (kt2, steps2 steps), all from algorithmic FLOPs / bytes booked per launch by convasr_amd.ops."""
 	main_name, fused_name = MAIN_FAMILY, MAIN_FAMILY + '+bn_bwd'
@@ -509,7 +546,7 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world):
 	roof = dict(bound = 'mfma', kernel = kernel, achieved = round(tf(k), 2), peak = peak, unit = 'TFLOP/s', frac = round(tf(k) / peak, 4), traffic = None, traffic_source = None,
 		algorithmic_mb_per_launch = round(k['bytes'] / k['launches'] / 1e6, 1), launches_per_step = k['launches'] // args.steps, avg_launch_us = round(k['avg_us'], 2),
 		ms_per_step = round(k['total_ms'] / args.steps, 3),
-		timing = (f'HIP events on the launching stream around every launch, in a second pass of {steps2} steps right after the timed region (the timed region runs wgrad on a side stream: overlapped launches would inflate each other\'s durations; the second pass runs without it)'
+		timing = (f'HIP events on the launching stream around every launch, in a second pass of {steps2} steps right after the timed region (the timed region ' + ('replays the step from HIP graphs' if graphed else 'runs wgrad on a side stream') + ': no launch of it can be bracketed, and overlapped launches would inflate each other\'s durations; the second pass launches the same kernels eagerly on one stream)'
 			if second_pass_main else f'HIP events on the launching stream around every launch of this kernel inside the timed region ({args.steps} steps); wgrad / conv_stack / hbm_kernels: the same way in a second pass of {steps2} steps right after it'))
 	hbm = {name[4:]: v for name, v in kt.items() if name.startswith('hbm:')}
 	kt = {name: v for name, v in kt.items() if not name.startswith('hbm:')}
@@ -531,6 +568,207 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world):
 	if 'logmel_kernel' in roof['hbm_kernels']:
 		roof['hbm_kernels']['logmel_kernel']['note'] = 'FFT-issue bound (three radix-8 Stockham passes through LDS per pair of frames), not HBM bound: under 1 % of the step'
 	return roof
+
+
+# ------------------------------------------------------------------------------------------------ device state over the timed region
+
+class DeviceProbe:
+	"""Host-side sampler of THIS rank's card over the timed region, so that a round-to-round difference of the headline can be
+	attributed from the line alone (the pool's devices differ by +-4 % on the MFMA kernels; the step is package-power limited):
+	* hwmon (sysfs) every ~5 ms from a thread: power1_input -> power_w_mean, freq1_input -> sclk_mhz_mean;
+	* the firmware's throttle accumulators from the gpu_metrics table (librocm_smi64 through convasr_amd/libconvasr_smi.so, ctypes) at
+	  start() and stop(): ppt_residency = d ppt_residency_acc / d accumulation_counter, likewise thermal / PROCHOT.
+	No HIP call is made here (the card is found by the PCI address torch already knows).  Every field is None when its source is not
+	readable on this box; `sources` says which were."""
+
+	def __init__(self, device):
+		import ctypes
+		import glob
+		import torch
+		self.hw, self.smi, self.dv, self.samples, self.acc = None, None, -1, [], [None, None]
+		self.thread, self.halt = None, False
+		self.why = []
+		try:
+			props = torch.cuda.get_device_properties(device)
+			dom, bus, dev = int(getattr(props, 'pci_domain_id', 0)), int(props.pci_bus_id), int(props.pci_device_id)
+			prefix = '%04x:%02x:%02x' % (dom, bus, dev)
+			cards = [c for c in glob.glob('/sys/class/drm/card*') if os.path.basename(os.path.realpath(c + '/device')).startswith(prefix)]
+			hw = glob.glob(cards[0] + '/device/hwmon/hwmon*') if cards else []
+			self.hw = hw[0] if hw else None
+			if self.hw is None:
+				self.why.append(f'no hwmon directory for PCI {prefix}')
+			lib = os.path.join(ROOT, 'convasr_amd', 'libconvasr_smi.so')
+			if os.path.exists(lib):
+				self.smi = ctypes.CDLL(lib)
+				self.smi.convasr_smi_open.restype, self.smi.convasr_smi_open.argtypes = ctypes.c_int, [ctypes.c_int] * 3
+				self.smi.convasr_smi_sample.restype, self.smi.convasr_smi_sample.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+				self.dv = self.smi.convasr_smi_open(dom, bus, dev)
+				if self.dv < 0:
+					self.why.append(f'rocm_smi: no device for PCI {prefix} (code {self.dv})')
+			else:
+				self.why.append('convasr_amd/libconvasr_smi.so not built')
+		except Exception as e:
+			self.why.append(f'{type(e).__name__}: {e}')
+
+	def _read(self, name):
+		try:
+			return int(open(os.path.join(self.hw, name)).read())
+		except Exception:
+			return None
+
+	def _metrics(self):
+		import ctypes
+		if self.smi is None or self.dv < 0:
+			return None
+		out = (ctypes.c_double * 10)()
+		return list(out) if self.smi.convasr_smi_sample(self.dv, out) == 0 else None
+
+	def start(self):
+		import threading
+		self.samples, self.halt = [], False
+		self.acc = [self._metrics(), None]
+
+		def run():
+			while not self.halt:
+				self.samples.append((self._read('power1_input'), self._read('freq1_input')))
+				time.sleep(0.005)
+		if self.hw is not None:
+			self.thread = threading.Thread(target = run, daemon = True)
+			self.thread.start()
+
+	def stop(self):
+		self.acc[1] = self._metrics()
+		self.halt = True
+		if self.thread is not None:
+			self.thread.join()
+			self.thread = None
+
+	def summary(self):
+		pw = [p / 1e6 for p, f in self.samples if p]
+		fq = [f / 1e6 for p, f in self.samples if f]
+		a, b = self.acc
+		res = None
+		if a is not None and b is not None and b[0] > a[0]:
+			ticks = b[0] - a[0]
+			res = dict(ppt = round((b[1] - a[1]) / ticks, 4), prochot = round((b[2] - a[2]) / ticks, 4), socket_thermal = round((b[3] - a[3]) / ticks, 4),
+				vr_thermal = round((b[4] - a[4]) / ticks, 4), hbm_thermal = round((b[5] - a[5]) / ticks, 4), accumulation_ticks = int(ticks))
+		cap = self._read('power1_cap') if self.hw is not None else None
+		return dict(sclk_mhz_mean = round(sum(fq) / len(fq), 1) if fq else None, power_w_mean = round(sum(pw) / len(pw), 1) if pw else None,
+			power_cap_w = None if cap is None else cap / 1e6, ppt_residency = None if res is None else res['ppt'], throttle_residency = res,
+			gfx_clk_mhz_end = None if b is None else round(b[7], 1), socket_power_w_end = None if b is None else b[6], hotspot_c_end = None if b is None else b[8], hbm_c_end = None if b is None else b[9],
+			hwmon_samples = len(self.samples), sources = dict(hwmon = self.hw is not None, gpu_metrics = self.dv >= 0), unavailable = self.why or None,
+			how = 'sysfs hwmon sampled every ~5 ms from a host thread over the timed region (power1_input, freq1_input); throttle residencies = differences of the gpu_metrics accumulators read at its two ends through librocm_smi64; no GPU call')
+
+
+def predicted_comm(engine, world, step_s):
+	"""dist.predicted: what convasr_amd.parallel.predict_exposed_comm expects for this run's buckets, rank count and measured step time."""
+	try:
+		p = engine.predict(world, step_s * 1e3)
+		p['per_bucket'] = p['per_bucket'][-4:]  # (the last buckets to complete: the ones that can be exposed; the full table is in DESIGN section 5)
+		return p
+	except Exception as e:
+		return dict(error = f'{type(e).__name__}: {e}')
+
+
+def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None):
+	"""One workload on this rank: W warm-up steps (+ the untimed priming of the step graphs), K timed steps between two fences, the
+	second (event-timed, eager) pass.  Returns (the JSON line as a dict -- rank 0 only, else None --, rank 0's launch sequence of one step)."""
+	import torch
+	import torch.distributed as dist
+	import convasr_amd as ca
+	from convasr_amd import _lib
+	torch.manual_seed(1)
+	ca.functional.manual_seed(int(os.environ.get('CONVASR_BENCH_DROPOUT_SEED', '1')) + rank)  # (the override: a measurement hook -- step time depends on the data through the chip's clock management)
+	wl = Workload(args, device, rank, world)
+	flat = wl.flat
+	engine = ca.parallel.DataParallelEngine(wl.model, device = device, force_collectives = use_dist, measure_exposed_comm = True) if use_dist else wl.model
+	graphed = bool(args.graph) and engine is wl.model
+	ca.functional.enable_side_stream_wgrad(device, bool(args.side_stream))
+
+	# with the side stream on or the step replayed from a graph nothing can be event-timed inside the timed region: every per-kernel duration
+	# (the dominant kernel included) then comes from the second pass, which runs eagerly on one stream
+	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0 and not args.side_stream and not graphed,
+		on_warm = (lambda: flat.loss_scaler.current[7].item()) if flat.loss_scaler is not None else None, probe = probe)
+	device_state = probe.summary() if probe is not None else None
+	overflows0 = run_timed.warm_value or 0.0  # the scaler's overflow count when the timed region starts (warm-up overflows are not the timed region's)
+	exposed = engine.exposed_comm_ms() if use_dist else None
+	scaler_info = None
+	if flat.loss_scaler is not None:
+		st = flat.loss_scaler.current.tolist()
+		scaler_info = dict(loss_scale = st[0], clean_steps = int(st[1]), overflowed_steps_in_timed_region = int(st[7] - overflows0), overflowed_steps_total = int(st[7]),
+			note = 'apex dynamic loss scaling (2^16, x2 per 2000 clean steps, /2 and skip on overflow); an overflowed step skips only the optimizer update')
+	graph_info = None
+	if graphed:
+		graph_info = dict(enabled = True, graphs = wl.stepper.captures, replays = wl.stepper.replays, eager_warmup_steps = wl.stepper.eager_steps, extra_untimed_warmup_steps = run_timed.extra_warmup,
+			note = 'every timed step is one hipGraphLaunch of the whole iteration (forward, CTC, backward, clip, optimizer), one graph per batch shape; the per-step inputs are copied into the graph\'s static buffers inside the timed region')
+	# host time of a step with the GPU drained first (the enqueue never waits for queue space): how far ahead of the GPU the Python side
+	# can run.  Eagerly the Wav2Letter step needs ~4 ms of it for 16 ms of GPU work and a JasperNetLarge step ~20 ms for ~44 (1,200 launches:
+	# one busy neighbour away from host-bound); replayed from a graph a step is a handful of calls.
+	host_ms = []
+	for i in range(3):
+		torch.cuda.synchronize()
+		h0 = time.perf_counter()
+		step(args.warmup + args.steps + i)
+		host_ms.append((time.perf_counter() - h0) * 1e3)
+	fence()
+	steps2, kt2, sequence2, calls2 = 0, {}, [], None
+	ca.functional.join_side_streams()
+	ca.functional.enable_side_stream_wgrad(device, False)  # the event-timed pass below runs every kernel alone on the main stream, eagerly
+	if wl.stepper is not None:
+		wl.stepper.enabled = False
+	if not args.no_kernel_timer:
+		steps2 = min(args.steps, 5)
+		if rank == 0:
+			_lib.timer = _lib.KernelTimer()
+		c0 = _lib.calls[0]
+		for i in range(steps2):
+			step(args.warmup + args.steps + i)
+		fence()
+		calls2 = (_lib.calls[0] - c0) / steps2
+		if rank == 0:
+			kt2 = _lib.timer.summary()
+			sequence2 = list(_lib.timer.sequence)
+			_lib.timer = None
+	if not sequence and sequence2:  # (side stream / graphs: the launch order of a step as the eager second pass saw it -- the order a profiler's child run sees with --graph off --side-stream off)
+		sequence = sequence2[:len(sequence2) // max(steps2, 1)] * args.steps
+	if use_dist:
+		# (the parameter checksum: after K identical updates from identical initial replicas every rank must hold the same bits)
+		mine = torch.stack([torch.tensor(elapsed, dtype = torch.float64, device = device), torch.tensor(exposed if exposed is not None else float('nan'), dtype = torch.float64, device = device), wl.flat.data.double().sum(), wl.flat.data.double().abs().sum()])
+		every = [torch.zeros_like(mine) for _ in range(world)]
+		dist.all_gather(every, mine)
+		per_rank = [float(t[0]) * 1e3 / args.steps for t in every]
+		exposed_all = [float(t[1]) for t in every]
+		elapsed = max(float(t[0]) for t in every)  # MAX over ranks
+		dist_info.update(per_rank_ms = dict(min = round(min(per_rank), 3), max = round(max(per_rank), 3), mean = round(sum(per_rank) / world, 3), all = [round(v, 3) for v in per_rank]),
+			exposed_comm_ms = dict(mean = round(sum(exposed_all) / world, 4), max = round(max(exposed_all), 4),
+				how = 'HIP event pair on the main stream per step: backward fully enqueued -> communication stream joined (what the step waits for the gradient exchange beyond its own backward pass), mean over the timed steps'),
+			bucket_mib = [round((b['hi'] - b['lo']) * 4 / 2 ** 20, 1) for b in engine.buckets], comm_thread = engine._jobs is not None,
+			replicas_equal = all(bool(torch.equal(t[2:], every[0][2:])) for t in every),
+			predicted = predicted_comm(engine, world, elapsed / args.steps))
+
+	line = None
+	if rank == 0:
+		# whole-job figures: every rank steps through batches of the same padded size (one bucket per iteration), rank 0's own count x world
+		value = world * audio[0] / elapsed
+		headline = args.workload == 'wav2letter' and args.batch is None and args.secs is None
+		conv_flops_per_s = world * (flops[0] + flops[1]) / elapsed
+		roof = roofline_of(args, wl, kt, kt2, steps2, conv_flops_per_s, world, graphed = graphed) if (kt or kt2) else None
+		metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s' if headline else f'audio-seconds/sec/node (fwd+bwd+CTC), {args.workload}' + ('' if args.batch is None and args.secs is None else ' (TEST-ONLY size)')
+		line = dict(metric = metric, value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup,
+			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
+			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', side_stream_wgrad = bool(args.side_stream), step_graphs = graph_info,
+				host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2), abi_calls_per_eager_step = None if calls2 is None else round(calls2, 1),
+				whole_step_frac = round(conv_flops_per_s / world / (PEAK_F32_MFMA if args.dtype == 'f32' else PEAK_BF16_DENSE), 4), device_state = device_state),
+			loss = round(float(last['loss']), 4), loss_scaler = scaler_info, dist = dist_info, roofline = roof, parity = None)
+		if args.workload == 'jasper_large':
+			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),
+				gflop_per_padded_audio_s_fwd = round(flops[0] / audio[1] / 1e9, 2), gflop_per_step_fwd_bwd = round((flops[0] + flops[1]) / args.steps / 1e9, 1),
+				batch_shapes_in_timed_region = len({tuple(wl.batches[wl.batch_of(args.warmup + i)][0].shape) for i in range(args.steps)}),
+				note = 'value counts the utterances\' own durations; the kernels also compute the padded frames (temporal_mask = False, like the reference): whole_step_frac is over the padded FLOPs')
+	del engine, last, flat, step
+	wl.release()
+	torch.cuda.empty_cache()
+	return line, sequence
 
 
 def main(argv = None):
@@ -586,109 +824,43 @@ def main(argv = None):
 	import convasr_amd as ca
 	from convasr_amd import _lib
 
-	torch.manual_seed(1)
-	ca.functional.manual_seed(int(os.environ.get('CONVASR_BENCH_DROPOUT_SEED', '1')) + rank)  # (the override: a measurement hook -- step time depends on the data through the chip's clock management)
-	wl = Workload(args, device, rank, world)
-	flat = wl.flat
-	engine = ca.parallel.DataParallelEngine(wl.model, device = device, force_collectives = use_dist, measure_exposed_comm = True) if use_dist else wl.model
-	if args.side_stream:
-		ca.functional.enable_side_stream_wgrad(device)
-
 	def fence():
 		if use_dist:
 			dist.barrier()
 		torch.cuda.synchronize()
 
-	elapsed, audio, flops, last, kt, sequence, step = run_timed(args, wl, engine, world, fence, time_main_kernel = not args.no_kernel_timer and rank == 0 and not args.side_stream,
-		on_warm = (lambda: flat.loss_scaler.current[7].item()) if flat.loss_scaler is not None else None)
-	overflows0 = run_timed.warm_value or 0.0  # the scaler's overflow count when the timed region starts (warm-up overflows are not the timed region's)
-	exposed = engine.exposed_comm_ms() if use_dist else None
-	scaler_info = None
-	if flat.loss_scaler is not None:
-		st = flat.loss_scaler.current.tolist()
-		scaler_info = dict(loss_scale = st[0], clean_steps = int(st[1]), overflowed_steps_in_timed_region = int(st[7] - overflows0), overflowed_steps_total = int(st[7]),
-			note = 'apex dynamic loss scaling (2^16, x2 per 2000 clean steps, /2 and skip on overflow); an overflowed step skips only the optimizer update')
-	# host time of a step with the GPU drained first (the enqueue never waits for queue space): how far ahead of the GPU the Python side
-	# can run.  The Wav2Letter step needs ~4 ms of it for 16 ms of GPU work; a JasperNetLarge step ~20 ms for ~44 (1,200 launches): on a
-	# host that is busy with other tenants that step turns host-bound (seen: 48 ms), and this number says so.
-	host_ms = []
-	for i in range(3):
-		torch.cuda.synchronize()
-		h0 = time.perf_counter()
-		step(args.warmup + args.steps + i)
-		host_ms.append((time.perf_counter() - h0) * 1e3)
-	fence()
-	steps2, kt2 = 0, {}
-	if args.side_stream:
-		ca.functional.join_side_streams()
-		ca.functional.enable_side_stream_wgrad(device, False)  # the event-timed pass below runs every kernel alone on the main stream
-	if not args.no_kernel_timer:
-		steps2 = min(args.steps, 5)
-		if rank == 0:
-			_lib.timer = _lib.KernelTimer()
-		for i in range(steps2):
-			step(args.warmup + args.steps + i)
-		fence()
-		if rank == 0:
-			kt2 = _lib.timer.summary()
-			_lib.timer = None
-	if use_dist:
-		# (the parameter checksum: after K identical updates from identical initial replicas every rank must hold the same bits)
-		mine = torch.stack([torch.tensor(elapsed, dtype = torch.float64, device = device), torch.tensor(exposed if exposed is not None else float('nan'), dtype = torch.float64, device = device), wl.flat.data.double().sum(), wl.flat.data.double().abs().sum()])
-		every = [torch.zeros_like(mine) for _ in range(world)]
-		dist.all_gather(every, mine)
-		per_rank = [float(t[0]) * 1e3 / args.steps for t in every]
-		exposed_all = [float(t[1]) for t in every]
-		elapsed = max(float(t[0]) for t in every)  # MAX over ranks
-		dist_info.update(per_rank_ms = dict(min = round(min(per_rank), 3), max = round(max(per_rank), 3), mean = round(sum(per_rank) / world, 3), all = [round(v, 3) for v in per_rank]),
-			exposed_comm_ms = dict(mean = round(sum(exposed_all) / world, 4), max = round(max(exposed_all), 4),
-				how = 'HIP event pair on the main stream per step: backward fully enqueued -> communication stream joined (what the step waits for the gradient exchange beyond its own backward pass), mean over the timed steps'),
-			bucket_mib = [round((b['hi'] - b['lo']) * 4 / 2 ** 20, 1) for b in engine.buckets], comm_thread = engine._jobs is not None,
-			replicas_equal = all(bool(torch.equal(t[2:], every[0][2:])) for t in every))
-
-	line = None
-	if rank == 0:
-		# whole-job figures: every rank steps through batches of the same padded size (one bucket per iteration), rank 0's own count x world
-		value = world * audio[0] / elapsed
-		headline = args.workload == 'wav2letter' and args.batch is None and args.secs is None
-		conv_flops_per_s = world * (flops[0] + flops[1]) / elapsed
-		roof = roofline_of(args, wl, kt, kt2, steps2, conv_flops_per_s, world) if (kt or kt2) else None
-		metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s' if headline else f'audio-seconds/sec/node (fwd+bwd+CTC), {args.workload}' + ('' if args.batch is None and args.secs is None else ' (TEST-ONLY size)')
-		line = dict(metric = metric, value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup,
-			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
-			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', side_stream_wgrad = bool(args.side_stream), host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2)), loss = round(float(last['loss']), 4), loss_scaler = scaler_info,
-			dist = dist_info, roofline = roof, parity = None)
-		if args.workload == 'jasper_large':
-			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),
-				gflop_per_padded_audio_s_fwd = round(flops[0] / audio[1] / 1e9, 2), gflop_per_step_fwd_bwd = round((flops[0] + flops[1]) / args.steps / 1e9, 1),
-				note = 'value counts the utterances\' own durations; the kernels also compute the padded frames (temporal_mask = False, like the reference): whole_step_frac is over the padded FLOPs')
+	probe = DeviceProbe(device) if rank == 0 else None  # host-side sampler of the card's clock / power / PPT residency (sysfs + librocm_smi64 through ctypes: no GPU call)
+	line, sequence = measure(args, device, rank, world, use_dist, dist_info, fence, probe)
 	if use_dist:
 		dist.destroy_process_group()
 	if rank == 0:
-		# the legs below start child processes / use the host cores: model, optimizer state and workspaces are released first
-		del engine, last, flat, step
-		wl.release()
-		torch.cuda.empty_cache()
+		# the legs below start child processes / use the host cores (measure() released model, optimizer state and workspaces)
 		roof = line['roofline']
 		if world == 1 and roof is not None and args.dtype in ('bf16', 'f16') and not args.no_traffic:
 			roof['traffic'], roof['traffic_source'] = measure_traffic(args, sequence, args.steps)  # (None + the reason when the counters could not be collected: no stale fallback)
 		f16_leg = None
+		headline_run = args.workload == 'wav2letter' and args.batch is None and args.secs is None and args.dtype == 'bf16'
 		if world == 1 and args.dtype == 'bf16' and not args.no_f16_leg and args.workload == 'wav2letter':
 			# the same workload in the storage type that meets north_star's 1e-4 CTC bound: its own model / arena / optimizer / loss scaler
 			# (at least 8 warm-up steps here: apex's dynamic scale starts at 2^16 and halves once per overflowed step until the gradients
 			# of this random-data workload fit -- that search belongs to the warm-up, not to the timed region)
-			args16 = argparse.Namespace(**dict(vars(args), warmup = max(args.warmup, 8)))
-			wl16 = Workload(args16, device, rank, world, dtype = 'f16')
-			ov0 = None
-			el16, au16, fl16, last16, _, _, _ = run_timed(args16, wl16, wl16.model, 1, lambda: torch.cuda.synchronize(), time_main_kernel = False, on_warm = lambda: wl16.flat.loss_scaler.current[7].item())
-			st = wl16.flat.loss_scaler.current.tolist()
-			ov0 = run_timed.warm_value
-			f16_leg = dict(f16_value = round(au16[0] / el16, 1), f16_ms_per_step = round(1e3 * el16 / args.steps, 3), f16_steps = args.steps, f16_warmup = args16.warmup,
-				f16_whole_step_frac = round((fl16[0] + fl16[1]) / el16 / PEAK_BF16_DENSE, 4), f16_loss_scale = st[0], f16_overflowed_steps_in_timed_region = int(st[7] - ov0),
+			args16 = argparse.Namespace(**dict(vars(args), warmup = max(args.warmup, 8), dtype = 'f16', no_kernel_timer = True))
+			l16, _ = measure(args16, device, rank, world, False, None, lambda: torch.cuda.synchronize(), None)
+			sc = l16['loss_scaler']
+			f16_leg = dict(f16_value = l16['value'], f16_ms_per_step = l16['ms_per_step'], f16_steps = args.steps, f16_warmup = args16.warmup,
+				f16_whole_step_frac = l16['config']['whole_step_frac'], f16_loss_scale = sc['loss_scale'], f16_overflowed_steps_in_timed_region = sc['overflowed_steps_in_timed_region'],
 				f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
-			del last16
-			wl16.release()
-			torch.cuda.empty_cache()
+		if world == 1 and headline_run and not args.no_jasper_leg:
+			# BASELINE configs[4] in the driver's record: a bounded run of `bench.py --workload jasper_large` (3 warm-up + 8 timed steps + the event-timed pass)
+			argsj = argparse.Namespace(**dict(vars(args), workload = 'jasper_large', dtype = 'f16', steps = 8, warmup = 3, side_stream = True, no_kernel_timer = False))
+			lj, _ = measure(argsj, device, rank, world, False, None, lambda: torch.cuda.synchronize(), DeviceProbe(device))
+			rj = lj['roofline'] or {}
+			line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 8, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],
+				dominant_kernel_frac = rj.get('frac'), wgrad_frac = (rj.get('wgrad') or {}).get('frac'), conv_stack_frac = (rj.get('conv_stack') or {}).get('frac'),
+				host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
+				side_stream_wgrad = True, batch_shapes_in_timed_region = lj['config'].get('batch_shapes_in_timed_region'), padding_overhead = lj['config'].get('padding_overhead'),
+				loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], workload = lj['config']['workload'],
+				note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: python bench.py --workload jasper_large runs the same thing longer'))
 		if world == 1 and not args.no_cpu_baseline:
 			ref = {}
 			line['cpu_baseline'] = cpu_baseline(keep = ref)

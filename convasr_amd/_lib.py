@@ -104,12 +104,14 @@ def load():
 
 
 _fns = {}
+calls = [0]  # C-ABI calls made so far (bench.py reads the difference over a step: what a step costs the host in calls, eager vs replayed)
 
 
 def call(name, *args):
 	fn = _fns.get(name)
 	if fn is None:
 		fn = _fns[name] = getattr(load(), name)
+	calls[0] += 1
 	rc = fn(*args)
 	if rc != 0:
 		raise ConvasrHipError(f'{name} failed ({rc}): {load().convasr_last_error().decode()}')
@@ -118,6 +120,7 @@ def call(name, *args):
 def call_rc(name, *args):
 	"""For entry points whose positive return codes are answers, not errors (negative codes still raise)."""
 	lib = load()
+	calls[0] += 1
 	rc = getattr(lib, name)(*args)
 	if rc < 0:
 		raise ConvasrHipError(f'{name} failed ({rc}): {lib.convasr_last_error().decode()}')

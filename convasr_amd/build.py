@@ -56,6 +56,27 @@ def build(force = False, verbose = True, variant = None, defines = ()):
 	return lib
 
 
+SMI_LIB = os.path.join(HERE, 'libconvasr_smi.so')
+
+
+def build_smi_probe(force = False, verbose = True):
+	"""libconvasr_smi.so: the host-side gpu_metrics reader of bench.py's device-state sampler (csrc/smi_probe.c, plain C over librocm_smi64;
+	measurement infrastructure, not part of the product library).  Returns its path, or None when it cannot be built here."""
+	src = os.path.join(CSRC, 'smi_probe.c')
+	if force or stale(SMI_LIB, [src]):
+		cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I/opt/rocm/include', '-o', SMI_LIB, src, '-L/opt/rocm/lib', '-lrocm_smi64', '-Wl,-rpath,/opt/rocm/lib']
+		if verbose:
+			print(' '.join(cmd), flush = True)
+		r = subprocess.run(cmd, capture_output = True, text = True)
+		if r.returncode != 0:
+			if verbose:
+				print(r.stderr, file = sys.stderr)
+			return None
+	return SMI_LIB
+
+
 if __name__ == '__main__':
 	variant = sys.argv[sys.argv.index('--variant') + 1] if '--variant' in sys.argv else None
 	print(build(force = '--force' in sys.argv or variant is not None, variant = variant, defines = [a for a in sys.argv[1:] if a.startswith('-D')]))
+	if variant is None:
+		print(build_smi_probe(force = '--force' in sys.argv))

@@ -48,10 +48,24 @@ class BucketingBatchSampler(torch.utils.data.Sampler):
 		self.batch_idx = state_dict['batch_idx']
 
 
-def _pad_on_gpu(tensors, rows, pad_multiple, device):
-	"""tensors: list of (rows, L_b) CPU tensors of one dtype -> ((B, rows, Lpad) device tensor, lengths list)."""
+def bucket_ceiling(max_samples, sample_rate = 16000, window_stride = 0.01, time_padding_multiple = 128):
+	"""The padded length (samples) every batch of one bucket can share: bucket k of train.py:597-601's bucket_fn holds the utterances with
+	ceil((duration / window_stride + 1) / time_padding_multiple) = k, i.e. at most (k * time_padding_multiple - 1) hops of audio; that
+	ceiling, rounded up to time_padding_multiple samples like collate_fn rounds (datasets.py:318).  Padding a batch to it instead of to its
+	own longest utterance costs a few hundredths of a second of zeros per utterance (32 draws from a 1.28-s bucket nearly reach its top
+	anyway) and leaves a training run with one batch shape per bucket -- what lets train.GraphedTrainStep replay a dozen captured graphs."""
+	hop = int(round(sample_rate * window_stride))
+	k = -(-(int(max_samples) + hop) // (hop * time_padding_multiple))
+	top = (k * time_padding_multiple - 1) * hop
+	return -(-top // time_padding_multiple) * time_padding_multiple
+
+
+def _pad_on_gpu(tensors, rows, pad_multiple, device, pad_to = None):
+	"""tensors: list of (rows, L_b) CPU tensors of one dtype -> ((B, rows, Lpad) device tensor, lengths list).
+	pad_to (optional): callable longest length -> padded length (instead of rounding up to pad_multiple)."""
 	lengths = [int(t.shape[-1]) for t in tensors]
-	Lpad = int(math.ceil(max(lengths) / pad_multiple)) * pad_multiple
+	Lpad = int(math.ceil(max(lengths) / pad_multiple)) * pad_multiple if pad_to is None else int(pad_to(max(lengths)))
+	assert Lpad >= max(lengths)
 	dtype = tensors[0].dtype
 	packed = torch.empty(sum(l * rows for l in lengths), dtype = dtype).pin_memory()
 	offsets, pos = [], 0
@@ -66,13 +80,14 @@ def _pad_on_gpu(tensors, rows, pad_multiple, device):
 	return out, lengths, Lpad
 
 
-def collate_gpu(batch, time_padding_multiple = 128, device = None, speaker_missing = 0):
+def collate_gpu(batch, time_padding_multiple = 128, device = None, speaker_missing = 0, pad_to = None):
 	"""batch: list of (meta, speaker (S,), x (C, T), *targets (L,)) CPU samples, as AudioTextDataset.__getitem__ returns them in
-	the default mode.  Returns (meta list, s, x, xlen, y, ylen) like collate_fn, with x / y / xlen / ylen on `device`."""
+	the default mode.  Returns (meta list, s, x, xlen, y, ylen) like collate_fn, with x / y / xlen / ylen on `device`.
+	pad_to (optional): callable longest waveform length -> padded length of x (e.g. bucket_ceiling: one shape per bucket)."""
 	device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
 	metas = [b[0] for b in batch]
 	n_t = len(batch[0]) - 3
-	x, xl, Tpad = _pad_on_gpu([b[2] for b in batch], len(batch[0][2]), time_padding_multiple, device)
+	x, xl, Tpad = _pad_on_gpu([b[2] for b in batch], len(batch[0][2]), time_padding_multiple, device, pad_to = pad_to)
 	xlen = torch.tensor([l / Tpad if Tpad > 0 else 1.0 for l in xl], dtype = torch.float32).to(device, non_blocking = True)
 	ys, yl = [], []
 	Lpad = max(int(math.ceil(max(b[3 + j].shape[-1] for b in batch) / time_padding_multiple)) * time_padding_multiple for j in range(n_t)) if n_t else 0
@@ -142,7 +157,7 @@ class SyntheticAudioTextDataset(torch.utils.data.Dataset):
 
 	def __init__(self, num_examples, min_duration = 5.0, max_duration = 20.0, sample_rate = 16000, window_stride = 0.01, time_padding_multiple = 128, num_labels = 37, labels_per_second = 5.0, seed = 0):
 		g = torch.Generator().manual_seed(seed)
-		self.sample_rate, self.num_labels, self.seed = sample_rate, num_labels, seed
+		self.sample_rate, self.num_labels, self.seed, self.window_stride = sample_rate, num_labels, seed, window_stride
 		self.time_padding_multiple = time_padding_multiple
 		self.duration = min_duration + (max_duration - min_duration) * torch.rand(num_examples, generator = g)
 		self.num_samples = (self.duration * sample_rate).long()
@@ -167,13 +182,19 @@ def keep_samples(batch):
 	return batch
 
 
-def gpu_batches(dataset, batch_sampler, device, num_workers = 0, time_padding_multiple = None, timeout = 0):
+def gpu_batches(dataset, batch_sampler, device, num_workers = 0, time_padding_multiple = None, timeout = 0, pad_to_bucket = False):
 	"""The reference's train DataLoader (train.py:647-655) with the batch assembly moved to the GPU: worker processes (or the main
 	process) produce lists of ragged CPU samples, collate_gpu packs each list into one pinned buffer, copies it once and pads on
 	the device.  Yields (meta, s, x, xlen, y, ylen) like the reference's loader, with x / xlen / y / ylen already on `device`;
-	x is (B, T) for a one-row waveform dataset (what model(x.squeeze(1), ...) consumes, train.py:748)."""
+	x is (B, T) for a one-row waveform dataset (what model(x.squeeze(1), ...) consumes, train.py:748).
+	pad_to_bucket: pad every batch to its bucket's ceiling (bucket_ceiling) instead of to its own longest utterance: one batch shape per
+	bucket, for train.GraphedTrainStep."""
 	loader = torch.utils.data.DataLoader(dataset, batch_sampler = batch_sampler, collate_fn = keep_samples, num_workers = num_workers, pin_memory = False, timeout = timeout if num_workers > 0 else 0)
 	mult = time_padding_multiple or getattr(dataset, 'time_padding_multiple', 128)
+	pad_to = None
+	if pad_to_bucket:
+		sr, ws = getattr(dataset, 'sample_rate', 16000), getattr(dataset, 'window_stride', 0.01)
+		pad_to = lambda longest: bucket_ceiling(longest, sr, ws, mult)
 	for samples in loader:
-		meta, s, x, xlen, y, ylen = collate_gpu(samples, time_padding_multiple = mult, device = device)
+		meta, s, x, xlen, y, ylen = collate_gpu(samples, time_padding_multiple = mult, device = device, pad_to = pad_to)
 		yield meta, s, (x.squeeze(1) if x.shape[1] == 1 else x), xlen, y, ylen

@@ -23,6 +23,38 @@ import torch.nn as nn
 from .train import FlatParameters
 
 
+XGMI_LINK_GBS_PER_DIRECTION = 76.8  # MI355X: 7 xGMI links per GPU, ~153.6 GB/s each bidirectional (one link to every peer of an 8-GPU node)
+
+
+def predict_exposed_comm(params_numel, offsets, buckets, world, step_ms, link_gbs = XGMI_LINK_GBS_PER_DIRECTION, efficiency = 0.7, latency_us = 40.0, forward_share = 0.33, tail_share = 0.04):
+	"""A prediction the first multi-GPU run can be wrong about (no curve has been measured: one GPU per box on this pool).
+
+	Model.  The backward pass produces gradients from the END of the arena to its start; its time is apportioned to the parameters by
+	their element counts (a conv's dgrad + wgrad FLOPs are proportional to its weight count at a fixed frame count; batch-norm vectors cost
+	nothing): bucket b (arena range [lo, hi)) is complete at  t_ready(b) = step * (forward_share + backward_share * (elements at offsets >=
+	lo) / all elements),  backward_share = 1 - forward_share - tail_share (tail: clip + optimizer, after the exchange).  The all-reduce of S
+	bytes over the node's fully connected xGMI (a direct link to every peer, `link_gbs` GB/s per direction): reduce-scatter + all-gather
+	each move S / N per link -> t = 2 (S / N) / (efficiency * link_gbs) + latency.  Collectives run one after the other on the communication
+	stream in the order the buckets complete.  exposed = how long the last collective runs past the end of the backward pass (what
+	finish_gradient_sync waits for).  Returns dict(exposed_comm_ms, comm_ms_total, backward_end_ms, per_bucket = [...])."""
+	total = float(sum(params_numel))
+	bwd_share = 1.0 - forward_share - tail_share
+	t_fwd, t_bwd_end = step_ms * forward_share, step_ms * (forward_share + bwd_share)
+	rows, t_free = [], 0.0
+	for b in sorted(buckets, key = lambda b: -b['lo']):  # completion order: from the end of the arena
+		above = sum(n for n, o in zip(params_numel, offsets) if o >= b['lo'])
+		ready = t_fwd + (t_bwd_end - t_fwd) * above / total
+		nbytes = (b['hi'] - b['lo']) * 4
+		t = 0.0 if world <= 1 else 2.0 * (nbytes / world) / (efficiency * link_gbs * 1e9) * 1e3 + latency_us * 1e-3
+		start = max(ready, t_free)
+		t_free = start + t
+		rows.append(dict(mib = round(nbytes / 2 ** 20, 1), ready_ms = round(ready, 3), start_ms = round(start, 3), comm_ms = round(t, 3), end_ms = round(t_free, 3)))
+	return dict(exposed_comm_ms = round(max(0.0, t_free - t_bwd_end), 3), comm_ms_total = round(sum(r['comm_ms'] for r in rows), 3), backward_end_ms = round(t_bwd_end, 3), step_ms = round(step_ms, 3),
+		world = world, link_gbs_per_direction = link_gbs, efficiency = efficiency, latency_us = latency_us, per_bucket = rows,
+		predicted_scaling = None if world <= 1 else round(world * step_ms / (step_ms + max(0.0, t_free - t_bwd_end)), 3),
+		model = 'direct reduce-scatter + all-gather over one xGMI link per peer; bucket ready times from the backward pass apportioned by parameter counts; serial collectives on the communication stream (convasr_amd.parallel.predict_exposed_comm)')
+
+
 class DataParallelEngine(nn.Module):
 	def __init__(self, module, device = None, bucket_bytes = int(os.environ.get('CONVASR_BUCKET_MIB', 64)) << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True, comm_thread = os.environ.get('CONVASR_COMM_THREAD', '0') == '1', measure_exposed_comm = False):
 		super().__init__()
@@ -85,6 +117,10 @@ class DataParallelEngine(nn.Module):
 			self.close()
 		except Exception:
 			pass
+
+	def predict(self, world, step_ms, **kw):
+		"""predict_exposed_comm for this engine's buckets (bench.py puts it next to the measured dist.exposed_comm_ms)."""
+		return predict_exposed_comm([p.numel() for p in self.flat.params], self.flat.offsets, self.buckets, world, step_ms, **kw)
 
 	def exposed_comm_ms(self):
 		"""Mean over the recorded steps of the time the main stream spent waiting for the communication stream (call after a device
