@@ -66,6 +66,8 @@ _SIGNATURES = dict(
 	convasr_bn_bwd_finalize = (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_int, c_p]),
 	convasr_novograd_step = (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_i64, c_p, c_int, c_p, c_p, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p, c_p]),
 	convasr_step_begin = (c_int, [c_p, c_p]),
+	convasr_conv1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_p]),
+	convasr_add16 = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
 	convasr_copy = (c_int, [c_p, c_p, c_i64, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),

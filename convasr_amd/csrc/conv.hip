@@ -381,6 +381,7 @@ int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s);      // wgra
 static int g_conv_use_v2 = 1;
 static int g_conv_debug = 0;
 // test / A-B hook: bit 0 clear forces the register-staged kernels for every dtype; bits 8.. are experiment flags (ConvParams::debug)
+int convasr_conv_debug_bits() { return g_conv_debug; }  // (for the other translation units' host entries)
 extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_use_v2; g_conv_use_v2 = enable & 1; g_conv_debug = enable >> 8; return prev; }
 
 static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,

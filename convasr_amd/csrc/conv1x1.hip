@@ -23,20 +23,24 @@
 #define C11_BM 128
 #define C11_STAGE (2 * C11_BM * ROW_BYTES)  // X tile + W tile of one 64-channel slab: 32 KiB
 
+// What one tile needs to know about its problem: the single-problem launch fills it from ConvParams, the grouped launch from its table.
+struct C11Args {
+	const void* x; const void* w; void* y; const float* bias; double* stats;
+	int Cin, Cout, CoutPad;
+	int64_t M;       // rows = B * T frames
+	int accumulate;  // y += (instead of y =): the grouped input-gradient launches add into the tapped block output's gradient
+};
+
 // NS = LDS stages: 2 = the next slab's DMA is in flight while this one is computed (64 KiB: two workgroups per CU); 1 = issue, wait, compute
 // (36.9 KiB incl. the epilogue's tile: four workgroups per CU, twice the bytes in flight per CU, the overlap left to occupancy alone).
-template <typename I, int NS> __global__ __launch_bounds__(C11_THREADS, NS == 1 ? 4 : 2) void conv1x1_kernel(ConvParams p) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+template <typename I, int NS> __device__ __forceinline__ void conv1x1_tile(const C11Args& p, const int mtile, const int ntile, char* const smem) {
 	constexpr int MI = 4, NB = 4;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, kb = lane >> 4, wm = wave >> 1, wn = wave & 1;
 
-	// consecutive workgroups of an XCD walk the n tiles of one m tile first: its X rows are fetched from beyond L2 once
-	const int v = xcd_remap(blockIdx.x, p.total_tiles);
-	const int ntile = v % p.n_tiles, mtile = v / p.n_tiles;
 	const int m0 = mtile * C11_BM, co0 = ntile * BN;
-	const int64_t M = (int64_t)p.B * p.Tout;
+	const int64_t M = p.M;
 
 	const int row_bytes = p.Cin * 2;
 	const v4i32 xsrc = make_srd(p.x, (unsigned)(M * row_bytes));
@@ -135,8 +139,51 @@ template <typename I, int NS> __global__ __launch_bounds__(C11_THREADS, NS == 1 
 	for (int it = 0; it < C11_BM * OCH / C11_THREADS; ++it) {
 		const int e = tid + it * C11_THREADS, row = e / OCH, ch = e % OCH;
 		const int64_t m = (int64_t)m0 + row;
-		if (m < M) *reinterpret_cast<uint4*>(yb + m * p.Cout + co0 + ch * 8) = *reinterpret_cast<const uint4*>(otile + row * OPITCH + ch * 16);
+		if (m < M) {
+			uint4 val = *reinterpret_cast<const uint4*>(otile + row * OPITCH + ch * 16);
+			uint4* const dst = reinterpret_cast<uint4*>(yb + m * p.Cout + co0 + ch * 8);
+			if (p.accumulate) {  // (workgroup-uniform) the sum of two stored 16-bit values, rounded once: what the pairwise add it replaces computed
+				float a[8], o[8];
+				unpack16<I>(val, a);
+				unpack16<I>(*dst, o);
+				val = make_uint4(pack16<I>(a[0] + o[0], a[1] + o[1]), pack16<I>(a[2] + o[2], a[3] + o[3]), pack16<I>(a[4] + o[4], a[5] + o[5]), pack16<I>(a[6] + o[6], a[7] + o[7]));
+			}
+			*dst = val;
+		}
 	}
+}
+
+template <typename I, int NS> __global__ __launch_bounds__(C11_THREADS, NS == 1 ? 4 : 2) void conv1x1_kernel(ConvParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// consecutive workgroups of an XCD walk the n tiles of one m tile first: its X rows are fetched from beyond L2 once
+	const int v = xcd_remap(blockIdx.x, p.total_tiles);
+	C11Args a;
+	a.x = p.x; a.w = p.w; a.y = p.y; a.bias = p.bias; a.stats = p.stats; a.Cin = p.Cin; a.Cout = p.Cout; a.CoutPad = p.CoutPad; a.M = (int64_t)p.B * p.Tout; a.accumulate = 0;
+	conv1x1_tile<I, NS>(a, v / p.n_tiles, v % p.n_tiles, smem);
+}
+
+// ---------------- grouped launches: up to C11_MAX_GROUP independent one-tap problems over the same B * T frames in ONE dispatch.
+// The residual branches of a dense block (models.py:107-110, 129-131: up to ten 1x1 convs per block, each feeding its OWN batch norm, so
+// they cannot share a GEMM -- but they can share a launch): every problem keeps its own operands, output, bias and statistics rows and
+// is computed exactly as by a launch of its own (bit-identical per element); the tile index picks the problem by a prefix sum.  Ten
+// launches of 0.2-1.5 rounds at the 10-25 us launch floor become one that fills the chip.
+#define C11_MAX_GROUP 12
+struct C11Group {
+	C11Args prob[C11_MAX_GROUP];
+	int first[C11_MAX_GROUP + 1];  // first tile of each problem; first[n] = all tiles
+	int n_tiles[C11_MAX_GROUP];    // n tiles (Cout / 128) of each problem
+	int n;
+};
+
+template <typename I, int NS> __global__ __launch_bounds__(C11_THREADS, NS == 1 ? 4 : 2) void conv1x1_grouped_kernel(C11Group g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int v = xcd_remap(blockIdx.x, g.first[g.n]);
+	int q = 0;
+#pragma unroll
+	for (int i = 1; i < C11_MAX_GROUP; ++i) q += (i < g.n && v >= g.first[i]) ? 1 : 0;
+	q = __builtin_amdgcn_readfirstlane(q);
+	const int local = v - g.first[q], nt = g.n_tiles[q];
+	conv1x1_tile<I, NS>(g.prob[q], local / nt, local % nt, smem);
 }
 
 // Returns 1 if this kernel took the launch (rows_out = partial statistics rows written), 0 if the shape is outside its envelope.
@@ -167,4 +214,48 @@ int convasr_conv1x1_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, i
 	if (hipLaunchKernel(kern, dim3(p.total_tiles), dim3(C11_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	if (rows_out) *rows_out = m_tiles;
 	return 1;
+}
+
+int convasr_conv_debug_bits();
+static bool c11_ok(int Cin, int Cout) { return (Cin & 63) == 0 && (Cout & 127) == 0 && Cin > 0 && Cout > 0; }
+
+// n one-tap problems y_i (+)= x_i * w_i^T (+ bias_i) over the same B * T frames (16-bit channels-last activations, packed forward-layout
+// weights [1][Cout_i][Cin_i]); stats_i (may be NULL): per-m-tile partial rows like convasr_conv1d_fwd's.  Problems whose reduction is
+// long against their output width run in the two-stage instantiation, the others in the one-stage one: at most two dispatches.
+extern "C" int convasr_conv1x1_grouped(int n, const void* const* x, const void* const* w, void* const* y, const float* const* bias, double* const* stats,
+                                       const int* cin, const int* cout, const int* accumulate, int dtype, int B, int T, int* stats_rows, void* stream) {
+	CONVASR_CHECK_ARG(n > 0 && n <= C11_MAX_GROUP && x && w && y && cin && cout && B > 0 && T > 0, "conv1x1_grouped: bad arguments (at most %d problems)", C11_MAX_GROUP);
+	if (!convasr_is_half(dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1x1_grouped: dtype %d (16-bit storage only)", dtype);
+	const int64_t M = (int64_t)B * T;
+	const int m_tiles = (int)((M + C11_BM - 1) / C11_BM);
+	for (int i = 0; i < n; ++i) {
+		CONVASR_CHECK_ARG(x[i] && w[i] && y[i], "conv1x1_grouped: problem %d has a NULL operand", i);
+		if (!c11_ok(cin[i], cout[i]) || M * cin[i] * 2 >= (1ll << 31) || M * cout[i] * 2 >= (1ll << 31) || (int64_t)cout[i] * cin[i] * 2 >= (1ll << 31))
+			return convasr_fail(CONVASR_EUNSUPPORTED, "conv1x1_grouped: problem %d (%d -> %d channels, %lld frames) is outside the one-tap kernel's envelope (Cin %% 64, Cout %% 128)", i, cin[i], cout[i], (long long)M);
+	}
+	const bool f16 = dtype == CONVASR_F16;
+	hipStream_t s = (hipStream_t)stream;
+	for (int two = 0; two < 2; ++two) {  // pass 0: the one-stage problems, pass 1: the two-stage ones
+		C11Group g = {};
+		for (int i = 0; i < n; ++i) {
+			const bool one_stage = (cin[i] < 3 * cout[i]) != ((convasr_conv_debug_bits() & 16384) != 0);
+			if (one_stage == (two != 0)) continue;
+			C11Args& a = g.prob[g.n];
+			a.x = x[i]; a.w = w[i]; a.y = y[i]; a.bias = bias ? bias[i] : nullptr; a.stats = stats ? stats[i] : nullptr;
+			a.Cin = cin[i]; a.Cout = cout[i]; a.CoutPad = cout[i]; a.M = M; a.accumulate = accumulate ? accumulate[i] : 0;
+			g.n_tiles[g.n] = cout[i] / BN;
+			g.first[g.n + 1] = g.first[g.n] + m_tiles * g.n_tiles[g.n];
+			++g.n;
+		}
+		if (g.n == 0) continue;
+		const size_t epi = (size_t)C11_BM * (BN * 2 + 16) + 4 * BN * sizeof(float);
+		const size_t smem = two ? 2 * (size_t)C11_STAGE : (epi > C11_STAGE ? epi : C11_STAGE);
+		const void* kern = two ? (f16 ? (const void*)conv1x1_grouped_kernel<f16_t, 2> : (const void*)conv1x1_grouped_kernel<bf16_t, 2>) : (f16 ? (const void*)conv1x1_grouped_kernel<f16_t, 1> : (const void*)conv1x1_grouped_kernel<bf16_t, 1>);
+		static unsigned long long set[2][2] = {};
+		convasr_allow_160k_lds(kern, set[two][f16]);
+		void* args[] = {&g};
+		if (hipLaunchKernel(kern, dim3(g.first[g.n]), dim3(C11_THREADS), args, smem, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "conv1x1_grouped: %s", hipGetErrorString(hipGetLastError()));
+	}
+	if (stats_rows) *stats_rows = m_tiles;
+	return 0;
 }

@@ -324,6 +324,26 @@ extern "C" int convasr_step_begin(uint64_t* state, void* stream) {
 	return 0;
 }
 
+// out = a + b over n 16-bit values (n % 8 == 0), 16 bytes per lane; in place allowed (out == a or out == b)
+template <typename H> __global__ __launch_bounds__(256) void add16_kernel(const H* __restrict__ a, const H* __restrict__ b, H* __restrict__ out, int64_t n8) {
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+		float x[8], y[8];
+		unpack16<H>(reinterpret_cast<const uint4*>(a)[i], x);
+		unpack16<H>(reinterpret_cast<const uint4*>(b)[i], y);
+		reinterpret_cast<uint4*>(out)[i] = make_uint4(pack16<H>(x[0] + y[0], x[1] + y[1]), pack16<H>(x[2] + y[2], x[3] + y[3]), pack16<H>(x[4] + y[4], x[5] + y[5]), pack16<H>(x[6] + y[6], x[7] + y[7]));
+	}
+}
+
+extern "C" int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+	CONVASR_CHECK_ARG(a && b && out && n > 0 && (n & 7) == 0 && convasr_is_half(dtype), "add16: n must be a positive multiple of 8 and dtype CONVASR_BF16 / CONVASR_F16");
+	int64_t blocks = ceil_div64(n >> 3, 256);
+	if (blocks > 8192) blocks = 8192;
+	if (dtype == CONVASR_F16) hipLaunchKernelGGL((add16_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)a, (const f16_t*)b, (f16_t*)out, n >> 3);
+	else hipLaunchKernelGGL((add16_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n >> 3);
+	CONVASR_CHECK_LAUNCH("add16");
+	return 0;
+}
+
 extern "C" int convasr_copy(const void* src, void* dst, int64_t nbytes, void* stream) {
 	CONVASR_CHECK_ARG(src && dst && nbytes >= 0, "copy: bad arguments");
 	if (nbytes == 0) return 0;

@@ -216,6 +216,8 @@ def _deliver(params, compute):
 	return outs
 
 
+GROUP_RES = os.environ.get('CONVASR_NO_GROUPED_RES') != '1'  # A/B hook: a dense block's residual branches in grouped launches + gradient accumulators on the tapped outputs
+_GACC_ATTR = '_convasr_gacc'
 RES_WGRAD_SIDE = os.environ.get('CONVASR_NO_RES_WGRAD_SIDE') != '1'  # A/B hook: the residual branches' weight gradients on the wgrad side stream too
 after_long_launch_hooks = {}  # id -> callable, run right after the backward pass has enqueued a long kernel (a dgrad): the data-parallel engine enqueues its ready collectives there, where their host cost hides behind queued GPU work
 _side_streams = {}  # device -> torch.cuda.Stream running the weight-gradient kernels (None entry = disabled)
@@ -406,17 +408,31 @@ class ConvBnActFunction(torch.autograd.Function):
 		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked)
 
 		res_x, res_y, res_bnp = [], [], []
+		# where each batch-normed branch's input gradient goes in backward: the gradient accumulator its producer left on the tapped tensor
+		# (GRAD_ACC below), or None = hand it to autograd
+		ctx.res_gacc = [getattr(flat_res[5 * r], _GACC_ATTR, None) if (GROUP_RES and flat_res[5 * r + 1] is not None) else None for r in range(n_res)]
+		res_x = [ops.as_cl(flat_res[5 * r], dt) for r in range(n_res)]
+		branches = [r for r in range(n_res) if flat_res[5 * r + 1] is not None]
+		ys = None
+		if GROUP_RES and len(branches) >= 2 and dt in ops.HALF_DTYPES:
+			# all of the block's 1x1 residual convs (+ bias, + BN statistics) in ONE dispatch: same values as a launch each
+			sts = [_stats_buffer(cfg['res_bn'][r], Cout, dev, B, Tout) for r in branches]
+			ys = ops.conv1x1_grouped([res_x[r] for r in branches], [packed_weight(flat_res[5 * r + 1], dt, _lib.PACK_FWD) for r in branches], [Cout] * len(branches), biases = [flat_res[5 * r + 2] for r in branches], stats = sts)
+			if ys is not None:
+				ys, sts = dict(zip(branches, ys)), dict(zip(branches, sts))
 		for r in range(n_res):
 			rx, rw, rb, rg, rbeta = flat_res[5 * r:5 * r + 5]
-			rx = ops.as_cl(rx, dt)
-			res_x.append(rx)
+			rx = res_x[r]
 			if rw is None:
 				res_y.append(rx)
 				res_bnp.append(None)
 			else:
 				rbn = cfg['res_bn'][r]
-				st = _stats_buffer(rbn, Cout, dev, B, Tout)
-				ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
+				if ys is not None:
+					ry, st = ys[r], sts[r]
+				else:
+					st = _stats_buffer(rbn, Cout, dev, B, Tout)
+					ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
 				res_y.append(ry)
 				res_bnp.append(ops.bn_finalize(st, B * Tout, rg, rbeta, rbn.running_mean, rbn.running_var, _momentum(rbn), rbn.eps, num_batches_tracked = rbn.num_batches_tracked))
 
@@ -440,6 +456,13 @@ class ConvBnActFunction(torch.autograd.Function):
 		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt in ops.HALF_DTYPES and Cout % 8 == 0:
 			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset, skey), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None, gate = gate)
 			setattr(z, _LINK_ATTR, ctx.bwd_link)
+		# GRAD_ACC: a 16-bit output that later blocks may tap as a residual input carries a gradient accumulator.  The tapping blocks' grouped
+		# input-gradient launches write / add into it (and hand autograd None); this layer's backward adds it to the gradient autograd
+		# delivers (the main path's): one explicit add per tapped output instead of autograd's pairwise one per branch.
+		ctx.gacc = None
+		if GROUP_RES and dt in ops.HALF_DTYPES and cfg.get('tappable'):
+			ctx.gacc = dict(buf = None)
+			setattr(z, _GACC_ATTR, ctx.gacc)
 		return z
 
 	@staticmethod
@@ -457,6 +480,9 @@ class ConvBnActFunction(torch.autograd.Function):
 		B, Cout, Tout = y.shape
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
+		if ctx.gacc is not None and ctx.gacc['buf'] is not None:  # the input gradients of the residual branches that tapped this output
+			acc, ctx.gacc['buf'] = ctx.gacc['buf'], None
+			dz = ops.add16(dz, acc, out = acc)
 		link, fused_sums = ctx.bwd_link, None
 		if link is not None:
 			if link['dz'] is not None and link['dz'].data_ptr() == dz.data_ptr() and link['dz'].shape == dz.shape:
@@ -520,18 +546,23 @@ class ConvBnActFunction(torch.autograd.Function):
 		if not arena_mode:
 			dw, = wg()
 
-		res_grads = []
+		res_grads = [None] * (5 * n_res)
+		pending = []  # branches whose input gradient goes into a gradient accumulator: (r, dry), launched together below
 		for r in range(n_res):
 			rw, rb, rg, rbeta = ctx.params[3 + 4 * r:3 + 4 * r + 4]
 			rx = res_x[r]
 			need_rx = ctx.needs_input_grad[6 + 5 * r]
 			if res_bnp[r] is None:
-				res_grads += [g if need_rx else None, None, None, None, None]
+				res_grads[5 * r] = g if need_rx else None
 				continue
 			p = res_bnp[r]
 			drg, drbeta, dry = _bn_backward_from_g(g, res_y[r], rg, rbeta, p, rsum_of[r], B * Tout)
-			join_prepack(dry.device)
-			drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), rx.shape[1], 1, 1, 1, 0) if need_rx else None
+			drx = None
+			if need_rx and ctx.res_gacc[r] is not None and rx.shape[1] % 128 == 0 and Cout % 64 == 0:
+				pending.append((r, dry))
+			elif need_rx:
+				join_prepack(dry.device)
+				drx = ops.conv1d(dry, packed_weight(rw, dt, _lib.PACK_DGRAD), rx.shape[1], 1, 1, 1, 0)
 			# The bias of a conv that feeds a train-mode batch norm has an identically zero gradient: dry sums to zero over (b, t) for
 			# every channel (sum of g minus N times its mean, minus mean(g xhat) times sum of xhat = 0).  The reference's autograd
 			# gets rounding noise around 0 from the column sum of dry; here the entry is set to exact zero and the pass is skipped.
@@ -548,7 +579,19 @@ class ConvBnActFunction(torch.autograd.Function):
 				drw, drb = _run_wgrad(dry.device, (rx, dry), lambda: _deliver([rw, rb], res_wgrad))
 			else:
 				drw, drb = _deliver([rw, rb], res_wgrad)
-			res_grads += [drx, drw, drb, drg, drbeta]
+			res_grads[5 * r:5 * r + 5] = [drx, drw, drb, drg, drbeta]
+		if pending:
+			# the branches' input gradients, all in one dispatch, straight into the tapped outputs' gradient accumulators (first writer of a
+			# step allocates and writes, later ones add): autograd gets None for these inputs
+			join_prepack(dev)
+			accs = [ctx.res_gacc[r] for r, _ in pending]
+			fresh = [a['buf'] is None for a in accs]
+			for (r, _), a, fr in zip(pending, accs, fresh):
+				if fr:
+					a['buf'] = ops.empty_cl(B, res_x[r].shape[1], Tout, dt, dev)
+			done = ops.conv1x1_grouped([dry for _, dry in pending], [packed_weight(ctx.params[3 + 4 * r], dt, _lib.PACK_DGRAD) for r, _ in pending], [res_x[r].shape[1] for r, _ in pending], outs = [a['buf'] for a in accs], accumulate = [not fr for fr in fresh])
+			if done is None:
+				raise _lib.ConvasrHipError('grouped input gradient of the residual branches: a shape left the one-tap kernel\'s envelope between forward and backward')
 		return (None, dx, dw, dgamma, dbeta, None, *res_grads)
 
 

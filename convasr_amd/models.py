@@ -238,11 +238,12 @@ class ConvBn1d(nn.Module):
 		self.activation = ResidualActivation(nonlinearity, dropout, invertible = inplace)
 		self.temporal_mask = temporal_mask
 		self.compute_dtype = torch.float32
+		self.tapped_output = False  # set by the network when later blocks take this block's output as a residual input: its gradient then has an accumulator the tapping blocks write into (functional.ConvBnActFunction, GRAD_ACC)
 		self.single_consumer_output = False  # set by the network when this block's output feeds exactly one conv (no residual taps): enables cross-layer backward fusion
 
 	def _cfg(self, i, last):
 		conv, bn = self.conv[i][-1], self.bn[i]
-		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output))
+		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
 
 	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
 		_lib.require_cuda(x)
@@ -378,6 +379,7 @@ class JasperNet(nn.Module):
 		for i, blk in enumerate(self.backbone):
 			tapped = bool(residual) and i < len(self.backbone) - self.num_epilogue_modules - 1
 			blk.single_consumer_output = (not tapped) and (i < len(self.backbone) - 1 or len(num_classes) == 1)
+			blk.tapped_output = tapped
 		self.set_compute_dtype(compute_dtype)
 
 	def set_compute_dtype(self, dtype):

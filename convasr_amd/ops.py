@@ -228,6 +228,41 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	return y
 
 
+def _int_array(vals):
+	return (ctypes.c_int * max(len(vals), 1))(*[int(v) for v in vals])
+
+
+def conv1x1_grouped(xs, wps, couts, biases = None, stats = None, outs = None, accumulate = None):
+	"""n one-tap convs over the same frames in one dispatch (include/convasr_hip.h, "grouped one-tap launches").  xs: channels-last
+	(B, Cin_i, T) tensors of one 16-bit dtype; wps: packed weights; stats: list of ConvStats / None; outs: list of preallocated
+	(B, Cout_i, T) outputs / None; accumulate: list of bools (add into outs[i]).  Returns the outputs, or None (nothing launched) when a
+	problem is outside the kernel's envelope."""
+	n = len(xs)
+	B, _, T = xs[0].shape
+	dt = xs[0].dtype
+	if n == 0 or n > 12 or dt not in HALF_DTYPES or any(x.dtype != dt or x.shape[0] != B or x.shape[2] != T or not is_cl(x) or x.shape[1] % 64 for x in xs) or any(c % 128 for c in couts):
+		return None
+	ys = [empty_cl(B, couts[i], T, dt, xs[0].device) if outs is None or outs[i] is None else outs[i] for i in range(n)]
+	rows = ctypes.c_int(0)
+	cins = [x.shape[1] for x in xs]
+	launch = lambda: call('convasr_conv1x1_grouped', n, _ptr_array(xs), _ptr_array(wps), _ptr_array(ys), _ptr_array(biases) if biases else None, _ptr_array([None if s_ is None else s_.buf for s_ in stats]) if stats else None,
+		_int_array(cins), _int_array(couts), _int_array(accumulate) if accumulate else None, dtype_code(dt), B, T, ctypes.byref(rows), stream_ptr())
+	_lib.timed('hbm:conv1x1_kernel (one-tap training launches)', 2.0 * B * T * sum(ci * co for ci, co in zip(cins, couts)), launch, nbytes = float(2 * B * T * sum(ci + co * (2 if accumulate and accumulate[i] else 1) for i, (ci, co) in enumerate(zip(cins, couts))) + 2 * sum(ci * co for ci, co in zip(cins, couts))))
+	if stats:
+		for s_ in stats:
+			if s_ is not None:
+				s_.rows = rows.value
+	return ys
+
+
+def add16(a, b, out = None):
+	"""out = a + b for two 16-bit tensors of the same (channels-last) layout; in place when out is a or b."""
+	assert a.dtype == b.dtype and a.dtype in HALF_DTYPES and a.shape == b.shape and a.stride() == b.stride() and a.numel() % 8 == 0
+	out = torch.empty_like(a) if out is None else out
+	call('convasr_add16', ptr(a), ptr(b), ptr(out), a.numel(), dtype_code(a.dtype), stream_ptr())
+	return out
+
+
 _workspaces = {}
 _capturing = [False]  # functional.CAPTURING (the same list object, installed by functional at import)
 

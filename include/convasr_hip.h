@@ -316,6 +316,22 @@ int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, voi
 int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamma, const float* mean, const float* invstd, float* coef,
                             float* dgamma, float* dbeta, int accumulate, int64_t n, int C, void* stream);
 
+/* ---- grouped one-tap launches: the residual branches of a dense block (models.py:107-110, 129-131) ------------------ */
+
+/* n (<= 12) independent Conv1d(kernel_size = 1) problems over the SAME B * T frames in one dispatch (two when some problems have a long
+ * reduction into few channels): y_i (+)= x_i * w_i^T (+ bias_i).  x_i channels-last (B, T, cin[i]) and y_i (B, T, cout[i]) of `dtype`
+ * (CONVASR_BF16 / CONVASR_F16), w_i the packed forward layout [1][cout[i]][cin[i]] (convasr_pack_conv_weight; for an input gradient: the
+ * packed dgrad layout with the roles of the channel counts swapped), bias (array or NULL; entries may be NULL), stats (array or NULL;
+ * entries may be NULL): per-m-tile partial rows exactly as convasr_conv1d_fwd writes them, *stats_rows rows each; accumulate (array or
+ * NULL): entry != 0 adds into y_i (the sum of the two stored 16-bit values, rounded once) -- the input gradients of the branches land in
+ * the tapped block output's gradient without autograd's pairwise adds.  Each problem is computed exactly as convasr_conv1d_fwd computes
+ * it alone (bit-identical per element).  cin[i] % 64 == 0, cout[i] % 128 == 0, else CONVASR_EUNSUPPORTED (launch them one by one). */
+int convasr_conv1x1_grouped(int n, const void* const* x, const void* const* w, void* const* y, const float* const* bias, double* const* stats,
+                            const int* cin, const int* cout, const int* accumulate, int dtype, int B, int T, int* stats_rows, void* stream);
+/* out = a + b over n 16-bit values (n % 8 == 0; in place allowed): the one explicit add a tapped block output's gradient needs (the main
+ * path's input gradient + the branches' accumulated ones), in place of autograd's InputBuffer accumulation (models.py:129-131 backward). */
+int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+
 /* ---- per-step device state: what lets train.py:745-783 replay from a HIP graph ------------------------------------- */
 
 /* state: four device words {dropout seed (the caller's, models.py:365-369 draws from torch's generator), steps begun, key of the
