@@ -68,6 +68,8 @@ _SIGNATURES = dict(
 	convasr_step_begin = (c_int, [c_p, c_p]),
 	convasr_conv1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_p]),
 	convasr_add16 = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+	convasr_wgrad1x1_grouped_workspace_bytes = (c_i64, [c_int, c_p, c_p, c_int, c_int]),
+	convasr_wgrad1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
 	convasr_copy = (c_int, [c_p, c_p, c_i64, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),

@@ -63,13 +63,20 @@ __device__ __forceinline__ uint4 w2_tr_frag(const char* p0, const char* p1) {
 	return make_uint4(l.x, l.y, h.x, h.y);
 }
 
-template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(WgradParams p) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+// Grouped launches: up to W2_MAX_GROUP independent weight-gradient problems (the one-tap residual branches of a dense block: same frames,
+// their own dY / X / slabs) in one dispatch; the workgroup index picks the problem by a prefix sum over units x splits.
+#define W2_MAX_GROUP 12
+struct WgradGroup {
+	WgradParams prob[W2_MAX_GROUP];
+	int first[W2_MAX_GROUP + 1];
+	int n;
+};
+
+template <typename H> __device__ __forceinline__ void wgrad_v2_body(const WgradParams& p, const int v, char* const smem) {
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int tp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
 
-	const int v = xcd_remap(blockIdx.x, p.units * p.splits);
 	const int unit = v % p.units, split = v / p.units;
 #ifdef CONVASR_AB_WGRAD_ORDER
 	// Diagnostic build only (scratch/ab_wgrad_order.py): which (co tile, ci tile, tap group) units run side by side on an XCD decides how
@@ -309,6 +316,21 @@ template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1
 #endif
 }
 
+template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_kernel(WgradParams p) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	wgrad_v2_body<H>(p, xcd_remap(blockIdx.x, p.units * p.splits), smem);
+}
+
+template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1d_wgrad_v2_grouped_kernel(WgradGroup g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int v = xcd_remap(blockIdx.x, g.first[g.n]);
+	int q = 0;
+#pragma unroll
+	for (int i = 1; i < W2_MAX_GROUP; ++i) q += (i < g.n && v >= g.first[i]) ? 1 : 0;
+	q = __builtin_amdgcn_readfirstlane(q);
+	wgrad_v2_body<H>(g.prob[q], v - g.first[q], smem);
+}
+
 // Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
 int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
 	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0) return 0;
@@ -328,4 +350,113 @@ int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
 	if (hipLaunchKernel(kern, dim3(q.units * q.splits), dim3(W2_ALL_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
 	p = q;
 	return 1;
+}
+
+// combine of a grouped launch: dw_i (+)= sum over splits of slab_i, every problem's 16-byte pieces in one streaming launch; plus the
+// zero fill of the branches' bias gradients (identically zero for a conv that feeds a train-mode batch norm: functional.py)
+struct WgradCombine {
+	const float* slab[W2_MAX_GROUP]; float* dw[W2_MAX_GROUP]; float* zero[W2_MAX_GROUP];
+	long long first4[W2_MAX_GROUP + 1];  // prefix sums of the problems' float4 counts
+	int zero_n[W2_MAX_GROUP];
+	int accumulate[W2_MAX_GROUP];
+	int n, S;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(WgradCombine c) {
+	const long long total = c.first4[c.n];
+	for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+		int q = 0;
+#pragma unroll
+		for (int k = 1; k < W2_MAX_GROUP; ++k) q += (k < c.n && i >= c.first4[k]) ? 1 : 0;
+		const long long j = i - c.first4[q], n4 = c.first4[q + 1] - c.first4[q];
+		const float4* const s4 = reinterpret_cast<const float4*>(c.slab[q]);
+		float4 a = s4[j];
+		for (int s = 1; s < c.S; ++s) { const float4 b = s4[(long long)s * n4 + j]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+		float4* const d4 = reinterpret_cast<float4*>(c.dw[q]);
+		if (c.accumulate[q]) { const float4 o = d4[j]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+		d4[j] = a;
+	}
+	if (blockIdx.x == 0)
+		for (int q = 0; q < c.n; ++q)
+			if (c.zero[q])
+				for (int k = threadIdx.x; k < c.zero_n[q]; k += 256) c.zero[q][k] = 0.f;
+}
+
+static void wgrad_group_plan(WgradParams* probs, int n) {
+	// one split count for all problems (they reduce over the same frames): rounds of workgroups over the 256 CUs x chunks per workgroup x
+	// time per chunk, plus every problem's partial-slab traffic (wgrad_plan's cost model over the summed units)
+	for (int i = 0; i < n; ++i) {
+		WgradParams& p = probs[i];
+		p.co_tiles = p.Cout / 128; p.ci_tiles = p.Cin / 128; p.tap_groups = 1; p.units = p.co_tiles * p.ci_tiles;
+		p.chunks_per_b = (p.Tout + W2_BKT - 1) / W2_BKT; p.total_chunks = p.B * p.chunks_per_b;
+		p.x_rows = W2_BKT;
+	}
+	const int total_chunks = probs[0].total_chunks;
+	int units = 0; double slab_us = 0;
+	for (int i = 0; i < n; ++i) { units += probs[i].units; slab_us += 2.0 * (double)probs[i].Cout * probs[i].Cin * 4.0 / 4e6; }
+	double best = 1e30; int best_s = 1;
+	for (int s = 1; s <= WGRAD_MAX_SPLITS && s <= total_chunks; ++s) {
+		const int cps = (total_chunks + s - 1) / s, s_eff = (total_chunks + cps - 1) / cps;
+		const int rounds = (units * s_eff + 255) / 256;
+		const double cost = rounds * cps * 1.6 + s_eff * slab_us;
+		if (cost < best) { best = cost; best_s = s_eff; }
+	}
+	for (int i = 0; i < n; ++i) {
+		WgradParams& p = probs[i];
+		p.chunks_per_split = (total_chunks + best_s - 1) / best_s;
+		p.splits = (total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+	}
+}
+
+extern "C" int64_t convasr_wgrad1x1_grouped_workspace_bytes(int n, const int* cin, const int* cout, int B, int T) {
+	if (n <= 0 || n > W2_MAX_GROUP || !cin || !cout || B <= 0 || T <= 0) return -1;
+	WgradParams probs[W2_MAX_GROUP];
+	for (int i = 0; i < n; ++i) { probs[i] = WgradParams(); probs[i].B = B; probs[i].Cin = cin[i]; probs[i].Cout = cout[i]; probs[i].Tin = probs[i].Tout = T; probs[i].K = 1; probs[i].stride = probs[i].dil = 1; }
+	wgrad_group_plan(probs, n);
+	int64_t bytes = 0;
+	for (int i = 0; i < n; ++i) bytes += (int64_t)probs[i].splits * cout[i] * cin[i] * 4;
+	return bytes;
+}
+
+// n one-tap weight gradients dw_i[co][ci] (+)= sum_(b,t) dy_i[b,t,co] * x_i[b,t,ci] over the same B * T frames: ONE dispatch of the LDS-DMA
+// wgrad kernel over all problems' (co tile, ci tile, split) units and ONE streaming combine.  zero_i (may be NULL): cout[i] floats set to
+// zero by the combine (the branch's bias gradient).  cin[i] % 128 == 0, cout[i] % 128 == 0, 16-bit storage.
+extern "C" int convasr_wgrad1x1_grouped(int n, const void* const* x, const void* const* dy, float* const* dw, float* const* zero, const int* cin, const int* cout,
+                                        const int* accumulate, void* workspace, int dtype, int B, int T, void* stream) {
+	CONVASR_CHECK_ARG(n > 0 && n <= W2_MAX_GROUP && x && dy && dw && cin && cout && workspace && B > 0 && T > 0, "wgrad1x1_grouped: bad arguments (at most %d problems)", W2_MAX_GROUP);
+	if (!convasr_is_half(dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "wgrad1x1_grouped: dtype %d (16-bit storage only)", dtype);
+	WgradGroup g = {};
+	WgradCombine c = {};
+	for (int i = 0; i < n; ++i) {
+		CONVASR_CHECK_ARG(x[i] && dy[i] && dw[i], "wgrad1x1_grouped: problem %d has a NULL operand", i);
+		if ((cin[i] & 127) || (cout[i] & 127) || cin[i] <= 0 || cout[i] <= 0 || (int64_t)T * cin[i] * 2 >= (1ll << 31) || (int64_t)T * cout[i] * 2 >= (1ll << 31))
+			return convasr_fail(CONVASR_EUNSUPPORTED, "wgrad1x1_grouped: problem %d (%d x %d channels) is outside the kernel's envelope (channel counts %% 128)", i, cout[i], cin[i]);
+		WgradParams& p = g.prob[i];
+		p = WgradParams();
+		p.x = x[i]; p.dy = dy[i]; p.B = B; p.Cin = cin[i]; p.Cout = cout[i]; p.Tin = p.Tout = T; p.K = 1; p.stride = p.dil = 1; p.pad = 0; p.debug = 0;
+	}
+	wgrad_group_plan(g.prob, n);
+	g.n = c.n = n;
+	c.S = g.prob[0].splits;
+	float* slab = (float*)workspace;
+	for (int i = 0; i < n; ++i) {
+		g.prob[i].slab = slab;
+		c.slab[i] = slab; c.dw[i] = dw[i]; c.zero[i] = zero ? zero[i] : nullptr; c.zero_n[i] = cout[i]; c.accumulate[i] = accumulate ? accumulate[i] : 0;
+		c.first4[i + 1] = c.first4[i] + (long long)cout[i] * cin[i] / 4;
+		slab += (int64_t)g.prob[i].splits * cout[i] * cin[i];
+		g.first[i + 1] = g.first[i] + g.prob[i].units * g.prob[i].splits;
+	}
+	const size_t smem = 4 * (size_t)(W2_YBYTES + W2_BKT * 256);
+	const bool f16 = dtype == CONVASR_F16;
+	const void* kern = f16 ? (const void*)conv1d_wgrad_v2_grouped_kernel<f16_t> : (const void*)conv1d_wgrad_v2_grouped_kernel<bf16_t>;
+	static unsigned long long set[2] = {0, 0};
+	convasr_allow_160k_lds(kern, set[f16]);
+	hipStream_t s = (hipStream_t)stream;
+	void* args[] = {&g};
+	if (hipLaunchKernel(kern, dim3(g.first[n]), dim3(W2_ALL_THREADS), args, smem, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "wgrad1x1_grouped: %s", hipGetErrorString(hipGetLastError()));
+	long long blocks = (c.first4[n] + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, c);
+	CONVASR_CHECK_LAUNCH("wgrad1x1_grouped");
+	return 0;
 }

@@ -548,6 +548,7 @@ class ConvBnActFunction(torch.autograd.Function):
 
 		res_grads = [None] * (5 * n_res)
 		pending = []  # branches whose input gradient goes into a gradient accumulator: (r, dry), launched together below
+		wg_group = []  # branches whose weight gradient goes into the gradient arena: (r, rx, dry), launched together below
 		for r in range(n_res):
 			rw, rb, rg, rbeta = ctx.params[3 + 4 * r:3 + 4 * r + 4]
 			rx = res_x[r]
@@ -566,6 +567,11 @@ class ConvBnActFunction(torch.autograd.Function):
 			# The bias of a conv that feeds a train-mode batch norm has an identically zero gradient: dry sums to zero over (b, t) for
 			# every channel (sum of g minus N times its mean, minus mean(g xhat) times sum of xhat = 0).  The reference's autograd
 			# gets rounding noise around 0 from the column sum of dry; here the entry is set to exact zero and the pass is skipped.
+			arena = getattr(rw, '_convasr_grad', None) is not None and (rb is None or getattr(rb, '_convasr_grad', None) is not None)
+			if GROUP_RES and arena and rw.requires_grad and dt in ops.HALF_DTYPES and rx.shape[1] % 128 == 0 and Cout % 128 == 0 and (rb is None or rb.requires_grad):
+				wg_group.append((r, rx, dry))  # all such branches' weight gradients in one dispatch, below
+				res_grads[5 * r:5 * r + 5] = [drx, None, None, drg, drbeta]
+				continue
 			def res_wgrad(outs, acc, rx = rx, dry = dry, rb = rb):
 				ops.conv1d_wgrad(rx, dry, Cout, 1, 1, 1, 0, outs[0], accumulate = acc)
 				if outs[1] is not None and not acc and not (outs[1] is getattr(rb, '_convasr_grad', None) and getattr(rb, '_convasr_grad_is_zero', False)):
@@ -573,7 +579,7 @@ class ConvBnActFunction(torch.autograd.Function):
 					# the arena segment of this bias gradient is written by nobody else (zero at allocation, zero again now, sums of zeros
 					# under data parallelism): later steps skip the fill -- dense blocks carry up to ten such biases
 					rb._convasr_grad_is_zero = outs[1] is getattr(rb, '_convasr_grad', None)
-			if RES_WGRAD_SIDE and getattr(rw, '_convasr_grad', None) is not None and getattr(rb, '_convasr_grad', rw._convasr_grad) is not None:
+			if RES_WGRAD_SIDE and arena:
 				# gradient arenas: the weight gradient of the branch goes to the wgrad side stream like the main conv's (it only reads rx and dry
 				# and writes the arena: the consumers of the arena join that stream, functional.join_side_streams / the data-parallel engine)
 				drw, drb = _run_wgrad(dry.device, (rx, dry), lambda: _deliver([rw, rb], res_wgrad))
@@ -592,6 +598,29 @@ class ConvBnActFunction(torch.autograd.Function):
 			done = ops.conv1x1_grouped([dry for _, dry in pending], [packed_weight(ctx.params[3 + 4 * r], dt, _lib.PACK_DGRAD) for r, _ in pending], [res_x[r].shape[1] for r, _ in pending], outs = [a['buf'] for a in accs], accumulate = [not fr for fr in fresh])
 			if done is None:
 				raise _lib.ConvasrHipError('grouped input gradient of the residual branches: a shape left the one-tap kernel\'s envelope between forward and backward')
+		if wg_group:
+			ps = [(ctx.params[3 + 4 * r], ctx.params[3 + 4 * r + 1]) for r, _, _ in wg_group]
+			fresh = [bool(getattr(w, '_convasr_fresh', True)) for w, _ in ps]
+			if any(b is not None and bool(getattr(b, '_convasr_fresh', True)) != fr for (_, b), fr in zip(ps, fresh)):
+				raise _lib.ConvasrHipError('gradient arenas of one residual branch are out of step (mixed fresh / accumulated state)')
+
+			def run():
+				# a fresh bias gradient is zeroed by the combine kernel (no flag to go stale: every step rewrites it); an accumulated one gets += 0
+				ok = ops.wgrad1x1_grouped([rx for _, rx, _ in wg_group], [dry for _, _, dry in wg_group], [w._convasr_grad for w, _ in ps], zeros = [b._convasr_grad if (b is not None and fr) else None for (_, b), fr in zip(ps, fresh)], accumulate = [not fr for fr in fresh])
+				if not ok:
+					raise _lib.ConvasrHipError('grouped weight gradient of the residual branches: a shape outside the kernel\'s envelope')
+			if RES_WGRAD_SIDE:
+				_run_wgrad(dev, tuple(t for _, rx, dry in wg_group for t in (rx, dry)), run)
+			else:
+				run()
+			for w, b in ps:
+				for p_ in (w, b):
+					if p_ is not None:
+						p_._convasr_fresh = False
+						p_._convasr_grad_is_zero = False
+						hook = getattr(p_, '_convasr_ready', None)
+						if hook is not None:
+							hook(p_)
 		return (None, dx, dw, dgamma, dbeta, None, *res_grads)
 
 

@@ -255,6 +255,30 @@ def conv1x1_grouped(xs, wps, couts, biases = None, stats = None, outs = None, ac
 	return ys
 
 
+_wgrad_group_ws = {}
+
+
+def wgrad1x1_grouped(xs, dys, dws, zeros = None, accumulate = None):
+	"""dws[i] (Cout_i, Cin_i, 1) fp32 (+)= the one-tap weight gradient of (xs[i], dys[i]); zeros[i] (optional): a (Cout_i,) fp32 tensor set to
+	zero (the branch's bias gradient).  One dispatch + one combine for all problems.  Returns False (nothing launched) outside the envelope."""
+	n = len(xs)
+	B, _, T = xs[0].shape
+	dt = xs[0].dtype
+	cins, couts = [x.shape[1] for x in xs], [dy.shape[1] for dy in dys]
+	if n == 0 or n > 12 or dt not in HALF_DTYPES or any(c % 128 for c in cins + couts) or any(not is_cl(t) or t.dtype != dt or t.shape[0] != B or t.shape[2] != T for t in list(xs) + list(dys)):
+		return False
+	for dw, ci, co in zip(dws, cins, couts):
+		assert dw.dtype == torch.float32 and tuple(dw.shape) == (co, ci, 1) and (dw.is_contiguous() or (dw.stride(0) == ci and dw.stride(1) == 1)), (dw.shape, dw.stride())
+	key = (tuple(cins), tuple(couts), B, T)
+	nb = _wgrad_group_ws.get(key)
+	if nb is None:
+		nb = _wgrad_group_ws[key] = _lib.load().convasr_wgrad1x1_grouped_workspace_bytes(n, _int_array(cins), _int_array(couts), B, T)
+	ws = workspace(nb, xs[0].device, 'wgrad')
+	_lib.timed('conv1d_wgrad', 2.0 * B * T * sum(ci * co for ci, co in zip(cins, couts)), lambda: call('convasr_wgrad1x1_grouped', n, _ptr_array(xs), _ptr_array(dys), _ptr_array(dws), _ptr_array(zeros) if zeros else None,
+		_int_array(cins), _int_array(couts), _int_array(accumulate) if accumulate else None, ptr(ws), dtype_code(dt), B, T, stream_ptr()))
+	return True
+
+
 def add16(a, b, out = None):
 	"""out = a + b for two 16-bit tensors of the same (channels-last) layout; in place when out is a or b."""
 	assert a.dtype == b.dtype and a.dtype in HALF_DTYPES and a.shape == b.shape and a.stride() == b.stride() and a.numel() % 8 == 0

@@ -328,6 +328,15 @@ int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamm
  * it alone (bit-identical per element).  cin[i] % 64 == 0, cout[i] % 128 == 0, else CONVASR_EUNSUPPORTED (launch them one by one). */
 int convasr_conv1x1_grouped(int n, const void* const* x, const void* const* w, void* const* y, const float* const* bias, double* const* stats,
                             const int* cin, const int* cout, const int* accumulate, int dtype, int B, int T, int* stats_rows, void* stream);
+/* The weight gradients of the same n branches, dw_i[co][ci] (+)= sum over (b, t) of dy_i[b, t, co] * x_i[b, t, ci] (fp32, cout[i] x cin[i],
+ * the memory order of a one-tap (Cout, Cin, 1) parameter in either layout), in ONE dispatch of the LDS-DMA weight-gradient kernel over all
+ * problems' (co tile, ci tile, split) units + ONE streaming combine of the split-K slabs (deterministic: fixed order, no atomics).
+ * zero (array or NULL; entries may be NULL): cout[i] floats set to zero by the combine -- the branch conv's bias gradient, identically zero
+ * ahead of a train-mode batch norm.  accumulate (array or NULL): add into dw_i.  workspace: convasr_wgrad1x1_grouped_workspace_bytes()
+ * bytes.  cin[i] % 128 == 0 and cout[i] % 128 == 0, else CONVASR_EUNSUPPORTED. */
+int64_t convasr_wgrad1x1_grouped_workspace_bytes(int n, const int* cin, const int* cout, int B, int T);
+int convasr_wgrad1x1_grouped(int n, const void* const* x, const void* const* dy, float* const* dw, float* const* zero, const int* cin, const int* cout,
+                             const int* accumulate, void* workspace, int dtype, int B, int T, void* stream);
 /* out = a + b over n 16-bit values (n % 8 == 0; in place allowed): the one explicit add a tapped block output's gradient needs (the main
  * path's input gradient + the branches' accumulated ones), in place of autograd's InputBuffer accumulation (models.py:129-131 backward). */
 int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);

@@ -195,7 +195,46 @@ def test_step_graphs_replayed_masks_change_from_step_to_step():
 	opt = ca.train.SGD(flat, lr = 0.0, momentum = 0.0, weight_decay = 0.0)
 	stepper = ca.train.GraphedTrainStep(model, opt, warmup = 1)
 	losses = [float(stepper(*b, iteration = it)['loss']) for it in range(6)]
-	assert stepper.replays == 4 and len(set(losses)) == 6, losses
+	assert stepper.replays == 5 and len(set(losses)) == 6, losses
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_grouped_residual_launches_match_the_launch_per_branch_path(dt):
+	"""A dense block's residual branches in grouped launches (one dispatch for the 1x1 convs + bias + BN statistics, one for their input
+	gradients -- accumulated straight into the tapped outputs' gradient buffers instead of autograd's pairwise adds --, one for their
+	weight gradients + combine) against a launch per branch: the forward pass is bit-identical (every problem of a grouped launch is computed
+	exactly as alone), gradients agree to the rounding of the 16-bit gradient sums (a different association of the same addends)."""
+	import convasr_amd as ca
+	from convasr_amd import functional as Fn
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = _batches(d, 1, [(4, 5)])[0]
+	res = {}
+	for grouped in (False, True):
+		prev, Fn.GROUP_RES = Fn.GROUP_RES, grouped
+		try:
+			model = _dense_small(ca, d, dt, 0.0)
+			for blk in model.backbone:
+				blk.compute_dtype = dt
+			flat = ca.train.FlatParameters(model)
+			out = model(x, xlen, y = y, ylen = ylen)
+			out['loss'].sum().backward()
+			Fn.join_side_streams()
+			flat.finalize_grads()
+			torch.cuda.synchronize()
+			res[grouped] = (out['loss'].detach().clone(), out['logits'][0].detach().clone(), flat.grad.clone(), {n: p._convasr_grad.clone() for n, p in model.named_parameters()})
+		finally:
+			Fn.GROUP_RES = prev
+	assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+	worst = 0.0
+	for n, ga in res[False][3].items():
+		gb = res[True][3][n]
+		if 'conv_residual' in n and n.endswith('bias'):
+			assert float(gb.abs().max()) == 0.0 and float(ga.abs().max()) == 0.0, n
+			continue
+		cos, rel = _cos_rel(gb, ga)
+		worst = max(worst, rel)
+		assert cos >= 0.9999 and rel <= (2e-2 if dt == torch.bfloat16 else 3e-3), (n, cos, rel)
+	print('grouped vs per-branch: worst relative L2 gradient difference', worst)
 
 
 def test_residual_bias_gradient_is_zero_again_after_a_pass_through_eval_mode_batch_norm():
