@@ -24,4 +24,15 @@ PY
 		done
 	done
 	tail -20 gpurun_out/${tag}_ab.err ;;
+prof)
+	# rocprofv3 kernel statistics of a bench run: scratch/r5_run.sh <tag> prof <steps+warmup+3 total steps> <bench args>
+	n=$1; shift
+	cd /tmp && export TMPDIR=/tmp
+	rm -rf $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof
+	timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-traffic --no-kernel-timer --no-f16-leg --no-jasper-leg > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof_line.json 2> $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.err
+	cd $GRAFT_REPO_ROOT
+	cp $(find gpurun_out/${tag}_prof -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats.csv
+	python scratch/kstat.py gpurun_out/${tag}_prof $n 45
+	cat gpurun_out/${tag}_prof_line.json | cut -c1-400
+	rm -rf gpurun_out/${tag}_prof ;;
 esac

@@ -221,7 +221,7 @@ def test_grouped_residual_launches_match_the_launch_per_branch_path(dt):
 			Fn.join_side_streams()
 			flat.finalize_grads()
 			torch.cuda.synchronize()
-			res[grouped] = (out['loss'].detach().clone(), out['logits'][0].detach().clone(), flat.grad.clone(), {n: p._convasr_grad.clone() for n, p in model.named_parameters()})
+			res[grouped] = (out['loss'].detach().clone(), out['logits'][0].detach().clone(), flat.grad.clone(), {n: p._convasr_grad.clone() for n, p in model.named_parameters() if hasattr(p, '_convasr_grad')})
 		finally:
 			Fn.GROUP_RES = prev
 	assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
