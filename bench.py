@@ -65,20 +65,21 @@ def parse_args(argv = None):
 	ap.add_argument('--no-f16-leg', action = 'store_true', help = 'skip the second timed region in fp16 (parity.f16_value)')
 	ap.add_argument('--no-traffic', action = 'store_true', help = 'skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic in this run')
 	ap.add_argument('--side-stream', default = 'auto', choices = ['auto', 'on', 'off'], nargs = '?', const = 'on',
-		help = 'run wgrad on a second HIP stream beside the dgrad of the same layer.  auto: on for jasper_large (launches of 0.5-3 rounds leave CUs idle: +2 % measured), '
-			'off for wav2letter (launches fill the chip: -1 %).  With the side stream on, every per-kernel HIP-event duration (the dominant kernel included) is measured in the '
+		help = 'run wgrad on a second HIP stream beside the dgrad of the same layer.  auto: on for jasper_large (launches of 0.5-3 rounds leave CUs idle: +2 %% measured), '
+			'off for wav2letter (launches fill the chip: -1 %%).  With the side stream on, every per-kernel HIP-event duration (the dominant kernel included) is measured in the '
 			'second pass, where the side stream is switched off again: overlapped launches would inflate each other')
 	ap.add_argument('--graph', default = 'auto', choices = ['auto', 'on', 'off'], nargs = '?', const = 'on',
 		help = 'replay the training step from HIP graphs, one per batch shape (convasr_amd.train.GraphedTrainStep); jasper_large batches are then padded to their bucket\'s '
-			'ceiling (one shape per bucket).  auto: on with one rank (N > 1 stays eager: RCCL has not run under capture on this pool).  With graphs on, per-kernel HIP-event '
-			'durations come from the second, eager pass')
+			'ceiling (one shape per bucket).  auto: on for jasper_large with one rank (~1,000 launches and ~20 ms of Python per ~38 ms step; a replay costs the host ~3 ms, and the replayed step itself is ~2 %% slower than the eager one '
+			'with the wgrad side stream, whose time the line also reports), off for wav2letter (~110 launches, GPU-bound either way: +-0 measured, and the dominant kernel stays event-timed '
+			'inside the timed region) and for N > 1 (RCCL has not run under capture on this pool).  With graphs on, per-kernel HIP-event durations come from the second, eager pass')
 	ap.add_argument('--no-jasper-leg', action = 'store_true', help = 'skip the bounded BASELINE configs[4] leg (extra.jasper_large) of the default line')
 	ap.add_argument('--launcher-dry-run', action = 'store_true', help = 'test hook: ranks only rendezvous (gloo, CPU tensors) and rank 0 prints a line; exercises the self-launch path without a GPU')
 	args = ap.parse_args(argv)
 	if args.dtype is None:
 		args.dtype = 'f16' if args.workload == 'jasper_large' else 'bf16'
 	args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.workload == 'jasper_large')
-	args.graph = args.graph == 'on' or (args.graph == 'auto' and args.gpus == 1 and os.environ.get('CONVASR_FORCE_DIST') != '1')
+	args.graph = args.graph == 'on' or (args.graph == 'auto' and args.workload == 'jasper_large' and args.gpus == 1 and os.environ.get('CONVASR_FORCE_DIST') != '1')
 	return args
 
 
@@ -699,7 +700,7 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 			note = 'apex dynamic loss scaling (2^16, x2 per 2000 clean steps, /2 and skip on overflow); an overflowed step skips only the optimizer update')
 	graph_info = None
 	if graphed:
-		graph_info = dict(enabled = True, graphs = wl.stepper.captures, replays = wl.stepper.replays, eager_warmup_steps = wl.stepper.eager_steps, extra_untimed_warmup_steps = run_timed.extra_warmup,
+		graph_info = dict(enabled = True, linear_capture = wl.stepper.linear, graphs = wl.stepper.captures, replays = wl.stepper.replays, eager_warmup_steps = wl.stepper.eager_steps, extra_untimed_warmup_steps = run_timed.extra_warmup,
 			note = 'every timed step is one hipGraphLaunch of the whole iteration (forward, CTC, backward, clip, optimizer), one graph per batch shape; the per-step inputs are copied into the graph\'s static buffers inside the timed region')
 	# host time of a step with the GPU drained first (the enqueue never waits for queue space): how far ahead of the GPU the Python side
 	# can run.  Eagerly the Wav2Letter step needs ~4 ms of it for 16 ms of GPU work and a JasperNetLarge step ~20 ms for ~44 (1,200 launches:
@@ -711,6 +712,24 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 		step(args.warmup + args.steps + i)
 		host_ms.append((time.perf_counter() - h0) * 1e3)
 	fence()
+	eager_info = None
+	if graphed:
+		# the same steps launched eagerly with the weight gradients on the side stream (what --graph off times): a short reference region
+		wl.stepper.enabled = False
+		ca.functional.enable_side_stream_wgrad(device, True)
+		n_e = min(args.steps, 8)
+		for i in range(2):
+			step(args.warmup + args.steps + i)
+		fence()
+		e0 = time.perf_counter()
+		for i in range(n_e):
+			step(args.warmup + i)
+		fence()
+		e_el = time.perf_counter() - e0
+		e_idx = [wl.batch_of(args.warmup + i) for i in range(n_e)]
+		eager_info = dict(ms_per_step = round(1e3 * e_el / n_e, 3), steps = n_e, value = round(sum(wl.audio[j][0] for j in e_idx) / e_el, 1),
+			whole_step_frac = round(sum(wl.flops[j][0] + wl.flops[j][1] for j in e_idx) / e_el / PEAK_BF16_DENSE, 4),
+			note = 'the same steps launched kernel by kernel (Python enqueues ~1,000 launches per step) with the weight gradients on a side stream, timed right after the graph-replayed region on the same device')
 	steps2, kt2, sequence2, calls2 = 0, {}, [], None
 	ca.functional.join_side_streams()
 	ca.functional.enable_side_stream_wgrad(device, False)  # the event-timed pass below runs every kernel alone on the main stream, eagerly
@@ -758,7 +777,7 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
 			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', side_stream_wgrad = bool(args.side_stream), step_graphs = graph_info,
 				host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2), abi_calls_per_eager_step = None if calls2 is None else round(calls2, 1),
-				whole_step_frac = round(conv_flops_per_s / world / (PEAK_F32_MFMA if args.dtype == 'f32' else PEAK_BF16_DENSE), 4), device_state = device_state),
+				whole_step_frac = round(conv_flops_per_s / world / (PEAK_F32_MFMA if args.dtype == 'f32' else PEAK_BF16_DENSE), 4), eager_side_stream = eager_info, device_state = device_state),
 			loss = round(float(last['loss']), 4), loss_scaler = scaler_info, dist = dist_info, roofline = roof, parity = None)
 		if args.workload == 'jasper_large':
 			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),
@@ -857,7 +876,7 @@ def main(argv = None):
 			rj = lj['roofline'] or {}
 			line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 8, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],
 				dominant_kernel_frac = rj.get('frac'), wgrad_frac = (rj.get('wgrad') or {}).get('frac'), conv_stack_frac = (rj.get('conv_stack') or {}).get('frac'),
-				host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
+				host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], eager_side_stream = lj['config']['eager_side_stream'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
 				side_stream_wgrad = True, batch_shapes_in_timed_region = lj['config'].get('batch_shapes_in_timed_region'), padding_overhead = lj['config'].get('padding_overhead'),
 				loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], workload = lj['config']['workload'],
 				note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: python bench.py --workload jasper_large runs the same thing longer'))

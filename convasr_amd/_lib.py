@@ -68,6 +68,11 @@ _SIGNATURES = dict(
 	convasr_step_begin = (c_int, [c_p, c_p]),
 	convasr_conv1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_p]),
 	convasr_add16 = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
+	convasr_pack_dgrad_item_bytes = (c_int, []),
+	convasr_pack_dgrad_grouped = (c_int, [c_p, c_int, c_int, c_p]),
+	convasr_bn_finalize_grouped = (c_int, [c_int, c_p, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p]),
+	convasr_bn_bwd_finalize_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_p]),
+	convasr_bn_bwd_apply_grouped = (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_wgrad1x1_grouped_workspace_bytes = (c_i64, [c_int, c_p, c_p, c_int, c_int]),
 	convasr_wgrad1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
 	convasr_copy = (c_int, [c_p, c_p, c_i64, c_p]),

@@ -36,9 +36,9 @@ template <typename P> __device__ __forceinline__ bool finalize_rows(const P* __r
 	return true;
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ stats, int rows, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
-                                                            float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt) {
+__device__ __forceinline__ void bn_finalize_body(const double* __restrict__ stats, int rows, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+                                                 float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt) {
 	__shared__ double red[2][FIN_LANES][FIN_CH];
 	const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
 	if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
@@ -59,6 +59,42 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 		rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
 		rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
 	}
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ stats, int rows, double n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C, long long* __restrict__ nbt) {
+	bn_finalize_body(stats, rows, n, gamma, beta, rmean, rvar, momentum, eps, mean, invstd, scale, shift, C, nbt);
+}
+
+// the same for up to BN_MAX_GROUP batch norms of one channel count in one launch (blockIdx.y = which): the residual branches of a dense block
+#define BN_MAX_GROUP 13
+struct BnFinGroup {
+	const double* stats[BN_MAX_GROUP]; const float* gamma[BN_MAX_GROUP]; const float* beta[BN_MAX_GROUP]; float* rmean[BN_MAX_GROUP]; float* rvar[BN_MAX_GROUP];
+	float* out[BN_MAX_GROUP];  // 4 C floats each: mean, invstd, scale, shift
+	long long* nbt[BN_MAX_GROUP];
+	float momentum[BN_MAX_GROUP], eps[BN_MAX_GROUP];
+};
+__global__ __launch_bounds__(1024) void bn_finalize_grouped_kernel(BnFinGroup g, int rows, double n, int C) {
+	const int q = blockIdx.y;
+	float* const o = g.out[q];
+	bn_finalize_body(g.stats[q], rows, n, g.gamma[q], g.beta[q], g.rmean[q], g.rvar[q], g.momentum[q], g.eps[q], o, o + C, o + 2 * C, o + 3 * C, C, g.nbt[q]);
+}
+
+extern "C" int convasr_bn_finalize_grouped(int count, const double* const* stats, int stats_rows, int64_t n, const float* const* gamma, const float* const* beta,
+                                           float* const* running_mean, float* const* running_var, const float* momentum, const float* eps, float* const* out,
+                                           int64_t* const* num_batches_tracked, int C, void* stream) {
+	CONVASR_CHECK_ARG(count > 0 && count <= BN_MAX_GROUP && stats && out && momentum && eps && stats_rows > 0 && n > 0 && C > 0, "bn_finalize_grouped: bad arguments (at most %d batch norms)", BN_MAX_GROUP);
+	BnFinGroup g = {};
+	for (int i = 0; i < count; ++i) {
+		CONVASR_CHECK_ARG(stats[i] && out[i], "bn_finalize_grouped: batch norm %d has a NULL buffer", i);
+		g.stats[i] = stats[i]; g.gamma[i] = gamma ? gamma[i] : nullptr; g.beta[i] = beta ? beta[i] : nullptr; g.rmean[i] = running_mean ? running_mean[i] : nullptr;
+		g.rvar[i] = running_var ? running_var[i] : nullptr; g.out[i] = out[i]; g.nbt[i] = num_batches_tracked ? (long long*)num_batches_tracked[i] : nullptr;
+		g.momentum[i] = momentum[i]; g.eps[i] = eps[i];
+	}
+	hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH, count), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, g, stats_rows, (double)n, C);
+	CONVASR_CHECK_LAUNCH("bn_finalize_grouped");
+	return 0;
 }
 
 extern "C" int convasr_bn_finalize(const double* stats, int stats_rows, int64_t n, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -575,6 +611,106 @@ extern "C" int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const 
 	sets.accumulate = accumulate; sets.invn = 1.0f / (float)n;
 	hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, sums, sums_rows, sets, C);
 	CONVASR_CHECK_LAUNCH("bn_bwd_finalize");
+	return 0;
+}
+
+// Grouped forms for a dense block's backward (main batch norm + up to twelve residual-branch batch norms of the same channel count):
+// one finalize launch (blockIdx.y = which), one apply launch that reads g ONCE and writes every dy_i = A_i g + B_i y_i + D_i.
+struct BnBwdFinGroup { const double* sums[BN_MAX_GROUP]; BnFinalizeSets sets[BN_MAX_GROUP]; int rows[BN_MAX_GROUP]; };
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_grouped_kernel(BnBwdFinGroup g, int C) {
+	__shared__ double red[2][FIN_LANES][FIN_CH];
+	const int q = blockIdx.y;
+	const BnFinalizeSets& sets = g.sets[q];
+	const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+	double sg, sgx;
+	if (!finalize_rows(g.sums[q], g.rows[q], C, red, sg, sgx)) return;
+	if (sets.coef) {
+		const float gm = sets.gamma ? sets.gamma[c] : 1.f, is = sets.invstd[c], m = sets.mean[c];
+		const float msg = (float)sg * sets.invn, msgx = (float)sgx * sets.invn;
+		sets.coef[c] = gm * is;
+		sets.coef[C + c] = -gm * is * is * msgx;
+		sets.coef[2 * C + c] = gm * is * (m * is * msgx - msg);
+	}
+	if (sets.dgamma) sets.dgamma[c] = sets.accumulate ? sets.dgamma[c] + (float)sgx : (float)sgx;
+	if (sets.dbeta) sets.dbeta[c] = sets.accumulate ? sets.dbeta[c] + (float)sg : (float)sg;
+}
+
+extern "C" int convasr_bn_bwd_finalize_grouped(int count, const double* const* sums, const int* sums_rows, const float* const* gamma, const float* const* mean,
+                                               const float* const* invstd, float* const* coef, float* const* dgamma, float* const* dbeta, const int* accumulate,
+                                               int64_t n, int C, void* stream) {
+	CONVASR_CHECK_ARG(count > 0 && count <= BN_MAX_GROUP && sums && sums_rows && mean && invstd && n > 0 && C > 0, "bn_bwd_finalize_grouped: bad arguments (at most %d batch norms)", BN_MAX_GROUP);
+	BnBwdFinGroup g = {};
+	for (int i = 0; i < count; ++i) {
+		CONVASR_CHECK_ARG(sums[i] && sums_rows[i] > 0 && mean[i] && invstd[i], "bn_bwd_finalize_grouped: batch norm %d has a NULL buffer", i);
+		g.sums[i] = sums[i]; g.rows[i] = sums_rows[i];
+		BnFinalizeSets& t = g.sets[i];
+		t.gamma = gamma ? gamma[i] : nullptr; t.mean = mean[i]; t.invstd = invstd[i]; t.coef = coef ? coef[i] : nullptr; t.dgamma = dgamma ? dgamma[i] : nullptr; t.dbeta = dbeta ? dbeta[i] : nullptr;
+		t.accumulate = accumulate ? accumulate[i] : 0; t.invn = 1.0f / (float)n;
+	}
+	hipLaunchKernelGGL(bn_bwd_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH, count), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, g, C);
+	CONVASR_CHECK_LAUNCH("bn_bwd_finalize_grouped");
+	return 0;
+}
+
+struct BnApplyGroup { const void* y[BN_MAX_GROUP]; const float* coef[BN_MAX_GROUP]; void* dy[BN_MAX_GROUP]; int n; };
+#define GA_ROWS 8
+// thread = 8 channels x GA_ROWS rows (rows rl, rl + rlanes, ...): its g values stay in registers (packed) while it walks the problems; per
+// problem the 24 coefficients are loaded once and the GA_ROWS y loads are issued together.
+template <typename T> __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_kernel(const T* __restrict__ g, BnApplyGroup grp, int64_t rows, int C, int cgroups, int rlanes) {
+	const int c8 = C >> 3;
+	const int cg = blockIdx.y * cgroups + threadIdx.x % cgroups, rl = threadIdx.x / cgroups;
+	if (cg >= c8) return;
+	const int c = cg << 3;
+	const int64_t r0 = (int64_t)blockIdx.x * (rlanes * GA_ROWS) + rl;
+	uint4 gr[GA_ROWS];
+#pragma unroll
+	for (int k = 0; k < GA_ROWS; ++k) {
+		const int64_t r = r0 + (int64_t)k * rlanes;
+		gr[k] = r < rows ? *reinterpret_cast<const uint4*>(g + r * C + c) : make_uint4(0u, 0u, 0u, 0u);
+	}
+	for (int q = 0; q < grp.n; ++q) {
+		const T* const y = reinterpret_cast<const T*>(grp.y[q]);
+		T* const dy = reinterpret_cast<T*>(grp.dy[q]);
+		const float* const coef = grp.coef[q];
+		float A[8], Bc[8], D[8];
+		load8<float>(coef + c, A);
+		load8<float>(coef + C + c, Bc);
+		load8<float>(coef + 2 * C + c, D);
+		uint4 yr[GA_ROWS];
+#pragma unroll
+		for (int k = 0; k < GA_ROWS; ++k) {
+			const int64_t r = r0 + (int64_t)k * rlanes;
+			yr[k] = r < rows ? *reinterpret_cast<const uint4*>(y + r * C + c) : make_uint4(0u, 0u, 0u, 0u);
+		}
+#pragma unroll
+		for (int k = 0; k < GA_ROWS; ++k) {
+			const int64_t r = r0 + (int64_t)k * rlanes;
+			if (r >= rows) continue;
+			float gv[8], yv[8], out[8];
+			unpack16<T>(gr[k], gv);
+			unpack16<T>(yr[k], yv);
+#pragma unroll
+			for (int e = 0; e < 8; ++e) out[e] = fmaf(A[e], gv[e], fmaf(Bc[e], yv[e], D[e]));
+			store8<T>(dy + r * C + c, out);
+		}
+	}
+}
+
+extern "C" int convasr_bn_bwd_apply_grouped(const void* g, int count, const void* const* y, const float* const* coef, void* const* dy, int dtype, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(g && count > 0 && count <= BN_MAX_GROUP && y && coef && dy && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_bwd_apply_grouped: bad arguments (at most %d outputs, C a multiple of 8)", BN_MAX_GROUP);
+	if (!convasr_is_half(dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_bwd_apply_grouped: dtype %d (16-bit storage only)", dtype);
+	BnApplyGroup grp = {};
+	grp.n = count;
+	for (int i = 0; i < count; ++i) {
+		CONVASR_CHECK_ARG(y[i] && coef[i] && dy[i], "bn_bwd_apply_grouped: output %d has a NULL buffer", i);
+		grp.y[i] = y[i]; grp.coef[i] = coef[i]; grp.dy[i] = dy[i];
+	}
+	const int c8 = C >> 3, cgroups = c8 < 256 ? c8 : 256, rlanes = 256 / cgroups;
+	const int64_t rows = (int64_t)B * T;
+	dim3 grid((unsigned)ceil_div64(rows, (int64_t)rlanes * GA_ROWS), (unsigned)((c8 + cgroups - 1) / cgroups)), block(cgroups * rlanes);
+	if (dtype == CONVASR_F16) hipLaunchKernelGGL((bn_bwd_apply_grouped_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (const f16_t*)g, grp, rows, C, cgroups, rlanes);
+	else hipLaunchKernelGGL((bn_bwd_apply_grouped_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)g, grp, rows, C, cgroups, rlanes);
+	CONVASR_CHECK_LAUNCH("bn_bwd_apply_grouped");
 	return 0;
 }
 

@@ -306,6 +306,52 @@ __global__ __launch_bounds__(256) void pack_dgrad_half2_kernel(const unsigned sh
 	}
 }
 
+// The same transpose for MANY layers in one launch: item i = {src, dst, Cout, Cin, K, co_pad, ci_pad, first block}; a block finds its item by
+// a search over the (device-resident, persistent) table.  The dense-residual networks re-pack ~110 dgrad operands per step, 2.5 M weights
+// on average: a launch each ran at 1.3 TB/s (7.7 us apiece, 0.83 ms per JasperNetLarge step).
+struct PackItem { const unsigned short* src; unsigned short* dst; int Cout, Cin, K, co_pad, ci_pad, first; };
+__global__ __launch_bounds__(256) void pack_dgrad_grouped_kernel(const PackItem* __restrict__ items, int n_items) {
+	__shared__ unsigned short tile[64][66];
+	int lo = 0, hi = n_items - 1;  // the last item whose first block is <= blockIdx.x
+	while (lo < hi) {
+		const int mid = (lo + hi + 1) >> 1;
+		if (items[mid].first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+	}
+	const PackItem it = items[lo];
+	const int local = blockIdx.x - it.first;
+	const int nci = (it.Cin + 63) / 64, nco = (it.Cout + 63) / 64;
+	const int ci0 = (local % nci) * 64, co0 = ((local / nci) % nco) * 64, k = local / (nci * nco);
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	const unsigned short* src = it.src + (int64_t)k * it.co_pad * it.Cin;
+	unsigned short* dst = it.dst + (int64_t)(it.K - 1 - k) * it.ci_pad * it.Cout;
+#pragma unroll 4
+	for (int i = 0; i < 8; ++i) {
+		const int co = co0 + ty + 8 * i, ci = ci0 + 2 * tx;
+		if (co < it.Cout && ci < it.Cin) {
+			const unsigned v = *reinterpret_cast<const unsigned*>(src + (int64_t)co * it.Cin + ci);
+			tile[ty + 8 * i][2 * tx] = (unsigned short)(v & 0xffffu);
+			tile[ty + 8 * i][2 * tx + 1] = (unsigned short)(v >> 16);
+		}
+	}
+	__syncthreads();
+#pragma unroll 4
+	for (int i = 0; i < 8; ++i) {
+		const int ci = ci0 + ty + 8 * i, co = co0 + 2 * tx;
+		if (co < it.Cout && ci < it.Cin)
+			*reinterpret_cast<unsigned*>(dst + (int64_t)ci * it.Cout + co) = (unsigned)tile[2 * tx][ty + 8 * i] | ((unsigned)tile[2 * tx + 1][ty + 8 * i] << 16);
+	}
+}
+
+extern "C" int convasr_pack_dgrad_item_bytes(void) { return (int)sizeof(PackItem); }
+// items: n_items records of convasr_pack_dgrad_item_bytes() bytes in DEVICE memory, laid out as {src pointer, dst pointer, Cout, Cin, K,
+// co_pad, ci_pad, first block} (two 64-bit words, six 32-bit ones); total_blocks = the sum of K * ceil(Cout / 64) * ceil(Cin / 64).
+extern "C" int convasr_pack_dgrad_grouped(const void* items, int n_items, int total_blocks, void* stream) {
+	CONVASR_CHECK_ARG(items && n_items > 0 && total_blocks > 0, "pack_dgrad_grouped: bad arguments");
+	hipLaunchKernelGGL(pack_dgrad_grouped_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items, n_items);
+	CONVASR_CHECK_LAUNCH("pack_dgrad_grouped");
+	return 0;
+}
+
 // K-major master weights (CONVASR_W_KMAJOR: w[k][co][ci], the layout of the MI355X training arena) -> packed forward copy: the
 // element order is already the packed one, so this is a streaming cast (8 elements per lane) into rows < Cout of each tap.
 template <typename T>

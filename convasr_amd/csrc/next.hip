@@ -87,6 +87,7 @@ template <typename H> __global__ __launch_bounds__(256) void ng_step_kernel(NgPa
 	const double total_sq = red[0] + red[1] + red[2] + red[3];
 	const LossScale ls = loss_scale_read(q.scaler_in, q.scaler_in ? total_sq : 0.0);
 	if (q.scaler_in && blockIdx.x == 0 && threadIdx.x == 0) loss_scale_advance(q.scaler_in, q.scaler_out, ls.overflow, gated);
+	if (blockIdx.x == 0 && threadIdx.x == 0 && q.norm_out) *q.norm_out = (float)sqrt(total_sq) * q.grad_scale * ls.inv;  // (also on a skipped step: inf / NaN after an overflow, like clip_grad_norm_ would return)
 	if (gated || ls.overflow) {  // skipped step: nothing changes; the caller still swaps its two EMA buffers, so carry the EMAs over
 		if (blockIdx.x == 0)
 			for (int s = threadIdx.x; s < n_carry; s += 256) q.ema_out[s] = q.ema_in[s];
@@ -103,7 +104,6 @@ template <typename H> __global__ __launch_bounds__(256) void ng_step_kernel(NgPa
 		float c = 1.f;
 		if (q.max_norm > 0.f) { c = q.max_norm / (total + 1e-6f); c = c < 1.f ? c : 1.f; }
 		s_clip = c * q.grad_scale;
-		if (blockIdx.x == 0 && q.norm_out) *q.norm_out = total;
 	}
 	__syncthreads();
 	const float clip = s_clip;

@@ -98,8 +98,47 @@ PREPACK = os.environ.get('CONVASR_NO_PREPACK') != '1'  # A/B hook
 _prepack_streams = {}  # device -> [side stream, packs pending on it?]
 
 
+_pack_tables = {}  # (device, dtype) -> dict(key = the (src, dst) addresses it was built for, items = device table, blocks)
+
+
+def _pack_dgrad_many(stale, dtype):
+	"""The transposed dgrad copies of the `stale` weights: ONE launch for all those whose packed forward copy is current and 16-bit (the
+	arena mirror's segments, or a forward pack refreshed here), a launch each for the rest."""
+	import struct
+	group = []
+	if dtype in ops.HALF_DTYPES and len(stale) > 1:
+		for w in stale:
+			fwd = packed_weight(w, dtype, _lib.PACK_FWD)  # (no launch when the optimizer's 16-bit mirror serves it)
+			ent = _pack_cache[(id(w), dtype)]
+			Cout, Cin, K = w.shape
+			if ent['dgr'] is not None and Cout % 2 == 0 and Cin % 2 == 0 and fwd.dtype == dtype:
+				group.append((w, ent, fwd))
+	grouped = {id(w) for w, _, _ in group}
+	for w in stale:
+		if id(w) not in grouped:
+			packed_weight(w, dtype, _lib.PACK_DGRAD)
+	if not group:
+		return
+	dev = group[0][0].device
+	key = tuple((fwd.data_ptr(), ent['dgr'].data_ptr()) for _, ent, fwd in group)
+	tab = _pack_tables.get((dev, dtype))
+	if tab is None or tab['key'] != key:
+		assert _lib.load().convasr_pack_dgrad_item_bytes() == 40
+		blob, first = b'', 0
+		for w, ent, fwd in group:
+			Cout, Cin, K = w.shape
+			blob += struct.pack('<QQiiiiii', fwd.data_ptr(), ent['dgr'].data_ptr(), Cout, Cin, K, ops.cout_pad(Cout), ops.cout_pad(Cin), first)
+			first += K * ((Cout + 63) // 64) * ((Cin + 63) // 64)
+		if capturing():
+			raise _lib.ConvasrHipError('the dgrad pack table changed while a step graph is being captured (run one eager step with this set of weights first)')
+		tab = _pack_tables[(dev, dtype)] = dict(key = key, items = torch.frombuffer(bytearray(blob), dtype = torch.uint8).to(dev), blocks = first, n = len(group))
+	_lib.call('convasr_pack_dgrad_grouped', _lib.ptr(tab['items']), tab['n'], tab['blocks'], _lib.stream_ptr())
+	for w, ent, _ in group:
+		ent['dgr_ver'] = param_version(w)
+
+
 def prepack_dgrad_weights(weights, dtype):
-	if not PREPACK or not weights:
+	if not weights:
 		return
 	dev = weights[0].device
 	join_prepack(dev)  # (a previous step that never reached its backward pass -- a loss skipped on the host -- left its packs unjoined)
@@ -112,14 +151,16 @@ def prepack_dgrad_weights(weights, dtype):
 			stale.append(w)
 	if not stale:
 		return
+	if not PREPACK:  # (A/B hook, and what a linear step-graph capture sets: the copies are made on the main stream, still in one launch)
+		_pack_dgrad_many(stale, dtype)
+		return
 	st = _prepack_streams.get(dev)
 	if st is None:
 		st = _prepack_streams[dev] = [torch.cuda.Stream(device = dev), False]
 	side, main = st[0], torch.cuda.current_stream(dev)
 	side.wait_stream(main)  # the parameters, their 16-bit mirror and every earlier reader of the buffers are ordered before the packs
 	with torch.cuda.stream(side):
-		for w in stale:
-			packed_weight(w, dtype, _lib.PACK_DGRAD)
+		_pack_dgrad_many(stale, dtype)
 	st[1] = True
 
 
@@ -214,6 +255,33 @@ def _deliver(params, compute):
 	outs = [torch.empty_like(p, dtype = torch.float32, memory_format = torch.contiguous_format) if ok else None for p, ok in zip(params, live)]
 	compute(outs, False)
 	return outs
+
+
+def _deliver_many(groups, compute):
+	"""_deliver for several parameter groups (e.g. the (gamma, beta) pairs of a dense block's batch norms) filled by ONE launch:
+	compute(outs, accs) with outs[i] the list of fp32 outputs of group i (None where no gradient is wanted) and accs[i] its accumulate
+	flag.  Returns per group what autograd should get (None for arena parameters)."""
+	outs, accs, ret, arena_groups = [], [], [], []
+	for params in groups:
+		live = [p is not None and p.requires_grad for p in params]
+		arenas = [getattr(p, '_convasr_grad', None) if ok else None for p, ok in zip(params, live)]
+		if any(live) and all(a is not None for a, ok in zip(arenas, live) if ok):
+			fresh = {bool(getattr(p, '_convasr_fresh', True)) for p, ok in zip(params, live) if ok}
+			if len(fresh) != 1:
+				raise _lib.ConvasrHipError('gradient arenas of one layer are out of step (mixed fresh / accumulated state)')
+			outs.append(arenas); accs.append(not fresh.pop()); ret.append([None] * len(params)); arena_groups.append((params, live))
+		else:
+			o = [torch.empty_like(p, dtype = torch.float32, memory_format = torch.contiguous_format) if ok else None for p, ok in zip(params, live)]
+			outs.append(o); accs.append(False); ret.append(o)
+	compute(outs, accs)
+	for params, live in arena_groups:
+		for p, ok in zip(params, live):
+			if ok:
+				p._convasr_fresh = False
+				hook = getattr(p, '_convasr_ready', None)
+				if hook is not None:
+					hook(p)
+	return ret
 
 
 GROUP_RES = os.environ.get('CONVASR_NO_GROUPED_RES') != '1'  # A/B hook: a dense block's residual branches in grouped launches + gradient accumulators on the tapped outputs
@@ -420,12 +488,20 @@ class ConvBnActFunction(torch.autograd.Function):
 			ys = ops.conv1x1_grouped([res_x[r] for r in branches], [packed_weight(flat_res[5 * r + 1], dt, _lib.PACK_FWD) for r in branches], [Cout] * len(branches), biases = [flat_res[5 * r + 2] for r in branches], stats = sts)
 			if ys is not None:
 				ys, sts = dict(zip(branches, ys)), dict(zip(branches, sts))
+		fin = None
+		if ys is not None:  # ... and their batch norms' finalize (statistics -> mean / invstd / scale / shift, running statistics) in one launch
+			rbns = [cfg['res_bn'][r] for r in branches]
+			fin = dict(zip(branches, ops.bn_finalize_grouped([sts[r] for r in branches], B * Tout, [flat_res[5 * r + 3] for r in branches], [flat_res[5 * r + 4] for r in branches], [m.running_mean for m in rbns], [m.running_var for m in rbns],
+				[_momentum(m) for m in rbns], [m.eps for m in rbns], [m.num_batches_tracked for m in rbns])))
 		for r in range(n_res):
 			rx, rw, rb, rg, rbeta = flat_res[5 * r:5 * r + 5]
 			rx = res_x[r]
 			if rw is None:
 				res_y.append(rx)
 				res_bnp.append(None)
+			elif fin is not None:
+				res_y.append(ys[r])
+				res_bnp.append(fin[r])
 			else:
 				rbn = cfg['res_bn'][r]
 				if ys is not None:
@@ -526,8 +602,22 @@ class ConvBnActFunction(torch.autograd.Function):
 				# g is materialised by now: the extra passes reduce it against two more residual branches each, reading g and those two
 				# tensors only (identity activation on g itself) instead of re-deriving g from dz and ALL residual inputs
 				ops.bn_act_bwd_reduce(g, g, None, None, None, None, (_lib.ACT_NONE, 0.0, 0.0), res = [res_y[r] for r in batch], rscale = [None] * len(batch), rshift = [None] * len(batch), rmean = [common['rmean'][r] for r in batch], rinvstd = [common['rinvstd'][r] for r in batch], rsums = [rsum_of[r] for r in batch], write_g = False)
-			dgamma, dbeta, dy = _bn_backward_from_g(g, y, gamma, beta, bnp, sums[:2 * Cout], B * Tout)
+			grouped_bn = GROUP_RES and dt in ops.HALF_DTYPES and len(bn_idx) >= 1 and len(bn_idx) <= 12
+			if grouped_bn:
+				# pass 2 of the main batch norm and of every branch's: ONE finalize launch (sums -> coefficients, dgamma / dbeta) and ONE apply
+				# launch that reads g once and writes all the dy_i
+				coefs = torch.empty(1 + len(bn_idx), 3 * Cout, dtype = torch.float32, device = dev)
+				sets = [(gamma, beta, bnp, sums[:2 * Cout])] + [(ctx.params[3 + 4 * r + 2], ctx.params[3 + 4 * r + 3], res_bnp[r], rsum_of[r]) for r in bn_idx]
+				dgb = _deliver_many([[gm, bt] for gm, bt, _, _ in sets], lambda outs, accs: ops.bn_bwd_finalize_grouped([t[3] for t in sets], [t[0] for t in sets], [t[2][0] for t in sets], [t[2][1] for t in sets], B * Tout,
+					[coefs[i] for i in range(len(sets))], [o[0] for o in outs], [o[1] for o in outs], accs))
+				dys = ops.bn_bwd_apply_grouped(g, [y] + [res_y[r] for r in bn_idx], [coefs[i] for i in range(len(sets))])
+				(dgamma, dbeta), dy = dgb[0], dys[0]
+				grouped_bn = {r: (dgb[1 + i][0], dgb[1 + i][1], dys[1 + i]) for i, r in enumerate(bn_idx)}
+			else:
+				dgamma, dbeta, dy = _bn_backward_from_g(g, y, gamma, beta, bnp, sums[:2 * Cout], B * Tout)
 
+		if n_res == 0:
+			grouped_bn = None
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
 		if ctx.fold is not None:
 			Bx, Cin, Tin = x.shape
@@ -557,7 +647,7 @@ class ConvBnActFunction(torch.autograd.Function):
 				res_grads[5 * r] = g if need_rx else None
 				continue
 			p = res_bnp[r]
-			drg, drbeta, dry = _bn_backward_from_g(g, res_y[r], rg, rbeta, p, rsum_of[r], B * Tout)
+			drg, drbeta, dry = grouped_bn[r] if grouped_bn else _bn_backward_from_g(g, res_y[r], rg, rbeta, p, rsum_of[r], B * Tout)
 			drx = None
 			if need_rx and ctx.res_gacc[r] is not None and rx.shape[1] % 128 == 0 and Cout % 64 == 0:
 				pending.append((r, dry))

@@ -402,6 +402,37 @@ def bn_finalize(stats, n, gamma, beta, running_mean, running_var, momentum, eps,
 	return out
 
 
+def _float_array(vals):
+	return (ctypes.c_float * max(len(vals), 1))(*[float(v) for v in vals])
+
+
+def bn_finalize_grouped(stats, n, gammas, betas, running_means, running_vars, momenta, epss, num_batches_tracked):
+	"""bn_finalize for several batch norms of one channel count in one launch; stats: ConvStats of equal row counts.  Returns one (4, C)
+	fp32 tensor per batch norm (mean, invstd, scale, shift)."""
+	k, C, rows = len(stats), stats[0].C, stats[0].rows
+	assert all(s_.C == C and s_.rows == rows for s_ in stats)
+	out = torch.empty(k, 4, C, dtype = torch.float32, device = stats[0].buf.device)
+	call('convasr_bn_finalize_grouped', k, _ptr_array([s_.buf for s_ in stats]), rows, n, _ptr_array(gammas), _ptr_array(betas), _ptr_array(running_means), _ptr_array(running_vars),
+		_float_array(momenta), _float_array(epss), _ptr_array([out[i] for i in range(k)]), _ptr_array(num_batches_tracked), C, stream_ptr())
+	return [out[i] for i in range(k)]
+
+
+def bn_bwd_finalize_grouped(sums, gammas, means, invstds, n, coefs, dgammas, dbetas, accumulate):
+	"""bn_bwd_finalize for several batch norms in one launch; sums: (2 C,) fp64 totals each."""
+	k, C = len(sums), sums[0].numel() // 2
+	call('convasr_bn_bwd_finalize_grouped', k, _ptr_array(sums), _int_array([1] * k), _ptr_array(gammas), _ptr_array(means), _ptr_array(invstds), _ptr_array(coefs), _ptr_array(dgammas), _ptr_array(dbetas),
+		_int_array(accumulate), int(n), C, stream_ptr())
+
+
+def bn_bwd_apply_grouped(g, ys, coefs):
+	"""dy_i = A_i g + B_i y_i + D_i for every (y_i, coef_i), g read once.  Returns the list of dy_i."""
+	B, C, T = g.shape
+	assert is_cl(g) and g.dtype in HALF_DTYPES and all(is_cl(y) and y.dtype == g.dtype and y.shape == g.shape for y in ys)
+	dys = [empty_cl(B, C, T, g.dtype, g.device) for _ in ys]
+	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_bwd_apply_grouped', ptr(g), len(ys), _ptr_array(ys), _ptr_array(coefs), _ptr_array(dys), dtype_code(g.dtype), B, T, C, stream_ptr()), nbytes = float(B * T * C * g.element_size() * (1 + 2 * len(ys))))
+	return dys
+
+
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
 	C = running_mean.numel()
 	out = torch.empty(2, C, dtype = torch.float32, device = running_mean.device)

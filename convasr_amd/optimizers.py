@@ -20,6 +20,8 @@ def _advance(opt, pair):
 
 
 class NovoGrad:
+	clips_in_step = True  # the fused step computes the total gradient norm itself (total_norm) and applies clip_grad_norm_'s factor: train_step skips the separate sumsq pass
+
 	def __init__(self, flat, lr = 1.0, betas = (0.95, 0.98), eps = 1e-8, weight_decay = 0.0, dampening = False):
 		self.flat = flat
 		self.defaults = dict(lr = lr, betas = betas, eps = eps, weight_decay = weight_decay, dampening = dampening)

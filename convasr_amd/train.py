@@ -297,11 +297,18 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 		if engine is not None:
 			engine.finish_gradient_sync()
 		flat = optimizer.flat
-		res['grad_norm'] = flat.clip_grad_norm_(max_norm)
+		own_norm = getattr(optimizer, 'clips_in_step', False)  # (NovoGrad forms the gradient norm inside its fused step: no separate reduction pass over the arena)
+		if own_norm:
+			flat.finalize_grads()
+			flat.clip = (None, float(max_norm))
+		else:
+			res['grad_norm'] = flat.clip_grad_norm_(max_norm)
 		if gate is not None:
 			optimizer.step(loss_gate = gate)
 		else:
 			optimizer.step()
+		if own_norm:
+			res['grad_norm'] = optimizer.total_norm[0]
 		optimizer.zero_grad()
 	return res
 
@@ -320,14 +327,15 @@ class GraphedTrainStep:
 	* every buffer a captured kernel touches is either persistent (parameters, arenas, optimizer state, packed weights) or was allocated
 	  inside the capture, from a memory pool all graphs of this object share (they never run concurrently): functional.CAPTURING turns the
 	  per-module / per-stream caches off;
-	* the weight-gradient side stream and the dgrad-weight prepack stream are forked and joined inside the capture.
+	* the capture is one chain of nodes (linear = True: side streams off while capturing; linear = False forks and joins the weight-gradient
+	  side stream and the dgrad-weight prepack stream inside the capture -- slower on ROCm 7.2, see _capture).
 
 	Inputs are copied into the graph's static buffers (one device-to-device copy each; pass the static buffers themselves -- .inputs(key)
 	-- to skip it).  Returned metrics are the graph's static output tensors: read them before the next call with the same shape.
 	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step."""
 
-	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True):
-		self.model, self.optimizer, self.max_norm, self.warmup = model, optimizer, max_norm, max(int(warmup), 1)
+	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = True):
+		self.model, self.optimizer, self.max_norm, self.warmup, self.linear = model, optimizer, max_norm, max(int(warmup), 1), linear
 		engine = model if hasattr(model, 'finish_gradient_sync') else None
 		self.enabled = bool(enabled) and not (engine is not None and engine.collectives)
 		self.graphs, self.seen = {}, {}
@@ -367,12 +375,24 @@ class GraphedTrainStep:
 		steps0 = opt.steps
 		self._sync_lr()
 		torch.cuda.synchronize(dev)
+		# The captured step is ONE chain of nodes unless linear = False: the weight-gradient side stream and the dgrad-weight prepack stream are
+		# switched off for the capture.  Measured on ROCm 7.2 (profiles/r05_graph_ab.json): a graph with forked branches replays 2 % SLOWER
+		# than the same nodes in one chain (the runtime spreads the branches over several queues and pays for the cross-queue signals; with
+		# DEBUG_HIP_FORCE_GRAPH_QUEUES=1 the forked capture matches the linear one), and never reaches the eager side stream's overlap.
+		side, prepack = dict(Fn._side_streams), Fn.PREPACK
+		if self.linear:
+			Fn.join_side_streams()
+			for k in Fn._side_streams:
+				Fn._side_streams[k] = None
+			Fn.PREPACK = False
 		Fn.CAPTURING[0] = True
 		try:
 			with torch.cuda.graph(graph, pool = self.pool):
 				res = train_step(self.model, opt, *static, max_norm = self.max_norm, iteration = iteration)
 		finally:
 			Fn.CAPTURING[0] = False
+			Fn._side_streams.update(side)
+			Fn.PREPACK = prepack
 		opt.steps = steps0  # (nothing ran: the replay below is this step)
 		self.graphs[key] = dict(graph = graph, static = static, res = res)
 		self.captures += 1

@@ -337,9 +337,29 @@ int convasr_conv1x1_grouped(int n, const void* const* x, const void* const* w, v
 int64_t convasr_wgrad1x1_grouped_workspace_bytes(int n, const int* cin, const int* cout, int B, int T);
 int convasr_wgrad1x1_grouped(int n, const void* const* x, const void* const* dy, float* const* dw, float* const* zero, const int* cin, const int* cout,
                              const int* accumulate, void* workspace, int dtype, int B, int T, void* stream);
+/* The batch norms of those branches (nn.BatchNorm1d at models.py:110, one per branch, all of the block's channel count C), grouped the same
+ * way.  convasr_bn_finalize_grouped: convasr_bn_finalize for `count` (<= 13) batch norms in one launch; out[i] receives 4 C floats (mean,
+ * invstd, scale, shift), stats[i] has stats_rows partial rows.  convasr_bn_bwd_finalize_grouped: convasr_bn_bwd_finalize for `count` sets of
+ * sums (sums_rows[i] partial rows each).  convasr_bn_bwd_apply_grouped: dy_i = coef_i[c] * g + coef_i[C + c] * y_i + coef_i[2 C + c] for
+ * `count` (y_i, coef_i, dy_i) triples sharing ONE g, which is read once (count + 1 launches of convasr_bn_act_bwd_apply(from_dz = 0) read it
+ * count + 1 times); 16-bit storage. */
+int convasr_bn_finalize_grouped(int count, const double* const* stats, int stats_rows, int64_t n, const float* const* gamma, const float* const* beta,
+                                float* const* running_mean, float* const* running_var, const float* momentum, const float* eps, float* const* out,
+                                int64_t* const* num_batches_tracked, int C, void* stream);
+int convasr_bn_bwd_finalize_grouped(int count, const double* const* sums, const int* sums_rows, const float* const* gamma, const float* const* mean,
+                                    const float* const* invstd, float* const* coef, float* const* dgamma, float* const* dbeta, const int* accumulate,
+                                    int64_t n, int C, void* stream);
+int convasr_bn_bwd_apply_grouped(const void* g, int count, const void* const* y, const float* const* coef, void* const* dy, int dtype, int B, int T, int C, void* stream);
 /* out = a + b over n 16-bit values (n % 8 == 0; in place allowed): the one explicit add a tapped block output's gradient needs (the main
  * path's input gradient + the branches' accumulated ones), in place of autograd's InputBuffer accumulation (models.py:129-131 backward). */
 int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+
+/* The dgrad operands (convasr_pack_conv_weight's packed_dgrad, from packed_fwd, 16-bit) of MANY layers in one launch.  items: n_items
+ * records in DEVICE memory, convasr_pack_dgrad_item_bytes() bytes each: {const void* packed_fwd; void* packed_dgrad; int Cout, Cin, K,
+ * co_pad (= convasr_conv_cout_pad(Cout)), ci_pad (= convasr_conv_cout_pad(Cin)), first;} with first = the running sum of the earlier items'
+ * K * ceil(Cout / 64) * ceil(Cin / 64) blocks and total_blocks = that sum over all items; Cout and Cin even. */
+int convasr_pack_dgrad_item_bytes(void);
+int convasr_pack_dgrad_grouped(const void* items, int n_items, int total_blocks, void* stream);
 
 /* ---- per-step device state: what lets train.py:745-783 replay from a HIP graph ------------------------------------- */
 

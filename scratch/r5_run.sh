@@ -35,4 +35,12 @@ prof)
 	python scratch/kstat.py gpurun_out/${tag}_prof $n 45
 	cat gpurun_out/${tag}_prof_line.json | cut -c1-400
 	rm -rf gpurun_out/${tag}_prof ;;
+trace)
+	# one step's dispatch list: scratch/r5_run.sh <tag> trace <bench args> -> gpurun_out/<tag>_step_trace.json
+	cd /tmp && export TMPDIR=/tmp
+	rm -rf $GRAFT_REPO_ROOT/gpurun_out/${tag}_trace
+	timeout 900 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_trace -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --steps 3 --warmup 2 --no-cpu-baseline --no-traffic --no-kernel-timer --no-f16-leg --no-jasper-leg > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/${tag}_trace.err
+	cd $GRAFT_REPO_ROOT
+	python scratch/step_trace.py gpurun_out/${tag}_trace gpurun_out/${tag}_step_trace.json "bench.py $*"
+	rm -rf gpurun_out/${tag}_trace ;;
 esac
