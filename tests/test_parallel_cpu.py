@@ -127,6 +127,31 @@ def test_bucket_grading_and_hook_lifetime():
 	assert set(Fn.after_long_launch_hooks) == before
 
 
+def test_predicted_exposed_comm_model():
+	"""parallel.predict_exposed_comm (the prediction a first multi-GPU curve can be checked against): buckets complete from
+	the end of the arena, collectives are serial on the communication stream, exposure is what runs past the end of the backward pass."""
+	import convasr_amd as ca
+	from convasr_amd.parallel import DataParallelEngine, predict_exposed_comm
+	model = ca.models.Wav2Letter(64, [38], base_width = 32).train()
+	eng = DataParallelEngine(model)
+	try:
+		p1 = eng.predict(1, 16.0)
+		assert p1['exposed_comm_ms'] == 0.0 and p1['comm_ms_total'] == 0.0 and p1['predicted_scaling'] is None
+		p = {n: eng.predict(n, 16.0) for n in (2, 4, 8)}
+		assert p[2]['comm_ms_total'] > p[4]['comm_ms_total'] > p[8]['comm_ms_total'] > 0  # S / N per link: more peers, more links
+		for n, q in p.items():
+			rows = q['per_bucket']
+			assert len(rows) == len(eng.buckets) and all(a['ready_ms'] <= b['ready_ms'] for a, b in zip(rows, rows[1:]))
+			assert all(r['start_ms'] >= r['ready_ms'] and abs(r['end_ms'] - r['start_ms'] - r['comm_ms']) < 2e-3 for r in rows)
+			assert all(a['end_ms'] <= b['start_ms'] + 1e-9 for a, b in zip(rows, rows[1:]))  # serial on the communication stream
+			assert abs(rows[-1]['ready_ms'] - q['backward_end_ms']) < 1e-3  # the first layers' bucket completes when backward ends
+			assert q['exposed_comm_ms'] >= rows[-1]['comm_ms'] - 1e-3 and 1.0 < q['predicted_scaling'] <= n
+		slow = eng.predict(8, 16.0, efficiency = 0.01)
+		assert slow['exposed_comm_ms'] > p[8]['exposed_comm_ms'] and slow['predicted_scaling'] < p[8]['predicted_scaling']
+	finally:
+		eng.close()
+
+
 def test_flat_parameters_views_and_state_dict_roundtrip():
 	from convasr_amd.train import FlatParameters
 	model = Toy()
