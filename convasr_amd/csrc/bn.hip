@@ -653,7 +653,7 @@ extern "C" int convasr_bn_bwd_finalize_grouped(int count, const double* const* s
 }
 
 struct BnApplyGroup { const void* y[BN_MAX_GROUP]; const float* coef[BN_MAX_GROUP]; void* dy[BN_MAX_GROUP]; int n; };
-#define GA_ROWS 8
+#define GA_ROWS 4  // (8 rows per thread: 150-178 VGPRs, two waves per SIMD, 0.62x the bandwidth of the one-output apply kernel; 4: see profiles/r05_ab_grouped_apply.json)
 // thread = 8 channels x GA_ROWS rows (rows rl, rl + rlanes, ...): its g values stay in registers (packed) while it walks the problems; per
 // problem the 24 coefficients are loaded once and the GA_ROWS y loads are issued together.
 template <typename T> __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_kernel(const T* __restrict__ g, BnApplyGroup grp, int64_t rows, int C, int cgroups, int rlanes) {

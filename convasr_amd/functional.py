@@ -101,37 +101,60 @@ _prepack_streams = {}  # device -> [side stream, packs pending on it?]
 _pack_tables = {}  # (device, dtype) -> dict(key = the (src, dst) addresses it was built for, items = device table, blocks)
 
 
-def _pack_dgrad_many(stale, dtype):
-	"""The transposed dgrad copies of the `stale` weights: ONE launch for all those whose packed forward copy is current and 16-bit (the
-	arena mirror's segments, or a forward pack refreshed here), a launch each for the rest."""
-	import struct
+def _pack_group(stale, dtype, refresh = True):
+	"""Which of the `stale` weights' dgrad copies can share the one grouped launch: 16-bit, even channel counts, buffers allocated, packed
+	forward copy current (the arena mirror's segment, or refreshed here when refresh is set)."""
 	group = []
 	if dtype in ops.HALF_DTYPES and len(stale) > 1:
 		for w in stale:
-			fwd = packed_weight(w, dtype, _lib.PACK_FWD)  # (no launch when the optimizer's 16-bit mirror serves it)
-			ent = _pack_cache[(id(w), dtype)]
+			ent = _pack_cache.get((id(w), dtype))
+			if ent is None or ent['dgr'] is None:
+				continue
+			fwd = packed_weight(w, dtype, _lib.PACK_FWD) if refresh else ent['fwd']  # (no launch when the optimizer's 16-bit mirror serves it)
 			Cout, Cin, K = w.shape
-			if ent['dgr'] is not None and Cout % 2 == 0 and Cin % 2 == 0 and fwd.dtype == dtype:
+			if fwd is not None and Cout % 2 == 0 and Cin % 2 == 0 and fwd.dtype == dtype:
 				group.append((w, ent, fwd))
-	grouped = {id(w) for w, _, _ in group}
-	for w in stale:
-		if id(w) not in grouped:
-			packed_weight(w, dtype, _lib.PACK_DGRAD)
-	if not group:
-		return
+	return group
+
+
+def _pack_table(group, dtype):
+	"""The device-resident item table of a group (rebuilt -- one small host-to-device copy -- only when the set of buffers changed)."""
+	import struct
 	dev = group[0][0].device
 	key = tuple((fwd.data_ptr(), ent['dgr'].data_ptr()) for _, ent, fwd in group)
 	tab = _pack_tables.get((dev, dtype))
 	if tab is None or tab['key'] != key:
+		if capturing():
+			raise _lib.ConvasrHipError('the dgrad pack table changed while a step graph is being captured (GraphedTrainStep prewarms it: functional.prewarm_dgrad_pack)')
 		assert _lib.load().convasr_pack_dgrad_item_bytes() == 40
 		blob, first = b'', 0
 		for w, ent, fwd in group:
 			Cout, Cin, K = w.shape
 			blob += struct.pack('<QQiiiiii', fwd.data_ptr(), ent['dgr'].data_ptr(), Cout, Cin, K, ops.cout_pad(Cout), ops.cout_pad(Cin), first)
 			first += K * ((Cout + 63) // 64) * ((Cin + 63) // 64)
-		if capturing():
-			raise _lib.ConvasrHipError('the dgrad pack table changed while a step graph is being captured (run one eager step with this set of weights first)')
 		tab = _pack_tables[(dev, dtype)] = dict(key = key, items = torch.frombuffer(bytearray(blob), dtype = torch.uint8).to(dev), blocks = first, n = len(group))
+	return tab
+
+
+def prewarm_dgrad_pack(weights, dtype):
+	"""Build the grouped pack's device table for the weights a training step will re-pack (all of them: every optimizer step makes every
+	copy stale), outside a graph capture -- the capture itself cannot copy a table to the device."""
+	group = _pack_group([w for w in weights], dtype, refresh = False)
+	if group:
+		_pack_table(group, dtype)
+
+
+def _pack_dgrad_many(stale, dtype):
+	"""The transposed dgrad copies of the `stale` weights: ONE launch for all those whose packed forward copy is current and 16-bit (the
+	arena mirror's segments, or a forward pack refreshed here), a launch each for the rest."""
+	group = _pack_group(stale, dtype)
+	grouped = {id(w) for w, _, _ in group}
+	for w in stale:
+		if id(w) not in grouped:
+			packed_weight(w, dtype, _lib.PACK_DGRAD)
+	if not group:
+		return
+	tab = _pack_table(group, dtype)
 	_lib.call('convasr_pack_dgrad_grouped', _lib.ptr(tab['items']), tab['n'], tab['blocks'], _lib.stream_ptr())
 	for w, ent, _ in group:
 		ent['dgr_ver'] = param_version(w)

@@ -374,6 +374,10 @@ class GraphedTrainStep:
 		opt = self.optimizer
 		steps0 = opt.steps
 		self._sync_lr()
+		net = M.master_module(self.model)
+		cached = getattr(net, '_dgrad_weights', None)
+		if cached is not None and cached[0] == Fn.structure_epoch():
+			Fn.prewarm_dgrad_pack(cached[1], net.compute_dtype)  # (a host-to-device table copy: not possible inside the capture)
 		torch.cuda.synchronize(dev)
 		# The captured step is ONE chain of nodes unless linear = False: the weight-gradient side stream and the dgrad-weight prepack stream are
 		# switched off for the capture.  Measured on ROCm 7.2 (profiles/r05_graph_ab.json): a graph with forked branches replays 2 % SLOWER
