@@ -50,6 +50,11 @@ MAIN_KERNEL_SYMBOLS = dict(
 MAIN_FAMILY = 'conv1d_igemm_v2s_kernel<bf16>'  # (family labels are shared by the two 16-bit types)
 
 
+def graph_policy(opt, workload, gpus):
+	"""--graph auto: step graphs for jasper_large on one rank."""
+	return opt == 'on' or (opt == 'auto' and workload == 'jasper_large' and gpus == 1 and os.environ.get('CONVASR_FORCE_DIST') != '1')
+
+
 def parse_args(argv = None):
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type = int, default = 1)
@@ -79,7 +84,8 @@ def parse_args(argv = None):
 	if args.dtype is None:
 		args.dtype = 'f16' if args.workload == 'jasper_large' else 'bf16'
 	args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.workload == 'jasper_large')
-	args.graph = args.graph == 'on' or (args.graph == 'auto' and args.workload == 'jasper_large' and args.gpus == 1 and os.environ.get('CONVASR_FORCE_DIST') != '1')
+	args.graph_opt = args.graph
+	args.graph = graph_policy(args.graph_opt, args.workload, args.gpus)
 	return args
 
 
@@ -871,7 +877,7 @@ def main(argv = None):
 				f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
 		if world == 1 and headline_run and not args.no_jasper_leg:
 			# BASELINE configs[4] in the driver's record: a bounded run of `bench.py --workload jasper_large` (3 warm-up + 8 timed steps + the event-timed pass)
-			argsj = argparse.Namespace(**dict(vars(args), workload = 'jasper_large', dtype = 'f16', steps = 8, warmup = 3, side_stream = True, no_kernel_timer = False))
+			argsj = argparse.Namespace(**dict(vars(args), workload = 'jasper_large', dtype = 'f16', steps = 8, warmup = 3, side_stream = True, no_kernel_timer = False, graph = graph_policy(args.graph_opt, 'jasper_large', args.gpus)))
 			lj, _ = measure(argsj, device, rank, world, False, None, lambda: torch.cuda.synchronize(), DeviceProbe(device))
 			rj = lj['roofline'] or {}
 			line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 8, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],

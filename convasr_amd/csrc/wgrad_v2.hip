@@ -103,10 +103,14 @@ template <typename H> __device__ __forceinline__ void wgrad_v2_body(const WgradP
 #else
 	const int tg = unit % p.tap_groups, ci_t = (unit / p.tap_groups) % p.ci_tiles, co_t = unit / (p.tap_groups * p.ci_tiles);
 #endif
-	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * WG_TG;
+	// taps per group, balanced: K = 13 is cut 4 + 3 + 3 + 3, not 4 + 4 + 4 + 1 -- a one-tap group moves the same dY / X rows into LDS as a
+	// four-tap one for a quarter of its MFMA work and runs operand-bound (~0.5 group-times instead of 0.25), a three-tap group stays
+	// MFMA-bound at 0.75: 3.25 group-times instead of ~3.5 for K = 13, 4.25 / ~4.5 for K = 17, ... (K = 11: 4 + 4 + 3 either way)
+	const int tbase = p.K / p.tap_groups, trem = p.K % p.tap_groups;
+	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * tbase + min(tg, trem);
 	const int c_begin = split * p.chunks_per_split, c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
 	// slot A / slot B of this wave: tap index, mask of the k-substeps (of 4 per chunk) it covers, shared with the other wave half?
-	const int ntaps = min(WG_TG, p.K - tap0);
+	const int ntaps = tbase + (tg < trem ? 1 : 0);
 	int tapA, tapB;
 	unsigned mA, mB;
 	bool shA = false, shB = false;

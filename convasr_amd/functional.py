@@ -43,7 +43,6 @@ def packed_weight(w, dtype, mode):
 			flat = ent.get('flat')
 			if flat is None or (flat.data16 is ent.get('mirror') and flat._mirror_ver.get(id(w)) == ver):
 				return ent['fwd']
-	both = w.requires_grad  # (grad mode is off inside autograd.Function.forward, so it cannot be consulted here)
 	if ent is None:
 		ent = _pack_cache[(id(w), dtype)] = dict(w = w, fwd = None, dgr = None, fwd_ver = None, dgr_ver = None)  # holds `w`: id() stays unique
 	arena = getattr(w, '_convasr_arena', None)
@@ -65,10 +64,10 @@ def packed_weight(w, dtype, mode):
 		return ent['fwd']
 	if mode == _lib.PACK_DGRAD and ent['dgr_ver'] == ver:
 		return ent['dgr']
-	if both or mode == _lib.PACK_DGRAD:
+	if mode == _lib.PACK_DGRAD:
 		ent['fwd'], ent['dgr'] = ops.pack_weight(w, dtype, None, out = (ent['fwd'], ent['dgr']), fwd_is_current = ent['fwd_ver'] == ver)
 		ent['fwd_ver'] = ent['dgr_ver'] = ver
-	else:
+	else:  # (the forward copy alone, also in training: the dgrad copies of a step are made together, by prepack_dgrad_weights' one launch)
 		ent['fwd'] = ops.pack_weight(w, dtype, _lib.PACK_FWD, out = (ent['fwd'], None))
 		ent['fwd_ver'] = ver
 	if in_place and dtype in ops.HALF_DTYPES:
