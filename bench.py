@@ -582,7 +582,8 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world, graphed = False):
 class DeviceProbe:
 	"""Host-side sampler of THIS rank's card over the timed region, so that a round-to-round difference of the headline can be
 	attributed from the line alone (the pool's devices differ by +-4 % on the MFMA kernels; the step is package-power limited):
-	* hwmon (sysfs) every ~5 ms from a thread: power1_input -> power_w_mean, freq1_input -> sclk_mhz_mean;
+	* hwmon (sysfs) every ~5 ms from a NATIVE thread (libconvasr_smi.so: a Python sampler thread took the GIL from the launching thread often
+	  enough to cost the eager step ~1 %): power1_input -> power_w_mean, freq1_input -> sclk_mhz_mean;
 	* the firmware's throttle accumulators from the gpu_metrics table (librocm_smi64 through convasr_amd/libconvasr_smi.so, ctypes) at
 	  start() and stop(): ppt_residency = d ppt_residency_acc / d accumulation_counter, likewise thermal / PROCHOT.
 	No HIP call is made here (the card is found by the PCI address torch already knows).  Every field is None when its source is not
@@ -593,7 +594,7 @@ class DeviceProbe:
 		import glob
 		import torch
 		self.hw, self.smi, self.dv, self.samples, self.acc = None, None, -1, [], [None, None]
-		self.thread, self.halt = None, False
+		self.native, self.hw_means = False, None
 		self.why = []
 		try:
 			props = torch.cuda.get_device_properties(device)
@@ -609,6 +610,8 @@ class DeviceProbe:
 				self.smi = ctypes.CDLL(lib)
 				self.smi.convasr_smi_open.restype, self.smi.convasr_smi_open.argtypes = ctypes.c_int, [ctypes.c_int] * 3
 				self.smi.convasr_smi_sample.restype, self.smi.convasr_smi_sample.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+				self.smi.convasr_hwmon_start.restype, self.smi.convasr_hwmon_start.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
+				self.smi.convasr_hwmon_stop.restype, self.smi.convasr_hwmon_stop.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]
 				self.dv = self.smi.convasr_smi_open(dom, bus, dev)
 				if self.dv < 0:
 					self.why.append(f'rocm_smi: no device for PCI {prefix} (code {self.dv})')
@@ -631,28 +634,23 @@ class DeviceProbe:
 		return list(out) if self.smi.convasr_smi_sample(self.dv, out) == 0 else None
 
 	def start(self):
-		import threading
-		self.samples, self.halt = [], False
+		self.samples, self.hw_means = [], None
 		self.acc = [self._metrics(), None]
-
-		def run():
-			while not self.halt:
-				self.samples.append((self._read('power1_input'), self._read('freq1_input')))
-				time.sleep(0.005)
-		if self.hw is not None:
-			self.thread = threading.Thread(target = run, daemon = True)
-			self.thread.start()
+		self.native = False
+		if self.hw is not None and self.smi is not None and hasattr(self.smi, 'convasr_hwmon_start'):
+			self.native = self.smi.convasr_hwmon_start(self.hw.encode(), 5000) == 0  # a native thread: no Python (no GIL traffic) in the sampling loop
 
 	def stop(self):
+		import ctypes
 		self.acc[1] = self._metrics()
-		self.halt = True
-		if self.thread is not None:
-			self.thread.join()
-			self.thread = None
+		if self.native:
+			out = (ctypes.c_double * 3)()
+			if self.smi.convasr_hwmon_stop(out) == 0:
+				self.hw_means = (out[0] or None, out[1] or None, int(out[2]))
+			self.native = False
 
 	def summary(self):
-		pw = [p / 1e6 for p, f in self.samples if p]
-		fq = [f / 1e6 for p, f in self.samples if f]
+		power, sclk, n_samples = self.hw_means if getattr(self, 'hw_means', None) else (None, None, 0)
 		a, b = self.acc
 		res = None
 		if a is not None and b is not None and b[0] > a[0]:
@@ -660,11 +658,11 @@ class DeviceProbe:
 			res = dict(ppt = round((b[1] - a[1]) / ticks, 4), prochot = round((b[2] - a[2]) / ticks, 4), socket_thermal = round((b[3] - a[3]) / ticks, 4),
 				vr_thermal = round((b[4] - a[4]) / ticks, 4), hbm_thermal = round((b[5] - a[5]) / ticks, 4), accumulation_ticks = int(ticks))
 		cap = self._read('power1_cap') if self.hw is not None else None
-		return dict(sclk_mhz_mean = round(sum(fq) / len(fq), 1) if fq else None, power_w_mean = round(sum(pw) / len(pw), 1) if pw else None,
+		return dict(sclk_mhz_mean = None if sclk is None else round(sclk, 1), power_w_mean = None if power is None else round(power, 1),
 			power_cap_w = None if cap is None else cap / 1e6, ppt_residency = None if res is None else res['ppt'], throttle_residency = res,
 			gfx_clk_mhz_end = None if b is None else round(b[7], 1), socket_power_w_end = None if b is None else b[6], hotspot_c_end = None if b is None else b[8], hbm_c_end = None if b is None else b[9],
-			hwmon_samples = len(self.samples), sources = dict(hwmon = self.hw is not None, gpu_metrics = self.dv >= 0), unavailable = self.why or None,
-			how = 'sysfs hwmon sampled every ~5 ms from a host thread over the timed region (power1_input, freq1_input); throttle residencies = differences of the gpu_metrics accumulators read at its two ends through librocm_smi64; no GPU call')
+			hwmon_samples = n_samples, sources = dict(hwmon = self.hw is not None, gpu_metrics = self.dv >= 0), unavailable = self.why or None,
+			how = 'sysfs hwmon sampled every ~5 ms over the timed region by a native thread of convasr_amd/libconvasr_smi.so (power1_input, freq1_input; no Python in the loop); throttle residencies = differences of the gpu_metrics accumulators read at its two ends through librocm_smi64; no GPU call')
 
 
 def predicted_comm(engine, world, step_s):
@@ -723,7 +721,7 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 		# the same steps launched eagerly with the weight gradients on the side stream (what --graph off times): a short reference region
 		wl.stepper.enabled = False
 		ca.functional.enable_side_stream_wgrad(device, True)
-		n_e = min(args.steps, 8)
+		n_e = min(args.steps, 20)  # (the same batches as the timed region's first n_e steps)
 		for i in range(2):
 			step(args.warmup + args.steps + i)
 		fence()

@@ -64,7 +64,7 @@ def build_smi_probe(force = False, verbose = True):
 	measurement infrastructure, not part of the product library).  Returns its path, or None when it cannot be built here."""
 	src = os.path.join(CSRC, 'smi_probe.c')
 	if force or stale(SMI_LIB, [src]):
-		cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I/opt/rocm/include', '-o', SMI_LIB, src, '-L/opt/rocm/lib', '-lrocm_smi64', '-Wl,-rpath,/opt/rocm/lib']
+		cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I/opt/rocm/include', '-o', SMI_LIB, src, '-L/opt/rocm/lib', '-lrocm_smi64', '-lpthread', '-Wl,-rpath,/opt/rocm/lib']
 		if verbose:
 			print(' '.join(cmd), flush = True)
 		r = subprocess.run(cmd, capture_output = True, text = True)

@@ -714,6 +714,140 @@ extern "C" int convasr_bn_bwd_apply_grouped(const void* g, int count, const void
 	return 0;
 }
 
+// ---------------- a dense block's backward pass 1 in ONE sweep (16-bit storage, stored gates)
+// g = gate ? dz * keep_scale : 0 (the forward pass stored, per element, whether the gradient passes: activation range, dropout, frame mask --
+// so the pre-activation, i.e. the block output's TEN residual inputs, need not be re-read), written once; and for each of the M batch norms
+// that feed the sum (the main one + the residual branches'): sum g (shared by all of them) and sum g * (y_q - mean_q), centred per element.
+// The per-branch form (bn_act_bwd_reduce_kernel) re-derives the pre-activation from every input and takes one extra sweep over g per two
+// branches: n + 3 + 3 ceil((n - 2) / 2) tensor sweeps for n branches against n + 3 here (27 -> 13 at n = 10).
+// Thread = 4 channels (8-byte loads; M + 1 accumulators and M means of 4 floats each stay in registers), one row per trip with all M + 1
+// loads in flight; a block owns a contiguous range of rows and every thread writes its partial sums itself (no cross-lane step):
+// ws[block][M + 1][C] floats, plane 0 = sum g.
+#define RM_MAX 13
+struct ReduceMany { const void* y[RM_MAX]; const float* mean[RM_MAX]; };
+template <typename T, int M> __global__ __launch_bounds__(256) void bn_bwd_reduce_many_kernel(const T* __restrict__ dz, const uint8_t* __restrict__ gate, float keep_scale, T* __restrict__ g_out,
+                                                                                            ReduceMany rm, float* __restrict__ ws, int64_t rows, int C, int rows_per_block) {
+	const int c4 = C >> 2;
+	const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+	for (int cg = threadIdx.x; cg < c4; cg += blockDim.x) {
+		const int c = cg << 2;
+		float sg[4] = {0.f, 0.f, 0.f, 0.f}, acc[M][4], mean[M][4];
+#pragma unroll
+		for (int q = 0; q < M; ++q) {
+			const float4 m4 = *reinterpret_cast<const float4*>(rm.mean[q] + c);
+			mean[q][0] = m4.x; mean[q][1] = m4.y; mean[q][2] = m4.z; mean[q][3] = m4.w;
+			acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+		}
+		const int shift = c & 4;  // the 4 gate bits of this thread's channels: low or high nibble of the byte of its 8-channel group
+		for (int64_t r = r0; r < r1; ++r) {
+			const int64_t idx = r * C + c;
+			const uint2 dzr = *reinterpret_cast<const uint2*>(dz + idx);
+			const unsigned gb = ((unsigned)gate[idx >> 3] >> shift) & 15u;
+			uint2 yr[M];
+#pragma unroll
+			for (int q = 0; q < M; ++q) yr[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(rm.y[q]) + idx);
+			float dzv[8], g[4];  // (unpack16 takes 16 bytes: the upper half is padding)
+			unpack16<T>(make_uint4(dzr.x, dzr.y, 0u, 0u), dzv);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { g[k] = ((gb >> k) & 1u) ? dzv[k] * keep_scale : 0.f; sg[k] += g[k]; }
+			*reinterpret_cast<uint2*>(g_out + idx) = make_uint2(pack16<T>(g[0], g[1]), pack16<T>(g[2], g[3]));
+#pragma unroll
+			for (int q = 0; q < M; ++q) {
+				float yv[8];
+				unpack16<T>(make_uint4(yr[q].x, yr[q].y, 0u, 0u), yv);
+#pragma unroll
+				for (int k = 0; k < 4; ++k) acc[q][k] = fmaf(g[k], yv[k] - mean[q][k], acc[q][k]);
+			}
+		}
+		float* const o = ws + (int64_t)blockIdx.x * (M + 1) * C + c;
+		*reinterpret_cast<float4*>(o) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+#pragma unroll
+		for (int q = 0; q < M; ++q) *reinterpret_cast<float4*>(o + (int64_t)(q + 1) * C) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+	}
+}
+
+// its finalize: set q (blockIdx.y) adds plane 0 and plane 1 + q of the blocks' partial rows in a fixed order (fp64), scales the second by
+// invstd_q and emits coef / dgamma / dbeta exactly like bn_bwd_finalize_sums_kernel
+struct ReduceManyFin { BnFinalizeSets sets[RM_MAX]; };
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_many_kernel(const float* __restrict__ ws, int nblocks, int planes, ReduceManyFin f, int C) {
+	__shared__ double red[2][FIN_LANES][FIN_CH];
+	const int q = blockIdx.y;
+	const BnFinalizeSets& sets = f.sets[q];
+	const int cl = threadIdx.x & (FIN_CH - 1), c = blockIdx.x * FIN_CH + cl, w = threadIdx.x >> 4;
+	double a = 0, b2 = 0;
+	if (c < C)
+		for (int r = w; r < nblocks; r += FIN_LANES) { a += (double)ws[((int64_t)r * planes) * C + c]; b2 += (double)ws[((int64_t)r * planes + 1 + q) * C + c]; }
+	red[0][w][cl] = a;
+	red[1][w][cl] = b2;
+	__syncthreads();
+	if (w != 0 || c >= C) return;
+	double sg = 0, sgx = 0;
+	for (int i = 0; i < FIN_LANES; ++i) { sg += red[0][i][cl]; sgx += red[1][i][cl]; }
+	sgx *= (double)sets.invstd[c];
+	if (sets.coef) {
+		const float gm = sets.gamma ? sets.gamma[c] : 1.f, is = sets.invstd[c], m = sets.mean[c];
+		const float msg = (float)sg * sets.invn, msgx = (float)sgx * sets.invn;
+		sets.coef[c] = gm * is;
+		sets.coef[C + c] = -gm * is * is * msgx;
+		sets.coef[2 * C + c] = gm * is * (m * is * msgx - msg);
+	}
+	if (sets.dgamma) sets.dgamma[c] = sets.accumulate ? sets.dgamma[c] + (float)sgx : (float)sgx;
+	if (sets.dbeta) sets.dbeta[c] = sets.accumulate ? sets.dbeta[c] + (float)sg : (float)sg;
+}
+
+static int reduce_many_blocks(int64_t rows, int& rows_per_block) {
+	const int64_t want = 768;  // three per CU, like the other backward reduce kernels
+	rows_per_block = (int)ceil_div64(rows, want);
+	if (rows_per_block < 1) rows_per_block = 1;
+	return (int)ceil_div64(rows, rows_per_block);
+}
+
+extern "C" int64_t convasr_bn_bwd_reduce_many_workspace_bytes(int count, int B, int T, int C) {
+	if (count <= 0 || count > RM_MAX || B <= 0 || T <= 0 || C <= 0) return -1;
+	int rpb;
+	return (int64_t)reduce_many_blocks((int64_t)B * T, rpb) * (count + 1) * C * 4;
+}
+
+template <typename T, int M> static void launch_reduce_many(const void* dz, const uint8_t* gate, float keep_scale, void* g, const ReduceMany& rm, float* ws, int64_t rows, int C, hipStream_t s) {
+	int rpb;
+	const int blocks = reduce_many_blocks(rows, rpb);
+	int threads = ((C >> 2) + 63) / 64 * 64;
+	if (threads > 256) threads = 256;
+	hipLaunchKernelGGL((bn_bwd_reduce_many_kernel<T, M>), dim3(blocks), dim3(threads), 0, s, (const T*)dz, gate, keep_scale, (T*)g, rm, ws, rows, C, rpb);
+}
+
+extern "C" int convasr_bn_bwd_reduce_many(const void* dz, const uint8_t* gate, float dropout_p, void* g, int count, const void* const* y, const float* const* mean, const float* const* invstd,
+                                          const float* const* gamma, float* const* coef, float* const* dgamma, float* const* dbeta, const int* accumulate, void* workspace,
+                                          int dtype, int B, int T, int C, void* stream) {
+	CONVASR_CHECK_ARG(dz && gate && g && count > 0 && count <= RM_MAX && y && mean && invstd && workspace && B > 0 && T > 0 && C > 0 && (C & 7) == 0 && dropout_p >= 0.f && dropout_p < 1.f, "bn_bwd_reduce_many: bad arguments (at most %d batch norms, C a multiple of 8)", RM_MAX);
+	if (!convasr_is_half(dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_bwd_reduce_many: dtype %d (16-bit storage only)", dtype);
+	ReduceMany rm = {};
+	ReduceManyFin fin = {};
+	const int64_t rows = (int64_t)B * T;
+	for (int i = 0; i < count; ++i) {
+		CONVASR_CHECK_ARG(y[i] && mean[i] && invstd[i], "bn_bwd_reduce_many: batch norm %d has a NULL buffer", i);
+		rm.y[i] = y[i]; rm.mean[i] = mean[i];
+		BnFinalizeSets& t = fin.sets[i];
+		t.gamma = gamma ? gamma[i] : nullptr; t.mean = mean[i]; t.invstd = invstd[i]; t.coef = coef ? coef[i] : nullptr; t.dgamma = dgamma ? dgamma[i] : nullptr; t.dbeta = dbeta ? dbeta[i] : nullptr;
+		t.accumulate = accumulate ? accumulate[i] : 0; t.invn = 1.0f / (float)rows;
+	}
+	unsigned thr = (unsigned)lrintf(dropout_p * 65536.f);
+	if (thr > 65535u) thr = 65535u;
+	const float keep_scale = thr ? 65536.f / (float)(65536u - thr) : 1.f;
+	hipStream_t s = (hipStream_t)stream;
+	float* const ws = (float*)workspace;
+	const uint8_t* const gt = gate;
+#define RM_CASE(M_) case M_: if (dtype == CONVASR_F16) launch_reduce_many<f16_t, M_>(dz, gt, keep_scale, g, rm, ws, rows, C, s); else launch_reduce_many<bf16_t, M_>(dz, gt, keep_scale, g, rm, ws, rows, C, s); break;
+	switch (count) { RM_CASE(1) RM_CASE(2) RM_CASE(3) RM_CASE(4) RM_CASE(5) RM_CASE(6) RM_CASE(7) RM_CASE(8) RM_CASE(9) RM_CASE(10) RM_CASE(11) RM_CASE(12) RM_CASE(13) }
+#undef RM_CASE
+	CONVASR_CHECK_LAUNCH("bn_bwd_reduce_many");
+	int rpb;
+	const int blocks = reduce_many_blocks(rows, rpb);
+	hipLaunchKernelGGL(bn_bwd_finalize_many_kernel, dim3((C + FIN_CH - 1) / FIN_CH, count), dim3(FIN_CH * FIN_LANES), 0, s, (const float*)ws, blocks, count + 1, fin, C);
+	CONVASR_CHECK_LAUNCH("bn_bwd_finalize_many");
+	return 0;
+}
+
 // at most BN_BWD_MAX_BLOCKS blocks (3 per CU): the finalize kernel reads one partial row per block and set (more blocks make THAT
 // kernel the cost: 2,048 partial rows of 2 C floats are 12 MB for it to walk); bytes in flight come from rows per trip instead
 #define BN_BWD_MAX_BLOCKS 768

@@ -540,7 +540,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		# one bit per element: does the gradient pass it (activation range, dropout, frame mask)?  The backward kernels of a residual-free
 		# layer take the bits back in instead of re-deriving the pre-activation, re-hashing the dropout mask and redoing the frame arithmetic
 		gate = None
-		if GATE_BITS and n_res == 0 and act[0] in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_HARDTANH) and Cout % 8 == 0 and (weight.requires_grad or x_needs_grad or gamma.requires_grad):
+		if GATE_BITS and (n_res == 0 or (GROUP_RES and dt in ops.HALF_DTYPES and 1 + len(branches) <= 13)) and act[0] in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_HARDTANH) and Cout % 8 == 0 and (weight.requires_grad or x_needs_grad or gamma.requires_grad):  # (a layer with residual inputs: its backward then needs none of them to re-derive the pre-activation, functional 'reduce_many')
 			gate = torch.empty(B * Tout * Cout // 8, dtype = torch.uint8, device = dev)
 		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, gate = gate, step_key = skey)
 		ctx.gate = gate
@@ -612,6 +612,22 @@ class ConvBnActFunction(torch.autograd.Function):
 			g = rsum_of = None
 		else:
 			bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
+			grouped_bn = None
+			if ctx.gate is not None and GROUP_RES and dt in ops.HALF_DTYPES and 1 + len(bn_idx) <= 13:
+				# the whole of pass 1 in ONE sweep from the stored gates: g written once, sum g / sum g xhat of the main batch norm and of every
+				# branch's, then their finalize; pass 2 = one grouped apply
+				sets = [(gamma, beta, bnp, y)] + [(ctx.params[3 + 4 * r + 2], ctx.params[3 + 4 * r + 3], res_bnp[r], res_y[r]) for r in bn_idx]
+				coefs = torch.empty(len(sets), 3 * Cout, dtype = torch.float32, device = dev)
+				holder = {}
+				def many(outs, accs):
+					holder['g'] = ops.bn_bwd_reduce_many(dz, ctx.gate, p_drop, [t[3] for t in sets], [t[2][0] for t in sets], [t[2][1] for t in sets], [t[0] for t in sets], [coefs[i] for i in range(len(sets))], [o[0] for o in outs], [o[1] for o in outs], accs)
+				dgb = _deliver_many([[gm, bt] for gm, bt, _, _ in sets], many)
+				g = holder['g']
+				dys = ops.bn_bwd_apply_grouped(g, [t[3] for t in sets], [coefs[i] for i in range(len(sets))])
+				(dgamma, dbeta), dy = dgb[0], dys[0]
+				grouped_bn = {r: (dgb[1 + i][0], dgb[1 + i][1], dys[1 + i]) for i, r in enumerate(bn_idx)}
+				rsum_of = None
+		if n_res > 0 and grouped_bn is None:
 			sums = torch.empty(2 * Cout * (1 + len(bn_idx)), dtype = torch.float64, device = dev)  # written by the reduce kernels
 			rsum_of = {r: sums[2 * Cout * (1 + i):2 * Cout * (2 + i)] for i, r in enumerate(bn_idx)}
 			common = dict(xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], rmean = [None if p is None else p[0] for p in res_bnp], rinvstd = [None if p is None else p[1] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, step_key = skey)

@@ -424,6 +424,18 @@ def bn_bwd_finalize_grouped(sums, gammas, means, invstds, n, coefs, dgammas, dbe
 		_int_array(accumulate), int(n), C, stream_ptr())
 
 
+def bn_bwd_reduce_many(dz, gate, dropout_p, ys, means, invstds, gammas, coefs, dgammas, dbetas, accumulate):
+	"""Pass 1 of a dense block's backward in one sweep from the stored gates (include/convasr_hip.h): returns g; fills coefs / dgammas / dbetas."""
+	B, C, T = dz.shape
+	assert is_cl(dz) and dz.dtype in HALF_DTYPES and all(is_cl(y) and y.dtype == dz.dtype and y.shape == dz.shape for y in ys) and gate.dtype == torch.uint8 and gate.numel() * 8 == dz.numel()
+	g = empty_cl(B, C, T, dz.dtype, dz.device)
+	k = len(ys)
+	ws = workspace(_lib.load().convasr_bn_bwd_reduce_many_workspace_bytes(k, B, T, C), dz.device, 'bn_bwd')
+	_lib.timed('hbm:bn_act_bwd_reduce_kernel', 0.0, lambda: call('convasr_bn_bwd_reduce_many', ptr(dz), ptr(gate), float(dropout_p), ptr(g), k, _ptr_array(ys), _ptr_array(means), _ptr_array(invstds), _ptr_array(gammas),
+		_ptr_array(coefs), _ptr_array(dgammas), _ptr_array(dbetas), _int_array(accumulate), ptr(ws), dtype_code(dz.dtype), B, T, C, stream_ptr()), nbytes = float(B * T * C * dz.element_size() * (2 + k)))
+	return g
+
+
 def bn_bwd_apply_grouped(g, ys, coefs):
 	"""dy_i = A_i g + B_i y_i + D_i for every (y_i, coef_i), g read once.  Returns the list of dy_i."""
 	B, C, T = g.shape

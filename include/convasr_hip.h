@@ -350,6 +350,16 @@ int convasr_bn_bwd_finalize_grouped(int count, const double* const* sums, const 
                                     const float* const* invstd, float* const* coef, float* const* dgamma, float* const* dbeta, const int* accumulate,
                                     int64_t n, int C, void* stream);
 int convasr_bn_bwd_apply_grouped(const void* g, int count, const void* const* y, const float* const* coef, void* const* dy, int dtype, int B, int T, int C, void* stream);
+/* Pass 1 of a dense block's backward (models.py:127-139 backward) in ONE sweep, from the one-bit gates convasr_bn_act_fwd stored for the block's
+ * output: g = gate ? dz / (1 - p) : 0 is written once, and for each of the `count` (<= 13) batch norms that feed the block's sum -- the main
+ * one and the residual branches' (y_i its input, mean_i / invstd_i its batch statistics) -- sum g and sum g * (y_i - mean_i) * invstd_i
+ * are formed (block partials in `workspace`, convasr_bn_bwd_reduce_many_workspace_bytes() bytes, then an fp64 sum in a fixed order: no
+ * atomics) and turned into coef_i (3 C floats, as convasr_bn_act_bwd_reduce's), dgamma_i, dbeta_i (added to when accumulate[i]).  Replaces
+ * convasr_bn_act_bwd_reduce (which re-derives the pre-activation from all residual inputs) + one further sweep per two branches. */
+int64_t convasr_bn_bwd_reduce_many_workspace_bytes(int count, int B, int T, int C);
+int convasr_bn_bwd_reduce_many(const void* dz, const uint8_t* gate, float dropout_p, void* g, int count, const void* const* y, const float* const* mean,
+                               const float* const* invstd, const float* const* gamma, float* const* coef, float* const* dgamma, float* const* dbeta,
+                               const int* accumulate, void* workspace, int dtype, int B, int T, int C, void* stream);
 /* out = a + b over n 16-bit values (n % 8 == 0; in place allowed): the one explicit add a tapped block output's gradient needs (the main
  * path's input gradient + the branches' accumulated ones), in place of autograd's InputBuffer accumulation (models.py:129-131 backward). */
 int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
