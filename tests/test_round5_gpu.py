@@ -266,3 +266,94 @@ def test_residual_bias_gradient_is_zero_again_after_a_pass_through_eval_mode_bat
 		m.train()
 	fwd_bwd()
 	assert float(rb._convasr_grad.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ grouped kernels, one by one
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_grouped_one_tap_launches_are_bit_identical_to_one_launch_per_problem(dt):
+	"""convasr_conv1x1_grouped: every problem of a grouped dispatch -- forward with bias + BN statistics, and the accumulate form the input
+	gradients use -- equals the single launch (conv1x1.hip) bit for bit; 333 frames (no multiple of the 128-row tile), a 768 -> 256 problem
+	(the two-stage instantiation) beside one-stage ones."""
+	from convasr_amd import ops, _lib
+	d = torch.device('cuda:0')
+	torch.manual_seed(0)
+	B, T = 3, 333
+	shapes = [(128, 256), (256, 256), (384, 256), (768, 256)]
+	xs = [ops.as_cl(torch.randn(B, ci, T, device = d), dt) for ci, _ in shapes]
+	ws = [torch.randn(co, ci, 1, device = d) / ci ** 0.5 for ci, co in shapes]
+	wps = [ops.pack_weight(w, dt, _lib.PACK_FWD) for w in ws]
+	bs = [torch.randn(co, device = d) for _, co in shapes]
+	sts = [ops.ConvStats(co, B, T, d) for _, co in shapes]
+	ys = ops.conv1x1_grouped(xs, wps, [co for _, co in shapes], biases = bs, stats = sts)
+	assert ys is not None
+	for x, wp, b, st, y, (ci, co) in zip(xs, wps, bs, sts, ys, shapes):
+		st1 = ops.ConvStats(co, B, T, d)
+		y1 = ops.conv1d(x, wp, co, 1, 1, 1, 0, bias = b, stats = st1)
+		assert torch.equal(y, y1) and st.rows == st1.rows and torch.equal(st.totals(), st1.totals()), (ci, co)
+	# accumulate: out += x * w^T, the sum of the two stored 16-bit values rounded once
+	base = [ops.as_cl(torch.randn(B, co, T, device = d), dt) for _, co in shapes]
+	outs = [t.clone() for t in base]
+	got = ops.conv1x1_grouped(xs, wps, [co for _, co in shapes], outs = outs, accumulate = [True, False, True, True])
+	for i, (x, wp, (ci, co)) in enumerate(zip(xs, wps, shapes)):
+		y1 = ops.conv1d(x, wp, co, 1, 1, 1, 0)
+		want = (y1.float() + base[i].float()).to(dt) if i != 1 else y1
+		assert torch.equal(got[i], want), (ci, co)
+	assert ops.conv1x1_grouped([ops.as_cl(torch.randn(B, 96, T, device = d), dt)], [wps[0]], [256]) is None  # 96 input channels: outside the envelope, nothing launched
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_grouped_one_tap_weight_gradients_against_one_launch_per_problem(dt):
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(1)
+	B, T = 4, 401
+	shapes = [(128, 256), (256, 384), (640, 128)]
+	xs = [ops.as_cl(torch.randn(B, ci, T, device = d), dt) for ci, _ in shapes]
+	dys = [ops.as_cl(torch.randn(B, co, T, device = d), dt) for _, co in shapes]
+	dws = [torch.full((co, ci, 1), 7.0, device = d) for ci, co in shapes]
+	zeros = [torch.full((co, ), 3.0, device = d) for _, co in shapes]
+	assert ops.wgrad1x1_grouped(xs, dys, dws, zeros = [zeros[0], None, zeros[2]], accumulate = [False, True, False])
+	for i, (x, dy, (ci, co)) in enumerate(zip(xs, dys, shapes)):
+		ref = torch.einsum('bot,bit->oi', dy.float(), x.float()).unsqueeze(-1) + (7.0 if i == 1 else 0.0)
+		err = float((dws[i] - ref).abs().max()) / float(ref.abs().max())
+		assert err <= 2e-5, (ci, co, err)
+	assert float(zeros[0].abs().max()) == 0.0 and float(zeros[2].abs().max()) == 0.0 and float(zeros[1].min()) == 3.0
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M', [1, 3, 11])
+def test_dense_block_backward_sweep_from_gates_against_torch(dt, M):
+	"""convasr_bn_bwd_reduce_many + convasr_bn_bwd_apply_grouped (pass 1 in one sweep from the stored gates, pass 2 with g read once) against
+	the formulas in float64: g = gate ? dz / (1 - p) : 0 (bit-exact), sum g and sum g xhat_i per batch norm -> dgamma / dbeta and the
+	coefficients, dy_i = gamma_i invstd_i (g - mean(g) - xhat_i mean(g xhat_i))."""
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(M)
+	B, T, C, p = 3, 211, 136, 0.25
+	dz = ops.as_cl(torch.randn(B, C, T, device = d), dt)
+	bits = torch.rand(B, T, C, device = d) < 0.6  # channels-last element order
+	gate = (bits.view(-1, 8).to(torch.uint8) << torch.arange(8, device = d, dtype = torch.uint8)).sum(dim = 1).to(torch.uint8)
+	ys = [ops.as_cl(torch.randn(B, C, T, device = d) * 2 + 1, dt) for _ in range(M)]
+	means = [y.float().mean(dim = (0, 2)).contiguous() for y in ys]
+	invstds = [(y.float().var(dim = (0, 2), unbiased = False) + 1e-5).rsqrt().contiguous() for y in ys]
+	gammas = [torch.rand(C, device = d) + 0.5 for _ in range(M)]
+	coefs = [torch.empty(3 * C, device = d) for _ in range(M)]
+	dgs, dbs = [torch.full((C, ), 2.0, device = d) for _ in range(M)], [torch.zeros(C, device = d) for _ in range(M)]
+	acc = [i == 0 for i in range(M)]
+	g = ops.bn_bwd_reduce_many(dz, gate, p, ys, means, invstds, gammas, coefs, dgs, dbs, acc)
+	thr = round(p * 65536)
+	ks = torch.tensor(65536.0 / (65536 - thr), dtype = torch.float32, device = d)
+	g32 = torch.where(bits.permute(0, 2, 1), dz.float() * ks, torch.zeros((), device = d))
+	assert torch.equal(g, g32.to(dt))
+	n = B * T
+	g64 = g32.double()
+	dys = ops.bn_bwd_apply_grouped(g, ys, coefs)
+	for i in range(M):
+		xhat = (ys[i].double() - means[i].double().view(1, C, 1)) * invstds[i].double().view(1, C, 1)
+		sg, sgx = g64.sum(dim = (0, 2)), (g64 * xhat).sum(dim = (0, 2))
+		tol = 2e-5 * float(sgx.abs().max() + sg.abs().max())
+		assert float((dgs[i].double() - (sgx + (2.0 if acc[i] else 0.0))).abs().max()) <= tol and float((dbs[i].double() - sg).abs().max()) <= tol, i
+		want = gammas[i].double().view(1, C, 1) * invstds[i].double().view(1, C, 1) * (g.double() - (sg / n).view(1, C, 1) - xhat * (sgx / n).view(1, C, 1))
+		err = float((dys[i].double() - want).abs().max()) / float(want.abs().max())
+		assert err <= (1.2e-2 if dt == torch.bfloat16 else 1.5e-3), (i, err)  # one 16-bit rounding of dy (and of the g the apply pass reads)
