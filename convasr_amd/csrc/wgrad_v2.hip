@@ -103,14 +103,13 @@ template <typename H> __device__ __forceinline__ void wgrad_v2_body(const WgradP
 #else
 	const int tg = unit % p.tap_groups, ci_t = (unit / p.tap_groups) % p.ci_tiles, co_t = unit / (p.tap_groups * p.ci_tiles);
 #endif
-	// taps per group, balanced: K = 13 is cut 4 + 3 + 3 + 3, not 4 + 4 + 4 + 1 -- a one-tap group moves the same dY / X rows into LDS as a
-	// four-tap one for a quarter of its MFMA work and runs operand-bound (~0.5 group-times instead of 0.25), a three-tap group stays
-	// MFMA-bound at 0.75: 3.25 group-times instead of ~3.5 for K = 13, 4.25 / ~4.5 for K = 17, ... (K = 11: 4 + 4 + 3 either way)
-	const int tbase = p.K / p.tap_groups, trem = p.K % p.tap_groups;
-	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * tbase + min(tg, trem);
+	// (Balanced tap groups -- K = 29 cut 5 x 4 + 3 x 3 instead of 7 x 4 + 1, K = 13 cut 4 + 3 + 3 + 3 -- were measured in round 5 and lost: a chunk's
+	// DMA and barrier cost is the same whatever the group's tap count, so a three-tap group costs ~0.85 of a full one, not 0.75, and the
+	// one-tap group only ~0.4: the K = 29 launch of the bench step went from 7.4 to 7.55 group-times, +38 us, profiles/r05_ab_rounds_wav2letter.json.)
+	const int co0 = co_t * 128, ci0 = ci_t * 128, tap0 = tg * WG_TG;
 	const int c_begin = split * p.chunks_per_split, c_end = min(p.total_chunks, c_begin + p.chunks_per_split);
 	// slot A / slot B of this wave: tap index, mask of the k-substeps (of 4 per chunk) it covers, shared with the other wave half?
-	const int ntaps = tbase + (tg < trem ? 1 : 0);
+	const int ntaps = min(WG_TG, p.K - tap0);
 	int tapA, tapB;
 	unsigned mA, mB;
 	bool shA = false, shB = false;

@@ -97,6 +97,7 @@ PREPACK = os.environ.get('CONVASR_NO_PREPACK') != '1'  # A/B hook
 _prepack_streams = {}  # device -> [side stream, packs pending on it?]
 
 
+GROUPED_PACK_MIN = int(os.environ.get('CONVASR_GROUPED_PACK_MIN', 32))
 _pack_tables = {}  # (device, dtype) -> dict(key = the (src, dst) addresses it was built for, items = device table, blocks)
 
 
@@ -104,7 +105,10 @@ def _pack_group(stale, dtype, refresh = True):
 	"""Which of the `stale` weights' dgrad copies can share the one grouped launch: 16-bit, even channel counts, buffers allocated, packed
 	forward copy current (the arena mirror's segment, or refreshed here when refresh is set)."""
 	group = []
-	if dtype in ops.HALF_DTYPES and len(stale) > 1:
+	# (a grouped launch only for MANY copies: the one launch floods every CU at once -- beside the CTC recursion, whose 64 polling workgroups
+	# it overlaps on the prepack stream, that cost the Wav2Letter step +40 us of CTC time for 18 copies, where 18 small launches cost nothing;
+	# JasperNetLarge's 108 copies drop from 0.83 to 0.24 ms: profiles/r05_ab_rounds_wav2letter.json, r05_config4_kernel_stats.csv)
+	if dtype in ops.HALF_DTYPES and len(stale) >= GROUPED_PACK_MIN:
 		for w in stale:
 			ent = _pack_cache.get((id(w), dtype))
 			if ent is None or ent['dgr'] is None:
