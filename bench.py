@@ -852,7 +852,7 @@ def main(argv = None):
 			dist.barrier()
 		torch.cuda.synchronize()
 
-	probe = DeviceProbe(device) if rank == 0 else None  # host-side sampler of the card's clock / power / PPT residency (sysfs + librocm_smi64 through ctypes: no GPU call)
+	probe = DeviceProbe(device) if rank == 0 and os.environ.get('CONVASR_NO_PROBE') != '1' else None  # (CONVASR_NO_PROBE=1: A/B hook) host-side sampler of the card's clock / power / PPT residency (sysfs + librocm_smi64 through ctypes: no GPU call)
 	line, sequence = measure(args, device, rank, world, use_dist, dist_info, fence, probe)
 	if use_dist:
 		dist.destroy_process_group()

@@ -396,6 +396,11 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
 	dist = out['dist']
 	assert out['n_gpus'] == 2 and dist['backend'].startswith('nccl') and dist['world_size'] == 2 and dist['replicas_equal'] is True
 	assert len(dist['per_rank_ms']['all']) == 2 and dist['exposed_comm_ms']['mean'] >= 0
+	# the first multi-GPU run has a prediction to be wrong about (convasr_amd.parallel.predict_exposed_comm): the measured
+	# exposed communication may not exceed twice the predicted one (+ 0.1 ms of event granularity)
+	pred = dist.get('predicted') or {}
+	assert 'exposed_comm_ms' in pred, dist
+	assert dist['exposed_comm_ms']['mean'] <= 2 * pred['exposed_comm_ms'] + 0.1, (dist['exposed_comm_ms'], pred)
 	print('2 GPUs over RCCL:', out['value'], 'audio-s/s', dist['per_rank_ms'], dist['exposed_comm_ms']['mean'], dist['rccl_version'])
 
 
