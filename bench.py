@@ -582,7 +582,7 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world, graphed = False):
 class DeviceProbe:
 	"""Host-side sampler of THIS rank's card over the timed region, so that a round-to-round difference of the headline can be
 	attributed from the line alone (the pool's devices differ by +-4 % on the MFMA kernels; the step is package-power limited):
-	* hwmon (sysfs) every ~5 ms from a NATIVE thread (libconvasr_smi.so: a Python sampler thread took the GIL from the launching thread often
+	* hwmon (sysfs) every ~20 ms from a NATIVE thread (libconvasr_smi.so: a Python sampler thread took the GIL from the launching thread often
 	  enough to cost the eager step ~1 %): power1_input -> power_w_mean, freq1_input -> sclk_mhz_mean;
 	* the firmware's throttle accumulators from the gpu_metrics table (librocm_smi64 through convasr_amd/libconvasr_smi.so, ctypes) at
 	  start() and stop(): ppt_residency = d ppt_residency_acc / d accumulation_counter, likewise thermal / PROCHOT.
@@ -638,7 +638,7 @@ class DeviceProbe:
 		self.acc = [self._metrics(), None]
 		self.native = False
 		if self.hw is not None and self.smi is not None and hasattr(self.smi, 'convasr_hwmon_start'):
-			self.native = self.smi.convasr_hwmon_start(self.hw.encode(), 5000) == 0  # a native thread: no Python (no GIL traffic) in the sampling loop
+			self.native = self.smi.convasr_hwmon_start(self.hw.encode(), 20000) == 0  # a native thread: no Python (no GIL traffic) in the sampling loop; every 20 ms (every 5 ms cost the Wav2Letter step 0.4 %: each hwmon read is an SMU query, profiles/r05_ab_probe.txt)
 
 	def stop(self):
 		import ctypes
@@ -662,7 +662,7 @@ class DeviceProbe:
 			power_cap_w = None if cap is None else cap / 1e6, ppt_residency = None if res is None else res['ppt'], throttle_residency = res,
 			gfx_clk_mhz_end = None if b is None else round(b[7], 1), socket_power_w_end = None if b is None else b[6], hotspot_c_end = None if b is None else b[8], hbm_c_end = None if b is None else b[9],
 			hwmon_samples = n_samples, sources = dict(hwmon = self.hw is not None, gpu_metrics = self.dv >= 0), unavailable = self.why or None,
-			how = 'sysfs hwmon sampled every ~5 ms over the timed region by a native thread of convasr_amd/libconvasr_smi.so (power1_input, freq1_input; no Python in the loop); throttle residencies = differences of the gpu_metrics accumulators read at its two ends through librocm_smi64; no GPU call')
+			how = 'sysfs hwmon sampled every ~20 ms over the timed region by a native thread of convasr_amd/libconvasr_smi.so (power1_input, freq1_input; no Python in the loop); throttle residencies = differences of the gpu_metrics accumulators read at its two ends through librocm_smi64; no GPU call')
 
 
 def predicted_comm(engine, world, step_s):
