@@ -874,16 +874,16 @@ def main(argv = None):
 				f16_whole_step_frac = l16['config']['whole_step_frac'], f16_loss_scale = sc['loss_scale'], f16_overflowed_steps_in_timed_region = sc['overflowed_steps_in_timed_region'],
 				f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
 		if world == 1 and headline_run and not args.no_jasper_leg:
-			# BASELINE configs[4] in the driver's record: a bounded run of `bench.py --workload jasper_large` (3 warm-up + 8 timed steps + the event-timed pass)
-			argsj = argparse.Namespace(**dict(vars(args), workload = 'jasper_large', dtype = 'f16', steps = 8, warmup = 3, side_stream = True, no_kernel_timer = False, graph = graph_policy(args.graph_opt, 'jasper_large', args.gpus)))
+			# BASELINE configs[4] in the driver's record: `bench.py --workload jasper_large --steps 12 --warmup 3` as a bounded leg (the step's efficiency depends on the mix of bucket lengths: the same 12 batches as the stand-alone line)
+			argsj = argparse.Namespace(**dict(vars(args), workload = 'jasper_large', dtype = 'f16', steps = 12, warmup = 3, side_stream = True, no_kernel_timer = False, graph = graph_policy(args.graph_opt, 'jasper_large', args.gpus)))
 			lj, _ = measure(argsj, device, rank, world, False, None, lambda: torch.cuda.synchronize(), DeviceProbe(device))
 			rj = lj['roofline'] or {}
-			line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 8, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],
+			line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 12, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],
 				dominant_kernel_frac = rj.get('frac'), wgrad_frac = (rj.get('wgrad') or {}).get('frac'), conv_stack_frac = (rj.get('conv_stack') or {}).get('frac'),
 				host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], eager_side_stream = lj['config']['eager_side_stream'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
 				side_stream_wgrad = True, batch_shapes_in_timed_region = lj['config'].get('batch_shapes_in_timed_region'), padding_overhead = lj['config'].get('padding_overhead'),
 				loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], workload = lj['config']['workload'],
-				note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: python bench.py --workload jasper_large runs the same thing longer'))
+				note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: the same 12 batches as python bench.py --workload jasper_large --steps 12 --warmup 3'))
 		if world == 1 and not args.no_cpu_baseline:
 			ref = {}
 			line['cpu_baseline'] = cpu_baseline(keep = ref)
