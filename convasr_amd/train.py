@@ -10,6 +10,8 @@ Conv weights live in the arena TAP-MAJOR ([K][Cout][Cin], include/convasr_hip.h 
 That is the element order of the packed MFMA operand and of the weight-gradient slabs, so (a) the optimizer kernel also writes a
 bf16 mirror of the arena whose conv segments ARE the packed forward weights (no packing launches per step), and (b) the split-K
 combine of the weight gradient is a streaming sum instead of a transpose."""
+import os
+
 import torch
 
 from . import ops, _lib
@@ -334,7 +336,7 @@ class GraphedTrainStep:
 	-- to skip it).  Returned metrics are the graph's static output tensors: read them before the next call with the same shape.
 	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step."""
 
-	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = True):
+	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = os.environ.get('CONVASR_GRAPH_FORKED') != '1'):
 		self.model, self.optimizer, self.max_norm, self.warmup, self.linear = model, optimizer, max_norm, max(int(warmup), 1), linear
 		engine = model if hasattr(model, 'finish_gradient_sync') else None
 		self.enabled = bool(enabled) and not (engine is not None and engine.collectives)
