@@ -357,3 +357,49 @@ def test_dense_block_backward_sweep_from_gates_against_torch(dt, M):
 		want = gammas[i].double().view(1, C, 1) * invstds[i].double().view(1, C, 1) * (g.double() - (sg / n).view(1, C, 1) - xhat * (sgx / n).view(1, C, 1))
 		err = float((dys[i].double() - want).abs().max()) / float(want.abs().max())
 		assert err <= (1.2e-2 if dt == torch.bfloat16 else 1.5e-3), (i, err)  # one 16-bit rounding of dy (and of the g the apply pass reads)
+
+
+def test_step_graphs_adamw_and_train_epoch_with_a_scheduler_bitwise_equal_to_eager():
+	"""train.train_epoch(..., graphs = GraphedTrainStep) with a learning-rate schedule (MultiStepLR: the rate changes between replays and reaches
+	the captured AdamW kernel through device memory) and AdamW's device-side applied-step counter (double-buffered: handed back inside the
+	graph) against the same epoch run eagerly: parameters, moments and the logged losses equal bit for bit."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	batches = _batches(d, 14, [(4, 4), (3, 6)])
+	out = {}
+	for graphed in (False, True):
+		ca.functional.manual_seed(5)
+		model = _wav2letter_small(ca, d, torch.bfloat16, 0.1)
+		flat = ca.train.FlatParameters(model)
+		opt = ca.optimizers.AdamW(flat, lr = 1e-3, betas = (0.9, 0.98), weight_decay = 1e-2)
+		sched = ca.optimizers.MultiStepLR(opt, gamma = 0.5, milestones = [4, 9])
+		stepper = ca.train.GraphedTrainStep(model, opt, max_norm = 10.0, warmup = 1, enabled = graphed)
+		losses = []
+		it = ca.train.train_epoch(model, opt, [(None, None) + b for b in batches], scheduler = sched, max_norm = 10.0, graphs = stepper, on_step = lambda i, b, r: losses.append((float(r['loss']), float(r['grad_norm']))))
+		torch.cuda.synchronize()
+		assert it == 14 and (not graphed or (stepper.captures == 2 and stepper.replays == 12))
+		out[graphed] = (losses, flat.data.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), float(opt.applied[opt._cur, 0]), opt.param_groups[0]['lr'])
+	a, b = out[False], out[True]
+	assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[4] == b[4] == 14.0 and a[5] == b[5] == 2.5e-4
+
+
+def test_learning_rate_from_device_memory_equals_the_by_value_argument():
+	"""The `lr_dev` argument of the three fused optimizer steps (ABI v7): one step with the rate passed by value against one with the same rate
+	read from a device float (and a WRONG by-value rate, which must be ignored)."""
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(0)
+	n = 4096 + 3
+	p0, g = torch.randn(n, device = d), torch.randn(n, device = d)
+	lr = torch.tensor([3e-3], device = d)
+	a, b = p0.clone(), p0.clone()
+	ba, bb = torch.zeros(n, device = d), torch.zeros(n, device = d)
+	ops.sgd_step(a, g, ba, n, None, 0.0, 3e-3, 0.9, 1e-3, False, True)
+	ops.sgd_step(b, g, bb, n, None, 0.0, 123.0, 0.9, 1e-3, False, True, lr_dev = lr)
+	assert torch.equal(a, b) and torch.equal(ba, bb)
+	a, b = p0.clone(), p0.clone()
+	ma, mb, va, vb = (torch.zeros(n, device = d) for _ in range(4))
+	sa, sb = torch.zeros(2, 1, device = d), torch.zeros(2, 1, device = d)
+	ops.adamw_step(a, g, ma, va, n, None, 0.0, 3e-3, 0.9, 0.999, 1e-8, 1e-2, sa[0], sa[1])
+	ops.adamw_step(b, g, mb, vb, n, None, 0.0, 123.0, 0.9, 0.999, 1e-8, 1e-2, sb[0], sb[1], lr_dev = lr)
+	assert torch.equal(a, b) and torch.equal(ma, mb) and torch.equal(va, vb) and float(sb[1]) == 1.0
