@@ -110,17 +110,20 @@ class DistributedSamplerWrapper(torch.utils.data.Sampler):
 	multiple of W, as torch's DistributedSampler does.  BucketingBatchSampler emits W consecutive batches per bucket group, so
 	the W ranks of one iteration always get batches of the same bucket (equal padded length: balanced steps)."""
 
-	def __init__(self, sampler, num_replicas = None, rank = None, shuffle = False):
+	def __init__(self, sampler, num_replicas = None, rank = None, shuffle = False, seed = 0):
 		import torch.distributed as dist
-		if shuffle:
-			raise ValueError('DistributedSamplerWrapper: shuffle = True is never used by the reference (train.py:643) and is not implemented')
 		self.sampler = sampler
 		self.num_replicas = num_replicas if num_replicas is not None else dist.get_world_size()
 		self.rank = rank if rank is not None else dist.get_rank()
 		self.epoch = 0
+		self.shuffle, self.seed = shuffle, seed  # shuffle = True (never passed by the reference's train.py:643): torch.utils.data.DistributedSampler's permutation of the BATCHES, seeded seed + epoch
 
 	def __iter__(self):
 		batches = list(self.sampler)
+		if self.shuffle:
+			g = torch.Generator()
+			g.manual_seed(self.seed + self.epoch)
+			batches = [batches[i] for i in torch.randperm(len(batches), generator = g).tolist()]
 		total = int(math.ceil(len(batches) / self.num_replicas)) * self.num_replicas
 		if batches and total > len(batches):
 			batches = (batches * int(math.ceil(total / len(batches))))[:total]

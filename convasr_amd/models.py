@@ -122,8 +122,7 @@ class LogFilterBankFrontend(nn.Module):
 		super().__init__()
 		if stft_mode not in (None, '', 'conv'):
 			raise ValueError(f'stft_mode {stft_mode!r}')
-		if debug_short_long_records_normalize_signal_multiplier != 1.0:
-			raise _lib.ConvasrHipError('debug_short_long_records_normalize_signal_multiplier != 1 is not supported')
+		self.debug_short_long_records_normalize_signal_multiplier = float(debug_short_long_records_normalize_signal_multiplier)
 		self.stft_mode, self.dither, self.dither0 = stft_mode or None, dither, dither0
 		self.preemphasis, self.normalize_signal, self.sample_rate = preemphasis, normalize_signal, sample_rate
 		self.win_length = int(window_size * sample_rate)
@@ -155,7 +154,7 @@ class LogFilterBankFrontend(nn.Module):
 			# a temporal_mask() prefix mask: recover the lengths exactly ((n - 0.5) / T -> ceil -> n)
 			n = mask.reshape(mask.shape[0], -1).sum(dim = -1).to(torch.float32)
 			xlen = (n - 0.5) / signal.shape[-1]
-		return ops.logmel(signal, xlen, self.window, self.mel.weight.view(self.mel.weight.shape[0], -1), self.mel.bias, self.nfft, self.hop_length, preemphasis = self.preemphasis, normalize = self.normalize_signal)
+		return ops.logmel(signal, xlen, self.window, self.mel.weight.view(self.mel.weight.shape[0], -1), self.mel.bias, self.nfft, self.hop_length, preemphasis = self.preemphasis, normalize = self.normalize_signal, denom_multiplier = self.debug_short_long_records_normalize_signal_multiplier)
 
 	@staticmethod
 	def compute_output_shape(time_dim_length, kernel_size, stride, padding, dilation = 1):

@@ -69,8 +69,9 @@ def xlen_f32(xlen, device):
 
 # ------------------------------------------------------------------------------------------------ frontend / instance norm
 
-def logmel(signal, xlen, window, mel_weight, mel_bias, nfft, hop, preemphasis = 0.97, normalize = True):
-	"""LogFilterBankFrontend.forward (models.py:565-597) -> channels-last (B, nmel, F) fp32."""
+def logmel(signal, xlen, window, mel_weight, mel_bias, nfft, hop, preemphasis = 0.97, normalize = True, denom_multiplier = 1.0):
+	"""LogFilterBankFrontend.forward (models.py:565-597) -> channels-last (B, nmel, F) fp32.
+	denom_multiplier: models.py:570's debug_short_long_records_normalize_signal_multiplier, x / ((absmax + 1e-5) * m)."""
 	require_cuda(signal, window, mel_weight, mel_bias)
 	assert signal.ndim == 2
 	if signal.dtype not in (torch.float32, torch.int16):
@@ -84,6 +85,10 @@ def logmel(signal, xlen, window, mel_weight, mel_bias, nfft, hop, preemphasis = 
 	if normalize:
 		absmax = torch.empty(B, dtype = torch.float32, device = signal.device)
 		call('convasr_signal_absmax', ptr(signal), dtype_code(signal.dtype), B, T, ptr(absmax), s)
+		if denom_multiplier != 1.0:
+			# the kernel divides by (absmax + 1e-5): hand it the peak that makes that (absmax + 1e-5) * m.  A debugging knob of the reference, off by
+			# default: two B-element torch launches, not on the path of any BASELINE config
+			absmax.mul_(float(denom_multiplier)).add_(1e-5 * (float(denom_multiplier) - 1.0))
 	out = empty_cl(B, nmel, F, torch.float32, signal.device)
 	xl = xlen_f32(xlen, signal.device)
 	_lib.timed('hbm:logmel_kernel', 0.0, lambda: call('convasr_logmel_fwd', ptr(signal), dtype_code(signal.dtype), ptr(absmax), ptr(xl), ptr(window), window.shape[0], ptr(mel_weight), ptr(mel_bias), ptr(out), B, T, nfft, hop, nmel, float(preemphasis), s), nbytes = float(B * T * signal.element_size() + B * F * nmel * 4))

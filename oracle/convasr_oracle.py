@@ -125,7 +125,8 @@ def logmel_frontend(
 	hop_length: int,
 	preemphasis: float = 0.97,
 	normalize_signal: bool = True,
-	stage: str = 'logmel'
+	stage: str = 'logmel',
+	denom_multiplier: float = 1.0
 ) -> torch.Tensor:
 	"""(B, T) waveform -> (B, n_mels, F) log-mel features.
 
@@ -138,7 +139,7 @@ def logmel_frontend(
 	win_length = window.shape[0]
 	signal = signal if signal.is_floating_point() else signal.to(torch.float32)
 	if normalize_signal and signal.numel() > 0:
-		signal = signal / (signal.abs().max(dim = -1, keepdim = True).values + 1e-5)
+		signal = signal / ((signal.abs().max(dim = -1, keepdim = True).values + 1e-5) * denom_multiplier)  # models.py:570, 684-686 (debug_short_long_records_normalize_signal_multiplier)
 	if preemphasis > 0:
 		signal = torch.cat([signal[..., :1], signal[..., 1:] - preemphasis * signal[..., :-1]], dim = -1)
 	if xlen is not None:

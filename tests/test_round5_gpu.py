@@ -403,3 +403,19 @@ def test_learning_rate_from_device_memory_equals_the_by_value_argument():
 	ops.adamw_step(a, g, ma, va, n, None, 0.0, 3e-3, 0.9, 0.999, 1e-8, 1e-2, sa[0], sa[1])
 	ops.adamw_step(b, g, mb, vb, n, None, 0.0, 123.0, 0.9, 0.999, 1e-8, 1e-2, sb[0], sb[1], lr_dev = lr)
 	assert torch.equal(a, b) and torch.equal(ma, mb) and torch.equal(va, vb) and float(sb[1]) == 1.0
+
+
+def test_frontend_normalize_signal_multiplier_against_the_oracle():
+	"""models.py:499 / 570: debug_short_long_records_normalize_signal_multiplier m divides the normalised signal once more, x / ((absmax + 1e-5) m)."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	torch.manual_seed(2)
+	x = torch.rand(3, 16000) * 0.6 - 0.3
+	xlen = torch.tensor([1.0, 0.7, 0.4])
+	for m in (0.5, 3.0):
+		fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window', debug_short_long_records_normalize_signal_multiplier = m).to(d)
+		got = fe(x.to(d), xlen = xlen.to(d)).cpu()
+		want = O.logmel_frontend(x, xlen, fe.window.cpu(), fe.mel.weight.cpu(), fe.mel.bias.cpu(), 512, 160, denom_multiplier = m)
+		plain = O.logmel_frontend(x, xlen, fe.window.cpu(), fe.mel.weight.cpu(), fe.mel.bias.cpu(), 512, 160)
+		err = float((got - want).abs().max())
+		assert err <= 2e-4 * float(want.abs().max()) and float((want - plain).abs().max()) > 0.5, (m, err)
