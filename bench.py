@@ -733,7 +733,7 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 		e_idx = [wl.batch_of(args.warmup + i) for i in range(n_e)]
 		eager_info = dict(ms_per_step = round(1e3 * e_el / n_e, 3), steps = n_e, value = round(sum(wl.audio[j][0] for j in e_idx) / e_el, 1),
 			whole_step_frac = round(sum(wl.flops[j][0] + wl.flops[j][1] for j in e_idx) / e_el / PEAK_BF16_DENSE, 4),
-			note = 'the same steps launched kernel by kernel (Python enqueues ~1,000 launches per step) with the weight gradients on a side stream, timed right after the graph-replayed region on the same device')
+			note = 'the same steps launched kernel by kernel (Python enqueues every launch: ~530 per JasperNetLarge step) with the weight gradients on a side stream, timed right after the graph-replayed region on the same device')
 	steps2, kt2, sequence2, calls2 = 0, {}, [], None
 	ca.functional.join_side_streams()
 	ca.functional.enable_side_stream_wgrad(device, False)  # the event-timed pass below runs every kernel alone on the main stream, eagerly
