@@ -336,8 +336,9 @@ class GraphedTrainStep:
 	-- to skip it).  Returned metrics are the graph's static output tensors: read them before the next call with the same shape.
 	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step."""
 
-	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = os.environ.get('CONVASR_GRAPH_FORKED') != '1'):
+	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = os.environ.get('CONVASR_GRAPH_FORKED') != '1', max_graphs = 64):
 		self.model, self.optimizer, self.max_norm, self.warmup, self.linear = model, optimizer, max_norm, max(int(warmup), 1), linear
+		self.max_graphs = max_graphs  # batch shapes beyond this many stay eager (a loader that does not pad to bucket ceilings produces a new shape per batch: every capture keeps its static inputs and outputs alive)
 		engine = model if hasattr(model, 'finish_gradient_sync') else None
 		self.enabled = bool(enabled) and not (engine is not None and engine.collectives)
 		self.graphs, self.seen = {}, {}
@@ -412,7 +413,7 @@ class GraphedTrainStep:
 		g = self.graphs.get(key)
 		if g is None:
 			n = self.seen.get(key, 0)
-			if n < self.warmup or self.optimizer.steps == 0:
+			if n < self.warmup or self.optimizer.steps == 0 or len(self.graphs) >= self.max_graphs:
 				self.seen[key] = n + 1
 				return self._eager(x, xlen, y, ylen, iteration)
 			self._capture(key, x, xlen, y, ylen, iteration)
