@@ -75,7 +75,7 @@ def parse_args(argv = None):
 			'second pass, where the side stream is switched off again: overlapped launches would inflate each other')
 	ap.add_argument('--graph', default = 'auto', choices = ['auto', 'on', 'off'], nargs = '?', const = 'on',
 		help = 'replay the training step from HIP graphs, one per batch shape (convasr_amd.train.GraphedTrainStep); jasper_large batches are then padded to their bucket\'s '
-			'ceiling (one shape per bucket).  auto: on for jasper_large with one rank (~1,000 launches and ~20 ms of Python per ~38 ms step; a replay costs the host ~3 ms, and the replayed step itself is ~2 %% slower than the eager one '
+			'ceiling (one shape per bucket).  auto: on for jasper_large with one rank (~530 launches and ~19 ms of Python per ~38 ms step; a replay costs the host ~0.4 ms, and the replayed step itself is ~2 %% slower than the eager one '
 			'with the wgrad side stream, whose time the line also reports), off for wav2letter (~110 launches, GPU-bound either way: +-0 measured, and the dominant kernel stays event-timed '
 			'inside the timed region) and for N > 1 (RCCL has not run under capture on this pool).  With graphs on, per-kernel HIP-event durations come from the second, eager pass')
 	ap.add_argument('--no-jasper-leg', action = 'store_true', help = 'skip the bounded BASELINE configs[4] leg (extra.jasper_large) of the default line')

@@ -318,7 +318,7 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 class GraphedTrainStep:
 	"""train_step(model, optimizer, x, xlen, y, ylen) with accumulate_iterations = 1, replayed from a HIP graph: one graph per batch shape
 	(x.shape, y.shape -- a bucketed loader that pads every batch of a bucket to the bucket's ceiling, datasets.bucket_ceiling, produces
-	about a dozen), captured after `warmup` eager steps of that shape.  A JasperNetLarge step is ~1,000 kernel launches and ~20 ms of
+	about a dozen), captured after `warmup` eager steps of that shape.  A JasperNetLarge step is ~530 kernel launches and ~19 ms of
 	Python for ~40 ms of GPU work; a replay is one call.
 
 	What makes the captured step a faithful replay (tests/test_graph_gpu.py compares 20 steps bit for bit with the eager path):
