@@ -321,7 +321,7 @@ class GraphedTrainStep:
 	about a dozen), captured after `warmup` eager steps of that shape.  A JasperNetLarge step is ~530 kernel launches and ~19 ms of
 	Python for ~40 ms of GPU work; a replay is one call.
 
-	What makes the captured step a faithful replay (tests/test_graph_gpu.py compares 20 steps bit for bit with the eager path):
+	What makes the captured step a faithful replay (tests/test_round5_gpu.py compares 20 / 24 steps bit for bit with the eager path):
 	* everything that changes from step to step is read from device memory when the kernels RUN -- the dropout step key
 	  (functional.begin_step), the loss scaler, the optimizer's step counters / EMAs, the learning rate (`optimizer.lr_dev`, refreshed here
 	  whenever the host's scheduler changed param_groups[0]['lr']), the device-side skip gates;
