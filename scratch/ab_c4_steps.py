@@ -25,13 +25,16 @@ def run(bits, n = 10):
 	lib.convasr_debug_set_conv_v2(1)
 	return (time.perf_counter() - t0) / n * 1e3
 VARIANTS = [('shipped', 0), ('no conv1x1 kernel', 8192), ('no conv1x1, K=1 not flattened', 8192 | 512), ('no short last tile', 128), ('none of the round-4 conv changes', 8192 | 512 | 128 | 2048)]
+if os.environ.get('AB_ONLY_1X1') == '1':
+	VARIANTS = VARIANTS[:2]
 res = {}
-for rnd in range(2):
+ROUNDS = int(os.environ.get('AB_ROUNDS', 2))
+for rnd in range(ROUNDS):
 	for name, bits in VARIANTS:
 		res.setdefault(name, []).append(run(bits))
-out = {name: dict(ms_per_step = round(min(v), 3), runs = [round(a, 3) for a in v]) for name, v in res.items()}
+out = {name: dict(ms_per_step = round(min(v), 3), median = round(sorted(v)[len(v) // 2], 3), runs = [round(a, 3) for a in v]) for name, v in res.items()}
 base = out['shipped']['ms_per_step']
 for name, v in out.items():
 	v['vs_shipped'] = round(v['ms_per_step'] / base, 4)
 	print(name, v, flush = True)
-json.dump(dict(workload = wl.name, note = 'same process, same device, same 10 batches per variant, two alternating rounds, best of each', variants = out), open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', f'r04_ab_steps_{workload}.json'), 'w'), indent = 1)
+json.dump(dict(workload = wl.name, note = f'same process, same device, same 10 batches per variant, {ROUNDS} alternating rounds, best (ms_per_step) and median of each', variants = out), open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', os.environ.get('AB_OUT', f'r04_ab_steps_{workload}.json')), 'w'), indent = 1)
