@@ -868,22 +868,47 @@ def main(argv = None):
 			# (at least 8 warm-up steps here: apex's dynamic scale starts at 2^16 and halves once per overflowed step until the gradients
 			# of this random-data workload fit -- that search belongs to the warm-up, not to the timed region)
 			args16 = argparse.Namespace(**dict(vars(args), warmup = max(args.warmup, 8), dtype = 'f16', no_kernel_timer = True))
-			l16, _ = measure(args16, device, rank, world, False, None, lambda: torch.cuda.synchronize(), None)
-			sc = l16['loss_scaler']
-			f16_leg = dict(f16_value = l16['value'], f16_ms_per_step = l16['ms_per_step'], f16_steps = args.steps, f16_warmup = args16.warmup,
-				f16_whole_step_frac = l16['config']['whole_step_frac'], f16_loss_scale = sc['loss_scale'], f16_overflowed_steps_in_timed_region = sc['overflowed_steps_in_timed_region'],
-				f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
+			try:
+				l16, _ = measure(args16, device, rank, world, False, None, lambda: torch.cuda.synchronize(), None)
+				sc = l16['loss_scaler']
+				f16_leg = dict(f16_value = l16['value'], f16_ms_per_step = l16['ms_per_step'], f16_steps = args.steps, f16_warmup = args16.warmup,
+					f16_whole_step_frac = l16['config']['whole_step_frac'], f16_loss_scale = sc['loss_scale'], f16_overflowed_steps_in_timed_region = sc['overflowed_steps_in_timed_region'],
+					f16_note = 'second timed region right after the headline, same device, same workload and step count, fp16 storage + MFMA under apex O2 dynamic loss scaling (an overflowed step skips only the optimizer update)')
+			except Exception as e:  # (a leg must never cost the headline its line)
+				import traceback
+				traceback.print_exc(file = sys.stderr)
+				f16_leg = dict(f16_error = f'{type(e).__name__}: {e}')
+				torch.cuda.synchronize()
+				torch.cuda.empty_cache()
 		if world == 1 and headline_run and not args.no_jasper_leg:
 			# BASELINE configs[4] in the driver's record: `bench.py --workload jasper_large --steps 12 --warmup 3` as a bounded leg (the step's efficiency depends on the mix of bucket lengths: the same 12 batches as the stand-alone line)
 			argsj = argparse.Namespace(**dict(vars(args), workload = 'jasper_large', dtype = 'f16', steps = 12, warmup = 3, side_stream = True, no_kernel_timer = False, graph = graph_policy(args.graph_opt, 'jasper_large', args.gpus)))
-			lj, _ = measure(argsj, device, rank, world, False, None, lambda: torch.cuda.synchronize(), DeviceProbe(device))
-			rj = lj['roofline'] or {}
-			line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 12, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],
-				dominant_kernel_frac = rj.get('frac'), wgrad_frac = (rj.get('wgrad') or {}).get('frac'), conv_stack_frac = (rj.get('conv_stack') or {}).get('frac'),
-				host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], eager_side_stream = lj['config']['eager_side_stream'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
-				side_stream_wgrad = True, batch_shapes_in_timed_region = lj['config'].get('batch_shapes_in_timed_region'), padding_overhead = lj['config'].get('padding_overhead'),
-				loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], workload = lj['config']['workload'],
-				note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: the same 12 batches as python bench.py --workload jasper_large --steps 12 --warmup 3'))
+			# (a leg must never cost the headline its line: a failure -- e.g. a runtime that cannot capture the step -- is recorded, and the replayed leg falls back to the eager step)
+			lj, leg_note = None, None
+			for attempt in (argsj, argparse.Namespace(**dict(vars(argsj), graph = False))):
+				try:
+					lj, _ = measure(attempt, device, rank, world, False, None, lambda: torch.cuda.synchronize(), DeviceProbe(device))
+					break
+				except Exception as e:
+					import traceback
+					traceback.print_exc(file = sys.stderr)
+					leg_note = (leg_note + '; ' if leg_note else '') + ('graph-replayed' if attempt.graph else 'eager') + f' leg failed: {type(e).__name__}: {e}'
+					_lib.timer = None
+					ca.functional.CAPTURING[0] = False
+					torch.cuda.synchronize()
+					torch.cuda.empty_cache()
+					if not attempt.graph:
+						break
+			if lj is None:
+				line['extra'] = dict(jasper_large = dict(error = leg_note))
+			else:
+				rj = lj['roofline'] or {}
+				line['extra'] = dict(jasper_large = dict(value = lj['value'], unit = lj['unit'], ms_per_step = lj['ms_per_step'], steps = 12, warmup = 3, dtype = 'f16', whole_step_frac = lj['config']['whole_step_frac'],
+					dominant_kernel_frac = rj.get('frac'), wgrad_frac = (rj.get('wgrad') or {}).get('frac'), conv_stack_frac = (rj.get('conv_stack') or {}).get('frac'),
+					host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], eager_side_stream = lj['config']['eager_side_stream'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
+					side_stream_wgrad = True, batch_shapes_in_timed_region = lj['config'].get('batch_shapes_in_timed_region'), padding_overhead = lj['config'].get('padding_overhead'),
+					loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], workload = lj['config']['workload'],
+						note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: the same 12 batches as python bench.py --workload jasper_large --steps 12 --warmup 3' + (' -- ' + leg_note if leg_note else '')))
 		if world == 1 and not args.no_cpu_baseline:
 			ref = {}
 			line['cpu_baseline'] = cpu_baseline(keep = ref)
