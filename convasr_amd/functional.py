@@ -464,8 +464,8 @@ def _pair_wanted(x, weight, spec, dt, fold, B, Tout):
 		return False
 	if PAIR_BWD == '1':
 		return True
-	if not CAPTURING[0]:
-		return False  # 'auto' pairs inside a step-graph capture only: the eager step has the side stream for this overlap (+-0 with both, profiles/r05_ab_pair.txt), and the eager Wav2Letter step keeps its launch sequence
+	if _side_streams.get(x.device) is not None:
+		return False  # the eager step with the weight-gradient side stream already has this overlap (measured +-0 with both: profiles/r05_ab_pair.txt); a linear graph capture switches the side stream off and lands here
 	tiles = B * ((x.shape[2] + 255) // 256) * (Cin // 128)  # the dgrad's output tiles: (b, 256 frames, 128 input channels)
 	return tiles < PAIR_MAX_ROUNDS * 256
 
