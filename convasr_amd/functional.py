@@ -450,10 +450,9 @@ def _after_long_launch():
 		hook()
 
 
-# Horizontal fusion of a layer's two backward MFMA launches (csrc/bwd_pair.hip).  PAIR_BWD: 'auto' (default) pairs, where no weight-gradient side
-# stream is on (a replayed step graph, a plain eager step), the launches whose dgrad covers fewer than PAIR_MAX_ROUNDS rounds of tiles on the
-# chip -- JasperNet at 32 utterances per GPU: +0.9 % on the replayed step, which thereby catches up with the eager step's side stream; a
-# launch of many rounds (Wav2Letter at 64 x 15 s) gains nothing from company (+-0 measured) --, '1' always, '0' never (A/B hook).
+# Horizontal fusion of a layer's two backward MFMA launches (csrc/bwd_pair.hip).  PAIR_BWD: 'auto' (default) pairs the launches whose dgrad
+# covers fewer than PAIR_MAX_ROUNDS rounds of tiles on the chip -- JasperNet at 32 utterances per GPU; a launch of many rounds (Wav2Letter at
+# 64 x 15 s: 3-4.5) gains nothing from company, the same finding as for the side stream --, '1' always, '0' never (A/B hook).
 PAIR_BWD = os.environ.get('CONVASR_PAIR_BWD', 'auto')
 PAIR_MAX_ROUNDS = float(os.environ.get('CONVASR_PAIR_MAX_ROUNDS', 2.6))
 
@@ -464,8 +463,6 @@ def _pair_wanted(x, weight, spec, dt, fold, B, Tout):
 		return False
 	if PAIR_BWD == '1':
 		return True
-	if _side_streams.get(x.device) is not None:
-		return False  # the eager step with the weight-gradient side stream already has this overlap (measured +-0 with both: profiles/r05_ab_pair.txt); a linear graph capture switches the side stream off and lands here
 	tiles = B * ((x.shape[2] + 255) // 256) * (Cin // 128)  # the dgrad's output tiles: (b, 256 frames, 128 input channels)
 	return tiles < PAIR_MAX_ROUNDS * 256
 
