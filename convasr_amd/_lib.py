@@ -68,7 +68,6 @@ _SIGNATURES = dict(
 	convasr_step_begin = (c_int, [c_p, c_p]),
 	convasr_conv1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_p]),
 	convasr_add16 = (c_int, [c_p, c_p, c_p, c_i64, c_int, c_p]),
-	convasr_conv1d_dgrad_wgrad = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_bwd_reduce_many_workspace_bytes = (c_i64, [c_int, c_int, c_int, c_int]),
 	convasr_bn_bwd_reduce_many = (c_int, [c_p, c_p, c_f32, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_pack_dgrad_item_bytes = (c_int, []),

@@ -424,7 +424,6 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out);  // conv_v2s.hip
 int convasr_conv1x1_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* rows_out);        // conv1x1.hip
 int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s);      // wgrad_v2.hip
-int convasr_bwd_pair_try(ConvParams pc, WgradParams& pw, int dtype, hipStream_t s, int* m_tiles_out);  // bwd_pair.hip
 static int g_conv_use_v2 = 1;
 static int g_conv_debug = 0;
 // test / A-B hook: bit 0 clear forces the register-staged kernels for every dtype; bits 8.. are experiment flags (ConvParams::debug)
@@ -433,7 +432,7 @@ extern "C" int convasr_debug_set_conv_v2(int enable) { const int prev = g_conv_u
 
 static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K,
                       int stride, int dil, int pad, const float* bias, double* stats, const float* scale, const float* shift, int act,
-                      float act_lo, float act_hi, const float* xlen, const ConvParams* bn_fusion, int* rows_out, void* stream, WgradParams* pair = nullptr, int* paired = nullptr) {
+                      float act_lo, float act_hi, const float* xlen, const ConvParams* bn_fusion, int* rows_out, void* stream) {
 	CONVASR_CHECK_ARG(x && wp && y && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0, "conv1d_fwd: bad arguments");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd: scale and shift go together");
 	const int64_t expect = ((int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1) - 1) / stride + 1;
@@ -465,14 +464,6 @@ static int conv1d_run(const void* x, const void* wp, void* y, int x_dtype, int y
 	CONVASR_CHECK_ARG(smem <= 160 * 1024, "conv1d_fwd: tile needs %zu B of LDS", smem);
 	hipStream_t s = (hipStream_t)stream;
 	int v2_rows = 0;
-	if (paired) *paired = 0;
-	// a dgrad that travels with the weight gradient of its layer in one dispatch (bwd_pair.hip; K = 1 layers keep their own kernel)
-	if (pair && K > 1 && x_dtype == y_dtype && convasr_is_half(x_dtype) && g_conv_use_v2 && convasr_bwd_pair_try(p, *pair, x_dtype, s, &v2_rows)) {
-		CONVASR_CHECK_LAUNCH("conv1d_bwd_pair");
-		if (rows_out) *rows_out = v2_rows;
-		if (paired) *paired = 1;
-		return 0;
-	}
 	if (convasr_is_half(x_dtype) && g_conv_use_v2 && convasr_conv1x1_try(p, x_dtype, y_dtype, s, &v2_rows)) {  // one-tap training launches with short reductions
 		CONVASR_CHECK_LAUNCH("conv1d_fwd (1x1)");
 		if (rows_out) *rows_out = v2_rows;
@@ -785,8 +776,24 @@ template <typename T> static int dispatch_wgrad(WgradParams& p, hipStream_t s) {
 	return 0;
 }
 
-// The second half of a weight gradient: the split-K combine into dw (either layout) and the optional bias gradient (column sums of dy).
-static int wgrad_finish(const WgradParams& p, const void* dy, float* dw, float* dbias, int dtype, int B, int Cin, int Cout, int Tout, int K, int accumulate, int dw_layout, hipStream_t s) {
+extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
+                                    int Tout, int K, int stride, int dil, int pad, int accumulate, int dw_layout, void* stream) {
+	CONVASR_CHECK_ARG(x && dy && dw && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0 && (dw_layout == CONVASR_W_REFERENCE || dw_layout == CONVASR_W_KMAJOR), "conv1d_wgrad: bad arguments");
+	CONVASR_CHECK_ARG(dw_layout == CONVASR_W_REFERENCE || (((int64_t)Cout * Cin) & 3) == 0, "conv1d_wgrad: K-major dw needs Cout * Cin %% 4 == 0");
+	CONVASR_CHECK_ARG(K <= 64, "conv1d_wgrad: K %d > 64", K);
+	WgradParams p;
+	p.debug = g_conv_debug;
+	p.x = x; p.dy = dy; p.slab = (float*)workspace;
+	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
+	hipStream_t s = (hipStream_t)stream;
+	int rc;
+	if (convasr_is_half(dtype) && g_conv_use_v2 && convasr_wgrad_v2_try(p, dtype, s)) rc = 0;
+	else if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
+	else if (dtype == CONVASR_BF16) rc = dispatch_wgrad<bf16_t>(p, s);
+	else if (dtype == CONVASR_F16) rc = dispatch_wgrad<f16_t>(p, s);
+	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: dtype %d", dtype);
+	if (rc) return rc;
+	CONVASR_CHECK_LAUNCH("conv1d_wgrad");
 	if (dw_layout == CONVASR_W_KMAJOR) {
 		const int64_t n4 = (int64_t)K * Cout * Cin / 4;
 		int64_t blocks = ceil_div64(n4, 256);
@@ -806,27 +813,6 @@ static int wgrad_finish(const WgradParams& p, const void* dy, float* dw, float* 
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
 	}
 	return 0;
-}
-
-extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
-                                    int Tout, int K, int stride, int dil, int pad, int accumulate, int dw_layout, void* stream) {
-	CONVASR_CHECK_ARG(x && dy && dw && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0 && (dw_layout == CONVASR_W_REFERENCE || dw_layout == CONVASR_W_KMAJOR), "conv1d_wgrad: bad arguments");
-	CONVASR_CHECK_ARG(dw_layout == CONVASR_W_REFERENCE || (((int64_t)Cout * Cin) & 3) == 0, "conv1d_wgrad: K-major dw needs Cout * Cin %% 4 == 0");
-	CONVASR_CHECK_ARG(K <= 64, "conv1d_wgrad: K %d > 64", K);
-	WgradParams p;
-	p.debug = g_conv_debug;
-	p.x = x; p.dy = dy; p.slab = (float*)workspace;
-	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
-	hipStream_t s = (hipStream_t)stream;
-	int rc;
-	if (convasr_is_half(dtype) && g_conv_use_v2 && convasr_wgrad_v2_try(p, dtype, s)) rc = 0;
-	else if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
-	else if (dtype == CONVASR_BF16) rc = dispatch_wgrad<bf16_t>(p, s);
-	else if (dtype == CONVASR_F16) rc = dispatch_wgrad<f16_t>(p, s);
-	else return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad: dtype %d", dtype);
-	if (rc) return rc;
-	CONVASR_CHECK_LAUNCH("conv1d_wgrad");
-	return wgrad_finish(p, dy, dw, dbias, dtype, B, Cin, Cout, Tout, K, accumulate, dw_layout, s);
 }
 
 // ------------------------------------------------------------------------------------------------ stride-2 fold
@@ -900,46 +886,4 @@ extern "C" int convasr_fold2_unfold_wgrad(const float* dw_folded, float* dw, int
 	hipLaunchKernelGGL(fold2_unfold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dw_folded, dw, dw_layout == CONVASR_W_KMAJOR, Cout, Cin, K, s0, accumulate);
 	CONVASR_CHECK_LAUNCH("fold2_unfold_wgrad");
 	return 0;
-}
-
-// ------------------------------------------------------------------------------------------------ dgrad + wgrad of one layer in one dispatch
-// The backward of one stride-1 Conv1d: dx = dgrad(dy) (optionally with the producer layer's BN-backward sums in the epilogue, as
-// convasr_conv1d_dgrad_bn_reduce) and dw (+)= wgrad(x, dy), the two MFMA kernels in ONE launch (bwd_pair.hip) followed by the split-K combine.
-// Outside the pair kernel's envelope the two run as launches of their own, exactly as the separate entry points run them.
-extern "C" int convasr_conv1d_dgrad_wgrad(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad_dgrad,
-                                          const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, int bn_act, float bn_act_lo,
-                                          float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* bn_xlen, double* bn_sums, int* bn_rows,
-                                          const uint8_t* bn_gate, const void* x, float* dw, void* workspace, int pad_fwd, int accumulate, int dw_layout, int* paired, void* stream) {
-	CONVASR_CHECK_ARG(dy && packed_dgrad && dx && x && dw && workspace && convasr_is_half(dtype) && B > 0 && Cin > 0 && Cout > 0 && T_dy > 0 && T_dx > 0 && K > 0 && dil > 0, "conv1d_dgrad_wgrad: bad arguments (16-bit storage only)");
-	CONVASR_CHECK_ARG(dw_layout == CONVASR_W_REFERENCE || (((int64_t)Cout * Cin) & 3) == 0, "conv1d_dgrad_wgrad: K-major dw needs Cout * Cin %% 4 == 0");
-	CONVASR_CHECK_ARG(!bn_y || (bn_scale && bn_shift && bn_mean && bn_invstd && bn_sums && bn_rows && dropout_p >= 0.f && dropout_p < 1.f && (Cin & 7) == 0), "conv1d_dgrad_wgrad: the fused BN-backward epilogue needs all of its operands");
-	CONVASR_CHECK_ARG(!bn_gate || bn_act == CONVASR_ACT_RELU || bn_act == CONVASR_ACT_HARDTANH || bn_act == CONVASR_ACT_NONE, "conv1d_dgrad_wgrad: the one-bit gate needs an activation whose derivative is 0 or 1");
-	ConvParams f = {};
-	if (bn_y) {
-		f.bn_y = bn_y; f.bn_scale = bn_scale; f.bn_shift = bn_shift; f.bn_mean = bn_mean; f.bn_invstd = bn_invstd; f.bn_xlen = bn_xlen; f.bn_sums = bn_sums;
-		f.bn_act = bn_act; f.bn_lo = bn_act_lo; f.bn_hi = bn_act_hi; f.bn_seed = convasr_mix_seed(seed); f.bn_offset = offset; f.bn_step_key = step_key; f.bn_gate = bn_gate;
-		f.bn_drop_thr = (unsigned)lrintf(dropout_p * 65536.f);
-		if (f.bn_drop_thr > 65535u) f.bn_drop_thr = 65535u;
-		f.bn_keep_scale = 65536.f / (float)(65536u - f.bn_drop_thr);
-	}
-	WgradParams w;
-	w.debug = g_conv_debug;
-	w.x = x; w.dy = dy; w.slab = (float*)workspace;
-	w.B = B; w.Cin = Cin; w.Cout = Cout; w.Tin = T_dx; w.Tout = T_dy; w.K = K; w.stride = 1; w.dil = dil; w.pad = pad_fwd;
-	hipStream_t s = (hipStream_t)stream;
-	int did_pair = 0;
-	// dgrad = the forward kernel on (dy, flipped packed weights): channels in = Cout, channels out = Cin, stride 1
-	int rc = conv1d_run(dy, packed_dgrad, dx, dtype, dtype, B, Cout, Cin, T_dy, T_dx, K, 1, dil, pad_dgrad, nullptr, nullptr, nullptr, nullptr, CONVASR_ACT_NONE, 0.f, 0.f, nullptr, bn_y ? &f : nullptr, bn_rows, stream, &w, &did_pair);
-	if (rc < 0) return rc;  // (rc == 1: the fused epilogue's shape is outside the LDS-DMA kernel's envelope -- nothing was launched for the dgrad; the caller runs it apart)
-	if (paired) *paired = did_pair;
-	if (!did_pair) {
-		int wrc;
-		if (g_conv_use_v2 && convasr_wgrad_v2_try(w, dtype, s)) wrc = 0;
-		else if (dtype == CONVASR_BF16) wrc = dispatch_wgrad<bf16_t>(w, s);
-		else wrc = dispatch_wgrad<f16_t>(w, s);
-		if (wrc) return wrc;
-		CONVASR_CHECK_LAUNCH("conv1d_wgrad");
-	}
-	if (int frc = wgrad_finish(w, dy, dw, nullptr, dtype, B, Cin, Cout, T_dy, K, accumulate, dw_layout, s)) return frc;
-	return rc;
 }

@@ -499,8 +499,10 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 #endif
 }
 
-// one workgroup of a launch: block index -> tile (the kernel below; bwd_pair.hip calls it for the dgrad half of a fused dgrad + wgrad launch)
-template <typename I, typename O, int BNF, int BM_> __device__ __forceinline__ void v2s_block(const ConvParams& p, const int bid, char* const smem) {
+template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
+
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int bid = blockIdx.x;
 	int v, half = 0;
 	const bool narrow = bid >= p.full_tiles;
 	if (!narrow) v = xcd_remap(bid, p.full_tiles);
@@ -536,24 +538,18 @@ template <typename I, typename O, int BNF, int BM_> __device__ __forceinline__ v
 	}
 }
 
-template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	v2s_block<I, O, BNF, BM_>(p, blockIdx.x, smem);
-}
-
-#ifndef CONVASR_PAIR_TU
+// Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
+// register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
 template <typename I, int BM_> static const void* v2s_kernel(int ki) {
 	if (ki == 0) return (const void*)conv1d_igemm_v2s_kernel<I, I, 0, BM_>;
 	if (ki == 1) return (const void*)conv1d_igemm_v2s_kernel<I, I, 1, BM_>;
 	if (ki == 3) return (const void*)conv1d_igemm_v2s_kernel<I, I, 2, BM_>;
 	return (const void*)conv1d_igemm_v2s_kernel<I, float, 0, BM_>;
 }
-#endif
 
-// The launch plan of one call (tile heights, LDS bytes, which instantiation, how many workgroups): fills the plan fields of `p`.  Returns 0 if the
-// shape is outside the LDS-DMA kernel's envelope.
-struct V2sPlan { size_t smem; int grid, ki, bi; bool f16; };
-static int v2s_plan(ConvParams& p, int x_dtype, int y_dtype, V2sPlan& pl) {
+// Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
+// register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
+int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out) {
 	if (p.stride != 1 || (p.Cin & 63) != 0 || !convasr_is_half(x_dtype) || (y_dtype != x_dtype && y_dtype != CONVASR_F32)) return 0;
 	static int n_cu = 0;
 	if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
@@ -597,24 +593,6 @@ static int v2s_plan(ConvParams& p, int x_dtype, int y_dtype, V2sPlan& pl) {
 	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
 	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
 	const int ki = wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0), bi = bm == 192 ? 1 : 0;  // (bm == 128 runs the 256-row kernel's 128-row instantiation)
-	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
-	p.full_tiles = p.total_tiles;
-	if (!(p.debug & 32)) {
-		const int rest = p.total_tiles % n_cu;
-		if (rest > 0 && 2 * rest <= n_cu && ((p.total_tiles - rest) & 7) == 0) p.full_tiles = p.total_tiles - rest;
-	}
-	pl.smem = smem; pl.grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles); pl.ki = ki; pl.bi = bi; pl.f16 = f16;
-	return 1;
-}
-
-#ifndef CONVASR_PAIR_TU
-// Returns 1 if the LDS-DMA kernel took the launch, 0 if the shape is outside its envelope (the caller falls back to conv.hip's
-// register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
-int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out) {
-	V2sPlan pl;
-	if (!v2s_plan(p, x_dtype, y_dtype, pl)) return 0;
-	const int ki = pl.ki, bi = pl.bi;
-	const bool f16 = pl.f16;
 #ifdef CONVASR_AB_TILE192
 	const void* kern = f16 ? (bi ? v2s_kernel<f16_t, 192>(ki) : v2s_kernel<f16_t, V2_BM>(ki)) : (bi ? v2s_kernel<bf16_t, 192>(ki) : v2s_kernel<bf16_t, V2_BM>(ki));
 #else
@@ -622,9 +600,15 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 #endif
 	static unsigned long long attr_set[2][2][4] = {};
 	convasr_allow_160k_lds(kern, attr_set[f16][bi][ki]);
+	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
+	p.full_tiles = p.total_tiles;
+	if (!(p.debug & 32)) {
+		const int rest = p.total_tiles % n_cu;
+		if (rest > 0 && 2 * rest <= n_cu && ((p.total_tiles - rest) & 7) == 0) p.full_tiles = p.total_tiles - rest;
+	}
+	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
 	void* args[] = {&p};
-	if (hipLaunchKernel(kern, dim3(pl.grid), dim3(V2S_THREADS), args, pl.smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
+	if (hipLaunchKernel(kern, dim3(grid), dim3(V2S_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
 	if (m_tiles_out) *m_tiles_out = p.B * p.m_tiles_per_b;
 	return 1;
 }
-#endif

@@ -25,7 +25,7 @@
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-#if defined(CONVASR_STAMPS) && !defined(CONVASR_PAIR_TU)
+#ifdef CONVASR_STAMPS
 // diagnostic build only (see conv_v2s.hip): per-wave cycle sums of the chunk loop's segments
 __device__ unsigned long long g_w2_stamps[256 * 8 * 8];
 extern "C" int convasr_debug_read_wgrad_stamps(unsigned long long* host, int count) {
@@ -334,25 +334,17 @@ template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1
 	wgrad_v2_body<H>(g.prob[q], v - g.first[q], smem);
 }
 
-// Fills the plan in `q` (a copy of the caller's parameters); returns 0 if the shape is outside this kernel's envelope.
-static int w2_plan(WgradParams& q, size_t& smem) {
-	if (q.stride != 1 || (q.Cin & 127) != 0 || (q.Cout & 127) != 0) return 0;
-	if ((int64_t)q.Tin * q.Cin * 2 >= (1ll << 31) || (int64_t)q.Tout * q.Cout * 2 >= (1ll << 31)) return 0;
+// Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
+int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
+	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0) return 0;
+	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.Tout * p.Cout * 2 >= (1ll << 31)) return 0;
+	WgradParams q = p;
 	wgrad_plan(q, W2_BKT, 1.6);
 	q.x_rows = (q.x_rows + 3) & ~3;
 	const int pieces = W2_BKT / 4 + q.x_rows / 4;
 	if (pieces > 40) return 0;  // at most 10 pieces per loader wave: the counted waits above
-	smem = 4 * (size_t)(W2_YBYTES + q.x_rows * 256);
+	const size_t smem = 4 * (size_t)(W2_YBYTES + q.x_rows * 256);
 	if (smem > 160 * 1024) return 0;
-	return 1;
-}
-
-#ifndef CONVASR_PAIR_TU
-// Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
-int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
-	WgradParams q = p;
-	size_t smem;
-	if (!w2_plan(q, smem)) return 0;
 	const bool f16 = dtype == CONVASR_F16;
 	const void* kern = f16 ? (const void*)conv1d_wgrad_v2_kernel<f16_t> : (const void*)conv1d_wgrad_v2_kernel<bf16_t>;
 	static unsigned long long set[2] = {0, 0};
@@ -471,4 +463,3 @@ extern "C" int convasr_wgrad1x1_grouped(int n, const void* const* x, const void*
 	CONVASR_CHECK_LAUNCH("wgrad1x1_grouped");
 	return 0;
 }
-#endif  // CONVASR_PAIR_TU

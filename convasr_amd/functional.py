@@ -450,45 +450,6 @@ def _after_long_launch():
 		hook()
 
 
-# Horizontal fusion of a layer's two backward MFMA launches (csrc/bwd_pair.hip).  PAIR_BWD: 'auto' (default) pairs the launches whose dgrad
-# covers fewer than PAIR_MAX_ROUNDS rounds of tiles on the chip -- JasperNet at 32 utterances per GPU; a launch of many rounds (Wav2Letter at
-# 64 x 15 s: 3-4.5) gains nothing from company, the same finding as for the side stream --, '1' always, '0' never (A/B hook).
-PAIR_BWD = os.environ.get('CONVASR_PAIR_BWD', 'auto')
-PAIR_MAX_ROUNDS = float(os.environ.get('CONVASR_PAIR_MAX_ROUNDS', 2.6))
-
-
-def _pair_wanted(x, weight, spec, dt, fold, B, Tout):
-	Cout, Cin, K = weight.shape
-	if PAIR_BWD == '0' or fold is not None or dt not in ops.HALF_DTYPES or spec.stride != 1 or K == 1 or Cin % 128 or Cout % 128 or ops.weight_layout(weight._convasr_grad) is None:
-		return False
-	if PAIR_BWD == '1':
-		return True
-	tiles = B * ((x.shape[2] + 255) // 256) * (Cin // 128)  # the dgrad's output tiles: (b, 256 frames, 128 input channels)
-	return tiles < PAIR_MAX_ROUNDS * 256
-
-
-def _dgrad_wgrad_pair(x, dy, weight, spec, dt, link):
-	"""dx (with the producer's BN-backward sums in the epilogue when it left a link, exactly like _dgrad) and the weight gradient, delivered
-	into the gradient arena, from one dispatch."""
-	join_prepack(dy.device)
-	wd = packed_weight(weight, dt, _lib.PACK_DGRAD)
-	fresh = bool(getattr(weight, '_convasr_fresh', True))
-	bn = None
-	if link is not None:
-		bn = dict(y = link['y'], scale = link['bnp'][2], shift = link['bnp'][3], mean = link['bnp'][0], invstd = link['bnp'][1], act = link['act'], drop = link['drop'], xl = link['xl'], sums = link['sums'], gate = link.get('gate'))
-	dx, _ = ops.conv1d_dgrad_wgrad(dy, wd, x, weight._convasr_grad, spec.K, spec.dilation, spec.padding, accumulate = not fresh, bn = bn)
-	weight._convasr_fresh = False
-	hook = getattr(weight, '_convasr_ready', None)
-	if hook is not None:
-		hook(weight)
-	if dx is None:  # the fused epilogue's shape is outside the envelope: the weight gradient is done, the input gradient runs apart (without the sums)
-		return _dgrad(x, dy, weight, spec, dt, None)
-	if link is not None:
-		link['dz'] = dx
-	_after_long_launch()
-	return dx
-
-
 def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
 	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it.
 	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad)."""
@@ -706,22 +667,16 @@ class ConvBnActFunction(torch.autograd.Function):
 			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad(xv, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
 		else:
 			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
+		if arena_mode:
+			# enqueue before dgrad: both only read dy, and the side stream can start while dgrad is still being issued
+			dw, = _run_wgrad(dev, (x, dy), wg)
 		dx = None
-		if arena_mode and ctx.x_needs_grad and _pair_wanted(x, weight, spec, dt, ctx.fold, B, Tout):
-			# both gradients from ONE dispatch (bwd_pair.hip): the weight gradient's units fill the CUs the dgrad's partial rounds leave idle --
-			# the side stream's overlap, but available to a replayed graph and without a second stream
-			dx = _dgrad_wgrad_pair(x, dy, weight, spec, dt, ctx.producer_link)
-			dw = None
-		else:
-			if arena_mode:
-				# enqueue before dgrad: both only read dy, and the side stream can start while dgrad is still being issued
-				dw, = _run_wgrad(dev, (x, dy), wg)
-			if ctx.x_needs_grad:
-				if spec.stride != 1:
-					raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
-				dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link)
-			if not arena_mode:
-				dw, = wg()
+		if ctx.x_needs_grad:
+			if spec.stride != 1:
+				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
+			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link)
+		if not arena_mode:
+			dw, = wg()
 
 		res_grads = [None] * (5 * n_res)
 		pending = []  # branches whose input gradient goes into a gradient accumulator: (r, dry), launched together below

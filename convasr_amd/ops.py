@@ -672,39 +672,6 @@ def conv1d_dgrad_bn_reduce(dy, packed_dgrad, Cin, K, dil, pad, bn_y, bn_scale, b
 	return dx if rc[0] == 0 else None
 
 
-def conv1d_dgrad_wgrad(dy, packed_dgrad, x, dw, K, dil, pad_fwd, accumulate = False, bn = None):
-	"""Both gradients of one stride-1 conv from one dispatch (include/convasr_hip.h, convasr_conv1d_dgrad_wgrad): dx = dgrad(dy), dw (+)= wgrad(x, dy).
-	bn (optional): dict(y, scale, shift, mean, invstd, act, drop = (p, seed, offset, step_key), xl, sums (ConvStats), gate) -- the producer layer's
-	BN-backward sums in the dgrad's epilogue (conv1d_dgrad_bn_reduce's arguments).  Returns (dx or None when the fused epilogue's shape is outside
-	the envelope -- the weight gradient is done, run the input gradient apart --, paired: did the fused launch take it?)."""
-	B, Cout, Tdy = dy.shape
-	Cin, Tdx = x.shape[1], x.shape[2]
-	pad_dgrad = dil * (K - 1) - pad_fwd
-	layout = weight_layout(dw)
-	assert is_cl(x) and is_cl(dy) and x.dtype == dy.dtype and dy.dtype in HALF_DTYPES and layout is not None and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, K) and conv_out_len(Tdy, K, 1, dil, pad_dgrad) == Tdx
-	wkey = (B, Cin, Cout, Tdx, Tdy, K, 1, dil)
-	nbytes = _wgrad_ws_bytes.get(wkey)
-	if nbytes is None:
-		nbytes = _wgrad_ws_bytes[wkey] = _lib.load().convasr_conv1d_wgrad_workspace_bytes(*wkey)
-	ws = workspace(nbytes, x.device, 'wgrad')
-	dx = empty_cl(B, Cin, Tdx, dy.dtype, dy.device)
-	rows, paired = ctypes.c_int(0), ctypes.c_int(0)
-	rc = [0]
-	if bn is not None:
-		st = bn['sums']
-		assert isinstance(st, ConvStats) and st.fits(Cin, B, Tdx, dy.device) and tuple(bn['y'].shape) == (B, Cin, Tdx)
-		p_drop, seed, offset, skey = bn['drop']
-		fuse = (ptr(bn['y']), ptr(bn['scale']), ptr(bn['shift']), ptr(bn['mean']), ptr(bn['invstd']), bn['act'][0], bn['act'][1], bn['act'][2], float(p_drop), int(seed), int(offset), skey, ptr(bn['xl']), ptr(st.buf), ctypes.byref(rows), ptr(bn.get('gate')))
-	else:
-		fuse = (None, None, None, None, None, _lib.ACT_NONE, 0.0, 0.0, 0.0, 0, 0, None, None, None, None, None)
-	def run():
-		rc[0] = _lib.call_rc('convasr_conv1d_dgrad_wgrad', ptr(dy), ptr(packed_dgrad), ptr(dx), dtype_code(dy.dtype), B, Cout, Cin, Tdy, Tdx, K, dil, pad_dgrad, *fuse, ptr(x), ptr(dw), ptr(ws), pad_fwd, int(accumulate), layout, ctypes.byref(paired), stream_ptr())
-	_lib.timed('conv1d_bwd_pair (dgrad + wgrad in one dispatch)', 4.0 * B * Tdy * Cout * Cin * K, run, nbytes = float(2 * B * Tdy * Cout * 2 + B * Tdx * Cin * 2 * (3 if bn is not None else 2) + K * Cout * Cin * 6))
-	if bn is not None:
-		bn['sums'].rows = rows.value
-	return (dx if rc[0] == 0 else None), bool(paired.value)
-
-
 def bn_bwd_finalize(sums, gamma, mean, invstd, n, coef = None, dgamma = None, dbeta = None, accumulate = False):
 	"""sums: the ConvStats the fused dgrad epilogue filled (partial rows of sum g, sum g*xhat), or a (2 C,) fp64 tensor of totals."""
 	buf, rows, C = (sums.buf, sums.rows, sums.C) if isinstance(sums, ConvStats) else (sums, 1, sums.numel() // 2)

@@ -312,19 +312,6 @@ int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, voi
                                    int dil, int pad, const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                    const float* bn_invstd, int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed,
                                    uint64_t offset, const uint64_t* step_key, const float* bn_xlen, double* bn_sums, int* bn_rows, const uint8_t* bn_gate, void* stream);
-/* Both gradients of one stride-1 Conv1d (models.py:47-77 backward) from ONE dispatch: dx = dgrad(dy) as convasr_conv1d_fwd(dy, packed_dgrad) --
- * or, with bn_y != NULL, as convasr_conv1d_dgrad_bn_reduce (same arguments) -- and dw (+)= wgrad(x, dy) as convasr_conv1d_wgrad (no bias
- * gradient; pad_fwd = the forward conv's padding, pad_dgrad = dil * (K - 1) - pad_fwd; workspace: convasr_conv1d_wgrad_workspace_bytes()
- * bytes).  The workgroups of the two MFMA kernels share one launch: at small batches a dgrad launch is 0.75-2.25 rounds of tiles on 256 CUs
- * and the weight gradient's units fill what its partial rounds leave idle -- the overlap a side stream gives the eager step, available to a
- * replayed HIP graph too.  Each half computes exactly what its own entry point computes (bit-identical).  *paired (may be NULL) = 1 if the
- * fused launch took it, 0 if the shape is outside its envelope (K = 1, Cin or Cout % 128 != 0, ...) and the two ran as launches of their
- * own.  Returns 0, or 1 when bn_y was given and the fused epilogue is outside the envelope: the weight gradient is done, the input
- * gradient was NOT launched (run the two steps of convasr_conv1d_dgrad_bn_reduce's contract apart). */
-int convasr_conv1d_dgrad_wgrad(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad_dgrad,
-                               const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, int bn_act, float bn_act_lo,
-                               float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* bn_xlen, double* bn_sums, int* bn_rows,
-                               const uint8_t* bn_gate, const void* x, float* dw, void* workspace, int pad_fwd, int accumulate, int dw_layout, int* paired, void* stream);
 /* coef / dgamma / dbeta from those partial rows (the second half of convasr_bn_act_bwd_reduce), added in a fixed order; n = B*T. */
 int convasr_bn_bwd_finalize(const double* sums, int sums_rows, const float* gamma, const float* mean, const float* invstd, float* coef,
                             float* dgamma, float* dbeta, int accumulate, int64_t n, int C, void* stream);

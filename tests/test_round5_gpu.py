@@ -419,64 +419,3 @@ def test_frontend_normalize_signal_multiplier_against_the_oracle():
 		plain = O.logmel_frontend(x, xlen, fe.window.cpu(), fe.mel.weight.cpu(), fe.mel.bias.cpu(), 512, 160)
 		err = float((got - want).abs().max())
 		assert err <= 2e-4 * float(want.abs().max()) and float((want - plain).abs().max()) > 0.5, (m, err)
-
-
-@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('shape', [(3, 300, 256, 384, 11, 1), (2, 513, 384, 256, 13, 1), (4, 200, 128, 128, 29, 2)])
-def test_dgrad_and_wgrad_from_one_dispatch_are_bit_identical_to_two(shape, dt):
-	"""convasr_conv1d_dgrad_wgrad (bwd_pair.hip: the workgroups of the input-gradient and of the weight-gradient kernel in ONE launch) against
-	the two launches of their own: dx, dw, and with the fused BN-backward epilogue the partial sums, bit for bit; `paired` says the fused
-	kernel took it."""
-	from convasr_amd import ops, _lib
-	d = torch.device('cuda:0')
-	B, T, cin, cout, K, dil = shape
-	torch.manual_seed(B * T + K)
-	pad = dil * (K // 2)
-	x = ops.as_cl(torch.randn(B, cin, T, device = d), dt)
-	dy = ops.as_cl(torch.randn(B, cout, T, device = d), dt)
-	w = torch.randn(cout, cin, K, device = d) / (cin * K) ** 0.5
-	wd = ops.pack_weight(w, dt, _lib.PACK_DGRAD)
-	dw1, dw2 = torch.zeros(cout, cin, K, device = d), torch.zeros(cout, cin, K, device = d)
-	dx1 = ops.conv1d(dy, wd, cin, K, 1, dil, dil * (K - 1) - pad)
-	ops.conv1d_wgrad(x, dy, cout, K, 1, dil, pad, dw1)
-	dx2, paired = ops.conv1d_dgrad_wgrad(dy, wd, x, dw2, K, dil, pad)
-	assert paired and torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
-	ops.conv1d_dgrad_wgrad(dy, wd, x, dw2, K, dil, pad, accumulate = True)
-	assert torch.equal(dw2, dw1 + dw1)
-	# with the producer layer's BN-backward sums in the epilogue (stored gates)
-	y = ops.as_cl(torch.randn(B, cin, T, device = d), dt)
-	sc, sh, mean, inv = torch.rand(cin, device = d) + 0.5, torch.randn(cin, device = d), torch.randn(cin, device = d), torch.rand(cin, device = d) + 0.5
-	gate = torch.randint(0, 256, (B * T * cin // 8, ), device = d, dtype = torch.uint8)
-	act = (_lib.ACT_HARDTANH, 0.0, 20.0)
-	s1, s2 = ops.ConvStats(cin, B, T, d), ops.ConvStats(cin, B, T, d)
-	dxa = ops.conv1d_dgrad_bn_reduce(dy, wd, cin, K, dil, dil * (K - 1) - pad, y, sc, sh, mean, inv, act, 0.2, 7, 11, None, s1, gate = gate)
-	dxb, paired = ops.conv1d_dgrad_wgrad(dy, wd, x, dw2, K, dil, pad, bn = dict(y = y, scale = sc, shift = sh, mean = mean, invstd = inv, act = act, drop = (0.2, 7, 11, None), xl = None, sums = s2, gate = gate))
-	assert paired and torch.equal(dxa, dxb) and s1.rows == s2.rows and torch.equal(s1.totals(), s2.totals()) and torch.equal(dw2, dw1)
-
-
-def test_paired_backward_launches_leave_the_training_step_bitwise_unchanged():
-	"""The whole training step with every eligible layer's dgrad + wgrad paired (CONVASR_PAIR_BWD = 1) against none paired: three steps on a
-	dense-residual network in fp16 with dropout -- losses, gradient norms and parameters bit for bit (each half of a paired launch computes
-	exactly what its own launch computes)."""
-	import convasr_amd as ca
-	from convasr_amd import functional as Fn
-	d = torch.device('cuda:0')
-	batches = _batches(d, 3, [(4, 5)])
-	out = {}
-	for mode in ('0', '1'):
-		prev, Fn.PAIR_BWD = Fn.PAIR_BWD, mode
-		try:
-			ca.functional.manual_seed(9)
-			model = _dense_small(ca, d, torch.float16, 0.2)
-			flat = ca.train.FlatParameters(model)
-			opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
-			ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2')
-			tr = []
-			for it, b in enumerate(batches):
-				r = ca.train.train_step(model, opt, *b, iteration = it)
-				tr.append((float(r['loss']), float(r['grad_norm'])))
-			torch.cuda.synchronize()
-			out[mode] = (tr, flat.data.clone())
-		finally:
-			Fn.PAIR_BWD = prev
-	assert out['0'][0] == out['1'][0] and torch.equal(out['0'][1], out['1'][1]), (out['0'][0], out['1'][0])
