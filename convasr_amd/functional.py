@@ -501,7 +501,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		Tout = y.shape[2]
 		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked)
 
-		res_x, res_y, res_bnp = [], [], []
+		res_y, res_bnp = [], []
 		# where each batch-normed branch's input gradient goes in backward: the gradient accumulator its producer left on the tapped tensor
 		# (GRAD_ACC below), or None = hand it to autograd
 		ctx.res_gacc = [getattr(flat_res[5 * r], _GACC_ATTR, None) if (GROUP_RES and flat_res[5 * r + 1] is not None) else None for r in range(n_res)]
