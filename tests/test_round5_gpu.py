@@ -419,3 +419,30 @@ def test_frontend_normalize_signal_multiplier_against_the_oracle():
 		plain = O.logmel_frontend(x, xlen, fe.window.cpu(), fe.mel.weight.cpu(), fe.mel.bias.cpu(), 512, 160)
 		err = float((got - want).abs().max())
 		assert err <= 2e-4 * float(want.abs().max()) and float((want - plain).abs().max()) > 0.5, (m, err)
+
+
+def test_step_graphs_with_frozen_blocks_bitwise_equal_to_eager():
+	"""JasperNet.freeze(backbone = 2) (models.py:328-339: the first blocks' batch norms on their running statistics, their parameters out of the
+	arena, dropout still applied there) under step graphs: the frozen blocks' eval-path launches -- their folded scale / shift vectors are
+	recomputed inside the capture, their dropout masks follow the device-resident step key -- replay bit for bit like the eager step."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	batches = _batches(d, 10, [(4, 5), (3, 6)])
+	out = {}
+	for graphed in (False, True):
+		ca.functional.manual_seed(21)
+		model = _dense_small(ca, d, torch.bfloat16, 0.2)
+		model.freeze(backbone = 2)
+		flat = ca.train.FlatParameters(model)
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		stepper = ca.train.GraphedTrainStep(model, opt, warmup = 1, enabled = graphed)
+		tr = []
+		for it, b in enumerate(batches):
+			r = stepper(*b, iteration = it)
+			tr.append((float(r['loss']), float(r['grad_norm'])))
+		torch.cuda.synchronize()
+		assert not graphed or (stepper.captures == 2 and stepper.replays == 8)
+		out[graphed] = (tr, flat.data.clone(), {k: v.clone() for k, v in model.state_dict().items()})
+	assert out[False][0] == out[True][0] and torch.equal(out[False][1], out[True][1])
+	assert all(torch.equal(v, out[True][2][k]) for k, v in out[False][2].items())
+	assert len({l for l, _ in out[False][0]}) == 10
