@@ -10,6 +10,12 @@
 #define FE_NFFT 512
 #define FE_BINS 257
 #define FE_WAVES 16
+// A wave's FFT buffer is written and read in three index patterns; two padded layouts keep every ds_read / ds_write_b64 of a half-wave on
+// 32 different bank pairs (the unpadded buffer had 8-way conflicts on the stage-1 and stage-2 writes and up to 8-way on the strided twiddle reads):
+// generation 1 (written lane * 8 + r, read lane + 64 r) one pad element per 32, generation 2 (written g * 64 + k + 8 r, read lane + 64 r) eight per 64.
+#define FE_BUF 576
+#define FE_P1(i) ((i) + ((i) >> 5))
+#define FE_P2(i) ((i) + (((i) >> 6) << 3))
 #define FE_SPAN 64  // LDS rows of the sparse mel table: melS[j][mel] = weight of bin klo[mel] + j (wider filters read the rest from global memory)
 
 // one atomic per workgroup: thousands of wave-level atomicMax on the same B addresses serialise in L2 and cost 5x the streaming time
@@ -73,20 +79,19 @@ __device__ __forceinline__ void dft8(cpx (&v)[8]) {
 
 template <typename S> __device__ __forceinline__ float sig_load(const S* p, int64_t i) { return (float)p[i]; }
 
-// one sample of the reference's padded signal (models.py:570-582) for utterance row `xs`
+// one sample of the reference's padded signal (models.py:570-582) for utterance row `xs`.  Branch-free: both loads are issued for every lane
+// (an out-of-range sample reads xs[0] and is replaced by zero afterwards), so the 24 loads of a frame pair are in flight together instead of
+// one dependent round trip per divergent branch.
 template <typename S>
 __device__ __forceinline__ float padded_sample(const S* xs, int i, int T, int pad, int nvalid, float inv_denom, bool normalize, float preemph) {
 	int t = i - pad;
 	if (i < pad) t = (pad < T) ? pad - i : -1;  // reflect (edge excluded) when T > pad, constant zeros otherwise
-	if (t < 0 || t >= T || t >= nvalid) return 0.f;
-	float cur = sig_load(xs, t);
-	if (normalize) cur = cur * inv_denom;
-	if (preemph > 0.f && t > 0) {
-		float prev = sig_load(xs, t - 1);
-		if (normalize) prev = prev * inv_denom;
-		cur = cur - preemph * prev;
-	}
-	return cur;
+	const bool ok = t >= 0 && t < T && t < nvalid;
+	const int tc = ok ? t : 0, tp = tc > 0 ? tc - 1 : 0;
+	float cur = sig_load(xs, tc), prev = sig_load(xs, tp);
+	if (normalize) { cur = cur * inv_denom; prev = prev * inv_denom; }
+	if (preemph > 0.f) cur = tc > 0 ? cur - preemph * prev : cur;
+	return ok ? cur : 0.f;
 }
 
 template <typename S>
@@ -98,20 +103,28 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 	float* const melS = reinterpret_cast<float*>(smem);                  // [FE_SPAN][64] sparse mel table
 	cpx* const tw = reinterpret_cast<cpx*>(melS + FE_SPAN * 64);         // [512] exp(-2 pi i m / 512)
 	float* const win = reinterpret_cast<float*>(tw + FE_NFFT);           // [512] window centred in nfft
-	cpx* const work = reinterpret_cast<cpx*>(win + FE_NFFT);             // [FE_WAVES][512]
-	float* const pw = reinterpret_cast<float*>(work + FE_WAVES * FE_NFFT);  // [FE_WAVES][2][FE_BINS + 7]
+	cpx* const tw2 = reinterpret_cast<cpx*>(win + FE_NFFT);              // [8][8]  stage 2: exp(-2 pi i 8 k r / 512) at [r][k]
+	cpx* const tw3 = tw2 + 64;                                           // [8][64] stage 3: exp(-2 pi i lane r / 512) at [r][lane]
+	cpx* const work = tw3 + 8 * 64;                                      // [FE_WAVES][FE_BUF]
+	float* const pw = reinterpret_cast<float*>(work + FE_WAVES * FE_BUF);  // [FE_WAVES][2][FE_BINS + 7]
+	int* const supp = reinterpret_cast<int*>(pw + FE_WAVES * 2 * (FE_BINS + 7));  // [2][64] first / one-past-last non-zero bin of every mel filter
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
 	// support of this lane's mel filter: the filterbank is ~97 % zeros (each triangle spans 3..30 of the 257 bins), so only each
 	// filter's support is kept in LDS (16 KiB instead of the 67 KiB dense matrix: room for 16 waves per CU) and the 257-term dot
 	// product is cut to the widest support in the wave; skipping exact zeros changes no result
-	int klo = FE_BINS, khi = 0;
-	if (lane < nmel)
-		for (int k = 0; k < FE_BINS; ++k)
-			if (melw[lane * FE_BINS + k] != 0.f) { klo = min(klo, k); khi = k + 1; }
+	if (tid < 64) { supp[tid] = FE_BINS; supp[64 + tid] = 0; }
+	__syncthreads();
+	if (lane < nmel) {  // every wave scans its slice of the bins for all filters
+		int lo = FE_BINS, hi = 0;
+		for (int k = wave; k < FE_BINS; k += FE_WAVES)
+			if (melw[lane * FE_BINS + k] != 0.f) { lo = min(lo, k); hi = k + 1; }
+		if (hi > 0) { atomicMin(supp + lane, lo); atomicMax(supp + 64 + lane, hi); }
+	}
+	__syncthreads();
+	int klo = supp[lane], khi = supp[64 + lane];
 	if (khi <= klo) { klo = 0; khi = 0; }
-	if (wave == 0)
-		for (int j = 0; j < FE_SPAN; ++j) melS[j * 64 + lane] = (lane < nmel && klo + j < khi) ? melw[lane * FE_BINS + klo + j] : 0.f;
+	for (int j = wave; j < FE_SPAN; j += FE_WAVES) melS[j * 64 + lane] = (lane < nmel && klo + j < khi) ? melw[lane * FE_BINS + klo + j] : 0.f;
 	for (int i = tid; i < FE_NFFT; i += blockDim.x) {
 		float s, c;
 		sincospif((float)i / 256.0f, &s, &c);
@@ -120,13 +133,15 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		win[i] = (i >= left && i < left + win_length) ? window[i - left] : 0.f;
 	}
 	__syncthreads();
+	if (tid < 64) tw2[tid] = tw[(tid & 7) * (tid >> 3) * 8];
+	if (tid < 512) tw3[tid] = tw[(tid & 63) * (tid >> 6)];
+	__syncthreads();
 	int span = khi - klo;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) span = max(span, __shfl_xor(span, o, 64));
 
-	cpx* const buf = work + wave * FE_NFFT;
-	float* const p0 = pw + wave * 2 * (FE_BINS + 7);
-	float* const p1 = p0 + FE_BINS + 7;
+	cpx* const buf = work + wave * FE_BUF;
+	float2* const pq = reinterpret_cast<float2*>(pw + wave * 2 * (FE_BINS + 7));  // power of bin k of the pair's two frames
 	const int pad = FE_NFFT / 2;
 	const float bias = lane < nmel ? melb[lane] : 1.f;
 
@@ -140,39 +155,61 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 
 		// ---- stage 1 (Ns = 1): no twiddles; inputs straight from global memory
 		cpx v[8];
-#pragma unroll
-		for (int rr = 0; rr < 8; ++rr) {
-			const int n = lane + 64 * rr;
-			const float w = win[n];
-			float a = 0.f, c = 0.f;
-			if (w != 0.f) {
-				a = w * padded_sample(xs, f0 * hop + n, T, pad, nvalid, denom, normalize, preemph);
-				if (has_f1) c = w * padded_sample(xs, (f0 + 1) * hop + n, T, pad, nvalid, denom, normalize, preemph);
+		const int t0 = f0 * hop - pad;  // source index of the pair's first sample
+		if (t0 >= nvalid && t0 >= 0) {  // both frames lie in the masked tail: a zero spectrum, log(eps) exactly as the full computation gives it
+			if (lane < nmel) {
+				const float z = logf(fmaf(0.f, 0.f, 0.f) + bias);
+				out[((int64_t)b * F + f0) * nmel + lane] = z;
+				if (has_f1) out[((int64_t)b * F + f0 + 1) * nmel + lane] = z;
 			}
-			v[rr] = cpx{a, c};
+			continue;
+		}
+		if (has_f1 && preemph > 0.f && t0 >= 1 && t0 + hop + FE_NFFT <= min(T, nvalid)) {
+			// interior pair (all but the first two and the last few of an utterance): every sample is a plain one with a predecessor, no reflection,
+			// no range or mask test -- 32 loads at immediate offsets from one address, no per-sample index arithmetic (the general form below spends
+			// ~25 integer / select instructions per sample: the kernel is VALU-bound and that was 45 % of its instructions).  Same arithmetic.
+			const S* const xp = xs + t0 + lane;
+#pragma unroll
+			for (int rr = 0; rr < 8; ++rr) {
+				const float w = win[lane + 64 * rr];
+				float ca = sig_load(xp, 64 * rr), pa = sig_load(xp, 64 * rr - 1), cb = sig_load(xp + hop, 64 * rr), pb = sig_load(xp + hop, 64 * rr - 1);
+				if (normalize) { ca = ca * denom; pa = pa * denom; cb = cb * denom; pb = pb * denom; }
+				ca = ca - preemph * pa;
+				cb = cb - preemph * pb;
+				v[rr] = cpx{w * ca, w * cb};  // outside the window's support w is +0 and the product +-0: the sign of a zero never reaches |.|^2
+			}
+		} else {
+#pragma unroll
+			for (int rr = 0; rr < 8; ++rr) {
+				const int n = lane + 64 * rr;
+				const float w = win[n];
+				const float sa = padded_sample(xs, f0 * hop + n, T, pad, nvalid, denom, normalize, preemph);
+				const float sc = padded_sample(xs, (has_f1 ? f0 + 1 : f0) * hop + n, T, pad, nvalid, denom, normalize, preemph);
+				v[rr] = cpx{w != 0.f ? w * sa : 0.f, (w != 0.f && has_f1) ? w * sc : 0.f};
+			}
 		}
 		dft8(v);
 #pragma unroll
-		for (int rr = 0; rr < 8; ++rr) buf[lane * 8 + rr] = v[rr];
+		for (int rr = 0; rr < 8; ++rr) buf[FE_P1(lane * 8 + rr)] = v[rr];
 		__builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are done before its next reads
 		__builtin_amdgcn_wave_barrier();
 		// ---- stage 2 (Ns = 8)
 		{
 			const int k = lane & 7;
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[lane + 64 * rr], tw[k * rr * 8]);
+			for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[FE_P1(lane + 64 * rr)], tw2[rr * 8 + k]);
 			dft8(v);
 			__builtin_amdgcn_wave_barrier();
 			const int j0 = (lane >> 3) * 64 + k;
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) buf[j0 + rr * 8] = v[rr];
+			for (int rr = 0; rr < 8; ++rr) buf[FE_P2(j0 + rr * 8)] = v[rr];
 			__builtin_amdgcn_s_waitcnt(0xc07f);
 			__builtin_amdgcn_wave_barrier();
 		}
 		// ---- stage 3 (Ns = 64)
 		{
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[lane + 64 * rr], tw[lane * rr]);
+			for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[FE_P2(lane + 64 * rr)], tw3[rr * 64 + lane]);
 			dft8(v);
 			__builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -185,18 +222,29 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 			const cpx z = buf[k], zc = buf[(FE_NFFT - k) & (FE_NFFT - 1)];
 			const float are = 0.5f * (z.re + zc.re), aim = 0.5f * (z.im - zc.im);
 			const float bre = 0.5f * (z.im + zc.im), bim = 0.5f * (zc.re - z.re);
-			p0[k] = are * are + aim * aim;
-			p1[k] = bre * bre + bim * bim;
+			pq[k] = float2{are * are + aim * aim, bre * bre + bim * bim};
 		}
 		__builtin_amdgcn_s_waitcnt(0xc07f);
 		__builtin_amdgcn_wave_barrier();
 		// ---- mel + eps bias + log: lane = mel channel
 		float m0 = 0.f, m1 = 0.f;
-		for (int j = 0; j < span; ++j) {
-			const int k = min(klo + j, FE_BINS - 1);
-			const float w = j < FE_SPAN ? melS[j * 64 + lane] : ((klo + j < khi) ? melw[lane * FE_BINS + k] : 0.f);
-			m0 = fmaf(w, p0[k], m0);
-			m1 = fmaf(w, p1[k], m1);
+		{
+			const int s_lds = min(span, FE_SPAN);
+#pragma unroll 4
+			for (int j = 0; j < s_lds; ++j) {  // rows past a filter's own support hold zeros
+				const int k = min(klo + j, FE_BINS - 1);
+				const float w = melS[j * 64 + lane];
+				const float2 pp = pq[k];
+				m0 = fmaf(w, pp.x, m0);
+				m1 = fmaf(w, pp.y, m1);
+			}
+			for (int j = FE_SPAN; j < span; ++j) {  // filters wider than the table (not with the reference's 64 mels over 257 bins)
+				const int k = min(klo + j, FE_BINS - 1);
+				const float w = (klo + j < khi) ? melw[lane * FE_BINS + k] : 0.f;
+				const float2 pp = pq[k];
+				m0 = fmaf(w, pp.x, m0);
+				m1 = fmaf(w, pp.y, m1);
+			}
 		}
 		if (lane < nmel) {
 			out[((int64_t)b * F + f0) * nmel + lane] = logf(m0 + bias);
@@ -214,7 +262,7 @@ extern "C" int convasr_logmel_fwd(const void* signal, int signal_dtype, const fl
 		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft == 512 (window 257..512 samples), nmel <= 64; got nfft %d nmel %d win %d", nfft, nmel, win_length);
 	const int F = 1 + T / hop;  // (T + 2 * pad - nfft) / hop + 1 with pad = nfft / 2
 	const int pairs_per_b = (F + 1) / 2, total_pairs = B * pairs_per_b;
-	const size_t smem = sizeof(float) * (FE_SPAN * 64 + 2 * FE_NFFT + FE_NFFT + 2 * FE_WAVES * FE_NFFT + FE_WAVES * 2 * (FE_BINS + 7));
+	const size_t smem = sizeof(float) * (FE_SPAN * 64 + 2 * FE_NFFT + FE_NFFT + 2 * (64 + 8 * 64) + 2 * FE_WAVES * FE_BUF + FE_WAVES * 2 * (FE_BINS + 7) + 2 * 64);
 	int grid = (total_pairs + FE_WAVES - 1) / FE_WAVES;
 	if (grid > 256) grid = 256;  // persistent: one workgroup per CU amortises the table set-up (mel transpose, twiddles) over ~190 frame pairs
 	hipStream_t s = (hipStream_t)stream;
