@@ -7,16 +7,23 @@
 // signal and the 197 MB complex spectrogram are never materialised.  HBM-bound: 4 B in per sample, 256 B out per frame.
 #include "common.h"
 
-#define FE_NFFT 512
-#define FE_BINS 257
-#define FE_WAVES 16
-// A wave's FFT buffer is written and read in three index patterns; two padded layouts keep every ds_read / ds_write_b64 of a half-wave on
+#define FE_SPAN 64  // LDS rows of the sparse mel table: melS[j][mel] = weight of bin klo[mel] + j (wider filters read the rest from global memory)
+// nfft = 2^LOG2N for LOG2N = 7..10 (the reference takes the power of two above the window, models.py:516: 512 for 16 kHz x 0.02 s, 256 for train.py's
+// default 8 kHz x 0.02 s, 1024 for 44.1 kHz).  512 has its own radix-8 x 3 schedule; the other sizes share a radix-2 Stockham loop.
+template <int LOG2N> struct FeCfg {
+	static constexpr int N = 1 << LOG2N, BINS = N / 2 + 1, RPL = N / 64;       // samples per lane
+	static constexpr int WAVES = LOG2N <= 9 ? 16 : 8;                           // per workgroup: what 160 KiB of LDS holds
+	static constexpr int BUF = LOG2N == 9 ? 576 : N;                            // a wave's FFT buffer, complex words (512: padded layouts, below)
+	static constexpr int PQ = 2 * (BINS + 7);                                   // a wave's power buffer, floats
+	static constexpr int TWX = LOG2N == 9 ? 64 + 8 * 64 : 0;                    // the radix-8 schedule's transposed twiddle tables
+	static constexpr size_t smem = sizeof(float) * (FE_SPAN * 64 + 2 * N + N + 2 * TWX + 2 * WAVES * BUF + WAVES * PQ + 2 * 64);
+};
+// nfft = 512: a wave's FFT buffer is written and read in three index patterns; two padded layouts keep every ds_read / ds_write_b64 of a half-wave on
 // 32 different bank pairs (the unpadded buffer had 8-way conflicts on the stage-1 and stage-2 writes and up to 8-way on the strided twiddle reads):
 // generation 1 (written lane * 8 + r, read lane + 64 r) one pad element per 32, generation 2 (written g * 64 + k + 8 r, read lane + 64 r) eight per 64.
 #define FE_BUF 576
 #define FE_P1(i) ((i) + ((i) >> 5))
 #define FE_P2(i) ((i) + (((i) >> 6) << 3))
-#define FE_SPAN 64  // LDS rows of the sparse mel table: melS[j][mel] = weight of bin klo[mel] + j (wider filters read the rest from global memory)
 
 // one atomic per workgroup: thousands of wave-level atomicMax on the same B addresses serialise in L2 and cost 5x the streaming time
 template <typename S> __global__ __launch_bounds__(256) void absmax_kernel(const S* __restrict__ x, int T, unsigned* __restrict__ out) {
@@ -94,58 +101,62 @@ __device__ __forceinline__ float padded_sample(const S* xs, int i, int T, int pa
 	return ok ? cur : 0.f;
 }
 
-template <typename S>
-__global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restrict__ signal, const float* __restrict__ absmax, const float* __restrict__ xlen,
-                                                               const float* __restrict__ window, int win_length, const float* __restrict__ melw,
-                                                               const float* __restrict__ melb, float* __restrict__ out, int B, int T, int F, int hop, int nmel,
-                                                               float preemph, int pairs_per_b, int total_pairs) {
+template <typename S, int LOG2N>
+__global__ __launch_bounds__(64 * FeCfg<LOG2N>::WAVES) void logmel_kernel(const S* __restrict__ signal, const float* __restrict__ absmax, const float* __restrict__ xlen,
+                                                                          const float* __restrict__ window, int win_length, const float* __restrict__ melw,
+                                                                          const float* __restrict__ melb, float* __restrict__ out, int B, int T, int F, int hop, int nmel,
+                                                                          float preemph, int pairs_per_b, int total_pairs) {
+	using Cfg = FeCfg<LOG2N>;
+	constexpr int N = Cfg::N, BINS = Cfg::BINS, RPL = Cfg::RPL, WAVES = Cfg::WAVES;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* const melS = reinterpret_cast<float*>(smem);                  // [FE_SPAN][64] sparse mel table
-	cpx* const tw = reinterpret_cast<cpx*>(melS + FE_SPAN * 64);         // [512] exp(-2 pi i m / 512)
-	float* const win = reinterpret_cast<float*>(tw + FE_NFFT);           // [512] window centred in nfft
-	cpx* const tw2 = reinterpret_cast<cpx*>(win + FE_NFFT);              // [8][8]  stage 2: exp(-2 pi i 8 k r / 512) at [r][k]
-	cpx* const tw3 = tw2 + 64;                                           // [8][64] stage 3: exp(-2 pi i lane r / 512) at [r][lane]
-	cpx* const work = tw3 + 8 * 64;                                      // [FE_WAVES][FE_BUF]
-	float* const pw = reinterpret_cast<float*>(work + FE_WAVES * FE_BUF);  // [FE_WAVES][2][FE_BINS + 7]
-	int* const supp = reinterpret_cast<int*>(pw + FE_WAVES * 2 * (FE_BINS + 7));  // [2][64] first / one-past-last non-zero bin of every mel filter
+	cpx* const tw = reinterpret_cast<cpx*>(melS + FE_SPAN * 64);         // [N] exp(-2 pi i m / N)
+	float* const win = reinterpret_cast<float*>(tw + N);                 // [N] window centred in nfft
+	cpx* const tw2 = reinterpret_cast<cpx*>(win + N);                    // 512 only: [8][8]  stage 2: exp(-2 pi i 8 k r / 512) at [r][k]
+	cpx* const tw3 = tw2 + 64;                                           // 512 only: [8][64] stage 3: exp(-2 pi i lane r / 512) at [r][lane]
+	cpx* const work = tw2 + Cfg::TWX;                                    // [WAVES][BUF]
+	float* const pw = reinterpret_cast<float*>(work + WAVES * Cfg::BUF); // [WAVES][PQ]
+	int* const supp = reinterpret_cast<int*>(pw + WAVES * Cfg::PQ);      // [2][64] first / one-past-last non-zero bin of every mel filter
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
 	// support of this lane's mel filter: the filterbank is ~97 % zeros (each triangle spans 3..30 of the 257 bins), so only each
 	// filter's support is kept in LDS (16 KiB instead of the 67 KiB dense matrix: room for 16 waves per CU) and the 257-term dot
 	// product is cut to the widest support in the wave; skipping exact zeros changes no result
-	if (tid < 64) { supp[tid] = FE_BINS; supp[64 + tid] = 0; }
+	if (tid < 64) { supp[tid] = BINS; supp[64 + tid] = 0; }
 	__syncthreads();
 	if (lane < nmel) {  // every wave scans its slice of the bins for all filters
-		int lo = FE_BINS, hi = 0;
-		for (int k = wave; k < FE_BINS; k += FE_WAVES)
-			if (melw[lane * FE_BINS + k] != 0.f) { lo = min(lo, k); hi = k + 1; }
+		int lo = BINS, hi = 0;
+		for (int k = wave; k < BINS; k += WAVES)
+			if (melw[lane * BINS + k] != 0.f) { lo = min(lo, k); hi = k + 1; }
 		if (hi > 0) { atomicMin(supp + lane, lo); atomicMax(supp + 64 + lane, hi); }
 	}
 	__syncthreads();
 	int klo = supp[lane], khi = supp[64 + lane];
 	if (khi <= klo) { klo = 0; khi = 0; }
-	for (int j = wave; j < FE_SPAN; j += FE_WAVES) melS[j * 64 + lane] = (lane < nmel && klo + j < khi) ? melw[lane * FE_BINS + klo + j] : 0.f;
-	for (int i = tid; i < FE_NFFT; i += blockDim.x) {
+	for (int j = wave; j < FE_SPAN; j += WAVES) melS[j * 64 + lane] = (lane < nmel && klo + j < khi) ? melw[lane * BINS + klo + j] : 0.f;
+	for (int i = tid; i < N; i += blockDim.x) {
 		float s, c;
-		sincospif((float)i / 256.0f, &s, &c);
+		sincospif((float)i / (float)(N / 2), &s, &c);
 		tw[i] = cpx{c, -s};
-		const int left = (FE_NFFT - win_length) / 2;
+		const int left = (N - win_length) / 2;
 		win[i] = (i >= left && i < left + win_length) ? window[i - left] : 0.f;
 	}
 	__syncthreads();
-	if (tid < 64) tw2[tid] = tw[(tid & 7) * (tid >> 3) * 8];
-	if (tid < 512) tw3[tid] = tw[(tid & 63) * (tid >> 6)];
-	__syncthreads();
+	if constexpr (LOG2N == 9) {
+		if (tid < 64) tw2[tid] = tw[(tid & 7) * (tid >> 3) * 8];
+		if (tid < 512) tw3[tid] = tw[(tid & 63) * (tid >> 6)];
+		__syncthreads();
+	}
 	int span = khi - klo;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) span = max(span, __shfl_xor(span, o, 64));
 
-	cpx* const buf = work + wave * FE_BUF;
-	float2* const pq = reinterpret_cast<float2*>(pw + wave * 2 * (FE_BINS + 7));  // power of bin k of the pair's two frames
-	const int pad = FE_NFFT / 2;
+	cpx* const buf = work + wave * Cfg::BUF;
+	float2* const pq = reinterpret_cast<float2*>(pw + wave * Cfg::PQ);  // power of bin k of the pair's two frames
+	const int pad = N / 2;
 	const float bias = lane < nmel ? melb[lane] : 1.f;
 
-	for (int pair = blockIdx.x * FE_WAVES + wave; pair < total_pairs; pair += gridDim.x * FE_WAVES) {
+	for (int pair = blockIdx.x * WAVES + wave; pair < total_pairs; pair += gridDim.x * WAVES) {
 		const int b = pair / pairs_per_b, f0 = (pair % pairs_per_b) * 2;
 		const bool has_f1 = f0 + 1 < F;
 		const S* xs = signal + (int64_t)b * T;
@@ -153,8 +164,6 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 		const float denom = absmax ? 1.f / (absmax[b] + 1e-5f) : 1.f;  // reciprocal: one division per utterance instead of two per sample
 		const bool normalize = absmax != nullptr;
 
-		// ---- stage 1 (Ns = 1): no twiddles; inputs straight from global memory
-		cpx v[8];
 		const int t0 = f0 * hop - pad;  // source index of the pair's first sample
 		if (t0 >= nvalid && t0 >= 0) {  // both frames lie in the masked tail: a zero spectrum, log(eps) exactly as the full computation gives it
 			if (lane < nmel) {
@@ -164,13 +173,15 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 			}
 			continue;
 		}
-		if (has_f1 && preemph > 0.f && t0 >= 1 && t0 + hop + FE_NFFT <= min(T, nvalid)) {
+		// ---- the pair's windowed samples: v[r] = (frame A, frame B) at n = lane + 64 r
+		cpx v[RPL];
+		if (has_f1 && preemph > 0.f && t0 >= 1 && t0 + hop + N <= min(T, nvalid)) {
 			// interior pair (all but the first two and the last few of an utterance): every sample is a plain one with a predecessor, no reflection,
-			// no range or mask test -- 32 loads at immediate offsets from one address, no per-sample index arithmetic (the general form below spends
+			// no range or mask test -- 4 RPL loads at immediate offsets from one address, no per-sample index arithmetic (the general form below spends
 			// ~25 integer / select instructions per sample: the kernel is VALU-bound and that was 45 % of its instructions).  Same arithmetic.
 			const S* const xp = xs + t0 + lane;
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) {
+			for (int rr = 0; rr < RPL; ++rr) {
 				const float w = win[lane + 64 * rr];
 				float ca = sig_load(xp, 64 * rr), pa = sig_load(xp, 64 * rr - 1), cb = sig_load(xp + hop, 64 * rr), pb = sig_load(xp + hop, 64 * rr - 1);
 				if (normalize) { ca = ca * denom; pa = pa * denom; cb = cb * denom; pb = pb * denom; }
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 			}
 		} else {
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) {
+			for (int rr = 0; rr < RPL; ++rr) {
 				const int n = lane + 64 * rr;
 				const float w = win[n];
 				const float sa = padded_sample(xs, f0 * hop + n, T, pad, nvalid, denom, normalize, preemph);
@@ -188,38 +199,67 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 				v[rr] = cpx{w != 0.f ? w * sa : 0.f, (w != 0.f && has_f1) ? w * sc : 0.f};
 			}
 		}
-		dft8(v);
-#pragma unroll
-		for (int rr = 0; rr < 8; ++rr) buf[FE_P1(lane * 8 + rr)] = v[rr];
-		__builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are done before its next reads
-		__builtin_amdgcn_wave_barrier();
-		// ---- stage 2 (Ns = 8)
-		{
-			const int k = lane & 7;
-#pragma unroll
-			for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[FE_P1(lane + 64 * rr)], tw2[rr * 8 + k]);
+		if constexpr (LOG2N == 9) {
+			// ---- stage 1 (Ns = 1): no twiddles; inputs straight from global memory
 			dft8(v);
-			__builtin_amdgcn_wave_barrier();
-			const int j0 = (lane >> 3) * 64 + k;
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) buf[FE_P2(j0 + rr * 8)] = v[rr];
-			__builtin_amdgcn_s_waitcnt(0xc07f);
+			for (int rr = 0; rr < 8; ++rr) buf[FE_P1(lane * 8 + rr)] = v[rr];
+			__builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are done before its next reads
 			__builtin_amdgcn_wave_barrier();
-		}
-		// ---- stage 3 (Ns = 64)
-		{
+			// ---- stage 2 (Ns = 8)
+			{
+				const int k = lane & 7;
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[FE_P2(lane + 64 * rr)], tw3[rr * 64 + lane]);
-			dft8(v);
-			__builtin_amdgcn_wave_barrier();
+				for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[FE_P1(lane + 64 * rr)], tw2[rr * 8 + k]);
+				dft8(v);
+				__builtin_amdgcn_wave_barrier();
+				const int j0 = (lane >> 3) * 64 + k;
 #pragma unroll
-			for (int rr = 0; rr < 8; ++rr) buf[lane + rr * 64] = v[rr];
-			__builtin_amdgcn_s_waitcnt(0xc07f);
-			__builtin_amdgcn_wave_barrier();
+				for (int rr = 0; rr < 8; ++rr) buf[FE_P2(j0 + rr * 8)] = v[rr];
+				__builtin_amdgcn_s_waitcnt(0xc07f);
+				__builtin_amdgcn_wave_barrier();
+			}
+			// ---- stage 3 (Ns = 64)
+			{
+#pragma unroll
+				for (int rr = 0; rr < 8; ++rr) v[rr] = cmul(buf[FE_P2(lane + 64 * rr)], tw3[rr * 64 + lane]);
+				dft8(v);
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int rr = 0; rr < 8; ++rr) buf[lane + rr * 64] = v[rr];
+				__builtin_amdgcn_s_waitcnt(0xc07f);
+				__builtin_amdgcn_wave_barrier();
+			}
+		} else {
+			// ---- radix-2 Stockham, LOG2N stages in place: a stage's N / 2 butterflies (j, j + N / 2) -> (j0, j0 + Ns) are all read into registers
+			// before any is written (the wave owns the buffer), the first stage's inputs are the registers of the load above; natural order out
+			constexpr int BPL = N / 128;  // butterflies per lane and stage
+			cpx lo[BPL], hi[BPL];
+#pragma unroll
+			for (int q = 0; q < BPL; ++q) { lo[q] = v[q]; hi[q] = v[q + BPL]; }  // j = lane + 64 q: n = j and n = j + N / 2 = lane + 64 (q + BPL)
+#pragma unroll
+			for (int st = 0; st < LOG2N; ++st) {
+				const int Ns = 1 << st;
+				if (st > 0) {
+#pragma unroll
+					for (int q = 0; q < BPL; ++q) { const int j = lane + 64 * q; lo[q] = buf[j]; hi[q] = buf[j + N / 2]; }
+					__builtin_amdgcn_wave_barrier();
+				}
+#pragma unroll
+				for (int q = 0; q < BPL; ++q) {
+					const int j = lane + 64 * q, k = j & (Ns - 1);
+					const cpx t = st > 0 ? cmul(hi[q], tw[k << (LOG2N - 1 - st)]) : hi[q];  // exp(-2 pi i k / (2 Ns))
+					const int j0 = ((j - k) << 1) + k;
+					buf[j0] = cadd(lo[q], t);
+					buf[j0 + Ns] = csub(lo[q], t);
+				}
+				__builtin_amdgcn_s_waitcnt(0xc07f);
+				__builtin_amdgcn_wave_barrier();
+			}
 		}
 		// ---- un-mix the two real spectra and take the power: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i
-		for (int k = lane; k < FE_BINS; k += 64) {
-			const cpx z = buf[k], zc = buf[(FE_NFFT - k) & (FE_NFFT - 1)];
+		for (int k = lane; k < BINS; k += 64) {
+			const cpx z = buf[k], zc = buf[(N - k) & (N - 1)];
 			const float are = 0.5f * (z.re + zc.re), aim = 0.5f * (z.im - zc.im);
 			const float bre = 0.5f * (z.im + zc.im), bim = 0.5f * (zc.re - z.re);
 			pq[k] = float2{are * are + aim * aim, bre * bre + bim * bim};
@@ -232,15 +272,15 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 			const int s_lds = min(span, FE_SPAN);
 #pragma unroll 4
 			for (int j = 0; j < s_lds; ++j) {  // rows past a filter's own support hold zeros
-				const int k = min(klo + j, FE_BINS - 1);
+				const int k = min(klo + j, BINS - 1);
 				const float w = melS[j * 64 + lane];
 				const float2 pp = pq[k];
 				m0 = fmaf(w, pp.x, m0);
 				m1 = fmaf(w, pp.y, m1);
 			}
 			for (int j = FE_SPAN; j < span; ++j) {  // filters wider than the table (not with the reference's 64 mels over 257 bins)
-				const int k = min(klo + j, FE_BINS - 1);
-				const float w = (klo + j < khi) ? melw[lane * FE_BINS + k] : 0.f;
+				const int k = min(klo + j, BINS - 1);
+				const float w = (klo + j < khi) ? melw[lane * BINS + k] : 0.f;
 				const float2 pp = pq[k];
 				m0 = fmaf(w, pp.x, m0);
 				m1 = fmaf(w, pp.y, m1);
@@ -254,29 +294,40 @@ __global__ __launch_bounds__(64 * FE_WAVES) void logmel_kernel(const S* __restri
 	}
 }
 
+template <typename S, int LOG2N>
+static void launch_logmel(const void* signal, const float* absmax, const float* xlen, const float* window, int win_length, const float* mel_weight, const float* mel_bias,
+                          float* out, int B, int T, int hop, int nmel, float preemphasis, hipStream_t s) {
+	using Cfg = FeCfg<LOG2N>;
+	const int F = 1 + T / hop;  // (T + 2 * pad - nfft) / hop + 1 with pad = nfft / 2
+	const int pairs_per_b = (F + 1) / 2, total_pairs = B * pairs_per_b;
+	int grid = (total_pairs + Cfg::WAVES - 1) / Cfg::WAVES;
+	if (grid > 256) grid = 256;  // persistent: one workgroup per CU amortises the table set-up (mel transpose, twiddles) over ~190 frame pairs
+	auto kern = logmel_kernel<S, LOG2N>;
+	static unsigned long long set = 0;
+	convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * Cfg::WAVES), Cfg::smem, s, (const S*)signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, F, hop, nmel, preemphasis, pairs_per_b, total_pairs);
+}
+
 extern "C" int convasr_logmel_fwd(const void* signal, int signal_dtype, const float* absmax, const float* xlen, const float* window, int win_length,
                                   const float* mel_weight, const float* mel_bias, float* out, int B, int T, int nfft, int hop, int nmel, float preemphasis,
                                   void* stream) {
 	CONVASR_CHECK_ARG(signal && window && mel_weight && mel_bias && out && B > 0 && T > 0 && hop > 0, "logmel_fwd: bad arguments");
-	if (nfft != FE_NFFT || nmel > 64 || nmel < 1 || win_length > nfft || win_length < 1)
-		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft == 512 (window 257..512 samples), nmel <= 64; got nfft %d nmel %d win %d", nfft, nmel, win_length);
-	const int F = 1 + T / hop;  // (T + 2 * pad - nfft) / hop + 1 with pad = nfft / 2
-	const int pairs_per_b = (F + 1) / 2, total_pairs = B * pairs_per_b;
-	const size_t smem = sizeof(float) * (FE_SPAN * 64 + 2 * FE_NFFT + FE_NFFT + 2 * (64 + 8 * 64) + 2 * FE_WAVES * FE_BUF + FE_WAVES * 2 * (FE_BINS + 7) + 2 * 64);
-	int grid = (total_pairs + FE_WAVES - 1) / FE_WAVES;
-	if (grid > 256) grid = 256;  // persistent: one workgroup per CU amortises the table set-up (mel transpose, twiddles) over ~190 frame pairs
+	if ((nfft != 128 && nfft != 256 && nfft != 512 && nfft != 1024) || nmel > 64 || nmel < 1 || win_length > nfft || win_length < 1)
+		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft 128 / 256 / 512 / 1024 (window <= nfft samples), nmel <= 64; got nfft %d nmel %d win %d", nfft, nmel, win_length);
+	if (signal_dtype != CONVASR_F32 && signal_dtype != CONVASR_I16) return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: signal dtype %d", signal_dtype);
 	hipStream_t s = (hipStream_t)stream;
-	if (signal_dtype == CONVASR_F32) {
-		auto kern = logmel_kernel<float>;
-		static unsigned long long set = 0;
-		convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set);
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FE_WAVES), smem, s, (const float*)signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, F, hop, nmel, preemphasis, pairs_per_b, total_pairs);
-	} else if (signal_dtype == CONVASR_I16) {
-		auto kern = logmel_kernel<short>;
-		static unsigned long long set = 0;
-		convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set);
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FE_WAVES), smem, s, (const short*)signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, F, hop, nmel, preemphasis, pairs_per_b, total_pairs);
-	} else return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: signal dtype %d", signal_dtype);
+#define FE_LAUNCH(L) \
+	do { \
+		if (signal_dtype == CONVASR_F32) launch_logmel<float, L>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
+		else launch_logmel<short, L>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
+	} while (0)
+	switch (nfft) {
+		case 128: FE_LAUNCH(7); break;
+		case 256: FE_LAUNCH(8); break;
+		case 512: FE_LAUNCH(9); break;
+		default: FE_LAUNCH(10); break;
+	}
+#undef FE_LAUNCH
 	CONVASR_CHECK_LAUNCH("logmel_fwd");
 	return 0;
 }

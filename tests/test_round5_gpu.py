@@ -12,6 +12,7 @@ import torch
 from oracle import convasr_oracle as O
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FE = dict(nfft = 512, hop_length = 160)
 
@@ -446,3 +447,39 @@ def test_step_graphs_with_frozen_blocks_bitwise_equal_to_eager():
 	assert out[False][0] == out[True][0] and torch.equal(out[False][1], out[True][1])
 	assert all(torch.equal(v, out[True][2][k]) for k, v in out[False][2].items())
 	assert len({l for l, _ in out[False][0]}) == 10
+
+
+def test_logmel_other_fft_sizes_against_the_reference_and_the_oracle():
+	"""models.py:516 takes nfft = 2 ** ceil(log2(window)): 256 at train.py's own defaults (8 kHz, 0.02 s), 128 / 1024 for other windows and
+	rates.  The radix-2 path of logmel_kernel against the reference's runs (frontend_nfft.npz: masked, unmasked, int16, shorter than the left
+	padding), at batch size against the oracle, and LogFilterBankFrontend built with those geometries."""
+	import convasr_amd as ca
+	from oracle import convasr_oracle as O
+	d = torch.device('cuda:0')
+	g = np.load(os.path.join(GOLDEN, 'frontend_nfft.npz'))
+	T_ = lambda a: torch.from_numpy(np.asarray(a))
+	def close(a, b, tol, what):
+		a, b = a.detach().float().cpu(), b.detach().float().cpu()
+		assert a.shape == b.shape, (what, a.shape, b.shape)
+		err = float((a - b).abs().max())
+		assert torch.allclose(a, b, rtol = tol, atol = tol), (what, err)
+	for n in sorted({k.split('/')[0] for k in g.files}):
+		sr, nfft, hop, win = (int(v) for v in g[f'{n}/cfg'])
+		w, mw, mb = T_(g[f'{n}/window']).to(d), T_(g[f'{n}/mel_weight']).contiguous().to(d), T_(g[f'{n}/mel_bias']).to(d)
+		x, xlen = T_(g[f'{n}/x']).to(d), T_(g[f'{n}/xlen']).to(d)
+		close(ca.ops.logmel(x, xlen, w, mw, mb, nfft, hop), T_(g[f'{n}/feat']), 2e-4, n + ' masked')
+		close(ca.ops.logmel(x, None, w, mw, mb, nfft, hop), T_(g[f'{n}/feat_nomask']), 2e-4, n + ' unmasked')
+		close(ca.ops.logmel(T_(g[f'{n}/x16']).to(d), xlen, w, mw, mb, nfft, hop), T_(g[f'{n}/feat16']), 2e-4, n + ' int16')
+		close(ca.ops.logmel(T_(g[f'{n}/short']).to(d), None, w, mw, mb, nfft, hop), T_(g[f'{n}/feat_short']), 2e-4, n + ' short')
+		# the module, built from the same arguments as the reference's (its buffers are the reference's to the last bit)
+		fe = ca.models.LogFilterBankFrontend(64, sr, dict(sr8k_w20 = 0.02, sr8k_w10 = 0.01, sr16k_w40 = 0.04, sr44k_w20 = 0.02)[n], 0.01, 'hann_window').to(d)
+		assert (fe.nfft, fe.hop_length, fe.win_length) == (nfft, hop, win)
+		assert torch.equal(fe.mel.weight.flatten(1).cpu(), T_(g[f'{n}/mel_weight'])) and torch.equal(fe.window.cpu(), T_(g[f'{n}/window']))
+		mask = ca.models.temporal_mask(x, ca.models.compute_output_lengths(x, xlen))
+		close(fe(x, mask = mask), T_(g[f'{n}/feat']), 2e-4, n + ' module')
+		# batch size: 16 x 12 s, ragged, against the oracle
+		torch.manual_seed(3)
+		B, T = 16, 12 * sr
+		xs, xl = torch.rand(B, T) * 2 - 1, torch.linspace(0.4, 1, B)
+		ref = O.logmel_frontend(xs, xl, w.cpu(), mw.cpu().unsqueeze(-1), mb.cpu(), nfft, hop)
+		close(ca.ops.logmel(xs.to(d), xl.to(d), w, mw, mb, nfft, hop), ref, 5e-4, n + ' 16 x 12 s')
