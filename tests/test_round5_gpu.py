@@ -483,3 +483,26 @@ def test_logmel_other_fft_sizes_against_the_reference_and_the_oracle():
 		xs, xl = torch.rand(B, T) * 2 - 1, torch.linspace(0.4, 1, B)
 		ref = O.logmel_frontend(xs, xl, w.cpu(), mw.cpu().unsqueeze(-1), mb.cpu(), nfft, hop)
 		close(ca.ops.logmel(xs.to(d), xl.to(d), w, mw, mb, nfft, hop), ref, 5e-4, n + ' 16 x 12 s')
+
+
+@pytest.mark.parametrize('sr, wsize, nmel, preemph, normalize', [(16000, 0.032, 40, 0.97, True), (8000, 0.032, 64, 0.0, True), (16000, 0.02, 23, 0.97, False), (22050, 0.04, 64, 0.5, True), (8000, 0.016, 17, 0.0, False)])
+def test_logmel_argument_envelope_against_the_oracle(sr, wsize, nmel, preemph, normalize):
+	"""LogFilterBankFrontend's other arguments (models.py:486-526) at the FFT sizes the kernel covers: a window that fills nfft exactly (0.032 s at
+	16 kHz = 512, at 8 kHz = 256), fewer mel channels than lanes, no pre-emphasis (every frame pair takes the general load path), no
+	normalisation, int16 and ragged lengths -- against the oracle's restatement of the same forward."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	fe = ca.models.LogFilterBankFrontend(nmel, sr, wsize, 0.01, 'hann_window', preemphasis = preemph, normalize_signal = normalize).to(d)
+	assert fe.nfft in (128, 256, 512, 1024) and fe.win_length <= fe.nfft
+	torch.manual_seed(sr + nmel)
+	B, T = 5, int(2.3 * sr) + 11
+	x = torch.rand(B, T) * 2 - 1
+	x[3] *= 1e-3
+	xlen = torch.tensor([1.0, 0.31, 0.77, 0.5, 0.02])
+	for sig in (x, (x * 12000).to(torch.int16)):
+		ref = O.logmel_frontend(sig, xlen, fe.window.cpu(), fe.mel.weight.cpu(), fe.mel.bias.cpu(), fe.nfft, fe.hop_length, preemphasis = preemph, normalize_signal = normalize)
+		got = ca.ops.logmel(sig.to(d), xlen.to(d), fe.window, fe.mel.weight.flatten(1), fe.mel.bias, fe.nfft, fe.hop_length, preemphasis = preemph, normalize = normalize).cpu()
+		assert got.shape == ref.shape == (B, nmel, 1 + T // fe.hop_length)
+		# un-normalised int16 samples put the power at ~1e8..1e11: compare the logs with the same bar as everywhere else
+		err = float((got - ref).abs().max())
+		assert torch.allclose(got, ref, rtol = 5e-4, atol = 5e-4), (sr, wsize, nmel, str(sig.dtype), err)
