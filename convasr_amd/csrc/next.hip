@@ -235,14 +235,97 @@ static int al_ns(int S_max) {
 	return -1;
 }
 
-extern "C" int64_t convasr_ctc_alignment_workspace_bytes(int B, int T) { return (int64_t)B * T * 64 * (int64_t)sizeof(unsigned); }
+// Targets longer than 511 labels (a whole recording aligned to its transcript, transcribe.py:176 without segmentation): one workgroup of
+// 16 waves per utterance, the forward column double-buffered in LDS (up to AL_WG_STATES states), thread j owns states j, j + 1024, ...
+// (neighbouring states sit in neighbouring lanes: conflict-free LDS reads), one barrier per frame.  Same arithmetic per state as the
+// one-wave kernel above -- the two give the same path bit for bit on targets both can take (tests).  Back-pointers: 2 bits per state, the
+// 16 states of a thread in one dword, workspace [B][T][1024].
+#define AL_WG_THREADS 1024
+#define AL_WG_PER 16
+#define AL_WG_STATES (AL_WG_THREADS * AL_WG_PER)
+__global__ __launch_bounds__(AL_WG_THREADS) void ctc_alignment_wg_kernel(const float* __restrict__ lp, const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len,
+                                                                         const int64_t* __restrict__ tgt_len, int64_t* __restrict__ out, unsigned* __restrict__ bp, int T, int C,
+                                                                         int S_max, int blank) {
+	extern __shared__ float al_col[];  // [2][per * 1024 + 2]: two "log zero" states in front of state 0
+	const int b = blockIdx.x, tid = threadIdx.x;
+	const int S = (int)tgt_len[b], Tb = (int)in_len[b], L = 2 * S + 1;
+	const int64_t* tg = targets + (int64_t)b * S_max;
+	int64_t* ob = out + (int64_t)b * S_max;
+	for (int j = tid; j < S_max; j += AL_WG_THREADS) ob[j] = 0;
+	if (S <= 0 || Tb <= 0 || Tb > T) return;
+	const int per = (L + AL_WG_THREADS - 1) / AL_WG_THREADS, pitch = per * AL_WG_THREADS + 2;
+	const float* lpb = lp + (int64_t)b * T * C;
+	unsigned* bpb = bp + (int64_t)b * T * AL_WG_THREADS;
+	float* cur = al_col + 2;
+	float* nxt = al_col + pitch + 2;
+	if (tid < 2) { cur[tid - 2] = AL_ZERO; nxt[tid - 2] = AL_ZERO; }
+
+	int cls[AL_WG_PER];
+	bool allow2[AL_WG_PER], valid[AL_WG_PER];
+#pragma unroll
+	for (int i = 0; i < AL_WG_PER; ++i) {
+		const int s = i * AL_WG_THREADS + tid;
+		valid[i] = i < per && s < L;
+		const bool lab = (s & 1) && valid[i];
+		cls[i] = lab ? (int)tg[s >> 1] : blank;
+		allow2[i] = lab && s >= 3 && tg[s >> 1] != tg[(s >> 1) - 1];
+		if (i < per) cur[s] = (valid[i] && s < 2) ? lpb[cls[i]] : AL_ZERO;
+	}
+	__syncthreads();
+	for (int t = 1; t < T; ++t) {
+		const float* row = lpb + (int64_t)t * C;
+		unsigned word = 0;
+#pragma unroll
+		for (int i = 0; i < AL_WG_PER; ++i) {
+			if (i < per) {  // uniform over the workgroup
+				const int s = i * AL_WG_THREADS + tid;
+				const float stay = cur[s], one = cur[s - 1], two = allow2[i] ? cur[s - 2] : AL_ZERO;
+				unsigned k = 0;
+				float best = stay;
+				if (one > best) { k = 1; best = one; }
+				if (two > best) { k = 2; best = two; }
+				word |= k << (2 * i);
+				nxt[s] = valid[i] ? row[cls[i]] + (best + logf(expf(stay - best) + expf(one - best) + expf(two - best))) : AL_ZERO;
+			}
+		}
+		bpb[(int64_t)t * AL_WG_THREADS + tid] = word;
+		__syncthreads();
+		float* sw = cur; cur = nxt; nxt = sw;
+	}
+	__threadfence_block();
+	__syncthreads();
+	if (tid == 0) {
+		int s = 2 * S - 1 + (cur[2 * S] > cur[2 * S - 1] ? 1 : 0);
+		int seen = -1;
+		for (int t = Tb - 1; t >= 0; --t) {
+			if (s != seen) { if (s & 1) ob[s >> 1] = t; seen = s; }
+			if (t > 0) s -= (int)((bpb[(int64_t)t * AL_WG_THREADS + (s & (AL_WG_THREADS - 1))] >> (2 * (s / AL_WG_THREADS))) & 3u);
+		}
+	}
+}
+
+int convasr_conv_debug_bits();  // conv.hip
+static bool al_use_wg(int S_max) { return al_ns(S_max) < 0 || (convasr_conv_debug_bits() & 32768); }  // debug bit 32768: the workgroup kernel for every target length (tests compare the two)
+
+extern "C" int64_t convasr_ctc_alignment_workspace_bytes(int B, int T, int S_max) {
+	return (int64_t)B * T * (al_use_wg(S_max) ? AL_WG_THREADS : 64) * (int64_t)sizeof(unsigned);
+}
 
 extern "C" int convasr_ctc_alignment(const float* log_probs, const int64_t* targets, const int64_t* input_lengths, const int64_t* target_lengths, int64_t* alignment,
                                      void* workspace, int B, int T, int C, int S_max, int blank, void* stream) {
 	CONVASR_CHECK_ARG(log_probs && targets && input_lengths && target_lengths && alignment && workspace && B > 0 && T > 0 && C > 1 && S_max > 0 && blank >= 0 && blank < C, "ctc_alignment: bad arguments");
 	const int ns = al_ns(S_max);
-	if (ns < 0) return convasr_fail(CONVASR_EUNSUPPORTED, "ctc_alignment: target length %d > 511", S_max);
 	hipStream_t s = (hipStream_t)stream;
+	if (al_use_wg(S_max)) {
+		if (2 * S_max + 1 > AL_WG_STATES) return convasr_fail(CONVASR_EUNSUPPORTED, "ctc_alignment: target length %d > %d", S_max, (AL_WG_STATES - 1) / 2);
+		const int per = (2 * S_max + 1 + AL_WG_THREADS - 1) / AL_WG_THREADS;
+		const size_t smem = 2 * ((size_t)per * AL_WG_THREADS + 2) * sizeof(float);
+		static unsigned long long set = 0;
+		convasr_allow_160k_lds(reinterpret_cast<const void*>(ctc_alignment_wg_kernel), set);
+		hipLaunchKernelGGL(ctc_alignment_wg_kernel, dim3(B), dim3(AL_WG_THREADS), smem, s, log_probs, targets, input_lengths, target_lengths, alignment, (unsigned*)workspace, T, C, S_max, blank);
+		CONVASR_CHECK_LAUNCH("ctc_alignment");
+		return 0;
+	}
 #define AL_CASE(NS) case NS: hipLaunchKernelGGL((ctc_alignment_kernel<NS>), dim3(B), dim3(64), 0, s, log_probs, targets, input_lengths, target_lengths, alignment, (unsigned*)workspace, T, C, S_max, blank); break;
 	switch (ns) { AL_CASE(1) AL_CASE(2) AL_CASE(3) AL_CASE(4) AL_CASE(6) AL_CASE(8) AL_CASE(12) AL_CASE(16) }
 #undef AL_CASE

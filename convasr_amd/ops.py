@@ -713,6 +713,6 @@ def ctc_alignment(log_probs_btc, targets, input_lengths, target_lengths, blank):
 	tl = target_lengths.to(device = dev, dtype = torch.int64).contiguous()
 	S_max = targets.shape[1]
 	out = torch.empty(B, S_max, dtype = torch.int64, device = dev)
-	ws = workspace(_lib.load().convasr_ctc_alignment_workspace_bytes(B, T), dev, 'ctc_alignment')
+	ws = workspace(_lib.load().convasr_ctc_alignment_workspace_bytes(B, T, S_max), dev, 'ctc_alignment')
 	call('convasr_ctc_alignment', ptr(log_probs_btc), ptr(targets), ptr(il), ptr(tl), ptr(out), ptr(ws), B, T, C, S_max, int(blank), stream_ptr())
 	return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 7
+#define CONVASR_ABI_VERSION 8
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2, CONVASR_F16 = 3 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -405,12 +405,15 @@ int convasr_novograd_step(float* p, const float* g, float* mom, const float* ema
 /* largest item the table may hold (elements) */
 int64_t convasr_novograd_item_elems(void);
 
-int64_t convasr_ctc_alignment_workspace_bytes(int B, int T);
+/* Bytes of back-pointer workspace for the call below (ABI v8: S_max added -- targets longer than 511 labels run one workgroup per
+ * utterance instead of one wave and keep 1024 packed words per frame instead of 64). */
+int64_t convasr_ctc_alignment_workspace_bytes(int B, int T, int S_max);
 /* ctc.alignment (ctc.py:7-75): forced alignment of targets[b, :target_lengths[b]] to log_probs[b, :input_lengths[b]]
  * (log_probs batch-major (B, T, C) fp32; the reference's (T, B, C) tensor permuted).  alignment (B, S_max) int64: the last
  * frame the best path spends in each label's state, 0 for padded labels.  Forward variable = the reference's sum recursion
  * with finfo.min as log-zero over all T frames, back-pointer = first maximum of (stay, s-1, s-2), end state chosen from the
- * column at T-1, walk started at input_lengths[b]-1. */
+ * column at T-1, walk started at input_lengths[b]-1.  S_max <= 8191 (a recording of ten minutes aligned to its transcript in one call,
+ * transcribe.py:176 without segmentation); longer targets return CONVASR_EUNSUPPORTED. */
 int convasr_ctc_alignment(const float* log_probs, const int64_t* targets, const int64_t* input_lengths, const int64_t* target_lengths,
                           int64_t* alignment, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);
 

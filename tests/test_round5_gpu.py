@@ -506,3 +506,54 @@ def test_logmel_argument_envelope_against_the_oracle(sr, wsize, nmel, preemph, n
 		# un-normalised int16 samples put the power at ~1e8..1e11: compare the logs with the same bar as everywhere else
 		err = float((got - ref).abs().max())
 		assert torch.allclose(got, ref, rtol = 5e-4, atol = 5e-4), (sr, wsize, nmel, str(sig.dtype), err)
+
+
+def test_ctc_alignment_of_long_targets_and_the_two_kernels_agree():
+	"""ctc.alignment (ctc.py:7-75) on targets longer than 511 labels -- a whole recording against its transcript, transcribe.py:176 without
+	segmentation -- runs one workgroup per utterance instead of one wave: bit-equal to the reference's own run (alignment_long.npz: 700 / 1,100
+	labels, 2,600 frames), equal to the one-wave kernel on every golden case both can take (debug bit 32768 routes every length to the
+	workgroup kernel), the oracle's path at 2,100 labels over 6,000 frames, and a clear error beyond 8,191 labels."""
+	import convasr_amd as ca
+	from convasr_amd import _lib
+	d = torch.device('cuda:0')
+	g = np.load(os.path.join(GOLDEN, 'alignment_long.npz'))
+	T_ = lambda k: torch.from_numpy(g[k])
+	al = ca.ctc.alignment(T_('log_probs').to(d), T_('targets'), T_('input_lengths'), T_('target_lengths'), blank = int(g['blank']))
+	assert torch.equal(al.cpu(), T_('alignment')), int((al.cpu() != T_('alignment')).sum())
+	# both kernels on the short golden cases and a 64-utterance batch
+	g0 = np.load(os.path.join(GOLDEN, 'alignment.npz'))
+	gen = torch.Generator().manual_seed(8)
+	B, C, T, S = 64, 38, 753, 150
+	cases = [tuple(torch.from_numpy(g0[f'c{c}/{k}']) for k in ('log_probs', 'targets', 'input_lengths', 'target_lengths')) + (int(g0[f'c{c}/blank']), ) for c in (0, 1, 2)]
+	cases.append((torch.randn(T, B, C, generator = gen).log_softmax(dim = -1), torch.randint(0, C - 1, (B, S), generator = gen), torch.randint(2 * S + 1, T + 1, (B, ), generator = gen), torch.randint(1, S + 1, (B, ), generator = gen), C - 1))
+	lib = _lib.load()
+	for k, (lp, tg, il, tl, blank) in enumerate(cases):
+		wave = ca.ctc.alignment(lp.to(d), tg, il, tl, blank = blank)
+		prev = lib.convasr_debug_set_conv_v2(1 | (32768 << 8))
+		try:
+			wg = ca.ctc.alignment(lp.to(d), tg, il, tl, blank = blank)
+		finally:
+			lib.convasr_debug_set_conv_v2(prev)
+		assert torch.equal(wave, wg), (k, int((wave != wg).sum()))
+	# 2,100 labels over 6,000 frames (five states per thread): against the oracle
+	B, T, S = 2, 6000, 2100
+	tg = torch.randint(0, C - 1, (B, S), generator = gen)
+	tl, il = torch.tensor([S, 1500]), torch.tensor([T, 5000])
+	logits = torch.randn(T, B, C, generator = gen)
+	for b in range(B):
+		pos = (torch.arange(int(tl[b])) * (int(il[b]) - 10) / int(tl[b])).long() + 3
+		logits[pos, b, tg[b, :int(tl[b])]] += 6.0
+	lp = logits.log_softmax(dim = -1)
+	al = ca.ctc.alignment(lp.to(d), tg, il, tl, blank = C - 1).cpu()
+	for b in range(B):
+		a = al[b, :tl[b]]
+		assert bool((a[1:] > a[:-1]).all()) and int(a[0]) >= 0 and int(a[-1]) < int(il[b]) and int(al[b, tl[b]:].abs().sum()) == 0
+	threads = torch.get_num_threads()
+	torch.set_num_threads(1)  # 6,000 sequential steps of tiny tensor ops: a 256-thread pool costs 13x the time of one thread here
+	try:
+		ref = O.ctc_alignment(lp, tg, il, tl, blank = C - 1)
+	finally:
+		torch.set_num_threads(threads)
+	assert torch.equal(al, ref)
+	with pytest.raises(_lib.ConvasrHipError, match = 'target length'):
+		ca.ctc.alignment(torch.zeros(4, 1, C, device = d), torch.zeros(1, 8192, dtype = torch.int64), torch.tensor([4]), torch.tensor([1]), blank = C - 1)
