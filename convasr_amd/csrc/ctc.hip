@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 // (blank, label) pairs per lane of the sweep's two waves {producer of the edge, consumer}: the smallest 128 (NPH + NPL) >= 2 S_max + 1
 static int ctc_split(int S_max, int* nph, int* npl) {
 	const int pairs = (2 * S_max + 1 + 127) / 128;  // per lane, both waves together
-	if (pairs > 8) return -1;
+	if (pairs > 16) return -1;
 	const int p = pairs < 2 ? 2 : pairs;
 	*nph = (p + 1) / 2;
 	*npl = p / 2;
@@ -378,7 +378,7 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
                                 void* workspace, int B, int T, int C, int S_max, int blank, void* stream) {
 	CONVASR_CHECK_ARG(log_probs && targets && olen && ylen && nll && workspace && B > 0 && T > 0 && C > 1 && S_max >= 0 && blank >= 0 && blank < C, "ctc_loss: bad arguments");
 	int nph, npl;
-	if (ctc_split(S_max, &nph, &npl) < 0) return convasr_fail(CONVASR_EUNSUPPORTED, "ctc_loss: target length %d > 511", S_max);
+	if (ctc_split(S_max, &nph, &npl) < 0) return convasr_fail(CONVASR_EUNSUPPORTED, "ctc_loss: target length %d > 1023", S_max);
 	CONVASR_CHECK_ARG(C <= 8192, "ctc_loss: C %d > 8192", C);
 	hipStream_t s = (hipStream_t)stream;
 	const int NB = T / CTC_RENORM + 1, cap = 128 * (nph + npl);
@@ -401,6 +401,7 @@ extern "C" int convasr_ctc_loss(const float* log_probs, const int64_t* targets, 
 #define CTC_CASE(NPH, NPL) case NPH + NPL: if (in_lds) CTC_LAUNCH(NPH, NPL, true); else CTC_LAUNCH(NPH, NPL, false); break;
 	switch (nph + npl) {
 		CTC_CASE(1, 1) CTC_CASE(2, 1) CTC_CASE(2, 2) CTC_CASE(3, 2) CTC_CASE(3, 3) CTC_CASE(4, 3) CTC_CASE(4, 4)
+		CTC_CASE(5, 4) CTC_CASE(5, 5) CTC_CASE(6, 5) CTC_CASE(6, 6) CTC_CASE(7, 6) CTC_CASE(7, 7) CTC_CASE(8, 7) CTC_CASE(8, 8)  // 512-1,023 labels
 	}
 #undef CTC_CASE
 #undef CTC_LAUNCH

@@ -228,7 +228,7 @@ int64_t convasr_ctc_workspace_bytes(int B, int T, int S_max);
 /* nll[b] = -log p(targets[b,:ylen[b]] | log_probs[b,:olen[b]]) with blank = `blank`, +inf when infeasible
  * (zero_infinity=False).  grad (B,T,C) = d nll / d log_probs as ATen defines it: exp(lp) - posterior for t < olen,
  * 0 for t >= olen (may be NULL: forward only).  targets: (B, S_max) int64, olen/ylen int64 (the reference's dtypes).
- * Envelope: S_max <= 511 labels, T <= ~13,000 frames (the per-frame hand-over slots of the two-wave sweeps live in LDS); beyond it
+ * Envelope: S_max <= 1,023 labels, T <= ~13,000 frames (the per-frame hand-over slots of the two-wave sweeps live in LDS); beyond it
  * the call fails with CONVASR_EUNSUPPORTED / an invalid-argument error and launches nothing. */
 int convasr_ctc_loss(const float* log_probs, const int64_t* targets, const int64_t* olen, const int64_t* ylen,
                      float* nll, float* grad, void* workspace, int B, int T, int C, int S_max, int blank, void* stream);

@@ -453,10 +453,11 @@ def test_ctc_against_oracle(shape):
 
 
 @gpu
-@pytest.mark.parametrize('S,T', [(64, 300), (128, 400), (200, 600), (300, 753), (383, 900), (447, 1000), (511, 1100)])
+@pytest.mark.parametrize('S,T', [(64, 300), (128, 400), (200, 600), (300, 753), (383, 900), (447, 1000), (511, 1100), (575, 1300), (639, 1400), (703, 1600), (767, 1700), (831, 1900),
+	(895, 2000), (959, 2200), (1023, 2400)])
 def test_ctc_every_split_of_the_states_over_the_two_waves(S, T):
 	"""csrc/ctc.hip gives the two waves of a sweep NPH and NPL (blank, label) pairs per lane: (1,1) (2,1) (2,2) (3,2) (3,3) (4,3) (4,4) for
-	up to 511 labels.  One case per split, target lengths chosen so that the last two states of the extended target sit on the two sides of
+	up to 511 labels, (5,4) ... (8,8) for up to 1,023 (round 5: F.ctc_loss takes any length; 20 s of fast speech stays below 511).  One case per split, target lengths chosen so that the last two states of the extended target sit on the two sides of
 	the waves' common edge (S = 64, 128) or deep in the upper wave; T = 900 .. 1100 runs with the log-probs left in global memory."""
 	from convasr_amd import ops
 	B, C = 2, 38
@@ -472,7 +473,14 @@ def test_ctc_every_split_of_the_states_over_the_two_waves(S, T):
 	ref.sum().backward()
 	nll, grad = ops.ctc_loss(ops.as_cl(lp.to(dev())), y, olen, ylen, C - 1)
 	close(nll.cpu(), ref.detach().float(), 1e-5, 1e-4, 'nll')
-	close(grad.cpu(), lpr.grad.float(), 1e-4, 2e-4, 'grad vs float64 oracle')
+	# the fp32 lattice's error in the gradient grows with the number of frames it is carried over (renormalised every 8 frames: ~1e-4 at
+	# T = 753, 2.6e-4 at 1,700, 4.4e-4 at 2,200-2,400, where ATen's unnormalised fp32 lattice is at 1e-3 already at 753): the bar of the <= 1,100-frame cases, scaled
+	close(grad.cpu(), lpr.grad.float(), 1e-4, 2e-4 * max(1.0, T / 1100) ** 1.5, 'grad vs float64 oracle')
+	if T > 1100:  # ... and never worse than the reference's own arithmetic (F.ctc_loss in fp32) is against float64
+		lp32 = lp.clone().requires_grad_(True)
+		O.ctc_loss(lp32, y, olen, ylen).sum().backward()
+		err_ref, err_hip = float((lp32.grad.double() - lpr.grad).abs().max()), float((grad.cpu().double() - lpr.grad).abs().max())
+		assert err_hip <= err_ref, (err_hip, err_ref)
 
 
 @gpu
