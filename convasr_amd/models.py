@@ -472,19 +472,48 @@ class Wav2Letter(JasperNet):
 		super().__init__(num_input_features, num_classes, base_width = base_width, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue, kernel_sizes = [kernel_size_prologue] * num_blocks, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], residual = False, dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend, **kwargs)
 
 
-def _wav2letter_variant(name, doc, **fixed):
-	def __init__(self, num_input_features, num_classes, dropout = 0.2, base_width = 128, nonlinearity = ('hardtanh', 0, 20), kernel_size_prologue = 11, kernel_size_epilogue = 29, kernel_sizes = [11, 13, 17, 21, 25], dilation = 2, num_blocks = 6, decoder_type = None, normalize_features = True, frontend = None, **kwargs):
-		args = dict(base_width = base_width, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue, kernel_sizes = [kernel_size_prologue] * num_blocks, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend)
-		args.update(fixed)
-		args.update(kwargs)
+# The Wav2Letter family (models.py:858-1369): one constructor signature, thirteen named settings of it.  Per name: the defaults that differ from
+# Wav2Letter's own (models.py:819-855) and what is passed on to JasperNet.  `large_kernels`: the blocks take `kernel_sizes` as given instead of
+# repeating the prologue's kernel size; `widths` / `widths_large`: out_width_factors (a number n stands for [n] * num_blocks) and
+# out_width_factors_large.
+_RELU_NO_DROPOUT = dict(dropout = 0.0, nonlinearity = ('relu', ))
+_WAV2LETTER_FAMILY = dict(
+	Wav2LetterResidual = ('models.py:858-894', dict(), dict(residual = True)),
+	Wav2LetterResidualNoDilation = ('models.py:897-933', dict(dilation = 1), dict(residual = True)),
+	Wav2LetterResidualBig = ('models.py:936-973', dict(), dict(residual = True, num_subblocks = 2)),
+	Wav2LetterDense = ('models.py:976-1012', dict(), dict(residual = 'dense')),
+	Wav2LetterDenseNoDilation = ('models.py:1015-1051', dict(dilation = 1), dict(residual = 'dense')),
+	Wav2LetterDenseNoDilationInplace = ('models.py:1054-1091: leaky-relu and the in-place memory tricks', dict(dilation = 1, nonlinearity = ('leaky_relu', 0.01)), dict(residual = 'dense', inplace = True)),
+	Wav2LetterDenseLargeKernels = ('models.py:1094-1130', dict(), dict(residual = 'dense', large_kernels = True)),
+	Wav2LetterDenseNoDilationLargeKernels = ('models.py:1133-1169', dict(dilation = 1), dict(residual = 'dense', large_kernels = True)),
+	Wav2LetterDenseBig = ('models.py:1172-1209', dict(), dict(residual = 'dense', num_subblocks = 2)),
+	Wav2LetterDenseBigLargeKernelsNoDropoutReLu = ('models.py:1212-1249', _RELU_NO_DROPOUT, dict(residual = 'dense', num_subblocks = 2, large_kernels = True)),
+	Wav2LetterDenseBigLargeKernelsNoDilationNoDropoutReLu = ('models.py:1252-1289', dict(dilation = 1, **_RELU_NO_DROPOUT), dict(residual = 'dense', num_subblocks = 2, large_kernels = True)),
+	Wav2LetterDenseBigLargeKernelsNoDilationNoTemporalMaskNoDropoutReLu = ('models.py:1292-1330', dict(dilation = 1, **_RELU_NO_DROPOUT), dict(residual = 'dense', num_subblocks = 2, large_kernels = True, temporal_mask = False)),
+	Wav2LetterFlat = ('models.py:1333-1369: identity residuals, constant width', dict(kernel_size_prologue = 13), dict(residual = 'flat', widths = 6, widths_large = [16, 16])),
+)
+
+
+def _wav2letter_variant(name, doc, defaults, passed):
+	passed = dict(passed)
+	large_kernels, widths, widths_large = passed.pop('large_kernels', False), passed.pop('widths', [2, 3, 4, 5, 6]), passed.pop('widths_large', [7, 8])
+	d = dict(dropout = 0.2, nonlinearity = ('hardtanh', 0, 20), kernel_size_prologue = 11, dilation = 2, num_blocks = 5)
+	d.update(defaults)
+
+	def __init__(self, num_input_features, num_classes, dropout = d['dropout'], base_width = 128, nonlinearity = d['nonlinearity'], kernel_size_prologue = d['kernel_size_prologue'], kernel_size_epilogue = 29, kernel_sizes = [11, 13, 17, 21, 25], dilation = d['dilation'], num_blocks = d['num_blocks'], decoder_type = None, normalize_features = True, frontend = None, **kwargs):
+		args = dict(base_width = base_width, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue,
+			kernel_sizes = kernel_sizes if large_kernels else [kernel_size_prologue] * num_blocks, out_width_factors = [widths] * num_blocks if isinstance(widths, int) else widths, out_width_factors_large = widths_large,
+			dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend)
+		args.update(passed)
+		args.update(kwargs)  # (this package's own: compute_dtype, check_time_dim_padded, ...)
 		JasperNet.__init__(self, num_input_features, num_classes, **args)
 
-	return type(name, (JasperNet, ), dict(__init__ = __init__, __doc__ = doc))
+	return type(name, (JasperNet, ), dict(__init__ = __init__, __doc__ = doc, __module__ = __name__))
 
 
-Wav2LetterResidual = _wav2letter_variant('Wav2LetterResidual', 'models.py:858-894', residual = True)
-Wav2LetterDense = _wav2letter_variant('Wav2LetterDense', 'models.py:976-1012', residual = 'dense')
-Wav2LetterFlat = _wav2letter_variant('Wav2LetterFlat', 'models.py:1333-1369', residual = 'flat')
+for _name, (_doc, _defaults, _passed) in _WAV2LETTER_FAMILY.items():
+	globals()[_name] = _wav2letter_variant(_name, _doc, _defaults, _passed)
+del _name, _doc, _defaults, _passed
 
 
 class JasperNetSmall(JasperNet):
@@ -534,11 +563,19 @@ class JasperNetBigInplace(JasperNet):
 		super().__init__(*args, num_subblocks = 2, temporal_mask = False, inplace = inplace, nonlinearity = ('leaky_relu', 0.01), **kwargs)
 
 
-class Wav2LetterDenseNoDilationInplace(JasperNet):
-	"""models.py:1054-1094: dense residuals, leaky-relu, no dilation in the epilogue, 5 blocks, the in-place memory tricks."""
+class JasperNetSmallInstanceNorm(JasperNet):
+	"""models.py:1382-1391: the feature normalisation as nn.InstanceNorm1d's own forward, without the length mask."""
 
-	def __init__(self, num_input_features, num_classes, dropout = 0.2, base_width = 128, nonlinearity = ('leaky_relu', 0.01), kernel_size_prologue = 11, kernel_size_epilogue = 29, kernel_sizes = [11, 13, 17, 21, 25], dilation = 1, num_blocks = 5, decoder_type = None, normalize_features = True, frontend = None, **kwargs):
-		super().__init__(num_input_features, num_classes, base_width = base_width, inplace = True, dropout = dropout, dropout_prologue = dropout, dropout_epilogue = dropout, dropouts = [dropout] * num_blocks, kernel_size_prologue = kernel_size_prologue, kernel_size_epilogue = kernel_size_epilogue, kernel_sizes = [kernel_size_prologue] * num_blocks, out_width_factors = [2, 3, 4, 5, 6], out_width_factors_large = [7, 8], residual = 'dense', dilation = dilation, nonlinearity = nonlinearity, decoder_type = decoder_type, normalize_features = normalize_features, frontend = frontend, **kwargs)
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 1, temporal_mask = False, normalize_features_legacy = False, normalize_features_temporal_mask = False, **kwargs)
+
+
+class JasperNetSmallTrainableInstanceNorm(JasperNet):
+	"""models.py:1394-1404: the same with running statistics in the feature normalisation -- a form MaskedInstanceNorm1d here refuses at
+	construction (only affine = False, track_running_stats = False, what every other configuration uses, has a kernel)."""
+
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, num_subblocks = 1, temporal_mask = False, normalize_features_legacy = False, normalize_features_track_running_stats = True, normalize_features_temporal_mask = False, **kwargs)
 
 
 # ------------------------------------------------------------------------------------------------ wrappers (models.py:736-765)

@@ -373,7 +373,7 @@ def fuse_conv_bn_eval(sd, eps = 1e-5):
 	return out
 
 
-def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None, frozen = None):
+def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None, frozen = None, normalize_features_temporal_mask = True):
 	"""JasperNet.forward (models.py:282-326).  sd: state dict (tensors, BN buffers are updated in place when
 	training), plan: jasper_plan(...), frontend: dict(window, nfft, hop_length) or None (x is features).
 	storage = torch.bfloat16 restates the same algorithm with the MI355X throughput path's storage precision: activations, conv
@@ -386,7 +386,8 @@ def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = N
 		x = logmel_frontend(x, xlen, sd['frontend.window'], sd['frontend.mel.weight'], sd['frontend.mel.bias'], frontend['nfft'], frontend['hop_length'])
 	assert x.ndim == 3
 	if normalize_features:
-		mask = temporal_mask(x.shape[-1], compute_output_lengths(x.shape[-1], xlen)) if xlen is not None else None
+		# (normalize_features_temporal_mask = False: JasperNetSmallInstanceNorm, models.py:1382-1391 -- MaskedInstanceNorm1d ignores the mask, 696)
+		mask = temporal_mask(x.shape[-1], compute_output_lengths(x.shape[-1], xlen)) if xlen is not None and normalize_features_temporal_mask else None
 		x = masked_instance_norm(x if x.dtype == torch.float64 else x.float(), mask)  # (float64 only in precision experiments)
 	x = _stored(x, storage) if x.requires_grad else (x if storage is None else x.to(storage).to(x.dtype))
 	residual = []

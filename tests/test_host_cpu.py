@@ -9,6 +9,8 @@ import convasr_amd as ca
 from convasr_amd import functional as Fn
 from convasr_amd.functional import ConvSpec
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
 
 def _small():
 	torch.manual_seed(0)
@@ -126,3 +128,32 @@ def test_ctc_workspace_query_follows_the_state_split():
 		want = (2 * B * T * cap + 4 * B * NB + 2 * B) * 4
 		assert lib.convasr_ctc_workspace_bytes(B, T, S) == want, (S, cap)
 	assert lib.convasr_ctc_workspace_bytes(B, T, 512) == -1
+
+
+def test_every_named_configuration_of_the_reference_builds_the_same_network():
+	"""`getattr(models, args.model)` (train.py:428, transcribe.py:44): all 24 JasperNet subclasses of the reference's models.py (819-1442) exist
+	here under the same names and build the same network -- per block the conv / batch-norm / residual-branch geometry, activation, dropout and
+	mask flag, the residual policy, the feature normalisation's flags, every state-dict key and shape -- as the reference's own constructors did
+	(tests/golden/model_zoo.json, written by make_golden_r5.py through tests/golden/describe_model.py).  The one configuration without a kernel
+	(running statistics in the feature normalisation) refuses at construction."""
+	import json
+	import sys
+	import convasr_amd as ca
+	sys.path.insert(0, GOLDEN)
+	from describe_model import describe
+	zoo = json.load(open(os.path.join(GOLDEN, 'model_zoo.json')))
+	assert len(zoo) == 27
+	for key, want in sorted(zoo.items()):
+		name, _, variant = key.partition(':')
+		cls = getattr(ca.models, name)
+		kw = dict(base_width = 128 if 'Separable' in name else 16)
+		args = (64, [38, 300]) if variant == 'bpe' else (64, [38])
+		if variant == 'bpe':
+			kw['decoder_type'] = 'bpe'
+		if name == 'JasperNetSmallTrainableInstanceNorm':
+			with pytest.raises(ca._lib.ConvasrHipError, match = 'track_running_stats'):
+				cls(*args, **kw)
+			continue
+		got = json.loads(json.dumps(describe(cls(*args, **kw))))
+		for field in want:
+			assert got[field] == want[field], (key, field)

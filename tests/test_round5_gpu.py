@@ -621,3 +621,59 @@ def test_utterance_length_extremes_against_the_oracle():
 		assert cos16 >= 0.985 and rel16 <= 0.16 and err16 <= 0.25 * scale, (cos16, rel16, err16, scale)
 	finally:
 		torch.set_num_threads(threads)
+
+
+FAMILY = ['Wav2LetterFlat', 'Wav2LetterResidualBig', 'Wav2LetterDenseBigLargeKernelsNoDilationNoTemporalMaskNoDropoutReLu', 'JasperNetSmallInstanceNorm', 'Wav2LetterResidualNoDilation']
+
+
+@pytest.mark.parametrize('name', FAMILY)
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_named_configurations_against_the_reference(name, dt):
+	"""Five of the reference's 24 named configurations (models.py:858-1404; all of them build the reference's network: tests/test_host_cpu.py) run
+	by the reference itself on a (3, 64, 96) feature batch (family.npz, make_golden_r5.py): identity residuals, one residual per block over two
+	sub-blocks, dense + relu + no temporal mask + per-block kernel sizes, nn.InstanceNorm1d's forward as the feature normalisation, no dilation.
+	fp32: logits and three to five gradients against the reference; bf16: the same network on the MFMA path within the storage type's error."""
+	import sys
+	import convasr_amd as ca
+	sys.path.insert(0, GOLDEN)
+	from describe_model import fill_parameters
+	d = torch.device('cuda:0')
+	g = np.load(os.path.join(GOLDEN, 'family.npz'))
+	net = getattr(ca.models, name)(64, [38], base_width = 8, dropout = 0.0, check_time_dim_padded = False, compute_dtype = torch.float32 if dt == 'f32' else torch.bfloat16)
+	fill_parameters(net, 100 + FAMILY.index(name))
+	net.to(d).train()
+	out = net(torch.from_numpy(g['x']).to(d), torch.from_numpy(g['xlen']).to(d))
+	logits = out['logits'][0]
+	ref = torch.from_numpy(g[f'{name}/logits'])
+	scale = float(ref.abs().max())
+	logits.float().square().mean().backward()
+	params = dict(net.named_parameters())
+	wanted = [k[len(name) + 6:] for k in g.files if k.startswith(name + '/grad/')]
+	assert len(wanted) >= 3
+	if dt == 'f32':
+		err = float((logits.detach().cpu() - ref).abs().max())
+		assert err <= 1e-3 * scale + 1e-4, err
+		for k in wanted:
+			cos, rel = _cos_rel(params[k].grad, torch.from_numpy(g[f'{name}/grad/{k}']))
+			assert cos >= 0.99999 and rel <= 5e-3, (k, cos, rel)
+		rv = net.backbone[-1].bn[0].running_var.cpu()
+		assert torch.allclose(rv, torch.from_numpy(g[f'{name}/running_var_last']), rtol = 1e-4, atol = 1e-6)
+	else:
+		# logits and gradients deep in a 16-bit network carry the storage type's rounding amplified layer by layer (the first conv of these 13- to 23-conv
+		# networks: relative error 0.2-0.45 against fp32): the bar is the oracle's restatement of the SAME algorithm with bf16 storage at the
+		# same points -- the GPU path may not deviate from the reference by more than 1.5x what that CPU restatement does, plus 0.02
+		from describe_model import describe, oracle_plan
+		cpu = getattr(ca.models, name)(64, [38], base_width = 8, dropout = 0.0)
+		fill_parameters(cpu, 100 + FAMILY.index(name))
+		sd = {k: v.clone() for k, v in cpu.state_dict().items()}
+		for k in wanted:
+			sd[k].requires_grad_(True)
+		o = O.jasper_forward(sd, oracle_plan(describe(cpu)), torch.from_numpy(g['x']), torch.from_numpy(g['xlen']), training = True, storage = torch.bfloat16, normalize_features_temporal_mask = name != 'JasperNetSmallInstanceNorm')
+		o['logits'].square().mean().backward()
+		rel_gpu, rel_cpu = _cos_rel(logits.float(), ref)[1], _cos_rel(o['logits'], ref)[1]
+		assert rel_gpu <= 1.5 * rel_cpu + 0.02, ('logits', rel_gpu, rel_cpu)
+		_dump(f'r05_family_bf16_{name[:28]}.json', dict(logits_rel_gpu = rel_gpu, logits_rel_cpu_bf16_storage = rel_cpu))
+		for k in wanted:
+			want = torch.from_numpy(g[f'{name}/grad/{k}'])
+			rel_gpu, rel_cpu = _cos_rel(params[k].grad, want)[1], _cos_rel(sd[k].grad, want)[1]
+			assert rel_gpu <= 1.5 * rel_cpu + 0.02, (k, rel_gpu, rel_cpu)
