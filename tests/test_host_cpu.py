@@ -119,15 +119,15 @@ def test_accepted_configuration_flags_build_the_reference_state_dict_layout():
 
 def test_ctc_workspace_query_follows_the_state_split():
 	"""convasr_ctc_workspace_bytes is host code (no GPU call): lattice rows hold 128 (NPH + NPL) states, the smallest split that covers
-	the 2 S + 1 states of the extended target -- (1,1) up to 127 labels, (2,1) to 191, ... (4,4) to 511; longer targets are refused (-1)."""
+	the 2 S + 1 states of the extended target -- (1,1) up to 127 labels, (2,1) to 191, ... (4,4) to 511, (5,4) ... (8,8) to 1,023; longer targets are refused (-1)."""
 	from convasr_amd import _lib
 	lib = _lib.load()
 	B, T = 3, 753
 	NB = T // 8 + 1
-	for S, cap in [(0, 256), (1, 256), (127, 256), (128, 384), (150, 384), (191, 384), (192, 512), (255, 512), (256, 640), (319, 640), (320, 768), (383, 768), (384, 896), (447, 896), (448, 1024), (511, 1024)]:
+	for S, cap in [(0, 256), (1, 256), (127, 256), (128, 384), (150, 384), (191, 384), (192, 512), (255, 512), (256, 640), (319, 640), (320, 768), (383, 768), (384, 896), (447, 896), (448, 1024), (511, 1024), (512, 1152), (575, 1152), (576, 1280), (831, 1664), (832, 1792), (959, 1920), (960, 2048), (1023, 2048)]:
 		want = (2 * B * T * cap + 4 * B * NB + 2 * B) * 4
 		assert lib.convasr_ctc_workspace_bytes(B, T, S) == want, (S, cap)
-	assert lib.convasr_ctc_workspace_bytes(B, T, 512) == -1
+	assert lib.convasr_ctc_workspace_bytes(B, T, 1024) == -1
 
 
 def test_every_named_configuration_of_the_reference_builds_the_same_network():
