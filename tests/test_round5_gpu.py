@@ -677,3 +677,41 @@ def test_named_configurations_against_the_reference(name, dt):
 			want = torch.from_numpy(g[f'{name}/grad/{k}'])
 			rel_gpu, rel_cpu = _cos_rel(params[k].grad, want)[1], _cos_rel(sd[k].grad, want)[1]
 			assert rel_gpu <= 1.5 * rel_cpu + 0.02, (k, rel_gpu, rel_cpu)
+
+
+@pytest.mark.parametrize('name', FAMILY)
+def test_named_configurations_eval_and_folded_batch_norm_against_the_oracle(name):
+	"""The inference path of the same five configurations (transcribe.py:44-57: model.eval(), model.fuse_conv_bn_eval()): running statistics
+	populated by two train-mode forwards, then the eval forward with live batch norms and with the batch norms folded into the convs
+	(models.py:141-151, residual branches included; identity residuals have nothing to fold), fp32 against the oracle's eval forward on the
+	same state dict; the bf16 forward of the folded network against the fp32 one."""
+	import sys
+	import convasr_amd as ca
+	sys.path.insert(0, GOLDEN)
+	from describe_model import describe, fill_parameters, oracle_plan
+	d = torch.device('cuda:0')
+	g = np.load(os.path.join(GOLDEN, 'family.npz'))
+	x, xlen = torch.from_numpy(g['x']), torch.from_numpy(g['xlen'])
+	net = getattr(ca.models, name)(64, [38], base_width = 8, dropout = 0.0, check_time_dim_padded = False)
+	fill_parameters(net, 100 + FAMILY.index(name))
+	plan = oracle_plan(describe(net))
+	net.to(d).train()
+	with torch.no_grad():
+		for scale in (1.0, 0.7):
+			net(x.to(d) * scale, xlen.to(d))
+		sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+		ref = O.jasper_forward(sd, plan, x, xlen, training = False, normalize_features_temporal_mask = name != 'JasperNetSmallInstanceNorm')['logits']
+		rng = float(ref.abs().max())
+		assert rng > 0.1  # (non-degenerate: the running statistics are populated)
+		net.eval()
+		live = net(x.to(d), xlen.to(d))['logits'][0].cpu()
+		net.fuse_conv_bn_eval()
+		assert all(isinstance(b, torch.nn.Identity) for blk in net.backbone for b in list(blk.bn) + list(blk.bn_residual))
+		folded = net(x.to(d), xlen.to(d))['logits'][0].cpu()
+		net.set_compute_dtype(torch.bfloat16)
+		folded16 = net(x.to(d), xlen.to(d))['logits'][0].float().cpu()
+	for what, got in (('live', live), ('folded', folded)):
+		err = float((got - ref).abs().max())
+		assert err <= 1e-3 * rng + 1e-4, (what, err, rng)
+	cos, rel = _cos_rel(folded16, ref)
+	assert cos >= 0.995 and rel <= 0.1, (cos, rel)
