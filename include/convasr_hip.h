@@ -121,8 +121,9 @@ int convasr_fold2_geometry(int K, int pad, int* K_folded, int* pad_folded);
 int convasr_fold2_pack_weight(const float* w, int w_layout, void* packed_fwd, int dtype, int Cout, int Cin, int K, int pad, void* stream);
 int convasr_fold2_unfold_wgrad(const float* dw_folded, float* dw, int dw_layout, int Cout, int Cin, int K, int pad, int accumulate, void* stream);
 
-/* A/B and test hook: 0 routes bf16 / fp16 launches through the general register-staged kernels instead of the LDS-DMA kernels.
- * Returns the previous setting. */
+/* A/B and test hook: bit 0 = 0 routes bf16 / fp16 launches through the general register-staged kernels instead of the LDS-DMA kernels;
+ * bits 8 and up are diagnostic switches documented where they are read (e.g. 8192 << 8: no one-tap kernel, 32768 << 8: the workgroup
+ * form of convasr_ctc_alignment for every target length).  Returns the previous setting of bit 0; the switches are cleared by the next call. */
 int convasr_debug_set_conv_v2(int enable);
 
 /* Bytes of fp32 workspace convasr_conv1d_wgrad needs (split-K partial slabs). */
