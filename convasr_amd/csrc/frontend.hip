@@ -10,13 +10,13 @@
 #define FE_SPAN 64  // LDS rows of the sparse mel table: melS[j][mel] = weight of bin klo[mel] + j (wider filters read the rest from global memory)
 // nfft = 2^LOG2N for LOG2N = 7..10 (the reference takes the power of two above the window, models.py:516: 512 for 16 kHz x 0.02 s, 256 for train.py's
 // default 8 kHz x 0.02 s, 1024 for 44.1 kHz).  512 has its own radix-8 x 3 schedule; the other sizes share a radix-2 Stockham loop.
-template <int LOG2N> struct FeCfg {
+template <int LOG2N, int NM = 1> struct FeCfg {  // NM: mel channels per lane (1: up to 64 channels, 2: up to 128)
 	static constexpr int N = 1 << LOG2N, BINS = N / 2 + 1, RPL = N / 64;       // samples per lane
 	static constexpr int WAVES = LOG2N <= 9 ? 16 : 8;                           // per workgroup: what 160 KiB of LDS holds
 	static constexpr int BUF = LOG2N == 9 ? 576 : N;                            // a wave's FFT buffer, complex words (512: padded layouts, below)
 	static constexpr int PQ = 2 * (BINS + 7);                                   // a wave's power buffer, floats
 	static constexpr int TWX = LOG2N == 9 ? 64 + 8 * 64 : 0;                    // the radix-8 schedule's transposed twiddle tables
-	static constexpr size_t smem = sizeof(float) * (FE_SPAN * 64 + 2 * N + N + 2 * TWX + 2 * WAVES * BUF + WAVES * PQ + 2 * 64);
+	static constexpr size_t smem = sizeof(float) * (NM * FE_SPAN * 64 + 2 * N + N + 2 * TWX + 2 * WAVES * BUF + WAVES * PQ + NM * 2 * 64);
 };
 // nfft = 512: a wave's FFT buffer is written and read in three index patterns; two padded layouts keep every ds_read / ds_write_b64 of a half-wave on
 // 32 different bank pairs (the unpadded buffer had 8-way conflicts on the stage-1 and stage-2 writes and up to 8-way on the strided twiddle reads):
@@ -101,39 +101,53 @@ __device__ __forceinline__ float padded_sample(const S* xs, int i, int T, int pa
 	return ok ? cur : 0.f;
 }
 
-template <typename S, int LOG2N>
+template <typename S, int LOG2N, int NM>
 __global__ __launch_bounds__(64 * FeCfg<LOG2N>::WAVES) void logmel_kernel(const S* __restrict__ signal, const float* __restrict__ absmax, const float* __restrict__ xlen,
                                                                           const float* __restrict__ window, int win_length, const float* __restrict__ melw,
                                                                           const float* __restrict__ melb, float* __restrict__ out, int B, int T, int F, int hop, int nmel,
                                                                           float preemph, int pairs_per_b, int total_pairs) {
-	using Cfg = FeCfg<LOG2N>;
+	using Cfg = FeCfg<LOG2N, NM>;
 	constexpr int N = Cfg::N, BINS = Cfg::BINS, RPL = Cfg::RPL, WAVES = Cfg::WAVES;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float* const melS = reinterpret_cast<float*>(smem);                  // [FE_SPAN][64] sparse mel table
-	cpx* const tw = reinterpret_cast<cpx*>(melS + FE_SPAN * 64);         // [N] exp(-2 pi i m / N)
+	float* const melS = reinterpret_cast<float*>(smem);                  // [NM][FE_SPAN][64] sparse mel table: channel lane + 64 q in plane q
+	cpx* const tw = reinterpret_cast<cpx*>(melS + NM * FE_SPAN * 64);    // [N] exp(-2 pi i m / N)
 	float* const win = reinterpret_cast<float*>(tw + N);                 // [N] window centred in nfft
 	cpx* const tw2 = reinterpret_cast<cpx*>(win + N);                    // 512 only: [8][8]  stage 2: exp(-2 pi i 8 k r / 512) at [r][k]
 	cpx* const tw3 = tw2 + 64;                                           // 512 only: [8][64] stage 3: exp(-2 pi i lane r / 512) at [r][lane]
 	cpx* const work = tw2 + Cfg::TWX;                                    // [WAVES][BUF]
 	float* const pw = reinterpret_cast<float*>(work + WAVES * Cfg::BUF); // [WAVES][PQ]
-	int* const supp = reinterpret_cast<int*>(pw + WAVES * Cfg::PQ);      // [2][64] first / one-past-last non-zero bin of every mel filter
+	int* const supp = reinterpret_cast<int*>(pw + WAVES * Cfg::PQ);      // [NM][2][64] first / one-past-last non-zero bin of every mel filter
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
 	// support of this lane's mel filter: the filterbank is ~97 % zeros (each triangle spans 3..30 of the 257 bins), so only each
 	// filter's support is kept in LDS (16 KiB instead of the 67 KiB dense matrix: room for 16 waves per CU) and the 257-term dot
 	// product is cut to the widest support in the wave; skipping exact zeros changes no result
-	if (tid < 64) { supp[tid] = BINS; supp[64 + tid] = 0; }
+	if (tid < 64 * NM) { supp[(tid >> 6) * 128 + (tid & 63)] = BINS; supp[(tid >> 6) * 128 + 64 + (tid & 63)] = 0; }
 	__syncthreads();
-	if (lane < nmel) {  // every wave scans its slice of the bins for all filters
-		int lo = BINS, hi = 0;
-		for (int k = wave; k < BINS; k += WAVES)
-			if (melw[lane * BINS + k] != 0.f) { lo = min(lo, k); hi = k + 1; }
-		if (hi > 0) { atomicMin(supp + lane, lo); atomicMax(supp + 64 + lane, hi); }
+	int klo[NM], khi[NM], span[NM];
+	float bias[NM];
+#pragma unroll
+	for (int q = 0; q < NM; ++q) {
+		const int m = lane + 64 * q;
+		if (m < nmel) {  // every wave scans its slice of the bins for all filters
+			int lo = BINS, hi = 0;
+			for (int k = wave; k < BINS; k += WAVES)
+				if (melw[m * BINS + k] != 0.f) { lo = min(lo, k); hi = k + 1; }
+			if (hi > 0) { atomicMin(supp + q * 128 + lane, lo); atomicMax(supp + q * 128 + 64 + lane, hi); }
+		}
 	}
 	__syncthreads();
-	int klo = supp[lane], khi = supp[64 + lane];
-	if (khi <= klo) { klo = 0; khi = 0; }
-	for (int j = wave; j < FE_SPAN; j += WAVES) melS[j * 64 + lane] = (lane < nmel && klo + j < khi) ? melw[lane * BINS + klo + j] : 0.f;
+#pragma unroll
+	for (int q = 0; q < NM; ++q) {
+		const int m = lane + 64 * q;
+		klo[q] = supp[q * 128 + lane]; khi[q] = supp[q * 128 + 64 + lane];
+		if (khi[q] <= klo[q]) { klo[q] = 0; khi[q] = 0; }
+		for (int j = wave; j < FE_SPAN; j += WAVES) melS[(q * FE_SPAN + j) * 64 + lane] = (m < nmel && klo[q] + j < khi[q]) ? melw[m * BINS + klo[q] + j] : 0.f;
+		bias[q] = m < nmel ? melb[m] : 1.f;
+		span[q] = khi[q] - klo[q];
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) span[q] = max(span[q], __shfl_xor(span[q], o, 64));
+	}
 	for (int i = tid; i < N; i += blockDim.x) {
 		float s, c;
 		sincospif((float)i / (float)(N / 2), &s, &c);
@@ -147,14 +161,10 @@ __global__ __launch_bounds__(64 * FeCfg<LOG2N>::WAVES) void logmel_kernel(const 
 		if (tid < 512) tw3[tid] = tw[(tid & 63) * (tid >> 6)];
 		__syncthreads();
 	}
-	int span = khi - klo;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) span = max(span, __shfl_xor(span, o, 64));
 
 	cpx* const buf = work + wave * Cfg::BUF;
 	float2* const pq = reinterpret_cast<float2*>(pw + wave * Cfg::PQ);  // power of bin k of the pair's two frames
 	const int pad = N / 2;
-	const float bias = lane < nmel ? melb[lane] : 1.f;
 
 	for (int pair = blockIdx.x * WAVES + wave; pair < total_pairs; pair += gridDim.x * WAVES) {
 		const int b = pair / pairs_per_b, f0 = (pair % pairs_per_b) * 2;
@@ -166,11 +176,13 @@ __global__ __launch_bounds__(64 * FeCfg<LOG2N>::WAVES) void logmel_kernel(const 
 
 		const int t0 = f0 * hop - pad;  // source index of the pair's first sample
 		if (t0 >= nvalid && t0 >= 0) {  // both frames lie in the masked tail: a zero spectrum, log(eps) exactly as the full computation gives it
-			if (lane < nmel) {
-				const float z = logf(fmaf(0.f, 0.f, 0.f) + bias);
-				out[((int64_t)b * F + f0) * nmel + lane] = z;
-				if (has_f1) out[((int64_t)b * F + f0 + 1) * nmel + lane] = z;
-			}
+#pragma unroll
+			for (int q = 0; q < NM; ++q)
+				if (lane + 64 * q < nmel) {
+					const float z = logf(fmaf(0.f, 0.f, 0.f) + bias[q]);
+					out[((int64_t)b * F + f0) * nmel + lane + 64 * q] = z;
+					if (has_f1) out[((int64_t)b * F + f0 + 1) * nmel + lane + 64 * q] = z;
+				}
 			continue;
 		}
 		// ---- the pair's windowed samples: v[r] = (frame A, frame B) at n = lane + 64 r
@@ -266,43 +278,45 @@ __global__ __launch_bounds__(64 * FeCfg<LOG2N>::WAVES) void logmel_kernel(const 
 		}
 		__builtin_amdgcn_s_waitcnt(0xc07f);
 		__builtin_amdgcn_wave_barrier();
-		// ---- mel + eps bias + log: lane = mel channel
-		float m0 = 0.f, m1 = 0.f;
-		{
-			const int s_lds = min(span, FE_SPAN);
+		// ---- mel + eps bias + log: lane = mel channel (+ 64 q)
+#pragma unroll
+		for (int q = 0; q < NM; ++q) {
+			float m0 = 0.f, m1 = 0.f;
+			const int s_lds = min(span[q], FE_SPAN);
+			const float* const tab = melS + q * FE_SPAN * 64;
 #pragma unroll 4
 			for (int j = 0; j < s_lds; ++j) {  // rows past a filter's own support hold zeros
-				const int k = min(klo + j, BINS - 1);
-				const float w = melS[j * 64 + lane];
+				const int k = min(klo[q] + j, BINS - 1);
+				const float w = tab[j * 64 + lane];
 				const float2 pp = pq[k];
 				m0 = fmaf(w, pp.x, m0);
 				m1 = fmaf(w, pp.y, m1);
 			}
-			for (int j = FE_SPAN; j < span; ++j) {  // filters wider than the table (not with the reference's 64 mels over 257 bins)
-				const int k = min(klo + j, BINS - 1);
-				const float w = (klo + j < khi) ? melw[lane * BINS + k] : 0.f;
+			for (int j = FE_SPAN; j < span[q]; ++j) {  // filters wider than the table (not with the reference's 64 mels over 257 bins)
+				const int k = min(klo[q] + j, BINS - 1);
+				const float w = (klo[q] + j < khi[q]) ? melw[(lane + 64 * q) * BINS + k] : 0.f;
 				const float2 pp = pq[k];
 				m0 = fmaf(w, pp.x, m0);
 				m1 = fmaf(w, pp.y, m1);
 			}
-		}
-		if (lane < nmel) {
-			out[((int64_t)b * F + f0) * nmel + lane] = logf(m0 + bias);
-			if (has_f1) out[((int64_t)b * F + f0 + 1) * nmel + lane] = logf(m1 + bias);
+			if (lane + 64 * q < nmel) {
+				out[((int64_t)b * F + f0) * nmel + lane + 64 * q] = logf(m0 + bias[q]);
+				if (has_f1) out[((int64_t)b * F + f0 + 1) * nmel + lane + 64 * q] = logf(m1 + bias[q]);
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
 }
 
-template <typename S, int LOG2N>
+template <typename S, int LOG2N, int NM>
 static void launch_logmel(const void* signal, const float* absmax, const float* xlen, const float* window, int win_length, const float* mel_weight, const float* mel_bias,
                           float* out, int B, int T, int hop, int nmel, float preemphasis, hipStream_t s) {
-	using Cfg = FeCfg<LOG2N>;
+	using Cfg = FeCfg<LOG2N, NM>;
 	const int F = 1 + T / hop;  // (T + 2 * pad - nfft) / hop + 1 with pad = nfft / 2
 	const int pairs_per_b = (F + 1) / 2, total_pairs = B * pairs_per_b;
 	int grid = (total_pairs + Cfg::WAVES - 1) / Cfg::WAVES;
 	if (grid > 256) grid = 256;  // persistent: one workgroup per CU amortises the table set-up (mel transpose, twiddles) over ~190 frame pairs
-	auto kern = logmel_kernel<S, LOG2N>;
+	auto kern = logmel_kernel<S, LOG2N, NM>;
 	static unsigned long long set = 0;
 	convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), set);
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * Cfg::WAVES), Cfg::smem, s, (const S*)signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, F, hop, nmel, preemphasis, pairs_per_b, total_pairs);
@@ -312,14 +326,16 @@ extern "C" int convasr_logmel_fwd(const void* signal, int signal_dtype, const fl
                                   const float* mel_weight, const float* mel_bias, float* out, int B, int T, int nfft, int hop, int nmel, float preemphasis,
                                   void* stream) {
 	CONVASR_CHECK_ARG(signal && window && mel_weight && mel_bias && out && B > 0 && T > 0 && hop > 0, "logmel_fwd: bad arguments");
-	if ((nfft != 128 && nfft != 256 && nfft != 512 && nfft != 1024) || nmel > 64 || nmel < 1 || win_length > nfft || win_length < 1)
-		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft 128 / 256 / 512 / 1024 (window <= nfft samples), nmel <= 64; got nfft %d nmel %d win %d", nfft, nmel, win_length);
+	if ((nfft != 128 && nfft != 256 && nfft != 512 && nfft != 1024) || nmel > 128 || nmel < 1 || win_length > nfft || win_length < 1)
+		return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: supports nfft 128 / 256 / 512 / 1024 (window <= nfft samples), nmel <= 128; got nfft %d nmel %d win %d", nfft, nmel, win_length);
 	if (signal_dtype != CONVASR_F32 && signal_dtype != CONVASR_I16) return convasr_fail(CONVASR_EUNSUPPORTED, "logmel_fwd: signal dtype %d", signal_dtype);
 	hipStream_t s = (hipStream_t)stream;
 #define FE_LAUNCH(L) \
 	do { \
-		if (signal_dtype == CONVASR_F32) launch_logmel<float, L>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
-		else launch_logmel<short, L>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
+		if (signal_dtype == CONVASR_F32 && nmel <= 64) launch_logmel<float, L, 1>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
+		else if (signal_dtype == CONVASR_F32) launch_logmel<float, L, 2>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
+		else if (nmel <= 64) launch_logmel<short, L, 1>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
+		else launch_logmel<short, L, 2>(signal, absmax, xlen, window, win_length, mel_weight, mel_bias, out, B, T, hop, nmel, preemphasis, s); \
 	} while (0)
 	switch (nfft) {
 		case 128: FE_LAUNCH(7); break;

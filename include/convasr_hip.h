@@ -51,7 +51,7 @@ int convasr_signal_absmax(const void* signal, int signal_dtype, int B, int T, fl
 /* Fused normalise -> pre-emphasis -> mask -> reflect/zero pad -> STFT(nfft, hop, window centred in nfft) -> power ->
  * mel (nmel x (nfft/2+1), + bias) -> log.  out is channels-last (B, F, nmel) fp32 with F = 1 + T / hop.
  * absmax may be NULL (normalize_signal=False); xlen may be NULL (no mask).  nfft = 128, 256, 512 or 1024 (models.py:516: the power
- * of two above the window -- 512 at 16 kHz x 0.02 s, 256 at train.py's default 8 kHz x 0.02 s), win_length <= nfft, nmel <= 64;
+ * of two above the window -- 512 at 16 kHz x 0.02 s, 256 at train.py's default 8 kHz x 0.02 s), win_length <= nfft, nmel <= 128 (one or two channels per lane);
  * anything else returns CONVASR_EUNSUPPORTED. */
 int convasr_logmel_fwd(const void* signal, int signal_dtype, const float* absmax, const float* xlen,
                        const float* window, int win_length, const float* mel_weight, const float* mel_bias,

@@ -451,7 +451,7 @@ def test_step_graphs_with_frozen_blocks_bitwise_equal_to_eager():
 
 def test_logmel_other_fft_sizes_against_the_reference_and_the_oracle():
 	"""models.py:516 takes nfft = 2 ** ceil(log2(window)): 256 at train.py's own defaults (8 kHz, 0.02 s), 128 / 1024 for other windows and
-	rates.  The radix-2 path of logmel_kernel against the reference's runs (frontend_nfft.npz: masked, unmasked, int16, shorter than the left
+	rates; 80 / 128 mel channels (two per lane).  The radix-2 path of logmel_kernel against the reference's runs (frontend_nfft.npz: masked, unmasked, int16, shorter than the left
 	padding), at batch size against the oracle, and LogFilterBankFrontend built with those geometries."""
 	import convasr_amd as ca
 	from oracle import convasr_oracle as O
@@ -472,7 +472,8 @@ def test_logmel_other_fft_sizes_against_the_reference_and_the_oracle():
 		close(ca.ops.logmel(T_(g[f'{n}/x16']).to(d), xlen, w, mw, mb, nfft, hop), T_(g[f'{n}/feat16']), 2e-4, n + ' int16')
 		close(ca.ops.logmel(T_(g[f'{n}/short']).to(d), None, w, mw, mb, nfft, hop), T_(g[f'{n}/feat_short']), 2e-4, n + ' short')
 		# the module, built from the same arguments as the reference's (its buffers are the reference's to the last bit)
-		fe = ca.models.LogFilterBankFrontend(64, sr, dict(sr8k_w20 = 0.02, sr8k_w10 = 0.01, sr16k_w40 = 0.04, sr44k_w20 = 0.02)[n], 0.01, 'hann_window').to(d)
+		nmel = mw.shape[0]
+		fe = ca.models.LogFilterBankFrontend(nmel, sr, dict(sr8k_w20 = 0.02, sr8k_w10 = 0.01, sr16k_w40 = 0.04, sr44k_w20 = 0.02, sr16k_w25_m80 = 0.025, sr8k_w20_m128 = 0.02)[n], 0.01, 'hann_window').to(d)
 		assert (fe.nfft, fe.hop_length, fe.win_length) == (nfft, hop, win)
 		assert torch.equal(fe.mel.weight.flatten(1).cpu(), T_(g[f'{n}/mel_weight'])) and torch.equal(fe.window.cpu(), T_(g[f'{n}/window']))
 		mask = ca.models.temporal_mask(x, ca.models.compute_output_lengths(x, xlen))
@@ -485,7 +486,7 @@ def test_logmel_other_fft_sizes_against_the_reference_and_the_oracle():
 		close(ca.ops.logmel(xs.to(d), xl.to(d), w, mw, mb, nfft, hop), ref, 5e-4, n + ' 16 x 12 s')
 
 
-@pytest.mark.parametrize('sr, wsize, nmel, preemph, normalize', [(16000, 0.032, 40, 0.97, True), (8000, 0.032, 64, 0.0, True), (16000, 0.02, 23, 0.97, False), (22050, 0.04, 64, 0.5, True), (8000, 0.016, 17, 0.0, False)])
+@pytest.mark.parametrize('sr, wsize, nmel, preemph, normalize', [(16000, 0.032, 40, 0.97, True), (16000, 0.02, 80, 0.97, True), (44100, 0.02, 96, 0.0, False), (8000, 0.032, 64, 0.0, True), (16000, 0.02, 23, 0.97, False), (22050, 0.04, 64, 0.5, True), (8000, 0.016, 17, 0.0, False)])
 def test_logmel_argument_envelope_against_the_oracle(sr, wsize, nmel, preemph, normalize):
 	"""LogFilterBankFrontend's other arguments (models.py:486-526) at the FFT sizes the kernel covers: a window that fills nfft exactly (0.032 s at
 	16 kHz = 512, at 8 kHz = 256), fewer mel channels than lanes, no pre-emphasis (every frame pair takes the general load path), no
@@ -715,3 +716,52 @@ def test_named_configurations_eval_and_folded_batch_norm_against_the_oracle(name
 		assert err <= 1e-3 * rng + 1e-4, (what, err, rng)
 	cos, rel = _cos_rel(folded16, ref)
 	assert cos >= 0.995 and rel <= 0.1, (cos, rel)
+
+
+@pytest.mark.parametrize('nmel, sr, wsize', [(80, 16000, 0.025), (40, 8000, 0.02)])
+def test_other_feature_counts_and_sample_rates_through_the_whole_network(nmel, sr, wsize):
+	"""--num-input-features / --sample-rate / --window-size other than the benchmark's (train.py:1015-1018): the 80-dimensional filterbank at 16 kHz x
+	0.025 s and train.py's default 8 kHz with 40 channels, waveform to loss and gradients through a reduced-width Wav2Letter -- fp32 against the
+	oracle on the same state dict, then the bf16 MFMA path (whose stride-2 prologue then has 160 / 80 folded input channels) against the
+	fp32 logits."""
+	import sys
+	import convasr_amd as ca
+	sys.path.insert(0, GOLDEN)
+	from describe_model import describe, fill_parameters, oracle_plan
+	d = torch.device('cuda:0')
+	def build(dt):
+		fe = ca.models.LogFilterBankFrontend(nmel, sr, wsize, 0.01, 'hann_window')
+		net = ca.models.Wav2Letter(nmel, [38], frontend = fe, base_width = 32, dropout = 0.0, check_time_dim_padded = False, compute_dtype = dt)
+		fill_parameters(net, 7)
+		return net
+	net = build(torch.float32)
+	sd = {k: v.clone() for k, v in net.state_dict().items()}
+	plan = oracle_plan(describe(net))
+	g = torch.Generator().manual_seed(nmel)
+	B, T = 4, int(3.1 * sr)
+	x = torch.rand(B, T, generator = g) * 2 - 1
+	xlen = torch.tensor([1.0, 0.8, 0.55, 0.9])
+	y = torch.randint(0, 37, (B, 1, 20), generator = g)
+	ylen = torch.tensor([[20], [12], [9], [17]])
+	wanted = ['backbone.0.conv.0.0.weight', 'backbone.4.conv.0.0.weight', 'decoder.0.weight']
+	for k in wanted:
+		sd[k].requires_grad_(True)
+	ref = O.jasper_forward(sd, plan, x, xlen, y, ylen, frontend = dict(nfft = net.frontend.nfft, hop_length = net.frontend.hop_length), training = True)
+	(ref['loss'] * ylen[:, 0]).mean().backward()
+	net.to(d).train()
+	out = net(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
+	(out['loss'] * ylen[:, 0].to(d)).mean().backward()
+	rng = float(ref['logits'].detach().abs().max())
+	err = float((out['logits'][0].detach().cpu() - ref['logits'].detach()).abs().max())
+	rel = float(((out['loss'].detach().cpu() - ref['loss'].detach()).abs() / ref['loss'].detach().abs()).max())
+	assert torch.equal(out['olen'][0].cpu(), ref['olen']) and err <= 1e-3 * rng + 1e-4 and rel <= 1e-4, (err, rng, rel)
+	params = dict(net.named_parameters())
+	for k in wanted:
+		cos, relg = _cos_rel(params[k].grad, sd[k].grad)
+		assert cos >= 0.9999 and relg <= 1.5e-2, (k, cos, relg)
+	net16 = build(torch.bfloat16).to(d).train()
+	out16 = net16(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
+	(out16['loss'] * ylen[:, 0].to(d)).mean().backward()
+	cos, rel16 = _cos_rel(out16['logits'][0].float(), ref['logits'].detach())
+	assert cos >= 0.985 and rel16 <= 0.16, (cos, rel16)  # (bf16 storage through 18 layers: 0.115 here, 0.12 on the full-width network: tests/test_round2_gpu.py)
+	assert all(bool(torch.isfinite(p.grad).all()) for p in net16.parameters() if p.grad is not None)
