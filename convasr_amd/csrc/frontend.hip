@@ -1,10 +1,10 @@
 // Log-mel frontend (reference: LogFilterBankFrontend.forward, models.py:565-597; normalize_signal, models.py:684-686).
 //
-// One pass over the waveform: every wave turns TWO frames into one 512-point complex FFT (frame A real, frame B imaginary),
-// Stockham radix-8 x 3 in LDS, un-mixes the two real spectra, takes |.|^2, applies the (nmel x 257) mel matrix held
-// transposed in LDS, adds the eps bias, takes the log and writes channels-last (B, F, nmel) fp32 rows.  The normalise /
-// pre-emphasis / mask / reflect-left / zero-right padding of the reference are index arithmetic on the load -- the padded
-// signal and the 197 MB complex spectrogram are never materialised.  HBM-bound: 4 B in per sample, 256 B out per frame.
+// One pass over the waveform: every wave turns TWO frames into one nfft-point complex FFT in LDS (frame A real, frame B imaginary; 512 points:
+// Stockham radix-8 x 3, other sizes radix-2), un-mixes the two real spectra, takes |.|^2, applies the (nmel x (nfft / 2 + 1)) mel matrix whose
+// non-zero spans are held transposed in LDS, adds the eps bias, takes the log and writes channels-last (B, F, nmel) fp32 rows.  The normalise /
+// pre-emphasis / mask / reflect-left / zero-right padding of the reference are index arithmetic on the load -- the padded signal and the
+// 197 MB complex spectrogram (64 x 15 s) are never materialised.  4 B in per sample, 4 nmel B out per frame; VALU-bound.
 #include "common.h"
 
 #define FE_SPAN 64  // LDS rows of the sparse mel table: melS[j][mel] = weight of bin klo[mel] + j (wider filters read the rest from global memory)
@@ -21,7 +21,6 @@ template <int LOG2N, int NM = 1> struct FeCfg {  // NM: mel channels per lane (1
 // nfft = 512: a wave's FFT buffer is written and read in three index patterns; two padded layouts keep every ds_read / ds_write_b64 of a half-wave on
 // 32 different bank pairs (the unpadded buffer had 8-way conflicts on the stage-1 and stage-2 writes and up to 8-way on the strided twiddle reads):
 // generation 1 (written lane * 8 + r, read lane + 64 r) one pad element per 32, generation 2 (written g * 64 + k + 8 r, read lane + 64 r) eight per 64.
-#define FE_BUF 576
 #define FE_P1(i) ((i) + ((i) >> 5))
 #define FE_P2(i) ((i) + (((i) >> 6) << 3))
 
