@@ -26,6 +26,7 @@ _SIGNATURES = dict(
 	convasr_signal_absmax = (c_int, [c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_logmel_fwd = (c_int, [c_p, c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_f32, c_p]),
 	convasr_instnorm_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_int, c_int, c_int, c_f32, c_p]),
+	convasr_instnorm_running_fwd = (c_int, [c_p, c_int, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_f32, c_p, c_p, c_p, c_f32, c_int, c_p, c_p]),
 	convasr_output_lengths = (c_int, [c_p, c_int, c_int, c_p, c_p]),
 	convasr_conv_cout_pad = (c_int, [c_int]),
 	convasr_pack_conv_weight = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),

@@ -64,7 +64,8 @@ extern "C" int convasr_convert_layout(const void* src, int src_dtype, int64_t ss
 // per block instead of 64: four times the workgroups -- 256 for 64 mel channels x 64 utterances, one per CU -- for a latency-bound kernel.)
 template <typename S, typename D>
 __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x, int64_t xsb, int64_t xsc, int64_t xst, D* __restrict__ y,
-                                                        int64_t ysb, int64_t ysc, int64_t yst, const float* __restrict__ xlen, int C, int T, int T_out, float eps) {
+                                                        int64_t ysb, int64_t ysc, int64_t yst, const float* __restrict__ xlen, int C, int T, int T_out, float eps,
+                                                        float* __restrict__ stats_out, const float* __restrict__ fixed_mean, const float* __restrict__ fixed_var) {
 	__shared__ float red[64][17];
 	__shared__ float bc[16];
 	const int b = blockIdx.y, cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, tl = threadIdx.x >> 4;  // 64 time lanes
@@ -78,12 +79,20 @@ __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x,
 		__syncthreads();
 		return bc[cl];
 	};
-	float acc = 0.f;
-	for (int t = tl; t < n; t += 64) acc += ok ? Elem<S>::load(xp + t * xst) : 0.f;
-	const float mean = block_sum(acc) / (float)n;
-	acc = 0.f;
-	for (int t = tl; t < n; t += 64) { float d = ok ? Elem<S>::load(xp + t * xst) - mean : 0.f; acc += d * d; }
-	const float stdv = sqrtf(block_sum(acc) / (float)n + eps);
+	float mean, stdv;
+	if (fixed_mean) {  // nn.InstanceNorm1d in eval mode with running statistics (F.instance_norm, use_input_stats = False)
+		mean = ok ? fixed_mean[c] : 0.f;
+		stdv = sqrtf((ok ? fixed_var[c] : 1.f) + eps);
+	} else {
+		float acc = 0.f;
+		for (int t = tl; t < n; t += 64) acc += ok ? Elem<S>::load(xp + t * xst) : 0.f;
+		mean = block_sum(acc) / (float)n;
+		acc = 0.f;
+		for (int t = tl; t < n; t += 64) { float d = ok ? Elem<S>::load(xp + t * xst) - mean : 0.f; acc += d * d; }
+		const float var = block_sum(acc) / (float)n;
+		stdv = sqrtf(var + eps);
+		if (stats_out && ok && tl == 0) { stats_out[((int64_t)b * C + c) * 2] = mean; stats_out[((int64_t)b * C + c) * 2 + 1] = var; }
+	}
 	if (!ok) return;
 	D* yp = y + b * ysb + c * ysc;
 	for (int t = tl; t < T_out; t += 64) {  // frames T .. T_out - 1 of y: zero padding
@@ -92,12 +101,20 @@ __global__ __launch_bounds__(1024) void instnorm_kernel(const S* __restrict__ x,
 	}
 }
 
+static int instnorm_launch(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb, int64_t ysc, int64_t yst, const float* xlen,
+                           int B, int C, int T, int T_out, float eps, float* stats_out, const float* fixed_mean, const float* fixed_var, hipStream_t s);
+
 extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb,
                                     int64_t ysc, int64_t yst, const float* xlen, int B, int C, int T, int T_out, float eps, void* stream) {
 	CONVASR_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && T_out >= T, "instnorm_fwd: bad arguments");
-	dim3 grid((C + 15) / 16, B);
 	hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(S, D) hipLaunchKernelGGL((instnorm_kernel<S, D>), grid, dim3(1024), 0, s, (const S*)x, xsb, xsc, xst, (D*)y, ysb, ysc, yst, xlen, C, T, T_out, eps)
+	return instnorm_launch(x, x_dtype, xsb, xsc, xst, y, y_dtype, ysb, ysc, yst, xlen, B, C, T, T_out, eps, nullptr, nullptr, nullptr, s);
+}
+
+static int instnorm_launch(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb, int64_t ysc, int64_t yst, const float* xlen,
+                           int B, int C, int T, int T_out, float eps, float* stats_out, const float* fixed_mean, const float* fixed_var, hipStream_t s) {
+	dim3 grid((C + 15) / 16, B);
+#define LAUNCH(S, D) hipLaunchKernelGGL((instnorm_kernel<S, D>), grid, dim3(1024), 0, s, (const S*)x, xsb, xsc, xst, (D*)y, ysb, ysc, yst, xlen, C, T, T_out, eps, stats_out, fixed_mean, fixed_var)
 	if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32) LAUNCH(float, float);
 	else if (x_dtype == CONVASR_F32 && y_dtype == CONVASR_BF16) LAUNCH(float, bf16_t);
 	else if (x_dtype == CONVASR_BF16 && y_dtype == CONVASR_F32) LAUNCH(bf16_t, float);
@@ -108,6 +125,32 @@ extern "C" int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t xsb, int
 	else return convasr_fail(CONVASR_EUNSUPPORTED, "instnorm_fwd: dtype %d -> %d", x_dtype, y_dtype);
 #undef LAUNCH
 	CONVASR_CHECK_LAUNCH("instnorm_fwd");
+	return 0;
+}
+
+// running statistics of nn.InstanceNorm1d(track_running_stats = True) (F.instance_norm): the batch mean of the per-instance means and UNBIASED
+// variances, blended in with `momentum`; one thread per channel, utterances in order
+__global__ void instnorm_running_kernel(const float* __restrict__ stats, int B, int C, int T, float momentum, float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c == 0 && nbt) *nbt += 1;
+	if (c >= C) return;
+	float m = 0.f, v = 0.f;
+	const float unbias = T > 1 ? (float)T / (float)(T - 1) : 1.f;
+	for (int b = 0; b < B; ++b) { m += stats[((int64_t)b * C + c) * 2]; v += stats[((int64_t)b * C + c) * 2 + 1] * unbias; }
+	rmean[c] = (1.f - momentum) * rmean[c] + momentum * (m / (float)B);
+	rvar[c] = (1.f - momentum) * rvar[c] + momentum * (v / (float)B);
+}
+
+extern "C" int convasr_instnorm_running_fwd(const void* x, int x_dtype, int64_t xsb, int64_t xsc, int64_t xst, void* y, int y_dtype, int64_t ysb, int64_t ysc, int64_t yst,
+                                            int B, int C, int T, int T_out, float eps, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                            int training, float* stats_workspace, void* stream) {
+	CONVASR_CHECK_ARG(x && y && running_mean && running_var && B > 0 && C > 0 && T > 0 && T_out >= T && (!training || stats_workspace), "instnorm_running_fwd: bad arguments");
+	hipStream_t s = (hipStream_t)stream;
+	if (!training) return instnorm_launch(x, x_dtype, xsb, xsc, xst, y, y_dtype, ysb, ysc, yst, nullptr, B, C, T, T_out, eps, nullptr, running_mean, running_var, s);
+	const int rc = instnorm_launch(x, x_dtype, xsb, xsc, xst, y, y_dtype, ysb, ysc, yst, nullptr, B, C, T, T_out, eps, stats_workspace, nullptr, nullptr, s);
+	if (rc) return rc;
+	hipLaunchKernelGGL(instnorm_running_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const float*)stats_workspace, B, C, T, momentum, running_mean, running_var, (long long*)num_batches_tracked);
+	CONVASR_CHECK_LAUNCH("instnorm_running_fwd");
 	return 0;
 }
 

@@ -162,15 +162,16 @@ class LogFilterBankFrontend(nn.Module):
 
 
 class MaskedInstanceNorm1d(nn.InstanceNorm1d):
-	"""models.py:688-719: per-(utterance, channel) masked mean / biased std over time, no affine, no running stats."""
+	"""models.py:688-719: per-(utterance, channel) masked mean / biased std over time, no affine; running statistics only in the un-masked
+	nn.InstanceNorm1d form (models.py:711)."""
 
 	def __init__(self, *args, temporal_mask = False, legacy = True, **kwargs):
 		super().__init__(*args, **kwargs)
 		self.temporal_mask, self.legacy = temporal_mask, legacy
 		# legacy = False hands the unmasked case to nn.InstanceNorm1d.forward (models.py:711): (x - mean) / sqrt(biased var + eps), the same
 		# expression the legacy branch spells out (models.py:704-710) -- one kernel serves both
-		if self.affine or self.track_running_stats:
-			raise _lib.ConvasrHipError('MaskedInstanceNorm1d: only the affine=False, track_running_stats=False form (Wav2Letter / JasperNet* defaults) is implemented')
+		if self.affine:
+			raise _lib.ConvasrHipError('MaskedInstanceNorm1d: affine = True is not implemented (no configuration of the reference passes it)')
 
 	def forward(self, x, mask = None, xlen = None, out_dtype = None, pad_time_to = 1):
 		_lib.require_cuda(x)
@@ -181,6 +182,11 @@ class MaskedInstanceNorm1d(nn.InstanceNorm1d):
 		if xlen is None and mask is not None:
 			n = mask.reshape(mask.shape[0], -1).sum(dim = -1).to(torch.float32)
 			xlen = (n - 0.5) / x.shape[-1]
+		if self.track_running_stats:
+			# models.py:711 (legacy = False, no mask: JasperNetSmallTrainableInstanceNorm); the masked branch asserts there are none (713), the legacy one too (698)
+			assert xlen is None and not self.legacy, 'running statistics only in the un-masked nn.InstanceNorm1d form (models.py:698, 713)'
+			# (torch's _InstanceNorm.forward passes momentum None on as 0.0 and never touches num_batches_tracked)
+			return ops.instnorm_running(x, self.running_mean, self.running_var, None, self.momentum or 0.0, self.training, self.eps, out_dtype = out_dtype or x.dtype, pad_time_to = pad_time_to)
 		return ops.instnorm(x, xlen, self.eps, out_dtype = out_dtype or x.dtype, pad_time_to = pad_time_to)
 
 
@@ -571,8 +577,8 @@ class JasperNetSmallInstanceNorm(JasperNet):
 
 
 class JasperNetSmallTrainableInstanceNorm(JasperNet):
-	"""models.py:1394-1404: the same with running statistics in the feature normalisation -- a form MaskedInstanceNorm1d here refuses at
-	construction (only affine = False, track_running_stats = False, what every other configuration uses, has a kernel)."""
+	"""models.py:1394-1404: the same with running statistics in the feature normalisation (instance statistics while training, the running
+	ones in eval mode: ops.instnorm_running)."""
 
 	def __init__(self, *args, **kwargs):
 		super().__init__(*args, num_subblocks = 1, temporal_mask = False, normalize_features_legacy = False, normalize_features_track_running_stats = True, normalize_features_temporal_mask = False, **kwargs)

@@ -110,6 +110,20 @@ def instnorm(x, xlen, eps, out_dtype = None, channels_last = True, pad_time_to =
 	return out
 
 
+def instnorm_running(x, running_mean, running_var, num_batches_tracked, momentum, training, eps, out_dtype = None, pad_time_to = 1):
+	"""nn.InstanceNorm1d(track_running_stats = True).forward (models.py:711): instance statistics + running-statistics update in training mode,
+	the running statistics in eval mode; channels-last result like instnorm()."""
+	require_cuda(x, running_mean, running_var)
+	B, C, T = x.shape
+	out_dtype = out_dtype or x.dtype
+	Tp = -(-T // pad_time_to) * pad_time_to
+	out = empty_cl(B, C, Tp, out_dtype, x.device)
+	ws = torch.empty(B, C, 2, dtype = torch.float32, device = x.device) if training else None
+	call('convasr_instnorm_running_fwd', ptr(x), dtype_code(x.dtype), x.stride(0), x.stride(1), x.stride(2), ptr(out), dtype_code(out_dtype), out.stride(0), out.stride(1), out.stride(2), B, C, T, Tp, float(eps),
+		ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum), int(bool(training)), ptr(ws), stream_ptr())
+	return out
+
+
 def output_lengths(xlen, B, T, device):
 	"""compute_output_lengths (models.py:611-614) in one launch: int64 (B,) = ceil(xlen * T) evaluated in fp32 (xlen None: T)."""
 	out = torch.empty(B, dtype = torch.int64, device = device)

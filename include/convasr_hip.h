@@ -65,6 +65,16 @@ int convasr_instnorm_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc,
                          void* y, int y_dtype, int64_t y_sb, int64_t y_sc, int64_t y_st,
                          const float* xlen, int B, int C, int T, int T_out, float eps, void* stream);
 
+/* nn.InstanceNorm1d(track_running_stats = True).forward as MaskedInstanceNorm1d reaches it (models.py:711, JasperNetSmallTrainableInstanceNorm
+ * 1394-1404; un-masked, no affine).  training != 0: y = (x - mean) / sqrt(biased var + eps) per (utterance, channel), and
+ * running = (1 - momentum) running + momentum * batch mean of the instance means / UNBIASED variances (num_batches_tracked += 1 when given:
+ * torch's InstanceNorm never counts, so the host mirror passes NULL);
+ * stats_workspace: 2 B C floats.  training == 0: y = (x - running_mean) / sqrt(running_var + eps), nothing written back. */
+int convasr_instnorm_running_fwd(const void* x, int x_dtype, int64_t x_sb, int64_t x_sc, int64_t x_st,
+                                 void* y, int y_dtype, int64_t y_sb, int64_t y_sc, int64_t y_st,
+                                 int B, int C, int T, int T_out, float eps, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float momentum, int training, float* stats_workspace, void* stream);
+
 /* ---- compute_output_lengths: models.py:611-614 ------------------------------------------------------------------ */
 
 /* out[b] = ceil(xlen[b] * T) in fp32 arithmetic, as (lengths_fraction * T).ceil().long() evaluates it (xlen NULL: T). */

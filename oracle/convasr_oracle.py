@@ -373,7 +373,7 @@ def fuse_conv_bn_eval(sd, eps = 1e-5):
 	return out
 
 
-def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None, frozen = None, normalize_features_temporal_mask = True):
+def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = None, training = True, normalize_features = True, storage = None, frozen = None, normalize_features_temporal_mask = True, normalize_features_running = False):
 	"""JasperNet.forward (models.py:282-326).  sd: state dict (tensors, BN buffers are updated in place when
 	training), plan: jasper_plan(...), frontend: dict(window, nfft, hop_length) or None (x is features).
 	storage = torch.bfloat16 restates the same algorithm with the MI355X throughput path's storage precision: activations, conv
@@ -388,7 +388,12 @@ def jasper_forward(sd, plan, x, xlen = None, y = None, ylen = None, frontend = N
 	if normalize_features:
 		# (normalize_features_temporal_mask = False: JasperNetSmallInstanceNorm, models.py:1382-1391 -- MaskedInstanceNorm1d ignores the mask, 696)
 		mask = temporal_mask(x.shape[-1], compute_output_lengths(x.shape[-1], xlen)) if xlen is not None and normalize_features_temporal_mask else None
-		x = masked_instance_norm(x if x.dtype == torch.float64 else x.float(), mask)  # (float64 only in precision experiments)
+		if normalize_features_running:
+			# JasperNetSmallTrainableInstanceNorm (models.py:1394-1404): MaskedInstanceNorm1d falls through to nn.InstanceNorm1d.forward (711), i.e.
+			# F.instance_norm with the module's running buffers (updated in place while training, used in eval mode), momentum 0.1, no affine
+			x = F.instance_norm(x.float(), sd['normalize_features.running_mean'], sd['normalize_features.running_var'], None, None, training, 0.1, float(torch.finfo(torch.float16).tiny))
+		else:
+			x = masked_instance_norm(x if x.dtype == torch.float64 else x.float(), mask)  # (float64 only in precision experiments)
 	x = _stored(x, storage) if x.requires_grad else (x if storage is None else x.to(storage).to(x.dtype))
 	residual = []
 	L = len(plan['layers'])

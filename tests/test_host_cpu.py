@@ -134,8 +134,7 @@ def test_every_named_configuration_of_the_reference_builds_the_same_network():
 	"""`getattr(models, args.model)` (train.py:428, transcribe.py:44): all 24 JasperNet subclasses of the reference's models.py (819-1442) exist
 	here under the same names and build the same network -- per block the conv / batch-norm / residual-branch geometry, activation, dropout and
 	mask flag, the residual policy, the feature normalisation's flags, every state-dict key and shape -- as the reference's own constructors did
-	(tests/golden/model_zoo.json, written by make_golden_r5.py through tests/golden/describe_model.py).  The one configuration without a kernel
-	(running statistics in the feature normalisation) refuses at construction."""
+	(tests/golden/model_zoo.json, written by make_golden_r5.py through tests/golden/describe_model.py)."""
 	import json
 	import sys
 	import convasr_amd as ca
@@ -150,10 +149,6 @@ def test_every_named_configuration_of_the_reference_builds_the_same_network():
 		args = (64, [38, 300]) if variant == 'bpe' else (64, [38])
 		if variant == 'bpe':
 			kw['decoder_type'] = 'bpe'
-		if name == 'JasperNetSmallTrainableInstanceNorm':
-			with pytest.raises(ca._lib.ConvasrHipError, match = 'track_running_stats'):
-				cls(*args, **kw)
-			continue
 		got = json.loads(json.dumps(describe(cls(*args, **kw))))
 		for field in want:
 			assert got[field] == want[field], (key, field)

@@ -624,13 +624,13 @@ def test_utterance_length_extremes_against_the_oracle():
 		torch.set_num_threads(threads)
 
 
-FAMILY = ['Wav2LetterFlat', 'Wav2LetterResidualBig', 'Wav2LetterDenseBigLargeKernelsNoDilationNoTemporalMaskNoDropoutReLu', 'JasperNetSmallInstanceNorm', 'Wav2LetterResidualNoDilation']
+FAMILY = ['Wav2LetterFlat', 'Wav2LetterResidualBig', 'Wav2LetterDenseBigLargeKernelsNoDilationNoTemporalMaskNoDropoutReLu', 'JasperNetSmallInstanceNorm', 'Wav2LetterResidualNoDilation', 'JasperNetSmallTrainableInstanceNorm']
 
 
 @pytest.mark.parametrize('name', FAMILY)
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_named_configurations_against_the_reference(name, dt):
-	"""Five of the reference's 24 named configurations (models.py:858-1404; all of them build the reference's network: tests/test_host_cpu.py) run
+	"""Six of the reference's 24 named configurations (models.py:858-1404; all of them build the reference's network: tests/test_host_cpu.py) run
 	by the reference itself on a (3, 64, 96) feature batch (family.npz, make_golden_r5.py): identity residuals, one residual per block over two
 	sub-blocks, dense + relu + no temporal mask + per-block kernel sizes, nn.InstanceNorm1d's forward as the feature normalisation, no dilation.
 	fp32: logits and three to five gradients against the reference; bf16: the same network on the MFMA path within the storage type's error."""
@@ -659,6 +659,14 @@ def test_named_configurations_against_the_reference(name, dt):
 			assert cos >= 0.99999 and rel <= 5e-3, (k, cos, rel)
 		rv = net.backbone[-1].bn[0].running_var.cpu()
 		assert torch.allclose(rv, torch.from_numpy(g[f'{name}/running_var_last']), rtol = 1e-4, atol = 1e-6)
+		if 'Trainable' in name:  # running statistics of the feature normalisation after this training forward, then the eval forward that uses them
+			nf = net.normalize_features
+			assert torch.allclose(nf.running_mean.cpu(), torch.from_numpy(g[f'{name}/features_running_mean']), rtol = 1e-5, atol = 1e-6)
+			assert torch.allclose(nf.running_var.cpu(), torch.from_numpy(g[f'{name}/features_running_var']), rtol = 1e-5, atol = 1e-6) and int(nf.num_batches_tracked) == 0
+			with torch.no_grad():
+				ev = net.eval()(torch.from_numpy(g['x']).to(d), torch.from_numpy(g['xlen']).to(d))['logits'][0].cpu()
+			want = torch.from_numpy(g[f'{name}/eval_logits'])
+			assert float((ev - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-4
 	else:
 		# logits and gradients deep in a 16-bit network carry the storage type's rounding amplified layer by layer (the first conv of these 13- to 23-conv
 		# networks: relative error 0.2-0.45 against fp32): the bar is the oracle's restatement of the SAME algorithm with bf16 storage at the
@@ -669,7 +677,7 @@ def test_named_configurations_against_the_reference(name, dt):
 		sd = {k: v.clone() for k, v in cpu.state_dict().items()}
 		for k in wanted:
 			sd[k].requires_grad_(True)
-		o = O.jasper_forward(sd, oracle_plan(describe(cpu)), torch.from_numpy(g['x']), torch.from_numpy(g['xlen']), training = True, storage = torch.bfloat16, normalize_features_temporal_mask = name != 'JasperNetSmallInstanceNorm')
+		o = O.jasper_forward(sd, oracle_plan(describe(cpu)), torch.from_numpy(g['x']), torch.from_numpy(g['xlen']), training = True, storage = torch.bfloat16, normalize_features_temporal_mask = 'InstanceNorm' not in name, normalize_features_running = 'Trainable' in name)
 		o['logits'].square().mean().backward()
 		rel_gpu, rel_cpu = _cos_rel(logits.float(), ref)[1], _cos_rel(o['logits'], ref)[1]
 		assert rel_gpu <= 1.5 * rel_cpu + 0.02, ('logits', rel_gpu, rel_cpu)
@@ -701,7 +709,7 @@ def test_named_configurations_eval_and_folded_batch_norm_against_the_oracle(name
 		for scale in (1.0, 0.7):
 			net(x.to(d) * scale, xlen.to(d))
 		sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-		ref = O.jasper_forward(sd, plan, x, xlen, training = False, normalize_features_temporal_mask = name != 'JasperNetSmallInstanceNorm')['logits']
+		ref = O.jasper_forward(sd, plan, x, xlen, training = False, normalize_features_temporal_mask = 'InstanceNorm' not in name, normalize_features_running = 'Trainable' in name)['logits']
 		rng = float(ref.abs().max())
 		assert rng > 0.1  # (non-degenerate: the running statistics are populated)
 		net.eval()
@@ -765,3 +773,26 @@ def test_other_feature_counts_and_sample_rates_through_the_whole_network(nmel, s
 	cos, rel16 = _cos_rel(out16['logits'][0].float(), ref['logits'].detach())
 	assert cos >= 0.985 and rel16 <= 0.16, (cos, rel16)  # (bf16 storage through 18 layers: 0.115 here, 0.12 on the full-width network: tests/test_round2_gpu.py)
 	assert all(bool(torch.isfinite(p.grad).all()) for p in net16.parameters() if p.grad is not None)
+
+
+def test_instance_norm_with_running_statistics_against_torch():
+	"""nn.InstanceNorm1d(track_running_stats = True), the arithmetic MaskedInstanceNorm1d hands over to at models.py:711 (third-party: torch's
+	F.instance_norm, here on the CPU): two training forwards (instance statistics out, running statistics blended in with the batch mean of
+	the unbiased instance variances), then eval mode on the running statistics; 16-bit output for the MFMA path."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	eps = float(torch.finfo(torch.float16).tiny)
+	ref = torch.nn.InstanceNorm1d(64, eps = eps, affine = False, track_running_stats = True)
+	mine = ca.models.MaskedInstanceNorm1d(64, eps = eps, affine = False, track_running_stats = True, temporal_mask = False, legacy = False).to(d)
+	g = torch.Generator().manual_seed(2)
+	for step, (B, T) in enumerate([(5, 301), (3, 96)]):
+		x = torch.randn(B, 64, T, generator = g) * (1 + step) + 0.3 * step
+		want, got = ref.train()(x), mine.train()(x.to(d))
+		assert got.shape == want.shape and float((got.cpu() - want).abs().max()) <= 2e-5
+		assert torch.allclose(mine.running_mean.cpu(), ref.running_mean, rtol = 1e-5, atol = 1e-6) and torch.allclose(mine.running_var.cpu(), ref.running_var, rtol = 1e-5, atol = 1e-6)
+	x = torch.randn(4, 64, 77, generator = g)
+	want = ref.eval()(x)
+	got = mine.eval()(x.to(d))
+	assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+	got16 = mine(x.to(d), out_dtype = torch.bfloat16, pad_time_to = 2)
+	assert got16.dtype == torch.bfloat16 and got16.shape[-1] == 78 and float(got16[..., 77].abs().max()) == 0 and float((got16[..., :77].float().cpu() - want).abs().max()) <= 1e-2 * float(want.abs().max())
