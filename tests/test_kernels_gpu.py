@@ -527,7 +527,7 @@ def test_ctc_repeated_launches_are_bitwise_identical():
 	stream perturbs the timing.  (scratch/ctc_soak.py: 18,000 launches over six shapes, 0 mismatches.)"""
 	from convasr_amd import ops
 	d = dev()
-	for (B, T, C, S) in [(64, 753, 38, 150), (8, 900, 129, 383)]:
+	for (B, T, C, S) in [(64, 753, 38, 150), (8, 900, 129, 383), (6, 2100, 38, 1000)]:
 		torch.manual_seed(S)
 		lp = (torch.randn(B, T, C, device = d) * 2).log_softmax(-1).contiguous().transpose(1, 2)
 		y = torch.randint(0, C - 1, (B, S), device = d)
