@@ -486,10 +486,10 @@ def test_logmel_other_fft_sizes_against_the_reference_and_the_oracle():
 		close(ca.ops.logmel(xs.to(d), xl.to(d), w, mw, mb, nfft, hop), ref, 5e-4, n + ' 16 x 12 s')
 
 
-@pytest.mark.parametrize('sr, wsize, nmel, preemph, normalize', [(16000, 0.032, 40, 0.97, True), (16000, 0.02, 80, 0.97, True), (44100, 0.02, 96, 0.0, False), (8000, 0.032, 64, 0.0, True), (16000, 0.02, 23, 0.97, False), (22050, 0.04, 64, 0.5, True), (8000, 0.016, 17, 0.0, False)])
+@pytest.mark.parametrize('sr, wsize, nmel, preemph, normalize', [(16000, 0.032, 40, 0.97, True), (16000, 0.02, 80, 0.97, True), (44100, 0.02, 96, 0.0, False), (16000, 0.04, 10, 0.97, True), (8000, 0.032, 64, 0.0, True), (16000, 0.02, 23, 0.97, False), (22050, 0.04, 64, 0.5, True), (8000, 0.016, 17, 0.0, False)])
 def test_logmel_argument_envelope_against_the_oracle(sr, wsize, nmel, preemph, normalize):
 	"""LogFilterBankFrontend's other arguments (models.py:486-526) at the FFT sizes the kernel covers: a window that fills nfft exactly (0.032 s at
-	16 kHz = 512, at 8 kHz = 256), fewer mel channels than lanes, no pre-emphasis (every frame pair takes the general load path), no
+	16 kHz = 512, at 8 kHz = 256), fewer mel channels than lanes (10 over 513 bins: filters wider than the kernel's 64-row LDS table, the rest read from global memory), no pre-emphasis (every frame pair takes the general load path), no
 	normalisation, int16 and ragged lengths -- against the oracle's restatement of the same forward."""
 	import convasr_amd as ca
 	d = torch.device('cuda:0')
