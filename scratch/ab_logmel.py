@@ -38,3 +38,17 @@ for B, secs, dt in ((64, 15, torch.float32), (32, 20, torch.int16), (3, 0.4, tor
 		out[f'{B}x{secs}s {str(dt)[6:]} {name} us'] = round(e0.elapsed_time(e1) * 1000 / 50, 1)
 	if len(res) == 2: out[f'{B}x{secs}s {str(dt)[6:]} bit-identical'] = bool(torch.equal(res['r04'], res['now']))
 print(json.dumps(out, indent = 1))
+
+# the other FFT sizes / channel counts of this tree (no round-4 counterpart: nfft 512 and 64 channels only there)
+other = {}
+for sr, wsize, nmel in ((8000, 0.02, 64), (8000, 0.01, 64), (16000, 0.04, 64), (44100, 0.02, 64), (16000, 0.025, 80), (16000, 0.02, 128)):
+	f2 = ca.models.LogFilterBankFrontend(nmel, sr, wsize, 0.01, 'hann_window').to(d)
+	x = torch.rand(64, 15 * sr, device = d) * 2 - 1
+	xl = torch.ones(64, device = d)
+	for _ in range(3): f2(x, xlen = xl)
+	e0, e1 = torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True)
+	e0.record()
+	for _ in range(20): f2(x, xlen = xl)
+	e1.record(); torch.cuda.synchronize()
+	other[f'64x15s {sr} Hz window {wsize} s nfft {f2.nfft} mels {nmel}: us incl. absmax'] = round(e0.elapsed_time(e1) * 1000 / 20, 1)
+print(json.dumps(other, indent = 1))
