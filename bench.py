@@ -683,6 +683,7 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 	import convasr_amd as ca
 	from convasr_amd import _lib
 	torch.manual_seed(1)
+	torch.cuda.reset_peak_memory_stats(device)
 	ca.functional.manual_seed(int(os.environ.get('CONVASR_BENCH_DROPOUT_SEED', '1')) + rank)  # (the override: a measurement hook -- step time depends on the data through the chip's clock management)
 	wl = Workload(args, device, rank, world)
 	flat = wl.flat
@@ -781,7 +782,8 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',
 			config = dict(workload = wl.name, global_batch = wl.batch * world, parallelism = f'dp{world}', side_stream_wgrad = bool(args.side_stream), step_graphs = graph_info,
 				host_enqueue_ms_per_step = round(sorted(host_ms)[1], 2), abi_calls_per_eager_step = None if calls2 is None else round(calls2, 1),
-				whole_step_frac = round(conv_flops_per_s / world / (PEAK_F32_MFMA if args.dtype == 'f32' else PEAK_BF16_DENSE), 4), eager_side_stream = eager_info, device_state = device_state),
+				whole_step_frac = round(conv_flops_per_s / world / (PEAK_F32_MFMA if args.dtype == 'f32' else PEAK_BF16_DENSE), 4), eager_side_stream = eager_info, device_state = device_state,
+				peak_hbm_gib = round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)),  # (this measure()'s allocations: parameters, arena, activations, workspaces, graph pool -- of the card's 288)
 			loss = round(float(last['loss']), 4), loss_scaler = scaler_info, dist = dist_info, roofline = roof, parity = None)
 		if args.workload == 'jasper_large':
 			line['config'].update(padded_audio_seconds_per_sec = round(world * audio[1] / elapsed, 1), padding_overhead = round(audio[1] / audio[0] - 1, 4),
@@ -907,7 +909,7 @@ def main(argv = None):
 					dominant_kernel_frac = rj.get('frac'), wgrad_frac = (rj.get('wgrad') or {}).get('frac'), conv_stack_frac = (rj.get('conv_stack') or {}).get('frac'),
 					host_enqueue_ms_per_step = lj['config']['host_enqueue_ms_per_step'], eager_side_stream = lj['config']['eager_side_stream'], abi_calls_per_eager_step = lj['config']['abi_calls_per_eager_step'], step_graphs = lj['config']['step_graphs'],
 					side_stream_wgrad = True, batch_shapes_in_timed_region = lj['config'].get('batch_shapes_in_timed_region'), padding_overhead = lj['config'].get('padding_overhead'),
-					loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], workload = lj['config']['workload'],
+					loss_scaler = lj['loss_scaler'], device_state = lj['config']['device_state'], peak_hbm_gib = lj['config'].get('peak_hbm_gib'), workload = lj['config']['workload'],
 						note = 'BASELINE configs[4] (JasperNetLarge, 32 x 5-20 s bucketed, fp16, NovoGrad) as a bounded leg of the default line: the same 12 batches as python bench.py --workload jasper_large --steps 12 --warmup 3' + (' -- ' + leg_note if leg_note else '')))
 		if world == 1 and not args.no_cpu_baseline:
 			ref = {}
