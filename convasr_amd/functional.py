@@ -714,7 +714,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			if RES_WGRAD_SIDE and arena:
 				# gradient arenas: the weight gradient of the branch goes to the wgrad side stream like the main conv's (it only reads rx and dry
 				# and writes the arena: the consumers of the arena join that stream, functional.join_side_streams / the data-parallel engine)
-				drw, drb = _run_wgrad(dry.device, (rx, dry), lambda: _deliver([rw, rb], res_wgrad))
+				drw, drb = _run_wgrad(dry.device, (rx, dry), lambda rw = rw, rb = rb, f = res_wgrad: _deliver([rw, rb], f))  # (bound now: the loop variables move on)
 			else:
 				drw, drb = _deliver([rw, rb], res_wgrad)
 			res_grads[5 * r:5 * r + 5] = [drx, drw, drb, drg, drbeta]
