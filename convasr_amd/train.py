@@ -334,10 +334,12 @@ class GraphedTrainStep:
 
 	Inputs are copied into the graph's static buffers (one device-to-device copy each; pass the static buffers themselves -- .inputs(key)
 	-- to skip it).  Returned metrics are the graph's static output tensors: read them before the next call with the same shape.
-	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step."""
+	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step
+	(with this object's world_size / sync_metrics)."""
 
-	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = os.environ.get('CONVASR_GRAPH_FORKED') != '1', max_graphs = 64):
+	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = os.environ.get('CONVASR_GRAPH_FORKED') != '1', max_graphs = 64, world_size = 1, sync_metrics = True):
 		self.model, self.optimizer, self.max_norm, self.warmup, self.linear = model, optimizer, max_norm, max(int(warmup), 1), linear
+		self.world_size, self.sync_metrics = world_size, sync_metrics  # (for the eager fall-through of a data-parallel engine: what train_step averages the logged metrics over)
 		self.max_graphs = max_graphs  # batch shapes beyond this many stay eager (a loader that does not pad to bucket ceilings produces a new shape per batch: every capture keeps its static inputs and outputs alive)
 		engine = model if hasattr(model, 'finish_gradient_sync') else None
 		self.enabled = bool(enabled) and not (engine is not None and engine.collectives)
@@ -357,7 +359,7 @@ class GraphedTrainStep:
 
 	def _eager(self, x, xlen, y, ylen, iteration):
 		self.eager_steps += 1
-		return train_step(self.model, self.optimizer, x, xlen, y, ylen, max_norm = self.max_norm, iteration = iteration)
+		return train_step(self.model, self.optimizer, x, xlen, y, ylen, max_norm = self.max_norm, iteration = iteration, world_size = self.world_size, sync_metrics = self.sync_metrics)
 
 	def _sync_lr(self):
 		lr = float(self.optimizer.param_groups[0]['lr'])

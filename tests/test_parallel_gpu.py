@@ -53,10 +53,14 @@ def _worker(rank, world, port, out_dir, side = False):
 		ca.functional.enable_side_stream_wgrad(d)
 	batch = _batch(rank, d)
 	losses = []
+	# (second iteration through train.GraphedTrainStep: an engine that runs collectives is never captured -- the call is train_step's)
+	stepper = ca.train.GraphedTrainStep(engine, opt, warmup = 1, world_size = world, sync_metrics = True)
+	assert not stepper.enabled
 	for it in range(2):
-		res = ca.train.train_step(engine, opt, *batch, world_size = world, iteration = it, sync_metrics = True)
+		res = ca.train.train_step(engine, opt, *batch, world_size = world, iteration = it, sync_metrics = True) if it == 0 else stepper(*batch, iteration = it)
 		assert not bool(res['skipped'])
 		losses.append(float(res['loss_cur']))
+	assert stepper.eager_steps == 1 and stepper.captures == 0
 	torch.cuda.synchronize()
 	torch.save(dict(params = flat.data.cpu(), losses = losses), os.path.join(out_dir, f'rank{rank}{"_side" if side else ""}.pt'))
 	dist.barrier()
