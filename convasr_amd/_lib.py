@@ -79,6 +79,8 @@ _SIGNATURES = dict(
 	convasr_wgrad1x1_grouped_workspace_bytes = (c_i64, [c_int, c_p, c_p, c_int, c_int]),
 	convasr_wgrad1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
 	convasr_copy = (c_int, [c_p, c_p, c_i64, c_p]),
+	convasr_split3 = (c_int, [c_p, c_p, c_int, c_i64, c_int, c_int, c_p]),
+	convasr_pack_conv_weight_split3 = (c_int, [c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
@@ -109,7 +111,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 8:
+		if lib.convasr_abi_version() != 9:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib

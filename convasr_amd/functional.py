@@ -82,7 +82,44 @@ def invalidate_pack_cache():
 	"""Called when conv modules were replaced (fuse_conv_bn_eval): packed copies are dropped and everything derived from the module tree
 	(JasperNet's list of dgrad weights, captured step graphs) is rebuilt on next use."""
 	_pack_cache.clear()
+	_split_cache.clear()
 	_structure_epoch[0] += 1
+
+
+_split_cache = {}
+
+
+def force_repack():
+	"""Declare every packed copy that a launch of this module keeps current stale (the arena's 16-bit mirror segments, which the fused
+	optimizer kernels write, stay vouched for): the next forward / backward re-packs them all.  train.GraphedTrainStep calls it right
+	before a capture so that the graph records every per-step pack launch whatever ran since the last optimizer step."""
+	for ent in _pack_cache.values():
+		ent['dgr_ver'] = None
+		if ent.get('flat') is None:
+			ent['fwd_ver'] = None
+	for cache in (Fold2._cache, _HeadPad._cache, _split_cache):
+		for ent in cache.values():
+			ent['ver'] = None
+
+
+def split_weight(w, dtype):
+	"""(forward, dgrad) split operands of a conv parameter for the split-operand path (csrc/split3.hip): hi / lo planes of the fp32 master
+	in the 16-bit type `dtype`, both refreshed by ONE launch when the parameter changed (in place: stable addresses)."""
+	ver = param_version(w)
+	ent = _split_cache.get((id(w), dtype))
+	if ent is None:
+		ent = _split_cache[(id(w), dtype)] = dict(w = w, ver = None, fwd = None, dgr = None)  # holds `w`: id() stays unique
+	if ent['ver'] != ver:
+		ent['fwd'], ent['dgr'] = ops.pack_weight_split3(w, dtype, out = (ent['fwd'], ent['dgr']))
+		ent['ver'] = ver
+	return ent['fwd'], ent['dgr']
+
+
+def split_applies(split, dt, spec, Cin, Cout):
+	"""Does a conv of this geometry run as a split-operand conv?  fp32 storage with a 16-bit plane type set, stride 1 and channel counts
+	inside the LDS-DMA kernels' envelope (3 Cin % 64 == 0; the weight gradient's 128-channel tiles take Cin, Cout % 128 == 0 and fall back to the
+	general 16-bit kernel otherwise).  Everything else of an fp32 network -- the strided prologue, a ragged head -- stays on the exact-fp32 kernels."""
+	return split is not None and dt == torch.float32 and spec.stride == 1 and Cin % 64 == 0 and Cout % 8 == 0
 
 
 def structure_epoch():
@@ -98,7 +135,7 @@ _prepack_streams = {}  # device -> [side stream, packs pending on it?]
 
 
 GROUPED_PACK_MIN = int(os.environ.get('CONVASR_GROUPED_PACK_MIN', 32))
-_pack_tables = {}  # (device, dtype) -> dict(key = the (src, dst) addresses it was built for, items = device table, blocks)
+_pack_tables = {}  # (device, dtype, the (src, dst) addresses of the group) -> dict(items = device table, blocks, n); entries live as long as the process: graphs bake their addresses
 
 
 def _pack_group(stale, dtype, refresh = True):
@@ -125,8 +162,8 @@ def _pack_table(group, dtype):
 	import struct
 	dev = group[0][0].device
 	key = tuple((fwd.data_ptr(), ent['dgr'].data_ptr()) for _, ent, fwd in group)
-	tab = _pack_tables.get((dev, dtype))
-	if tab is None or tab['key'] != key:
+	tab = _pack_tables.get((dev, dtype, key))  # one table per set of buffers, never dropped: a captured step graph holds its address (a few KB each)
+	if tab is None:
 		if capturing():
 			raise _lib.ConvasrHipError('the dgrad pack table changed while a step graph is being captured (GraphedTrainStep prewarms it: functional.prewarm_dgrad_pack)')
 		assert _lib.load().convasr_pack_dgrad_item_bytes() == 40
@@ -135,7 +172,7 @@ def _pack_table(group, dtype):
 			Cout, Cin, K = w.shape
 			blob += struct.pack('<QQiiiiii', fwd.data_ptr(), ent['dgr'].data_ptr(), Cout, Cin, K, ops.cout_pad(Cout), ops.cout_pad(Cin), first)
 			first += K * ((Cout + 63) // 64) * ((Cin + 63) // 64)
-		tab = _pack_tables[(dev, dtype)] = dict(key = key, items = torch.frombuffer(bytearray(blob), dtype = torch.uint8).to(dev), blocks = first, n = len(group))
+		tab = _pack_tables[(dev, dtype, key)] = dict(key = key, items = torch.frombuffer(bytearray(blob), dtype = torch.uint8).to(dev), blocks = first, n = len(group))
 	return tab
 
 
@@ -348,6 +385,9 @@ def _run_wgrad(dev, tensors, fn):
 	return out
 
 
+SPLIT_FAMILY, SPLIT_WGRAD_FAMILY = 'conv1d_igemm_v2s_kernel<x3>', 'conv1d_wgrad<x3>'  # the bench's per-kernel timer books the split-operand launches apart (algorithmic FLOPs, three MFMAs each)
+
+
 class ConvSpec:
 	"""Static description of one Conv1d (+ optional BatchNorm) as the kernels need it."""
 
@@ -450,11 +490,18 @@ def _after_long_launch():
 		hook()
 
 
-def _dgrad(x, dy, weight, spec, dt, link = None, wd = None):
+def _dgrad(x, dy, weight, spec, dt, link = None, wd = None, split = None):
 	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it.
-	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad)."""
-	Cin = x.shape[1]
+	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad).
+	split: the 16-bit plane type of a split-operand conv -- dy is then its (B, 3 Cout, T) plane tensor (ops.split3, SPLIT_GRAD) and dx is fp32."""
 	pad = spec.dilation * (spec.K - 1) - spec.padding
+	if split is not None:
+		Cout, Cin, K = weight.shape
+		B, _, Tdy = dy.shape
+		dx = ops.conv1d(dy, split_weight(weight, split)[1], Cin, spec.K, 1, spec.dilation, pad, out_dtype = torch.float32, work = 2.0 * B * ops.conv_out_len(Tdy, K, 1, spec.dilation, pad) * Cout * Cin * K, family = SPLIT_FAMILY)
+		_after_long_launch()
+		return dx
+	Cin = x.shape[1]
 	join_prepack(dy.device)
 	wd = packed_weight(weight, dt, _lib.PACK_DGRAD) if wd is None else wd
 	if link is not None and dt in ops.HALF_DTYPES and spec.stride == 1:
@@ -492,10 +539,17 @@ class ConvBnActFunction(torch.autograd.Function):
 		stats = _stats_buffer(bn, Cout, dev, B, ops.conv_out_len(Tin, spec.K, spec.stride, spec.dilation, spec.padding))
 		x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
 		ctx.fold = Fold2.plan(x, weight, spec, dt, x_needs_grad)
+		ctx.split = None
 		if ctx.fold is not None:
 			xv, Kf, Pf, Tout = ctx.fold
 			y = ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, stats = stats, Tout = Tout, work = 2.0 * B * Tout * Cout * Cin * spec.K)
 			ctx.fold = (Kf, Pf)
+		elif split_applies(cfg.get('split'), dt, spec, Cin, Cout):
+			# split-operand conv (csrc/split3.hip): the fp32 input as three 16-bit planes per frame, read by the LDS-DMA kernel as 3 Cin channels;
+			# the planes, not x, are what backward keeps (the weight gradient reads the same memory as 3 Tin frames of Cin channels)
+			ctx.split = cfg['split']
+			x = ops.split3(x, ctx.split, ops.SPLIT_INPUT)
+			y = ops.conv1d(x, split_weight(weight, ctx.split)[0], Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, stats = stats, work = 2.0 * B * ops.conv_out_len(Tin, spec.K, 1, spec.dilation, spec.padding) * Cout * Cin * spec.K, family = SPLIT_FAMILY)
 		else:
 			y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
 		Tout = y.shape[2]
@@ -661,7 +715,13 @@ class ConvBnActFunction(torch.autograd.Function):
 		if n_res == 0:
 			grouped_bn = None
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
-		if ctx.fold is not None:
+		if ctx.split is not None:
+			# split-operand conv: dy as its three planes (hi, hi, lo) once, for both gradients; the weight gradient pairs plane p of x with plane p of
+			# dy by reading both plane tensors as 3 T frames of C channels with the conv's dilation and padding tripled
+			dy = ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
+			xf, dyf = ops.split3_frames(x), ops.split3_frames(dy)
+			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(xf, dyf, Cout, spec.K, 1, 3 * spec.dilation, 3 * spec.padding, outs[0], accumulate = acc, work = 2.0 * B * Tout * Cout * weight.shape[1] * spec.K, family = SPLIT_WGRAD_FAMILY))
+		elif ctx.fold is not None:
 			Bx, Cin, Tin = x.shape
 			xv = x.as_strided((Bx, 2 * Cin, Tin // 2), (Tin * Cin, 1, 2 * Cin))
 			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad(xv, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
@@ -674,7 +734,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		if ctx.x_needs_grad:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
-			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link)
+			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link, split = ctx.split)
 		if not arena_mode:
 			dw, = wg()
 

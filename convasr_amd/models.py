@@ -243,12 +243,13 @@ class ConvBn1d(nn.Module):
 		self.activation = ResidualActivation(nonlinearity, dropout, invertible = inplace)
 		self.temporal_mask = temporal_mask
 		self.compute_dtype = torch.float32
+		self.split_dtype = None  # bf16 / fp16: the convs of an fp32 network run as split-operand MFMA convs (JasperNet.set_compute_dtype('bf16x3'))
 		self.tapped_output = False  # set by the network when later blocks take this block's output as a residual input: its gradient then has an accumulator the tapping blocks write into (functional.ConvBnActFunction, GRAD_ACC)
 		self.single_consumer_output = False  # set by the network when this block's output feeds exactly one conv (no residual taps): enables cross-layer backward fusion
 
 	def _cfg(self, i, last):
 		conv, bn = self.conv[i][-1], self.bn[i]
-		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
+		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
 
 	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
 		_lib.require_cuda(x)
@@ -387,15 +388,24 @@ class JasperNet(nn.Module):
 			blk.tapped_output = tapped
 		self.set_compute_dtype(compute_dtype)
 
+	SPLIT_DTYPES = {'bf16x3': torch.bfloat16, 'f16x3': torch.float16}
+
 	def set_compute_dtype(self, dtype):
 		"""fp32 (exact-fp32 MFMA path: parity runs), or bf16 / fp16 (16-bit storage of activations and compute weights, MFMA with fp32
 		accumulation, fp32 master weights: throughput runs; fp16 is what the reference's apex O1-O3 levels compute in and trains under a
-		dynamic loss scaler, convasr_amd.train.LossScaler)."""
+		dynamic loss scaler, convasr_amd.train.LossScaler), or 'bf16x3' / 'f16x3': fp32 storage everywhere, the training convs as
+		split-operand products on the 16-bit matrix pipe (three MFMAs per product, fp32-class accuracy: csrc/split3.hip) -- the path that
+		meets the reference's fp32 results to 1e-4 in the CTC loss at MFMA rate; evaluation runs the exact-fp32 kernels."""
+		split = None
+		if isinstance(dtype, str):
+			dtype, split = torch.float32, self.SPLIT_DTYPES[dtype]
 		assert dtype in (torch.float32, ) + ops.HALF_DTYPES
-		self.compute_dtype = dtype
+		self.compute_dtype, self.split_dtype = dtype, split
 		for m in self.modules():
 			if isinstance(m, (ConvBn1d, Decoder)):
 				m.compute_dtype = dtype
+			if isinstance(m, ConvBn1d):
+				m.split_dtype = split
 		return self
 
 	def forward(self, x, xlen = None, y = None, ylen = None):
@@ -436,7 +446,8 @@ class JasperNet(nn.Module):
 			if cached is None or cached[0] != Fn.structure_epoch():  # (the module tree is walked once, not per step: any fuse_conv_bn_eval -- the network's or a single block's -- replaces conv modules and bumps the epoch)
 				convs = [c[-1] for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv] + [c for blk in self.modules() if isinstance(blk, ConvBn1d) for c in blk.conv_residual if isinstance(c, nn.Conv1d)]
 				cached = self._dgrad_weights = (Fn.structure_epoch(), [c.weight for c in convs[1:] if c.stride[0] == 1])
-			Fn.prepack_dgrad_weights(cached[1], self.compute_dtype)
+			if self.split_dtype is None:  # (a split-operand network packs both operands of a conv in one launch at its forward pass: functional.split_weight)
+				Fn.prepack_dgrad_weights(cached[1], self.compute_dtype)
 		log_probs = [Fn.LogSoftmaxFunction.apply(l) for l in logits]
 		olen = [ops.output_lengths(xlen, l.shape[0], l.shape[-1], l.device) for l in logits]  # compute_output_lengths (models.py:611-614) as one launch
 		aux = {}

@@ -210,7 +210,7 @@ class ConvStats:
 		return out
 
 
-def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, Tout = None, work = None):
+def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, Tout = None, work = None, family = None):
 	"""x: channels-last (B, Cin, Tin); wp: packed weights.  Returns channels-last (B, Cout, Tout).
 	Tout (optional): compute only the first Tout frames of the output; work: FLOPs to book for the bench's timer (the stride-2 fold).
 	stats: None, a ConvStats (the production path: partial rows, consumed by bn_finalize), or a (2 Cout,) fp64 tensor that
@@ -231,7 +231,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 				stats.copy_(part.totals())
 		return y
 	# which kernel the C side picks (conv.hip: convasr_conv1d_fwd -> convasr_conv1d_v2_try), for the bench's per-kernel timer only
-	family = 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype in HALF_DTYPES and stride == 1 and Cin % 64 == 0) else 'conv1d_igemm (other variants)'  # (the family name is a label: fp16 launches of the same kernel are booked under it too)
+	label, family = family, 'conv1d_igemm_v2s_kernel<bf16>' if (x.dtype in HALF_DTYPES and stride == 1 and Cin % 64 == 0) else 'conv1d_igemm (other variants)'  # (the family name is a label: fp16 launches of the same kernel are booked under it too)
 	es, osz = x.element_size(), (2 if out_dtype in HALF_DTYPES else 4)
 	flops, nbytes_ = 2.0 * B * Tout * Cout * Cin * K if work is None else work, float(B * Tin * Cin * es + K * Cout * Cin * es + B * Tout * Cout * osz)
 	symbol = 'v2s16' if family.startswith('conv1d_igemm_v2s') and out_dtype == x.dtype else None
@@ -239,7 +239,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 		family, symbol = 'hbm:conv1x1_kernel (one-tap training launches)', None  # conv1x1.hip takes these (csrc/conv.hip: conv1d_run); bound by bytes moved, booked under the HBM roofline
 	elif family.startswith('conv1d_igemm_v2s') and memory_bound(flops, nbytes_):
 		family = 'hbm:conv1d_igemm_v2s_kernel (memory-bound launches: the 38-class decoder)'
-	_lib.timed(family, flops, launch, nbytes = nbytes_, symbol = symbol)
+	_lib.timed(label or family, flops, launch, nbytes = nbytes_, symbol = symbol)
 	if part is not None:
 		part.rows = rows.value
 		if part is not stats:
@@ -260,6 +260,8 @@ def conv1x1_grouped(xs, wps, couts, biases = None, stats = None, outs = None, ac
 	B, _, T = xs[0].shape
 	dt = xs[0].dtype
 	if n == 0 or n > 12 or dt not in HALF_DTYPES or any(x.dtype != dt or x.shape[0] != B or x.shape[2] != T or not is_cl(x) or x.shape[1] % 64 for x in xs) or any(c % 128 for c in couts):
+		return None
+	if any(B * T * max(x.shape[1], c) * 2 >= 2 ** 31 or c * x.shape[1] * 2 >= 2 ** 31 for x, c in zip(xs, couts)):  # the kernel's 32-bit buffer offsets (csrc/conv1x1.hip): the caller launches such branches one by one
 		return None
 	ys = [empty_cl(B, couts[i], T, dt, xs[0].device) if outs is None or outs[i] is None else outs[i] for i in range(n)]
 	rows = ctypes.c_int(0)
@@ -355,10 +357,50 @@ def fold2_unfold_wgrad(dwf, dw, pad, accumulate = False):
 	return dw
 
 
+# ------------------------------------------------------------------------------------------------ split-operand ("x3") convs
+
+SPLIT_INPUT, SPLIT_GRAD = 0, 1  # plane orders of split3(): (hi, lo, hi) for a conv input, (hi, hi, lo) for an output gradient
+
+
+def split3(x, dtype, order):
+	"""fp32 channels-last (B, C, T) -> its three 16-bit planes per frame, memory [B][T][3][C] (include/convasr_hip.h, "split-operand
+	convs"), returned as the channels-last (B, 3 C, T) tensor the forward / dgrad kernels read; split3_frames() is the weight gradient's view."""
+	B, C, T = x.shape
+	assert is_cl(x) and x.dtype == torch.float32 and dtype in HALF_DTYPES and C % 8 == 0
+	out = empty_cl(B, 3 * C, T, dtype, x.device)
+	_lib.timed('hbm:split3_kernel', 0.0, lambda: call('convasr_split3', ptr(x), ptr(out), dtype_code(dtype), B * T, C, int(order), stream_ptr()), nbytes = float(B * T * C * 10))
+	return out
+
+
+def split3_frames(x3):
+	"""The (B, 3 C, T) plane tensor of split3() read as (B, C, 3 T): frame 3 t + p = plane p of frame t (the same memory)."""
+	B, C3, T = x3.shape
+	assert is_cl(x3) and C3 % 3 == 0
+	return x3.as_strided((B, C3 // 3, 3 * T), (T * C3, 1, C3 // 3))
+
+
+def pack_weight_split3(w, dtype, out = None):
+	"""(Cout, Cin, K) fp32 parameter -> (fwd [K][cout_pad][3 Cin], dgrad [K][cin_pad][3 Cout]) split operands, refreshed in place when
+	`out` = (fwd, dgrad) of an earlier call."""
+	require_cuda(w)
+	w = w.detach()
+	layout = weight_layout(w) if w.dtype == torch.float32 else None
+	if layout is None:
+		w, layout = w.float().contiguous(), _lib.W_REFERENCE
+	Cout, Cin, K = w.shape
+	fwd, dgr = out if out is not None else (None, None)
+	if fwd is None:
+		fwd = torch.zeros(K, cout_pad(Cout), 3 * Cin, dtype = dtype, device = w.device)
+	if dgr is None:
+		dgr = torch.zeros(K, cout_pad(Cin), 3 * Cout, dtype = dtype, device = w.device)
+	call('convasr_pack_conv_weight_split3', ptr(w), layout, ptr(fwd), ptr(dgr), dtype_code(dtype), Cout, Cin, K, stream_ptr())
+	return fwd, dgr
+
+
 _wgrad_ws_bytes = {}
 
 
-def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate = False, work = None):
+def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate = False, work = None, family = None):
 	"""dw (Cout, Cin, K) fp32 (+)= wgrad; x, dy channels-last of the same dtype.  dw is torch-contiguous (the reference's layout) or a
 	view of tap-major memory (weight_layout: the training arena's gradients)."""
 	B, Cin, Tin = x.shape
@@ -372,7 +414,7 @@ def conv1d_wgrad(x, dy, Cout, K, stride, dil, pad, dw, dbias = None, accumulate 
 	if nbytes is None:
 		nbytes = _wgrad_ws_bytes[wkey] = _lib.load().convasr_conv1d_wgrad_workspace_bytes(*wkey)
 	ws = workspace(nbytes, x.device, 'wgrad')
-	_lib.timed('conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), layout, stream_ptr()))
+	_lib.timed(family or 'conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad', ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), dtype_code(x.dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, int(accumulate), layout, stream_ptr()))
 	return dw
 
 

@@ -11,9 +11,12 @@ from . import functional as Fn
 
 
 def _advance(opt, pair):
-	"""The fused launch read pair[opt._cur] and wrote the other row: make that one current -- by swapping, or, while a step graph is
-	being captured (its kernels read the same row at every replay), by enqueueing the copy that hands the new values back."""
-	if Fn.capturing():
+	"""The fused launch read pair[opt._cur] and wrote the other row: make that one current -- by swapping, or, once a step graph has been
+	captured from this optimizer (its kernels read the row that was current at capture time at EVERY replay), by enqueueing the copy that
+	hands the new values back.  From the first capture on (`_pinned`, set by train.GraphedTrainStep) the current row never moves again, in
+	eager steps either: an eager step between two replays -- the warm-up of a new batch shape, a shape beyond max_graphs -- that flipped the
+	rows would leave every existing graph reading the row that is one step old."""
+	if Fn.capturing() or getattr(opt, '_pinned', False):
 		_lib.call('convasr_copy', _lib.ptr(pair[1 - opt._cur]), _lib.ptr(pair[opt._cur]), pair[0].numel() * pair.element_size(), _lib.stream_ptr())
 	else:
 		opt._cur = 1 - opt._cur

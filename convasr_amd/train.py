@@ -143,6 +143,7 @@ class LossScaler:
 		assert len(state) == _lib.LOSS_SCALER_FLOATS
 		self.state = torch.tensor([state, state], dtype = torch.float32, device = device)
 		self.cur = 0
+		self.pinned = False  # set by the first step-graph capture: from then on the current row stays where the graphs read it (see advance)
 
 	@property
 	def current(self):
@@ -152,9 +153,10 @@ class LossScaler:
 		return self.state[self.cur], self.state[1 - self.cur]
 
 	def advance(self):
-		"""After an optimizer launch wrote the next state into the other buffer: swap the two -- or, while a step graph is being captured
-		(its kernels will read THIS buffer at every replay), enqueue the copy that hands the new state back to it."""
-		if Fn.capturing():
+		"""After an optimizer launch wrote the next state into the other buffer: swap the two -- or, once a step graph has been captured
+		(its kernels read THIS buffer at every replay; `pinned`, eager steps included: optimizers._advance), enqueue the copy that hands the
+		new state back to it."""
+		if Fn.capturing() or self.pinned:
 			_lib.call('convasr_copy', _lib.ptr(self.state[1 - self.cur]), _lib.ptr(self.state[self.cur]), 4 * _lib.LOSS_SCALER_FLOATS, _lib.stream_ptr())
 		else:
 			self.cur = 1 - self.cur
@@ -383,6 +385,15 @@ class GraphedTrainStep:
 		cached = getattr(net, '_dgrad_weights', None)
 		if cached is not None and cached[0] == Fn.structure_epoch():
 			Fn.prewarm_dgrad_pack(cached[1], net.compute_dtype)  # (a host-to-device table copy: not possible inside the capture)
+		# double-buffered device state (NovoGrad's EMAs, AdamW's applied-step counter, the loss scaler): the rows stop swapping for good --
+		# this graph, and every later eager step, hands the new state back to the row that is current now
+		opt._pinned = True
+		if getattr(opt.flat, 'loss_scaler', None) is not None:
+			opt.flat.loss_scaler.pinned = True
+		# every version-keyed packed copy (padded-Cout forward operands, the folded prologue, the padded head, fp32 / split operands) is
+		# declared stale, so that ALL per-step pack launches are recorded in the graph: a copy that happens to be current now -- a validation
+		# forward ran since the last optimizer step -- would otherwise get no pack node and go stale under replays
+		Fn.force_repack()
 		torch.cuda.synchronize(dev)
 		# The captured step is ONE chain of nodes unless linear = False: the weight-gradient side stream and the dgrad-weight prepack stream are
 		# switched off for the capture.  Measured on ROCm 7.2 (profiles/r05_graph_ab.json): a graph with forked branches replays 2 % SLOWER

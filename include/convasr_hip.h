@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 8
+#define CONVASR_ABI_VERSION 9
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2, CONVASR_F16 = 3 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -382,6 +382,24 @@ int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype,
  * K * ceil(Cout / 64) * ceil(Cin / 64) blocks and total_blocks = that sum over all items; Cout and Cin even. */
 int convasr_pack_dgrad_item_bytes(void);
 int convasr_pack_dgrad_grouped(const void* items, int n_items, int total_blocks, void* stream);
+
+/* ---- split-operand ("x3") convs: fp32-class accuracy on the 16-bit matrix pipe (models.py:47-77 computed as nn.Conv1d does in fp32) ---- */
+
+/* A value v travels as hi = rn16(v), lo = rn16(v - hi) and a product as hi*hi + hi*lo + lo*hi: three 16-bit MFMAs, each exact in fp32,
+ * fp32 accumulation (bf16 planes: 16 significant bits per operand; fp16 planes: 22, but fp16's range).  The three products ride in the
+ * REDUCTION axis of the ordinary conv entry points above, so no conv kernel of its own exists:
+ *   convasr_split3: x fp32 channels-last [rows = B * T][C] -> out [rows][3][C] of `dtype` (CONVASR_BF16 / CONVASR_F16), planes
+ *     order 0 = (hi, lo, hi) for a conv INPUT, order 1 = (hi, hi, lo) for an OUTPUT GRADIENT.  C % 8 == 0.
+ *   forward:  convasr_conv1d_fwd(x3 as a (B, T, 3 Cin) input, packed_fwd of convasr_pack_conv_weight_split3, y fp32, Cin -> 3 Cin);
+ *   dgrad:    convasr_conv1d_fwd(dy3 as a (B, T, 3 Cout) input, packed_dgrad of the same call, dx fp32, the usual transposed geometry);
+ *   wgrad:    convasr_conv1d_wgrad(x3 read as (B, 3 Tin, Cin), dy3 read as (B, 3 Tout, Cout), dil -> 3 dil, pad -> 3 pad): frame 3 t + p is
+ *             plane p of frame t, so the reduction over frames pairs plane p of x with plane p of dy.
+ * convasr_pack_conv_weight_split3: (Cout, Cin, K) fp32 parameter in layout w_layout ->
+ *   packed_fwd   [K][cout_pad(Cout)][3 Cin] : row (k, co)         = (w_hi[co][.][k], w_hi[co][.][k], w_lo[co][.][k])
+ *   packed_dgrad [K][cout_pad(Cin)][3 Cout] : row (K - 1 - k, ci) = (w_hi[.][ci][k], w_lo[.][ci][k], w_hi[.][ci][k])
+ * either may be NULL; rows beyond Cout / Cin are not written (zero-fill once). */
+int convasr_split3(const float* x, void* out, int dtype, int64_t rows, int C, int order, void* stream);
+int convasr_pack_conv_weight_split3(const float* w, int w_layout, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
 
 /* ---- per-step device state: what lets train.py:745-783 replay from a HIP graph ------------------------------------- */
 

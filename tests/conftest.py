@@ -19,8 +19,16 @@ def pytest_sessionstart(session):
 	once (hipcc cross-compiles gfx950 without a GPU, ~1 min) instead of failing every test that checks the C ABI."""
 	from convasr_amd import _lib
 	if not os.path.exists(_lib.LIB_PATH) and not os.environ.get('CONVASR_HIP_LIB'):
+		import shutil
+		import warnings
 		from convasr_amd import build
-		build.build(verbose = False)
+		if shutil.which(build.HIPCC) is None:  # no compiler here: the pure-CPU oracle / golden / host tests still run, the C-ABI tests fail one by one
+			warnings.warn(f'{_lib.LIB_PATH} is missing and {build.HIPCC} was not found: tests that load the library will fail')
+			return
+		try:
+			build.build(verbose = False)
+		except Exception as e:  # a broken toolchain must not take the whole session down with an INTERNALERROR
+			warnings.warn(f'building {_lib.LIB_PATH} failed: {e}')
 
 
 @pytest.fixture(scope = 'session')

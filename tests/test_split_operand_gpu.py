@@ -1,0 +1,231 @@
+"""The split-operand ("x3") conv path on the MI355X (csrc/split3.hip, functional.split_weight, JasperNet.set_compute_dtype('bf16x3')):
+fp32 storage, every stride-1 conv as hi*hi + hi*lo + lo*hi on the 16-bit matrix pipe.  Reference arithmetic: nn.Conv1d in fp32
+(models.py:47-77); bars: the planes are exact splits, the three conv directions agree with float64 to the split's own 2^-16 / 2^-22, a
+training step agrees with the exact-fp32 path to 1e-5 in the CTC loss (north_star: 1e-4 against the reference; the 64 x 15 s case against
+the CPU oracle lives in test_round5_gpu.py), and replays bit for bit from a step graph."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+	a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+	return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_split3_planes_are_the_exact_hi_lo_split_in_both_orders(dt):
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(0)
+	B, C, T = 3, 72, 41
+	x = ops.as_cl((torch.randn(B, C, T) * torch.logspace(-3, 1, C).view(1, C, 1)).to(d), torch.float32)
+	hi = x.to(dt)
+	lo = (x - hi.float()).to(dt)
+	for order, planes in ((ops.SPLIT_INPUT, (hi, lo, hi)), (ops.SPLIT_GRAD, (hi, hi, lo))):
+		x3 = ops.split3(x, dt, order)
+		assert x3.shape == (B, 3 * C, T) and ops.is_cl(x3)
+		for p, want in enumerate(planes):
+			assert torch.equal(x3[:, p * C:(p + 1) * C, :], want), (order, p)
+		# the weight gradient's view of the same memory: frame 3 t + p = plane p of frame t
+		xf = ops.split3_frames(x3)
+		assert xf.shape == (B, C, 3 * T) and ops.is_cl(xf) and xf.data_ptr() == x3.data_ptr()
+		for p, want in enumerate(planes):
+			assert torch.equal(xf[:, :, p::3], want), (order, p)
+	bits = 8 if dt == torch.bfloat16 else 11
+	assert float(((hi.float() + lo.float() - x).abs() / x.abs().clamp(min = 1e-30)).max()) <= 2.0 ** (-2 * bits)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('kmajor', [False, True])
+def test_pack_conv_weight_split3_layouts(dt, kmajor):
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(1)
+	Cout, Cin, K = 136, 192, 5
+	w = (torch.randn(Cout, Cin, K) / 30).to(d)
+	if kmajor:  # the training arena's element order [K][Cout][Cin] behind the same (Cout, Cin, K) view
+		w = w.permute(2, 0, 1).contiguous().permute(1, 2, 0)
+		assert ops.weight_layout(w) == 1
+	fwd, dgr = ops.pack_weight_split3(w, dt)
+	hi = w.to(dt)
+	lo = (w - hi.float()).to(dt)
+	assert fwd.shape == (K, ops.cout_pad(Cout), 3 * Cin) and dgr.shape == (K, ops.cout_pad(Cin), 3 * Cout)
+	for k in range(K):
+		for p, want in enumerate((hi, hi, lo)):
+			assert torch.equal(fwd[k, :Cout, p * Cin:(p + 1) * Cin], want[:, :, k]), ('fwd', k, p)
+		for p, want in enumerate((hi, lo, hi)):
+			assert torch.equal(dgr[K - 1 - k, :Cin, p * Cout:(p + 1) * Cout], want[:, :, k].t()), ('dgrad', k, p)
+	assert float(fwd[:, Cout:].abs().max()) == 0 and float(dgr[:, Cin:].abs().max()) == 0
+	# refreshed in place: same buffers
+	f2, d2 = ops.pack_weight_split3(w * 2, dt, out = (fwd, dgr))
+	assert f2.data_ptr() == fwd.data_ptr() and d2.data_ptr() == dgr.data_ptr() and torch.equal(f2[0, :Cout, :Cin], (w * 2).to(dt)[:, :, 0])
+
+
+@pytest.mark.parametrize('dt,tol', [(torch.bfloat16, 1.5e-5), (torch.float16, 6e-5)])
+@pytest.mark.parametrize('shape', [(3, 256, 384, 300, 11, 1, 5), (2, 768, 896, 200, 29, 2, 29), (3, 896, 1024, 257, 1, 1, 0), (2, 192, 136, 77, 3, 1, 1)])
+def test_split_conv_forward_dgrad_wgrad_against_float64(dt, tol, shape):
+	"""(fp16 planes: the test's output gradient of ~1e-3 puts its lo plane into fp16's subnormals -- 1.7e-5; a training run scales the loss)"""
+	from convasr_amd import ops, functional as Fn
+	d = torch.device('cuda:0')
+	B, Cin, Cout, T, K, dil, pad = shape
+	torch.manual_seed(2)
+	x = torch.randn(B, Cin, T)
+	w = torch.randn(Cout, Cin, K) / (Cin * K) ** 0.5
+	ref = torch.nn.functional.conv1d(x.double(), w.double(), padding = pad, dilation = dil)
+	dy = torch.randn_like(ref).float() * 1e-3
+	dx_ref = torch.nn.grad.conv1d_input(x.shape, w.double(), dy.double(), padding = pad, dilation = dil)
+	dw_ref = torch.nn.grad.conv1d_weight(x.double(), w.shape, dy.double(), padding = pad, dilation = dil)
+	xg, wg, dyg = ops.as_cl(x.to(d), torch.float32), w.to(d), ops.as_cl(dy.to(d), torch.float32)
+	x3, dy3 = ops.split3(xg, dt, ops.SPLIT_INPUT), ops.split3(dyg, dt, ops.SPLIT_GRAD)
+	wf, wd = Fn.split_weight(wg, dt)
+	y = ops.conv1d(x3, wf, Cout, K, 1, dil, pad, out_dtype = torch.float32)
+	dx = ops.conv1d(dy3, wd, Cin, K, 1, dil, dil * (K - 1) - pad, out_dtype = torch.float32)
+	dw = torch.empty(Cout, Cin, K, device = d)
+	ops.conv1d_wgrad(ops.split3_frames(x3), ops.split3_frames(dy3), Cout, K, 1, 3 * dil, 3 * pad, dw)
+	errs = dict(y = _rel(y, ref), dx = _rel(dx, dx_ref), dw = _rel(dw, dw_ref))
+	assert y.dtype == dx.dtype == torch.float32 and max(errs.values()) <= tol, errs
+
+
+def _small(ca, d, dt, dropout = 0.0, seed = 3):
+	torch.manual_seed(seed)
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	return ca.models.Wav2Letter(64, [38], frontend = fe, dropout = dropout, base_width = 64, check_time_dim_padded = False, compute_dtype = dt).to(d).train()
+
+
+def _batch(d, B, secs, seed = 5):
+	g = torch.Generator().manual_seed(seed)
+	x = torch.rand(B, 16000 * secs, generator = g) * 2 - 1
+	xlen = torch.linspace(0.6, 1, B)
+	y = torch.randint(0, 37, (B, 1, 64), generator = g)
+	ylen = torch.randint(10, 5 * secs, (B, 1), generator = g)
+	return tuple(t.to(d) for t in (x, xlen, y, ylen))
+
+
+@pytest.mark.parametrize('name', ['bf16x3', 'f16x3'])
+def test_split_operand_training_step_tracks_the_exact_fp32_path(name):
+	"""Two SGD steps of a small Wav2Letter: the first loss within 1e-5 of the exact-fp32 path's, parameters after the steps within 5 % of the
+	largest update; the split convs are the launches that ran (16-bit operands in, fp32 out)."""
+	import convasr_amd as ca
+	from convasr_amd import _lib
+	d = torch.device('cuda:0')
+	batch = _batch(d, 6, 4)
+	res = {}
+	for dt in (torch.float32, name):
+		model = _small(ca, d, dt)
+		assert (model.split_dtype is not None) == (dt == name) and model.compute_dtype == torch.float32
+		flat = ca.train.FlatParameters(model)
+		p0 = flat.data.clone()
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		timer = _lib.KernelTimer(only = ())
+		_lib.timer = timer
+		try:
+			losses = [float(ca.train.train_step(model, opt, *batch)['loss']) for _ in range(2)]
+		finally:
+			_lib.timer = None
+		torch.cuda.synchronize()
+		res[dt] = (losses, flat.data.clone(), p0, [f for f, _ in timer.sequence])
+	fams = res[name][3]
+	assert fams.count('conv1d_igemm_v2s_kernel<x3>') == 2 * 2 * 17 and fams.count('conv1d_wgrad<x3>') == 2 * 17 and 'conv1d_igemm_v2s_kernel<x3>' not in res[torch.float32][3]
+	# (first step: the same parameters in both runs; second step: after one update each -- two exact-fp32 implementations of this random-init
+	# network already differ by ~1e-2 in their deep gradients, summation-order noise amplified per layer: DESIGN section 2)
+	for (a, b), bar in zip(zip(res[name][0], res[torch.float32][0]), (1e-5, 1e-3)):
+		assert abs(a - b) / abs(b) <= bar, (res[name][0], res[torch.float32][0])
+	step = float((res[torch.float32][1] - res[torch.float32][2]).abs().max())
+	assert float((res[name][1] - res[torch.float32][1]).abs().max()) <= 5e-2 * step, (float((res[name][1] - res[torch.float32][1]).abs().max()), step)
+
+
+def test_split_operand_eval_and_no_grad_run_the_exact_fp32_kernels():
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = _batch(d, 4, 3)
+	a, b = _small(ca, d, torch.float32), _small(ca, d, 'bf16x3')
+	with torch.no_grad():
+		la, lb = a(x, xlen)['logits'][0], b(x, xlen)['logits'][0]
+	assert torch.equal(la, lb)
+	a.eval(); b.eval()
+	with torch.no_grad():
+		assert torch.equal(a(x, xlen)['logits'][0], b(x, xlen)['logits'][0])
+
+
+def test_split_operand_step_replays_bitwise_from_a_graph_with_dropout():
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	batches = [_batch(d, 5, 4, seed = 10 + i) for i in range(8)]
+	out = {}
+	for graphed in (False, True):
+		ca.functional.manual_seed(17)
+		model = _small(ca, d, 'bf16x3', dropout = 0.2)
+		flat = ca.train.FlatParameters(model)
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		stepper = ca.train.GraphedTrainStep(model, opt, warmup = 1, enabled = graphed)
+		trace = [float(stepper(*b, iteration = i)['loss']) for i, b in enumerate(batches)]
+		torch.cuda.synchronize()
+		out[graphed] = (trace, flat.data.clone(), stepper)
+	assert out[True][2].captures == 1 and out[True][2].replays == 6
+	assert out[False][0] == out[True][0] and torch.equal(out[False][1], out[True][1])
+
+
+# ------------------------------------------------------------------------------------------------ graphs and eager steps interleaved
+
+def _interleaved(ca, d, make_opt, dt, opt_level, graphed, order, shapes, max_graphs = 64, validate_before_capture = False):
+	ca.functional.manual_seed(23)
+	torch.manual_seed(4)
+	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0.1, base_width = 64, check_time_dim_padded = False, compute_dtype = dt).to(d).train()
+	flat = ca.train.FlatParameters(model)
+	opt = make_opt(flat)
+	if opt_level is not None:
+		ca.models.data_parallel_and_autocast(model, opt, opt_level = opt_level)
+	stepper = ca.train.GraphedTrainStep(model, opt, warmup = 1, enabled = graphed, max_graphs = max_graphs)
+	data = {k: _batch(d, *shapes[k], seed = 30 + i) for i, k in enumerate(sorted(shapes))}
+	trace = []
+	for it, k in enumerate(order):
+		if validate_before_capture and it in validate_before_capture:
+			model.eval()
+			with torch.no_grad():
+				model(data[k][0], data[k][1])  # a validation pass between two optimizer steps: refreshes the version-keyed packed copies
+			model.train()
+		r = stepper(*data[k], iteration = it)
+		trace.append((float(r['loss']), float(r['grad_norm'])))
+	torch.cuda.synchronize()
+	scaler = None if flat.loss_scaler is None else flat.loss_scaler.current.tolist()
+	return trace, flat.data.clone(), scaler, stepper
+
+
+@pytest.mark.parametrize('optname', ['novograd_fp16', 'adamw_bf16'])
+def test_graphs_interleaved_with_eager_steps_keep_the_double_buffered_state_current(optname):
+	"""Shape order A A B A B B C A B: the eager warm-up of B (and of C, which stays eager for good with max_graphs = 2) runs AFTER graph A
+	was captured.  NovoGrad's EMAs / AdamW's applied-step counter / the fp16 loss scaler are double-buffered on the device; a flip by those
+	eager steps would leave graph A reading a row that is one step old.  Bit for bit against the eager run."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	shapes = dict(A = (4, 4), B = (3, 5), C = (5, 3))
+	order = list('AABABBCABCA')
+	if optname == 'novograd_fp16':
+		make_opt, dt, lvl = (lambda flat: ca.optimizers.NovoGrad(flat, lr = 1e-3, betas = (0.95, 0.5), weight_decay = 1e-3)), torch.float16, 'O2'
+	else:
+		make_opt, dt, lvl = (lambda flat: ca.optimizers.AdamW(flat, lr = 1e-3, weight_decay = 1e-2)), torch.bfloat16, None
+	eager = _interleaved(ca, d, make_opt, dt, lvl, False, order, shapes)
+	graph = _interleaved(ca, d, make_opt, dt, lvl, True, order, shapes, max_graphs = 2)
+	assert graph[3].captures == 2 and graph[3].replays >= 5 and graph[3].eager_steps >= 4, (graph[3].captures, graph[3].replays, graph[3].eager_steps)
+	assert eager[0] == graph[0], list(zip(eager[0], graph[0]))
+	assert torch.equal(eager[1], graph[1]) and eager[2] == graph[2]
+
+
+def test_capture_after_a_validation_pass_still_records_every_pack_launch():
+	"""fp32 compute (every packed copy is version-keyed, none is served by the optimizer's 16-bit mirror): a validation forward right before
+	the step that gets captured makes the packed forward copies current, so without functional.force_repack() the graph would hold no pack
+	node for them and replay with frozen weights."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	shapes = dict(A = (4, 3))
+	order = list('AAAAAA')
+	make_opt = lambda flat: ca.train.SGD(flat, lr = 5e-2, momentum = 0.9, weight_decay = 1e-3)
+	for dt in (torch.float32, 'bf16x3'):
+		eager = _interleaved(ca, d, make_opt, dt, None, False, order, shapes, validate_before_capture = {1})
+		graph = _interleaved(ca, d, make_opt, dt, None, True, order, shapes, validate_before_capture = {1})
+		assert graph[3].captures == 1 and graph[3].replays == 5
+		assert eager[0] == graph[0], (dt, list(zip(eager[0], graph[0])))
+		assert torch.equal(eager[1], graph[1])
