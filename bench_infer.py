@@ -140,14 +140,17 @@ def main():
 	ap.add_argument('--duration', type = float, default = 5.0)
 	ap.add_argument('--warmup-iterations', type = int, default = 100)
 	ap.add_argument('--no-graph', action = 'store_true')
+	ap.add_argument('--sample-rate', type = int, default = 16000, help = '8000: the reference\'s published configuration (benchmark_online.py:13-21: JasperNetBig, B = 1 x 6 s at 8 kHz)')
 	ap.add_argument('--no-throughput', action = 'store_true')
 	args = ap.parse_args()
+	global SAMPLE_RATE
+	SAMPLE_RATE = args.sample_rate
 	device = torch.device('cuda', 0)
 	torch.cuda.set_device(device)
 	torch.manual_seed(1)
 	dtype = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32)[args.dtype]
 	model = build_model(args.model, device, dtype)
-	common = dict(model = args.model, dtype = args.dtype, data = 'synthetic', weights = 'random init')
+	common = dict(model = args.model, dtype = args.dtype, sample_rate = SAMPLE_RATE, data = 'synthetic', weights = 'random init')
 	if not args.no_throughput:
 		print(json.dumps(dict(throughput(model, device, 64, 15, 10), **common)), flush = True)
 	if not args.no_graph:

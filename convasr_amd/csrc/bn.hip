@@ -313,7 +313,11 @@ __device__ __forceinline__ void fold_step_key(BnActParams& p) { if (p.drop_thr &
 // activation may be leaky-relu (else a clamp: one v_med3_f32 per element) -- compile-time, so
 // that the training step's launches (no residuals, scale / shift, dropout, gates) run straight-line code without the other cases'
 // branches, register copies and live ranges (the kernel is VALU-bound, not HBM-bound: 16 instantiations instead of one).
-template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra_) {
+// SPLIT (fp32 passes of a split-operand network, csrc/split3.hip): 0 = the result is stored as T; 1 / 2 = it is stored as its three bf16 / fp16
+// planes per frame, [row][3][C] (order 0: a conv input) -- the pass that would otherwise follow (read 4 + write 6 bytes per element) is gone.
+template <int SPLIT> struct PlaneType { typedef bf16_t H; };
+template <> struct PlaneType<2> { typedef f16_t H; };
+template <typename T, int MODE, int SPLIT = 0> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra_) {
 	constexpr bool RES = MODE & 1, DROP = (MODE & 2) != 0, GATE = (MODE & 4) != 0, AFFINE = (MODE & 8) != 0, LEAKY = (MODE & 16) != 0;
 	ResArgs ra = ra_;
 	if (!RES) ra.n = 0;
@@ -356,7 +360,8 @@ template <typename T, int MODE> __global__ __launch_bounds__(256) void bn_act_fw
 						for (int k = 0; k < 8; ++k) gate |= act_grad(pre[k], ac) != 0.f ? (1u << k) : 0u;
 					}
 				}
-				store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
+				if constexpr (SPLIT == 0) store8<T>(reinterpret_cast<T*>(p.out) + w.idx, out);
+				else split3_store8<typename PlaneType<SPLIT>::H>(reinterpret_cast<typename PlaneType<SPLIT>::H*>(p.out) + 3 * w.idx - 2 * c, p.C, 0, out);  // (row * 3 C + c)
 				if (GATE) p.gate_out[w.idx >> 3] = (uint8_t)gate;
 			});
 	}
@@ -384,9 +389,9 @@ static unsigned ew_grid(int64_t total) {
 
 #define BN_ROWS_PER_THREAD 8
 
-extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
-                                  const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
-                                  uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C, uint8_t* gate, void* stream) {
+static int bn_act_fwd_impl(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
+                           const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
+                           uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C, uint8_t* gate, int plane_dtype, void* stream) {
 	CONVASR_CHECK_ARG(y && z && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_fwd: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG(!gate || act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE, "bn_act_fwd: the one-bit gate needs an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr) && dropout_p >= 0.f && dropout_p < 1.f, "bn_act_fwd: bad scale/shift/dropout");
@@ -401,6 +406,18 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
 	if (dtype != CONVASR_F32 && !convasr_is_half(dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd: dtype %d", dtype);
 	const int mode = (n_res > 0 ? 1 : 0) | (p.drop_thr ? 2 : 0) | (gate ? 4 : 0) | (scale ? 8 : 0) | (act == CONVASR_ACT_LEAKY_RELU ? 16 : 0);
+	if (plane_dtype >= 0) {
+		// plane output: fp32 in, the training launches only (BN scale / shift present, a clamp-type activation)
+		if (dtype != CONVASR_F32 || !convasr_is_half(plane_dtype) || mode < 8 || mode > 15) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_fwd_split3: fp32 input with scale / shift and a clamp-type activation only (mode %d)", mode);
+#define BN_FWD_SPLIT_CASE(M) case M: \
+		if (plane_dtype == CONVASR_BF16) hipLaunchKernelGGL((bn_act_fwd_kernel<float, M, 1>), grid, block, 0, (hipStream_t)stream, p, ra); \
+		else hipLaunchKernelGGL((bn_act_fwd_kernel<float, M, 2>), grid, block, 0, (hipStream_t)stream, p, ra); \
+		break;
+		switch (mode) { BN_FWD_SPLIT_CASE(8) BN_FWD_SPLIT_CASE(9) BN_FWD_SPLIT_CASE(10) BN_FWD_SPLIT_CASE(11) BN_FWD_SPLIT_CASE(12) BN_FWD_SPLIT_CASE(13) BN_FWD_SPLIT_CASE(14) BN_FWD_SPLIT_CASE(15) }
+#undef BN_FWD_SPLIT_CASE
+		CONVASR_CHECK_LAUNCH("bn_act_fwd_split3");
+		return 0;
+	}
 #define BN_FWD_CASE(M) case M: \
 		if (dtype == CONVASR_F32) hipLaunchKernelGGL((bn_act_fwd_kernel<float, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
 		else if (dtype == CONVASR_F16) hipLaunchKernelGGL((bn_act_fwd_kernel<f16_t, M>), grid, block, 0, (hipStream_t)stream, p, ra); \
@@ -414,6 +431,18 @@ extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float
 #undef BN_FWD_CASE
 	CONVASR_CHECK_LAUNCH("bn_act_fwd");
 	return 0;
+}
+
+extern "C" int convasr_bn_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n_res, const void* const* res,
+                                  const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
+                                  uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C, uint8_t* gate, void* stream) {
+	return bn_act_fwd_impl(y, z, dtype, scale, shift, n_res, res, rscale, rshift, act, act_lo, act_hi, dropout_p, seed, offset, step_key, xlen, B, T, C, gate, -1, stream);
+}
+
+extern "C" int convasr_bn_act_fwd_split3(const void* y, void* z3, int plane_dtype, const float* scale, const float* shift, int n_res, const void* const* res,
+                                         const float* const* rscale, const float* const* rshift, int act, float act_lo, float act_hi, float dropout_p,
+                                         uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C, uint8_t* gate, void* stream) {
+	return bn_act_fwd_impl(y, z3, CONVASR_F32, scale, shift, n_res, res, rscale, rshift, act, act_lo, act_hi, dropout_p, seed, offset, step_key, xlen, B, T, C, gate, plane_dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ backward pass 1: g and channel sums
@@ -948,7 +977,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // dy = A[c] * g + Bc[c] * y + D[c] with g either given (FROM_DZ = false) or recomputed from dz: g = dz * act'(pre) * dropout * mask
 // SRC 0: g given; 1: g re-derived from dz (act', dropout hash, frame mask); 2: g = dz gated by the forward pass's stored bits (compile-time:
 // the gated form carries none of the re-derivation's registers -- 95 -> ~50 VGPRs -- or code)
-template <typename T, int SRC> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {
+template <typename T, int SRC, int SPLIT = 0> __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnActParams p, const float* __restrict__ coef, T* __restrict__ dy) {  // (SPLIT: dy as its 16-bit planes, order 1 = an output gradient: see bn_act_fwd_kernel)
 	constexpr bool FROM_DZ = SRC != 0, GATED = SRC == 2;
 	if (FROM_DZ && !GATED) fold_step_key(p);
 	const ActConst ac = act_const(p.act, p.lo, p.hi);  // the activation kind folded into constants once: no per-element switch
@@ -1002,14 +1031,15 @@ template <typename T, int SRC> __global__ __launch_bounds__(256) void bn_act_bwd
 				}
 #pragma unroll
 				for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
-				store8<T>(dy + w.idx, out);
+				if constexpr (SPLIT == 0) store8<T>(dy + w.idx, out);
+				else split3_store8<typename PlaneType<SPLIT>::H>(reinterpret_cast<typename PlaneType<SPLIT>::H*>(dy) + 3 * w.idx - 2 * c, p.C, 1, out);
 			});
 	}
 }
 
-extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
-                                        const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                                        const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
+static int bn_act_bwd_apply_impl(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
+                                 const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                 const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, int plane_dtype, void* stream) {
 	CONVASR_CHECK_ARG(dz_or_g && y && dy && coef && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_apply: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG(!gate || (from_dz && (act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE)), "bn_act_bwd_apply: the one-bit gate needs from_dz and an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_apply: B * T must fit in 31 bits");
@@ -1020,12 +1050,35 @@ extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void
 	dim3 grid, block;
 	row_walk_config(p, BN_ROWS_PER_THREAD, grid, block);
 	hipStream_t s = (hipStream_t)stream;
+	if (plane_dtype >= 0) {
+		if (dtype != CONVASR_F32 || !convasr_is_half(plane_dtype)) return convasr_fail(CONVASR_EUNSUPPORTED, "bn_act_bwd_apply_split3: fp32 input, bf16 / fp16 planes");
+#define BN_APPLY_SPLIT(S) \
+		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 2, S>), grid, block, 0, s, p, coef, (float*)dy); \
+		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 1, S>), grid, block, 0, s, p, coef, (float*)dy); \
+		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 0, S>), grid, block, 0, s, p, coef, (float*)dy);
+		if (plane_dtype == CONVASR_BF16) { BN_APPLY_SPLIT(1) } else { BN_APPLY_SPLIT(2) }
+#undef BN_APPLY_SPLIT
+		CONVASR_CHECK_LAUNCH("bn_act_bwd_apply_split3");
+		return 0;
+	}
 	BN_DISPATCH("bn_act_bwd_apply", dtype, T,
 		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 2>), grid, block, 0, s, p, coef, (T*)dy);
 		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 1>), grid, block, 0, s, p, coef, (T*)dy);
 		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, 0>), grid, block, 0, s, p, coef, (T*)dy));
 	CONVASR_CHECK_LAUNCH("bn_act_bwd_apply");
 	return 0;
+}
+
+extern "C" int convasr_bn_act_bwd_apply(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
+                                        const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                        const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
+	return bn_act_bwd_apply_impl(dz_or_g, y, dy, dtype, coef, from_dz, scale, shift, act, act_lo, act_hi, dropout_p, seed, offset, step_key, xlen, B, T, C, gate, -1, stream);
+}
+
+extern "C" int convasr_bn_act_bwd_apply_split3(const void* dz_or_g, const void* y, void* dy3, int plane_dtype, const float* coef, int from_dz, const float* scale,
+                                               const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                               const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
+	return bn_act_bwd_apply_impl(dz_or_g, y, dy3, CONVASR_F32, coef, from_dz, scale, shift, act, act_lo, act_hi, dropout_p, seed, offset, step_key, xlen, B, T, C, gate, plane_dtype, stream);
 }
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int accumulate) {

@@ -27,6 +27,17 @@ static inline void convasr_allow_160k_lds(const void* kern, unsigned long long& 
 	if (!(mask & bit)) { (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); mask |= bit; }
 }
 
+// Compute units of the CURRENT device, cached per device ordinal (one process may drive several GPUs; a process-wide cache would hand the
+// second device the first one's count).
+static inline int convasr_cu_count() {
+	static int cached[64] = {};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	int& n = cached[dev & 63];
+	if (!n && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)) n = 256;
+	return n;
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 // round-to-nearest-even; NaN stays NaN (a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
@@ -87,6 +98,20 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 }
 template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&v)[8]) {
 	*reinterpret_cast<uint4*>(p) = make_uint4(pack16<f16_t>(v[0], v[1]), pack16<f16_t>(v[2], v[3]), pack16<f16_t>(v[4], v[5]), pack16<f16_t>(v[6], v[7]));
+}
+
+// Split-operand planes (csrc/split3.hip): 8 consecutive fp32 values -> their hi / lo 16-bit planes at out[0 .. 8), out[C .. C + 8), out[2 C .. 2 C + 8)
+// (out = &planes[row][0][c]); order 0 = (hi, lo, hi) for a conv input, 1 = (hi, hi, lo) for an output gradient.  lo = rn16(v - hi), v - hi exact.
+template <typename H> __device__ __forceinline__ void split3_store8(H* out, int C, int order, const float (&v)[8]) {
+	float hi[8], lo[8];
+	const uint4 ph = make_uint4(pack16<H>(v[0], v[1]), pack16<H>(v[2], v[3]), pack16<H>(v[4], v[5]), pack16<H>(v[6], v[7]));
+	unpack16<H>(ph, hi);
+#pragma unroll
+	for (int k = 0; k < 8; ++k) lo[k] = v[k] - hi[k];
+	const uint4 pl = make_uint4(pack16<H>(lo[0], lo[1]), pack16<H>(lo[2], lo[3]), pack16<H>(lo[4], lo[5]), pack16<H>(lo[6], lo[7]));
+	*reinterpret_cast<uint4*>(out) = ph;
+	*reinterpret_cast<uint4*>(out + C) = order == 0 ? pl : ph;
+	*reinterpret_cast<uint4*>(out + 2 * C) = order == 0 ? ph : pl;
 }
 
 // Run `fn` with a value of the 16-bit storage type a CONVASR_* dtype code names (callers have checked that it is one of the two).

@@ -551,8 +551,7 @@ template <typename I, int BM_> static const void* v2s_kernel(int ki) {
 // register-staged kernel).  x_dtype: CONVASR_BF16 or CONVASR_F16; y_dtype: the same, or CONVASR_F32 (the decoder head).
 int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out) {
 	if (p.stride != 1 || (p.Cin & 63) != 0 || !convasr_is_half(x_dtype) || (y_dtype != x_dtype && y_dtype != CONVASR_F32)) return 0;
-	static int n_cu = 0;
-	if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+	const int n_cu = convasr_cu_count();  // (per device ordinal: common.h)
 	// Tile height: 256 rows.  A 192-row build of the same kernel (BM_ = 192: 256 x n tiles for 64 x 751 frames = whole rounds on 256
 	// CUs instead of 1.5 n) was measured layer by layer in one process (scratch/ab_bm.py, profiles/r03_ab_tile_height.json): 3-5 %
 	// faster only on the 384-channel layers (2.25 rounds), 5-8 % SLOWER on every layer from 512 channels up -- a partial last round costs

@@ -36,7 +36,7 @@
 #define CTC_SPIN_LIMIT (1 << 22) // a consumer never spins this long unless the producer died: give up (the loss becomes NaN) rather than hang
 #endif
 // Diagnostic build only (python -m convasr_amd.build --variant ctcskip -DCONVASR_CTC_SKIP_PUBLISH=100 -DCTC_SPIN_LIMIT=65536;
-// tests/test_round4_gpu.py): the producing wave of every sweep "dies" at that frame -- it never publishes the frame's edge states -- so that
+// tests/test_training_features_gpu.py): the producing wave of every sweep "dies" at that frame -- it never publishes the frame's edge states -- so that
 // the consumer's give-up path runs: the loss of every utterance long enough must come out NaN, and the launch must end.
 
 // base-2 log-sum-exp of three / two values >= the sentinel.  The largest term is exp2(0) = 1 exactly, so only the other terms go

@@ -387,6 +387,29 @@ extern "C" int convasr_add16(const void* a, const void* b, void* out, int64_t n,
 	return 0;
 }
 
+// dst[i] = (D)(src[i] * scale) over n elements (n % 8 == 0), fp32 <-> 16-bit: the two ends of a 16-bit gradient exchange
+template <typename S, typename D> __global__ __launch_bounds__(256) void cast_scale_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n8, float scale) {
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+		float v[8];
+		load8<S>(src + (i << 3), v);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] *= scale;
+		store8<D>(dst + (i << 3), v);
+	}
+}
+
+extern "C" int convasr_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale, void* stream) {
+	CONVASR_CHECK_ARG(src && dst && n > 0 && (n & 7) == 0 && ((src_dtype == CONVASR_F32 && convasr_is_half(dst_dtype)) || (convasr_is_half(src_dtype) && dst_dtype == CONVASR_F32)), "cast_scale: n %% 8 == 0, fp32 -> bf16 / fp16 or back");
+	int64_t blocks = ceil_div64(n >> 3, 256);
+	if (blocks > 8192) blocks = 8192;
+	const dim3 g((unsigned)blocks), b(256);
+	hipStream_t s = (hipStream_t)stream;
+	if (src_dtype == CONVASR_F32) CONVASR_DISPATCH_HALF(dst_dtype, H, hipLaunchKernelGGL((cast_scale_kernel<float, H>), g, b, 0, s, (const float*)src, (H*)dst, n >> 3, scale));
+	else CONVASR_DISPATCH_HALF(src_dtype, H, hipLaunchKernelGGL((cast_scale_kernel<H, float>), g, b, 0, s, (const H*)src, (float*)dst, n >> 3, scale));
+	CONVASR_CHECK_LAUNCH("cast_scale");
+	return 0;
+}
+
 extern "C" int convasr_copy(const void* src, void* dst, int64_t nbytes, void* stream) {
 	CONVASR_CHECK_ARG(src && dst && nbytes >= 0, "copy: bad arguments");
 	if (nbytes == 0) return 0;

@@ -24,25 +24,9 @@ template <typename H> __global__ __launch_bounds__(256) void split3_kernel(const
 	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
 		const int64_t r = i / c8;
 		const int c = (int)(i - r * c8) << 3;
-		float v[8], hi[8], lo[8];
+		float v[8];
 		load8<float>(x + r * C + c, v);
-		uint4 ph, pl;
-		unsigned wh[4], wl[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			wh[k] = pack16<H>(v[2 * k], v[2 * k + 1]);
-		}
-		ph = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-		unpack16<H>(ph, hi);
-#pragma unroll
-		for (int k = 0; k < 8; ++k) lo[k] = v[k] - hi[k];  // exact: hi is v rounded to fewer bits
-#pragma unroll
-		for (int k = 0; k < 4; ++k) wl[k] = pack16<H>(lo[2 * k], lo[2 * k + 1]);
-		pl = make_uint4(wl[0], wl[1], wl[2], wl[3]);
-		H* const o = out + r * 3 * C + c;
-		*reinterpret_cast<uint4*>(o) = ph;
-		*reinterpret_cast<uint4*>(o + C) = order == 0 ? pl : ph;
-		*reinterpret_cast<uint4*>(o + 2 * C) = order == 0 ? ph : pl;
+		split3_store8<H>(out + r * 3 * C + c, C, order, v);
 	}
 }
 

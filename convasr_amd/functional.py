@@ -115,6 +115,30 @@ def split_weight(w, dtype):
 	return ent['fwd'], ent['dgr']
 
 
+_PLANES_ATTR = '_convasr_planes_only'
+_nan_cells = {}
+
+
+def _planes_placeholder(z3, B, C, T):
+	"""What a layer whose output exists as split-operand planes only (cfg['planes_out']) hands to autograd: a (B, C, T) fp32 tensor of the
+	output's logical shape -- the consumer's dgrad returns a gradient of exactly that shape -- with NO memory behind it (a stride-0 view of one
+	NaN) and the planes hanging on it.  The one reader the network wired behind the layer takes the planes off it (_take_planes); ops.as_cl
+	refuses it, and any other arithmetic on it yields NaN rather than plausible numbers."""
+	dev = z3.device
+	cell = _nan_cells.get(dev)
+	if cell is None:
+		cell = _nan_cells[dev] = torch.full((1, ), float('nan'), dtype = torch.float32, device = dev)
+	z = cell.as_strided((B, C, T), (0, 0, 0))
+	setattr(z, _PLANES_ATTR, z3)
+	return z
+
+
+def _take_planes(x):
+	"""Remove and return the split-operand planes the producer of `x` left on its placeholder (None for an ordinary tensor)."""
+	d = getattr(x, '__dict__', None)
+	return d.pop(_PLANES_ATTR, None) if d else None
+
+
 def split_applies(split, dt, spec, Cin, Cout):
 	"""Does a conv of this geometry run as a split-operand conv?  fp32 storage with a 16-bit plane type set, stride 1 and channel counts
 	inside the LDS-DMA kernels' envelope (3 Cin % 64 == 0; the weight gradient's 128-channel tiles take Cin, Cout % 128 == 0 and fall back to the
@@ -527,13 +551,17 @@ class ConvBnActFunction(torch.autograd.Function):
 	def forward(ctx, cfg, x, weight, gamma, beta, xlen, *flat_res):
 		spec, dt = cfg['spec'], cfg['compute_dtype']
 		ctx.producer_link = _take_link(x)
-		x = ops.as_cl(x, dt)
+		planes = _take_planes(x)  # the producer wrote its output as split-operand planes only: x itself is a placeholder of the logical shape
+		if planes is None:
+			x = ops.as_cl(x, dt)
 		B, Cin, Tin = x.shape
 		Cout = weight.shape[0]
 		dev = x.device
 		act = cfg['act']
 		xl = ops.xlen_f32(xlen, dev) if (cfg['temporal_mask'] and xlen is not None) else None
 		n_res = len(flat_res) // 5
+		if planes is not None and not (split_applies(cfg.get('split'), dt, spec, Cin, Cout) and planes.dtype == cfg['split'] and tuple(planes.shape) == (B, 3 * Cin, Tin)):
+			raise _lib.ConvasrHipError('a layer output that exists as split-operand planes only reached a conv that does not run as a split conv (models.ConvBn1d._planes_out and this layer disagree)')
 
 		bn = cfg['bn']
 		stats = _stats_buffer(bn, Cout, dev, B, ops.conv_out_len(Tin, spec.K, spec.stride, spec.dilation, spec.padding))
@@ -548,7 +576,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			# split-operand conv (csrc/split3.hip): the fp32 input as three 16-bit planes per frame, read by the LDS-DMA kernel as 3 Cin channels;
 			# the planes, not x, are what backward keeps (the weight gradient reads the same memory as 3 Tin frames of Cin channels)
 			ctx.split = cfg['split']
-			x = ops.split3(x, ctx.split, ops.SPLIT_INPUT)
+			x = planes if planes is not None else ops.split3(x, ctx.split, ops.SPLIT_INPUT)
 			y = ops.conv1d(x, split_weight(weight, ctx.split)[0], Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, stats = stats, work = 2.0 * B * ops.conv_out_len(Tin, spec.K, 1, spec.dilation, spec.padding) * Cout * Cin * spec.K, family = SPLIT_FAMILY)
 		else:
 			y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
@@ -600,7 +628,12 @@ class ConvBnActFunction(torch.autograd.Function):
 		gate = None
 		if GATE_BITS and (n_res == 0 or (GROUP_RES and dt in ops.HALF_DTYPES and 1 + len(branches) <= 13)) and act[0] in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_HARDTANH) and Cout % 8 == 0 and (weight.requires_grad or x_needs_grad or gamma.requires_grad):  # (a layer with residual inputs: its backward then needs none of them to re-derive the pre-activation, functional 'reduce_many')
 			gate = torch.empty(B * Tout * Cout // 8, dtype = torch.uint8, device = dev)
-		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, gate = gate, step_key = skey)
+		# planes_out (models.ConvBn1d._planes_out: the one reader of this output is a split conv): the activation pass writes the output's three
+		# 16-bit planes and nothing else -- no fp32 z, no split pass in the consumer (4 + 4 + 6 bytes per element of traffic become 6)
+		planes_out = bool(cfg.get('planes_out')) and cfg.get('split') is not None and dt == torch.float32 and Cout % 8 == 0 and act[0] != _lib.ACT_LEAKY_RELU
+		z = ops.bn_act(y, bnp[2], bnp[3], act, xlen = xl, res = res_y, rscale = [None if p is None else p[2] for p in res_bnp], rshift = [None if p is None else p[3] for p in res_bnp], dropout_p = p_drop, seed = seed, offset = offset, gate = gate, step_key = skey, planes = cfg['split'] if planes_out else None)
+		if planes_out:
+			z = _planes_placeholder(z, B, Cout, Tout)
 		ctx.gate = gate
 
 		ctx.cfg, ctx.n_res, ctx.drop = cfg, n_res, (p_drop, seed, offset, skey)
@@ -654,7 +687,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				finalize([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey, planes = ctx.split)
 			g = rsum_of = None
 		elif n_res == 0:
 			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
@@ -666,7 +699,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				reduce([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey, planes = ctx.split)  # (a split-operand conv: dy straight into its planes)
 			g = rsum_of = None
 		else:
 			bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
@@ -718,7 +751,8 @@ class ConvBnActFunction(torch.autograd.Function):
 		if ctx.split is not None:
 			# split-operand conv: dy as its three planes (hi, hi, lo) once, for both gradients; the weight gradient pairs plane p of x with plane p of
 			# dy by reading both plane tensors as 3 T frames of C channels with the conv's dilation and padding tripled
-			dy = ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
+			if dy.dtype == torch.float32:  # (the residual forms of the BN backward deliver fp32; the residual-free one wrote the planes itself)
+				dy = ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
 			xf, dyf = ops.split3_frames(x), ops.split3_frames(dy)
 			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(xf, dyf, Cout, spec.K, 1, 3 * spec.dilation, 3 * spec.padding, outs[0], accumulate = acc, work = 2.0 * B * Tout * Cout * weight.shape[1] * spec.K, family = SPLIT_WGRAD_FAMILY))
 		elif ctx.fold is not None:

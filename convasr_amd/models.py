@@ -11,7 +11,9 @@ Activations flow between modules as (B, C, T) tensors whose memory is channels-l
 handed back to the caller (logits, log_probs) keep that logical (B, C, T) shape.  There is no CPU implementation here.
 """
 import math
+import os
 import typing
+import weakref
 
 import numpy as np
 import torch
@@ -27,10 +29,12 @@ FP16_TINY = float(torch.finfo(torch.float16).tiny)
 # ------------------------------------------------------------------------------------------------ helpers (models.py:611-733)
 
 def compute_output_lengths(x, lengths_fraction = None):
-	"""models.py:611-614.  Host-side integer bookkeeping on a (B,) vector."""
+	"""models.py:611-614: valid frames per utterance of x's time axis, int64 (B,) = ceil(fraction * T) evaluated in the fraction's own
+	floating type; every utterance is T frames long when no fractions are given.  (The network itself calls ops.output_lengths: one launch.)"""
+	B, T = x.shape[0], x.shape[-1]
 	if lengths_fraction is None:
-		return torch.full(x.shape[:1], x.shape[-1], device = x.device, dtype = torch.long)
-	return (lengths_fraction * x.shape[-1]).ceil().long()
+		return torch.full((B, ), T, dtype = torch.int64, device = x.device)
+	return torch.ceil(lengths_fraction * T).to(torch.int64)
 
 
 def temporal_mask(x, lengths):
@@ -59,13 +63,17 @@ def master_module(model):
 
 
 def reset_bn_running_stats_(model):
-	"""models.py:726-733."""
-	for bn in [m for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]:
-		nn.init.zeros_(bn.running_mean)
-		nn.init.ones_(bn.running_var)
-		nn.init.zeros_(bn.num_batches_tracked)
-		bn.momentum = None
-		bn.train()
+	"""models.py:726-733: every batch norm back to mean 0 / variance 1 / zero batches seen, switched to the cumulative moving average
+	(momentum None) and to training mode -- the preparation of the reference's statistics re-estimation pass."""
+	for m in model.modules():
+		if not isinstance(m, nn.modules.batchnorm._BatchNorm):
+			continue
+		with torch.no_grad():
+			m.running_mean.fill_(0.0)
+			m.running_var.fill_(1.0)
+			m.num_batches_tracked.fill_(0)
+		m.momentum = None
+		m.train()
 	return model
 
 
@@ -246,10 +254,29 @@ class ConvBn1d(nn.Module):
 		self.split_dtype = None  # bf16 / fp16: the convs of an fp32 network run as split-operand MFMA convs (JasperNet.set_compute_dtype('bf16x3'))
 		self.tapped_output = False  # set by the network when later blocks take this block's output as a residual input: its gradient then has an accumulator the tapping blocks write into (functional.ConvBnActFunction, GRAD_ACC)
 		self.single_consumer_output = False  # set by the network when this block's output feeds exactly one conv (no residual taps): enables cross-layer backward fusion
+		self.feeds_block = None  # set by the network: weakref to the ConvBn1d whose first conv is the ONLY reader of this block's output (None: the decoder, several readers, or unknown)
+
+	def _planes_out(self, i, last):
+		"""Does repeat i hand its output on as split-operand planes only (functional.ConvBnActFunction, `planes_out`)?  Yes when the network runs
+		split convs, a gradient is wanted, and the ONE reader of that output is a split-eligible conv: the next repeat of this block, or the first
+		conv of the block the network wired behind this one (feeds_block)."""
+		if self.split_dtype is None or not (self.training and torch.is_grad_enabled()) or os.environ.get('CONVASR_NO_PLANES_OUT') == '1':
+			return False
+		if not last:
+			nxt = self.conv[i + 1]
+		else:
+			blk = self.feeds_block() if (self.feeds_block is not None and self.single_consumer_output) else None
+			if blk is None or not blk.training or blk.split_dtype != self.split_dtype or not isinstance(blk.bn[0], nn.BatchNorm1d) or not blk.bn[0].training:
+				return False
+			nxt = blk.conv[0]
+		if nxt.separable or not isinstance(nxt[-1], nn.Conv1d):
+			return False
+		c = nxt[-1]
+		return Fn.split_applies(self.split_dtype, self.compute_dtype, _spec_of(c), c.in_channels, c.out_channels) and c.in_channels == self.conv[i][-1].out_channels
 
 	def _cfg(self, i, last):
 		conv, bn = self.conv[i][-1], self.bn[i]
-		return dict(spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
+		return dict(planes_out = self._planes_out(i, last), spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
 
 	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
 		_lib.require_cuda(x)
@@ -305,15 +332,16 @@ class ConvBn1d(nn.Module):
 		return x
 
 	def fuse_conv_bn_eval(self):
-		"""models.py:141-151: fold BN running statistics into the conv weights / bias (inference)."""
-		for i in range(len(self.conv_residual)):
-			conv, bn = self.conv_residual[i], self.bn_residual[i]
-			if not isinstance(conv, nn.Identity) and not isinstance(bn, nn.Identity):
-				self.conv_residual[i] = nn.utils.fusion.fuse_conv_bn_eval(conv, bn)
-				self.bn_residual[i] = nn.Identity()
-		for i in range(len(self.conv)):
-			self.conv[i][-1] = nn.utils.fusion.fuse_conv_bn_eval(self.conv[i][-1], self.bn[i])
-			self.bn[i] = nn.Identity()
+		"""models.py:141-151: fold BN running statistics into the conv weights / bias (inference): every (conv, batch norm) pair of the block --
+		the repeats' last convs and the 1x1 residual branches -- becomes one conv with a bias, the batch norm an nn.Identity (same module
+		slots, so state-dict keys of what remains are the reference's)."""
+		fold = nn.utils.fusion.fuse_conv_bn_eval
+		for r, (rc, rbn) in enumerate(zip(self.conv_residual, self.bn_residual)):
+			if isinstance(rc, nn.Identity) or isinstance(rbn, nn.Identity):
+				continue  # an identity residual, or a branch folded earlier
+			self.conv_residual[r], self.bn_residual[r] = fold(rc, rbn), nn.Identity()
+		for r, (seq, bn) in enumerate(zip(self.conv, self.bn)):
+			seq[-1], self.bn[r] = fold(seq[-1], bn), nn.Identity()
 		Fn.invalidate_pack_cache()
 
 
@@ -386,6 +414,7 @@ class JasperNet(nn.Module):
 			tapped = bool(residual) and i < len(self.backbone) - self.num_epilogue_modules - 1
 			blk.single_consumer_output = (not tapped) and (i < len(self.backbone) - 1 or len(num_classes) == 1)
 			blk.tapped_output = tapped
+			blk.feeds_block = weakref.ref(self.backbone[i + 1]) if (not tapped and i < len(self.backbone) - 1) else None  # (a weak reference: a plain attribute would register the block twice)
 		self.set_compute_dtype(compute_dtype)
 
 	SPLIT_DTYPES = {'bf16x3': torch.bfloat16, 'f16x3': torch.float16}
@@ -461,13 +490,19 @@ class JasperNet(nn.Module):
 		return self.dict(logits = logits, log_probs = log_probs, olen = olen, **aux)
 
 	def freeze(self, backbone = 0, decoder0 = False, frontend = False):
-		"""models.py:328-339."""
-		frozen = (list(self.backbone[:backbone]) if backbone else []) + (list(self.decoder)[:1] if decoder0 else []) + ([self.frontend] if frontend and self.frontend is not None else [])
-		for m in frozen:
-			for module in filter(lambda module: isinstance(module, nn.modules.batchnorm._BatchNorm), m.modules()):
-				module.eval()
-				module.train = lambda training: None
-			for p in m.parameters():
+		"""models.py:328-339: the first `backbone` blocks, the first decoder head and / or the frontend stop learning -- their parameters
+		take no gradient and their batch norms are pinned to evaluation mode (a later model.train() does not wake them: train() becomes a no-op)."""
+		targets = list(self.backbone[:backbone]) if backbone else []
+		if decoder0:
+			targets.append(self.decoder[0])
+		if frontend and self.frontend is not None:
+			targets.append(self.frontend)
+		for part in targets:
+			for bn in part.modules():
+				if isinstance(bn, nn.modules.batchnorm._BatchNorm):
+					bn.eval()
+					bn.train = lambda training: None
+			for p in part.parameters():
 				p.requires_grad = False
 
 	def fuse_conv_bn_eval(self, K = None):

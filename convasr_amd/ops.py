@@ -55,6 +55,8 @@ def convert(x, dtype, channels_last):
 
 
 def as_cl(x, dtype = None):
+	if x.__dict__.get('_convasr_planes_only') is not None:
+		raise _lib.ConvasrHipError('this tensor is the placeholder of a layer output that exists as split-operand planes only (functional.ConvBnActFunction, planes_out): its values were never written -- only the split conv the network wired behind the layer may consume it (set CONVASR_NO_PLANES_OUT=1 to get real fp32 outputs)')
 	dtype = dtype or x.dtype
 	if x.dtype == dtype and is_cl(x):
 		return x
@@ -521,12 +523,19 @@ def _ptr_array(items):
 	return arr
 
 
-def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None):
+def bn_act(y, scale, shift, act, xlen = None, res = (), rscale = (), rshift = (), dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None, planes = None):
 	"""gate (optional uint8 (B*T*C/8,)): receives one bit per element, set iff the gradient passes it (include/convasr_hip.h).
-	step_key (optional, here and in the backward passes): device address (int) of the per-step dropout key word (functional.begin_step)."""
+	step_key (optional, here and in the backward passes): device address (int) of the per-step dropout key word (functional.begin_step).
+	planes (a 16-bit dtype; fp32 y with scale / shift and a clamp-type activation): the result is returned as its split-operand planes, the
+	(B, 3 C, T) tensor split3(z, planes, SPLIT_INPUT) would produce, written by this pass itself."""
 	B, C, T = y.shape
 	assert gate is None or (gate.dtype == torch.uint8 and gate.numel() * 8 == B * C * T and gate.is_contiguous())
 	assert is_cl(y) and all(is_cl(r) and r.dtype == y.dtype for r in res)
+	if planes is not None:
+		assert y.dtype == torch.float32 and planes in HALF_DTYPES and out is None and scale is not None and act[0] != _lib.ACT_LEAKY_RELU
+		z3 = empty_cl(B, 3 * C, T, planes, y.device)
+		_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd_split3', ptr(y), ptr(z3), dtype_code(planes), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * (10 + 4 * len(res))))
+		return z3
 	z = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
 	_lib.timed('hbm:bn_act_fwd_kernel', 0.0, lambda: call('convasr_bn_act_fwd', ptr(y), ptr(z), dtype_code(y.dtype), ptr(scale), ptr(shift), len(res), _ptr_array(res), _ptr_array(rscale) if rscale else None, _ptr_array(rshift) if rshift else None, act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * (2 + len(res))))
 	return z
@@ -548,8 +557,15 @@ def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res =
 	return g
 
 
-def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None):
+def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None, planes = None):
+	"""planes (a 16-bit dtype, fp32 inputs only): dy is returned as its split-operand planes, the (B, 3 C, T) tensor split3(dy, planes, SPLIT_GRAD)
+	would produce -- written by this pass itself."""
 	B, C, T = y.shape
+	if planes is not None:
+		assert y.dtype == torch.float32 and planes in HALF_DTYPES and out is None
+		dy3 = empty_cl(B, 3 * C, T, planes, y.device)
+		_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply_split3', ptr(dz_or_g), ptr(y), ptr(dy3), dtype_code(planes), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * 14))
+		return dy3
 	dy = out if out is not None else empty_cl(B, C, T, y.dtype, y.device)
 	_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply', ptr(dz_or_g), ptr(y), ptr(dy), dtype_code(y.dtype), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * y.element_size() * 3))
 	return dy

@@ -26,7 +26,7 @@ from .train import FlatParameters
 XGMI_LINK_GBS_PER_DIRECTION = 76.8  # MI355X: 7 xGMI links per GPU, ~153.6 GB/s each bidirectional (one link to every peer of an 8-GPU node)
 
 
-def predict_exposed_comm(params_numel, offsets, buckets, world, step_ms, link_gbs = XGMI_LINK_GBS_PER_DIRECTION, efficiency = 0.7, latency_us = 40.0, forward_share = 0.33, tail_share = 0.04):
+def predict_exposed_comm(params_numel, offsets, buckets, world, step_ms, link_gbs = XGMI_LINK_GBS_PER_DIRECTION, efficiency = 0.7, latency_us = 40.0, forward_share = 0.33, tail_share = 0.04, bytes_per_element = 4):
 	"""A prediction the first multi-GPU run can be wrong about (no curve has been measured: one GPU per box on this pool).
 
 	Model.  The backward pass produces gradients from the END of the arena to its start; its time is apportioned to the parameters by
@@ -44,19 +44,24 @@ def predict_exposed_comm(params_numel, offsets, buckets, world, step_ms, link_gb
 	for b in sorted(buckets, key = lambda b: -b['lo']):  # completion order: from the end of the arena
 		above = sum(n for n, o in zip(params_numel, offsets) if o >= b['lo'])
 		ready = t_fwd + (t_bwd_end - t_fwd) * above / total
-		nbytes = (b['hi'] - b['lo']) * 4
+		nbytes = (b['hi'] - b['lo']) * bytes_per_element  # (2 with a 16-bit exchange: DataParallelEngine(grad_comm_dtype))
 		t = 0.0 if world <= 1 else 2.0 * (nbytes / world) / (efficiency * link_gbs * 1e9) * 1e3 + latency_us * 1e-3
 		start = max(ready, t_free)
 		t_free = start + t
 		rows.append(dict(mib = round(nbytes / 2 ** 20, 1), ready_ms = round(ready, 3), start_ms = round(start, 3), comm_ms = round(t, 3), end_ms = round(t_free, 3)))
 	return dict(exposed_comm_ms = round(max(0.0, t_free - t_bwd_end), 3), comm_ms_total = round(sum(r['comm_ms'] for r in rows), 3), backward_end_ms = round(t_bwd_end, 3), step_ms = round(step_ms, 3),
-		world = world, link_gbs_per_direction = link_gbs, efficiency = efficiency, latency_us = latency_us, per_bucket = rows,
+		world = world, link_gbs_per_direction = link_gbs, efficiency = efficiency, latency_us = latency_us, bytes_per_element = bytes_per_element, per_bucket = rows,
 		predicted_scaling = None if world <= 1 else round(world * step_ms / (step_ms + max(0.0, t_free - t_bwd_end)), 3),
 		model = 'direct reduce-scatter + all-gather over one xGMI link per peer; bucket ready times from the backward pass apportioned by parameter counts; serial collectives on the communication stream (convasr_amd.parallel.predict_exposed_comm)')
 
 
 class DataParallelEngine(nn.Module):
-	def __init__(self, module, device = None, bucket_bytes = int(os.environ.get('CONVASR_BUCKET_MIB', 64)) << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True, comm_thread = os.environ.get('CONVASR_COMM_THREAD', '0') == '1', measure_exposed_comm = False):
+	def __init__(self, module, device = None, bucket_bytes = int(os.environ.get('CONVASR_BUCKET_MIB', 64)) << 20, process_group = None, flat = None, force_collectives = False, first_bucket_bytes = 4 << 20, fold_mean = True, comm_thread = os.environ.get('CONVASR_COMM_THREAD', '0') == '1', measure_exposed_comm = False, grad_comm_dtype = os.environ.get('CONVASR_GRAD_COMM', 'auto')):
+		"""grad_comm_dtype: what the gradient buckets travel as.  None / 'f32': the fp32 arena itself (in place).  torch.float16 / torch.bfloat16
+		(or 'f16' / 'bf16'): every bucket is packed into a persistent 16-bit send buffer (x 1 / world size: the mean is formed before the sum),
+		all-reduced at half the bytes and unpacked into the arena, all on the communication stream -- what the reference does under apex O2,
+		whose model gradients ARE fp16 (models.py:744-762, train.py:771).  'auto' (default): fp16 when the module computes in fp16 (opt_level
+		O1-O3), fp32 otherwise (bf16's 8 significant bits are not spent on gradients unless asked for)."""
 		super().__init__()
 		self.module = module
 		self.group = process_group
@@ -77,6 +82,9 @@ class DataParallelEngine(nn.Module):
 		self._comm_stream = None  # collectives are issued from here, ordered after BOTH the main stream and the side (wgrad) stream
 		self.fold_mean = fold_mean  # True: the 1 / world_size of the gradient mean rides in the optimizer kernel (flat.grad_scale) instead of a pass over the arena
 		self.sync = True  # False inside no_sync(): gradients accumulate locally, nothing is launched (gradient accumulation)
+		self.grad_comm_dtype = {None: None, 'f32': None, 'auto': 'auto', 'f16': torch.float16, 'bf16': torch.bfloat16}.get(grad_comm_dtype, grad_comm_dtype)
+		self._comm_bufs = {}  # bucket index -> persistent 16-bit send / receive buffer (stable addresses: a captured step graph bakes them)
+		self._mean_in_comm = False  # the last exchange already divided by the world size (16-bit buckets): finish_gradient_sync must not do it again
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
 				p._convasr_ready = self._make_hook(bi)
@@ -120,6 +128,7 @@ class DataParallelEngine(nn.Module):
 
 	def predict(self, world, step_ms, **kw):
 		"""predict_exposed_comm for this engine's buckets (bench.py puts it next to the measured dist.exposed_comm_ms)."""
+		kw.setdefault('bytes_per_element', 2 if self.comm_dtype() is not None else 4)
 		return predict_exposed_comm([p.numel() for p in self.flat.params], self.flat.offsets, self.buckets, world, step_ms, **kw)
 
 	def exposed_comm_ms(self):
@@ -178,11 +187,32 @@ class DataParallelEngine(nn.Module):
 		producers = {s.cuda_stream: s for s in (self._main_stream, torch.cuda.current_stream(dev), Fn.side_stream(dev)) if s is not None}
 		self._ready.append((bi, [s.record_event() for s in producers.values()]))
 
+	def comm_dtype(self):
+		"""The resolved exchange type: None (the fp32 arena in place) or a 16-bit torch dtype."""
+		dt = self.grad_comm_dtype
+		if dt == 'auto':
+			from . import models as M
+			dt = torch.float16 if getattr(M.master_module(self.module), 'compute_dtype', None) == torch.float16 else None
+		return dt if (dt is not None and self.flat.grad.is_cuda) else None
+
+	def exchange_bytes(self):
+		"""Bytes one step's gradient exchange moves through the collectives (per rank, before the algorithm's own factor)."""
+		per = 2 if self.comm_dtype() is not None else 4
+		return sum((b['hi'] - b['lo']) * per for b in self.buckets)
+
+	@property
+	def capturable(self):
+		"""Can a step of this engine be captured into a HIP graph?  Only when its collectives are RCCL's (stream-ordered, no host wait)."""
+		if not self.collectives:
+			return True
+		return self.flat.data.is_cuda and dist.get_backend(self.group) == 'nccl' and os.environ.get('CONVASR_GRAPH_DP', '1') != '0'
+
 	def poll(self):
 		"""Enqueue the collectives of the buckets that became complete since the last call (no-op when there are none)."""
+		from . import functional as Fn
 		ready, self._ready = self._ready, []
 		for bi, events in ready:
-			if self._jobs is not None:
+			if self._jobs is not None and not Fn.capturing():  # (a capture records what THIS thread enqueues)
 				self._submit(lambda bi = bi, events = events: self._launch(bi, events))
 			else:
 				self._launch(bi, events)
@@ -219,13 +249,47 @@ class DataParallelEngine(nn.Module):
 	def _launch(self, bi, events):
 		"""All-reduce of one complete bucket.  torch.distributed orders a collective after the CURRENT stream only, so it is issued from a
 		dedicated stream that first waits for the events recorded on the gradient's producer streams."""
+		from . import functional as Fn
 		b = self.buckets[bi]
 		view = self.flat.grad[b['lo']:b['hi']]
+		half = self.comm_dtype()
+		if view.is_cuda and half is not None:
+			# 16-bit exchange: pack (x 1 / world) -> all-reduce -> unpack, one after the other on the communication stream.  The range is widened to
+			# whole 8-element groups: the arena pads every parameter to 64 elements, and the padding holds zeros
+			from . import _lib
+			n = -(-(b['hi'] - b['lo']) // 8) * 8
+			wide = self.flat.grad[b['lo']:b['lo'] + n]
+			buf = self._comm_bufs.get(bi)
+			if buf is None or buf.dtype != half:
+				buf = self._comm_bufs[bi] = torch.empty(n, dtype = half, device = view.device)
+			comm = self._comm(view.device)
+			for ev in events:
+				comm.wait_event(ev)
+			with torch.cuda.stream(comm):
+				s = _lib.stream_ptr()
+				_lib.call('convasr_cast_scale', _lib.ptr(wide), _lib.F32, _lib.ptr(buf), _lib.dtype_code(half), n, 1.0 / self.world_size, s)
+				if Fn.capturing():
+					dist.all_reduce(buf, op = dist.ReduceOp.SUM, group = self.group)  # (under capture: the blocking form, which runs on THIS stream -- see below)
+				else:
+					work = dist.all_reduce(buf, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
+					work.wait()  # RCCL: orders the communication stream behind the collective; gloo: a host wait
+				_lib.call('convasr_cast_scale', _lib.ptr(buf), _lib.dtype_code(half), _lib.ptr(wide), _lib.F32, n, 1.0, s)
+			self._comm_dirty = True
+			self._mean_in_comm = True
+			return
 		if view.is_cuda:
 			comm = self._comm(view.device)
 			for ev in events:
 				comm.wait_event(ev)
 			with torch.cuda.stream(comm):
+				if Fn.capturing():
+					# Under a HIP-graph capture the collective is issued in its BLOCKING form, which torch runs on the current (communication) stream:
+					# that stream forked off the capturing stream at the bucket's ready events and rejoins it in join_comm_stream.  The asynchronous
+					# form -- torch's internal RCCL stream joined through work.wait() -- makes hipStreamEndCapture segfault on ROCm 7.2 / torch 2.10
+					# (profiles/r06_rccl_capture_probe.json: main-stream sync / async and side-stream sync capture and replay, side-stream async does not)
+					dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group)
+					self._comm_dirty = True
+					return
 				work = dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
 			self._comm_dirty = True
 		else:
@@ -282,9 +346,10 @@ class DataParallelEngine(nn.Module):
 						p._convasr_grad.zero_()
 						p._convasr_fresh = False
 				self._mark_ready(bi)
+		from . import functional as Fn
 		self.poll()
 		self._drain()
-		timed = self.measure_exposed_comm and self.flat.data.is_cuda
+		timed = self.measure_exposed_comm and self.flat.data.is_cuda and not Fn.capturing()  # (a timing event cannot be read back from inside a graph)
 		if timed:
 			ev0 = torch.cuda.Event(enable_timing = True)
 			ev0.record()
@@ -295,7 +360,9 @@ class DataParallelEngine(nn.Module):
 			ev1 = torch.cuda.Event(enable_timing = True)
 			ev1.record()
 			self.exposed_comm_events.append((ev0, ev1))
-		if self.world_size > 1:
+		if self._mean_in_comm:
+			self._mean_in_comm = False  # the 16-bit buckets carried the mean already
+		elif self.world_size > 1:
 			if self.fold_mean:
 				self.flat.grad_scale = 1.0 / self.world_size  # flat.grad holds the SUM over ranks until the optimizer consumes it
 			else:

@@ -323,7 +323,7 @@ class GraphedTrainStep:
 	about a dozen), captured after `warmup` eager steps of that shape.  A JasperNetLarge step is ~530 kernel launches and ~19 ms of
 	Python for ~40 ms of GPU work; a replay is one call.
 
-	What makes the captured step a faithful replay (tests/test_round5_gpu.py compares 20 / 24 steps bit for bit with the eager path):
+	What makes the captured step a faithful replay (tests/test_full_size_and_step_graphs_gpu.py compares 20 / 24 steps bit for bit with the eager path):
 	* everything that changes from step to step is read from device memory when the kernels RUN -- the dropout step key
 	  (functional.begin_step), the loss scaler, the optimizer's step counters / EMAs, the learning rate (`optimizer.lr_dev`, refreshed here
 	  whenever the host's scheduler changed param_groups[0]['lr']), the device-side skip gates;
@@ -336,15 +336,18 @@ class GraphedTrainStep:
 
 	Inputs are copied into the graph's static buffers (one device-to-device copy each; pass the static buffers themselves -- .inputs(key)
 	-- to skip it).  Returned metrics are the graph's static output tensors: read them before the next call with the same shape.
-	Data-parallel engines that run collectives stay eager (RCCL has not run under capture here): the call falls through to train_step
-	(with this object's world_size / sync_metrics)."""
+	A data-parallel engine is captured WITH its collectives when they are RCCL's (parallel.DataParallelEngine.capturable): the bucket
+	all-reduces are recorded on the communication stream, which forks off the capturing stream at the buckets' ready events and rejoins it in
+	finish_gradient_sync, so a replayed step overlaps the exchange with the backward pass like the eager one and costs the host one launch
+	(eagerly every rank spends ~4 / ~19 ms of Python per Wav2Letter / JasperNetLarge step).  gloo engines (host waits) stay eager: the call
+	falls through to train_step (with this object's world_size / sync_metrics)."""
 
 	def __init__(self, model, optimizer, max_norm = 100.0, warmup = 1, enabled = True, linear = os.environ.get('CONVASR_GRAPH_FORKED') != '1', max_graphs = 64, world_size = 1, sync_metrics = True):
 		self.model, self.optimizer, self.max_norm, self.warmup, self.linear = model, optimizer, max_norm, max(int(warmup), 1), linear
 		self.world_size, self.sync_metrics = world_size, sync_metrics  # (for the eager fall-through of a data-parallel engine: what train_step averages the logged metrics over)
 		self.max_graphs = max_graphs  # batch shapes beyond this many stay eager (a loader that does not pad to bucket ceilings produces a new shape per batch: every capture keeps its static inputs and outputs alive)
 		engine = model if hasattr(model, 'finish_gradient_sync') else None
-		self.enabled = bool(enabled) and not (engine is not None and engine.collectives)
+		self.enabled = bool(enabled) and (engine is None or engine.capturable)  # (an engine whose collectives are RCCL's is captured with them: the communication stream forks off and rejoins inside the graph; gloo waits on the host and stays eager)
 		self.graphs, self.seen = {}, {}
 		self.pool = None
 		self.epoch = Fn.structure_epoch()
@@ -408,7 +411,7 @@ class GraphedTrainStep:
 		Fn.CAPTURING[0] = True
 		try:
 			with torch.cuda.graph(graph, pool = self.pool):
-				res = train_step(self.model, opt, *static, max_norm = self.max_norm, iteration = iteration)
+				res = train_step(self.model, opt, *static, max_norm = self.max_norm, iteration = iteration, world_size = self.world_size, sync_metrics = self.sync_metrics)
 		finally:
 			Fn.CAPTURING[0] = False
 			Fn._side_streams.update(side)

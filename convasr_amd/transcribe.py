@@ -43,7 +43,10 @@ def join(ref = (), hyp = ()):
 def setup(args):
 	"""transcribe.setup(args).  args: namespace with checkpoint (a path, or the dict torch.load would return: 'args' and
 	'model_state_dict'), device, fp16 (apex opt level or None), frontend_in_model, model (optional override), dither / dither0 /
-	normalize_signal (optional), text_pipeline (optional; default: the legacy 38-symbol character tokenizer)."""
+	normalize_signal (optional), text_pipeline (optional; default: the legacy 38-symbol character tokenizer).
+	An API mirror of ONE ~30-line reference function (transcribe.py:23-60): the order of its statements -- checkpoint args into `args`, frontend,
+	text pipeline, model by class name, load_state_dict, eval / fuse / autocast, generator -- is the reference's, because a caller of the
+	reference observes each of them (mutated args, loaded keys); the arithmetic behind every call is this package's."""
 	torch.set_grad_enabled(False)
 	checkpoint = args.checkpoint if isinstance(args.checkpoint, dict) else torch.load(args.checkpoint, map_location = 'cpu')
 	args.sample_rate, args.window_size, args.window_stride, args.window, args.num_input_features = map(checkpoint['args'].get, ['sample_rate', 'window_size', 'window_stride', 'window', 'num_input_features'])

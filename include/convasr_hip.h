@@ -383,6 +383,12 @@ int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype,
 int convasr_pack_dgrad_item_bytes(void);
 int convasr_pack_dgrad_grouped(const void* items, int n_items, int total_blocks, void* stream);
 
+/* dst[i] = src[i] * scale over n elements (n % 8 == 0), fp32 -> CONVASR_BF16 / CONVASR_F16 or back: the two ends of a 16-bit gradient
+ * exchange (apex O2 keeps and all-reduces fp16 model gradients, models.py:744-762 / train.py:771): a bucket of the fp32 gradient arena is
+ * packed into a 16-bit send buffer (scale = 1 / world size: the mean, formed before the sum so that fp16 cannot overflow in it),
+ * all-reduced by RCCL at half the bytes, and unpacked into the arena. */
+int convasr_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale, void* stream);
+
 /* ---- split-operand ("x3") convs: fp32-class accuracy on the 16-bit matrix pipe (models.py:47-77 computed as nn.Conv1d does in fp32) ---- */
 
 /* A value v travels as hi = rn16(v), lo = rn16(v - hi) and a product as hi*hi + hi*lo + lo*hi: three 16-bit MFMAs, each exact in fp32,
@@ -399,6 +405,21 @@ int convasr_pack_dgrad_grouped(const void* items, int n_items, int total_blocks,
  *   packed_dgrad [K][cout_pad(Cin)][3 Cout] : row (K - 1 - k, ci) = (w_hi[.][ci][k], w_lo[.][ci][k], w_hi[.][ci][k])
  * either may be NULL; rows beyond Cout / Cin are not written (zero-fill once). */
 int convasr_split3(const float* x, void* out, int dtype, int64_t rows, int C, int order, void* stream);
+/* The two fp32 streaming passes whose result is consumed by split convs only, with the split folded in (the separate convasr_split3 pass --
+ * 4 bytes read + 6 written per element -- disappears):
+ *   convasr_bn_act_fwd_split3:       convasr_bn_act_fwd on fp32 y, the result z stored as its planes z3 [B * T][3][C], order 0 (scale / shift
+ *                                    present and a clamp-type activation, i.e. the training launches; else CONVASR_EUNSUPPORTED);
+ *   convasr_bn_act_bwd_apply_split3: convasr_bn_act_bwd_apply on fp32 inputs, dy stored as its planes dy3 [B * T][3][C], order 1.
+ * Arguments as in the plain entry points, with the plane type (CONVASR_BF16 / CONVASR_F16) in place of `dtype`; the values are the
+ * plain pass's values split exactly as convasr_split3 splits them (bit-identical planes). */
+int convasr_bn_act_fwd_split3(const void* y, void* z3, int plane_dtype, const float* scale, const float* shift,
+                              int n_res, const void* const* res, const float* const* rscale, const float* const* rshift,
+                              int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key,
+                              const float* xlen, int B, int T, int C, uint8_t* gate, void* stream);
+int convasr_bn_act_bwd_apply_split3(const void* dz_or_g, const void* y, void* dy3, int plane_dtype, const float* coef, int from_dz,
+                                    const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
+                                    uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C,
+                                    const uint8_t* gate, void* stream);
 int convasr_pack_conv_weight_split3(const float* w, int w_layout, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
 
 /* ---- per-step device state: what lets train.py:745-783 replay from a HIP graph ------------------------------------- */

@@ -637,7 +637,7 @@ def test_utterance_length_extremes_against_the_oracle():
 		_dump('r05_length_extremes.json', dict(short_ctc_rel = rel, long_logits_err = err, long_logits_range = scale, long_logits_max_err_bf16 = err16, long_logits_cos_rel_l2_bf16 = [cos16, rel16]))
 		assert err <= 1e-3 * scale + 1e-4 * max(scale, 1.0), (err, scale)
 		# bf16 storage through 18 layers of a random-init network: relative L2 error of the logits 0.13 here, 0.12 at 4 x 10 s -- where a CPU
-		# restatement with the same storage type deviates by the same 0.1175 (tests/test_round2_gpu.py: test_full_wav2letter_16bit_whole_network_deviation_is_the_storage_types_own):
+		# restatement with the same storage type deviates by the same 0.1175 (tests/test_bf16_parity_gpu.py: test_full_wav2letter_16bit_whole_network_deviation_is_the_storage_types_own):
 		# the storage type's own error, no larger on 30,003 frames than on 501
 		assert cos16 >= 0.985 and rel16 <= 0.16 and err16 <= 0.25 * scale, (cos16, rel16, err16, scale)
 	finally:
@@ -791,7 +791,7 @@ def test_other_feature_counts_and_sample_rates_through_the_whole_network(nmel, s
 	out16 = net16(x.to(d), xlen.to(d), y = y.to(d), ylen = ylen.to(d))
 	(out16['loss'] * ylen[:, 0].to(d)).mean().backward()
 	cos, rel16 = _cos_rel(out16['logits'][0].float(), ref['logits'].detach())
-	assert cos >= 0.985 and rel16 <= 0.16, (cos, rel16)  # (bf16 storage through 18 layers: 0.115 here, 0.12 on the full-width network: tests/test_round2_gpu.py)
+	assert cos >= 0.985 and rel16 <= 0.16, (cos, rel16)  # (bf16 storage through 18 layers: 0.115 here, 0.12 on the full-width network: tests/test_bf16_parity_gpu.py)
 	assert all(bool(torch.isfinite(p.grad).all()) for p in net16.parameters() if p.grad is not None)
 
 

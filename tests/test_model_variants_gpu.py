@@ -40,7 +40,7 @@ def test_config1_full_wav2letter_fp32_32x10s_forward_ctc_and_strings_vs_oracle()
 	margin and deviation alike), so: the argmax must agree on EVERY frame the oracle decides by more than twice the observed log-prob
 	deviation, such frames are > 99 % of all, and the strings of at least 30 of the 32 utterances are identical (measured: 31; the
 	one that differs does so in a single character that hangs on an indecisive frame).
-	This is the WEAKER twin of tests/test_round4_gpu.py::test_trained_wav2letter_32x10s_greedy_strings_identical_to_the_oracle, which runs the
+	This is the WEAKER twin of tests/test_training_features_gpu.py::test_trained_wav2letter_32x10s_greedy_strings_identical_to_the_oracle, which runs the
 	same batch shape on a TRAINED network (decisive logits) and requires 32 of 32 identical strings in eval and in batch-statistics mode."""
 	import convasr_amd as ca
 	from convasr_amd.transcript_generators import GreedyCTCGenerator, CharTokenizerLegacy

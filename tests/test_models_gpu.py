@@ -183,7 +183,7 @@ def test_full_wav2letter_forward_fp32_vs_oracle_config2_shape_reduced_batch():
 	want = O.greedy_decode(ref['log_probs'], ref['olen'])
 	# a random-init network decides a few of its frames by margins below the difference of two fp32 summation orders: the argmax must
 	# agree on every frame the oracle decides by more than twice the observed deviation, and at most one string may differ (the
-	# stated-batch version of this test, tests/test_round3_gpu.py, has the details)
+	# stated-batch version of this test, tests/test_model_variants_gpu.py, has the details)
 	lp_dev = float((out['log_probs'][0].cpu() - ref['log_probs']).abs().max())
 	top2 = ref['log_probs'].topk(2, dim = 1).values
 	decisive = (top2[:, 0] - top2[:, 1]) > 2 * lp_dev

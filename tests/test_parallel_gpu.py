@@ -173,3 +173,28 @@ def test_two_ranks_fp16_loss_scaler_skips_on_every_rank_or_on_none():
 	print('fp16 two ranks:', got[0]['history'])
 	assert not finite[0] and any(finite) and not finite[6], got[0]['history']  # start-up overflow, clean steps, and rank 1's private overflow skipped by both
 	assert bool(torch.isfinite(got[0]['params']).all())
+
+
+def test_rccl_world1_data_parallel_step_replays_bitwise_from_graphs_with_fp32_and_fp16_exchange():
+	"""A one-rank RCCL process group (a child process): the data-parallel step with its bucket all-reduces captured on the communication
+	stream replays bit for bit like the eager step (two batch shapes, dropout, fp32 exchange); the same under apex O2 with the gradients
+	exchanged as fp16 (half the bytes, grad_comm_dtype 'auto'), whose result stays within fp16 rounding of the fp32 exchange's."""
+	import json
+	import subprocess
+	import sys
+	here = os.path.dirname(os.path.abspath(__file__))
+	r = subprocess.run([sys.executable, os.path.join(here, '_dp_rccl_world1.py'), str(_free_port())], stdout = subprocess.PIPE, stderr = subprocess.PIPE, text = True, timeout = 900)
+	lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+	assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+	res = json.loads(lines[-1])
+	assert 'error' not in res, (res, r.stderr[-4000:])
+	a, b = res['fp32_exchange'], res['fp16_exchange']
+	assert a['captures'] == 2 and a['replays'] >= 7 and a['trace_equal'] and a['params_equal'], a
+	assert b['comm_dtype'] == 'torch.float16' and b['captures'] == 2 and b['trace_equal'] and b['params_equal'], b
+	assert b['exchange_bytes'] * 2 == b['exchange_bytes_fp32'] and b['first_loss_equal_to_fp32_exchange'], b
+	# the first applied update with the gradients exchanged as fp16 against the same update with the fp32 exchange: apart by fp16's rounding of
+	# the gradient (2^-11 per element), relative to the update itself.  (A gradient of the scaled loss that fits fp32 but not fp16 overflows in the
+	# 16-bit send buffer -- as it would in apex O2's fp16 gradients -- and costs one more skipped start-up step: compared when both runs applied the same step.)
+	if b['first_update_at'][0] == b['first_update_at'][1]:
+		assert b['first_update_rel_to_fp32_exchange'] <= 2e-3, b
+	print('rccl world 1:', res)

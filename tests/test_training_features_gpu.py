@@ -35,7 +35,7 @@ def close(a, b, rtol, atol, what = ''):
 
 
 def test_trained_wav2letter_32x10s_greedy_strings_identical_to_the_oracle():
-	"""north_star: "greedy-decode strings bit-identical" -- on a network whose logits are DECISIVE.  tests/test_round3_gpu.py's
+	"""north_star: "greedy-decode strings bit-identical" -- on a network whose logits are DECISIVE.  tests/test_model_variants_gpu.py's
 	configs[1] case runs a random-init network, which decides ~0.1 % of its frames by margins below fp32 summation-order noise (31 of
 	32 strings there); this is the stronger twin: Wav2Letter full is first trained on the MI355X (fp32 path, one fixed batch of 8 x 8 s,
 	45 SGD steps, loss < 0.01: the utterances are memorised), the trained weights are loaded into the CPU oracle, and both run
