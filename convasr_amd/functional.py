@@ -155,6 +155,7 @@ def structure_epoch():
 # (64 of 256 CUs, ~0.3 ms of dependent steps).  prepack_dgrad_weights() -- called by the network between the decoder and the loss --
 # runs those launches on a side stream there; the first dgrad of the backward pass joins it (join_prepack).
 PREPACK = os.environ.get('CONVASR_NO_PREPACK') != '1'  # A/B hook
+GRAPHS_CAPTURED = [False]  # set by train.GraphedTrainStep at its first capture: from then on an eager step (the warm-up of a new batch shape, a shape beyond max_graphs) makes its dgrad copies on the MAIN stream -- see prepack_dgrad_weights
 _prepack_streams = {}  # device -> [side stream, packs pending on it?]
 
 
@@ -238,7 +239,13 @@ def prepack_dgrad_weights(weights, dtype):
 			stale.append(w)
 	if not stale:
 		return
-	if not PREPACK:  # (A/B hook, and what a linear step-graph capture sets: the copies are made on the main stream, still in one launch)
+	# Once step graphs exist in this process, eager steps stay off the prepack stream too.  Measured in round 6 (scratch/r6_interleave_debug2.py,
+	# profiles/r06_interleave_race.txt): an eager step that packed on the side stream, followed by a replay of a graph whose pack nodes rewrite
+	# the same buffers, gave a different loss in the replayed step in roughly every other run (step 10 of the order A A B A B B C A B C A, small
+	# Wav2Letter, AdamW); with the copies on the main stream, or with a device synchronisation per step, never.  Every stream hand-over the
+	# host code makes is in place (side waits for main before the packs, main joins side before the first dgrad), so the overlap is between
+	# the replay and the side stream's tail inside the runtime; eager steps are the exception once graphs exist, so they simply do not fork.
+	if not PREPACK or GRAPHS_CAPTURED[0]:  # (A/B hook, and what a linear step-graph capture sets: the copies are made on the main stream, still in one launch)
 		_pack_dgrad_many(stale, dtype)
 		return
 	st = _prepack_streams.get(dev)

@@ -85,6 +85,7 @@ class DataParallelEngine(nn.Module):
 		self.grad_comm_dtype = {None: None, 'f32': None, 'auto': 'auto', 'f16': torch.float16, 'bf16': torch.bfloat16}.get(grad_comm_dtype, grad_comm_dtype)
 		self._comm_bufs = {}  # bucket index -> persistent 16-bit send / receive buffer (stable addresses: a captured step graph bakes them)
 		self._mean_in_comm = False  # the last exchange already divided by the world size (16-bit buckets): finish_gradient_sync must not do it again
+		self._capture_comm = None  # rccl.Communicator of this engine's own, used for the collectives of CAPTURED steps only (enable_capture)
 		for bi, b in enumerate(self.buckets):
 			for p in b['params']:
 				p._convasr_ready = self._make_hook(bi)
@@ -119,6 +120,12 @@ class DataParallelEngine(nn.Module):
 		if worker is not None and self._jobs is not None:
 			self._jobs.put(None)  # the sentinel: run() returns
 			worker.join(timeout = 5)
+
+	def destroy_capture_comm(self):
+		"""Free the engine's own RCCL communicator (after the step graphs that recorded its kernels are gone; not done implicitly)."""
+		comm, self._capture_comm = self._capture_comm, None
+		if comm is not None:
+			comm.destroy()
 
 	def __del__(self):
 		try:
@@ -202,10 +209,26 @@ class DataParallelEngine(nn.Module):
 
 	@property
 	def capturable(self):
-		"""Can a step of this engine be captured into a HIP graph?  Only when its collectives are RCCL's (stream-ordered, no host wait)."""
+		"""Can a step of this engine be captured into a HIP graph?  Only when its collectives are RCCL's (stream-ordered, no host wait) and
+		librccl can be called directly (rccl.py: torch.distributed's wrapper does not survive a capture on ROCm 7.2)."""
 		if not self.collectives:
 			return True
-		return self.flat.data.is_cuda and dist.get_backend(self.group) == 'nccl' and os.environ.get('CONVASR_GRAPH_DP', '1') != '0'
+		from . import rccl
+		return self.flat.data.is_cuda and dist.get_backend(self.group) == 'nccl' and os.environ.get('CONVASR_GRAPH_DP', '1') != '0' and rccl.library() is not None
+
+	def enable_capture(self):
+		"""Create this engine's own RCCL communicator for captured steps (a rendezvous: every rank calls it -- train.GraphedTrainStep does, from
+		its constructor).  Eager steps keep torch.distributed."""
+		if self.collectives and self._capture_comm is None:
+			from . import rccl
+			self._capture_comm = rccl.Communicator(self.flat.data.device, self.group)
+
+	def _captured_all_reduce(self, t):
+		"""SUM all-reduce on the CURRENT stream through the engine's own communicator (what a capture records)."""
+		from . import _lib
+		if self._capture_comm is None:
+			raise _lib.ConvasrHipError('DataParallelEngine: a step with collectives is being captured but enable_capture() was not called (train.GraphedTrainStep does it on every rank)')
+		self._capture_comm.all_reduce(t, _lib.stream_ptr())
 
 	def poll(self):
 		"""Enqueue the collectives of the buckets that became complete since the last call (no-op when there are none)."""
@@ -269,7 +292,7 @@ class DataParallelEngine(nn.Module):
 				s = _lib.stream_ptr()
 				_lib.call('convasr_cast_scale', _lib.ptr(wide), _lib.F32, _lib.ptr(buf), _lib.dtype_code(half), n, 1.0 / self.world_size, s)
 				if Fn.capturing():
-					dist.all_reduce(buf, op = dist.ReduceOp.SUM, group = self.group)  # (under capture: the blocking form, which runs on THIS stream -- see below)
+					self._captured_all_reduce(buf)  # (under capture: RCCL directly, on THIS stream -- see below)
 				else:
 					work = dist.all_reduce(buf, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
 					work.wait()  # RCCL: orders the communication stream behind the collective; gloo: a host wait
@@ -283,11 +306,12 @@ class DataParallelEngine(nn.Module):
 				comm.wait_event(ev)
 			with torch.cuda.stream(comm):
 				if Fn.capturing():
-					# Under a HIP-graph capture the collective is issued in its BLOCKING form, which torch runs on the current (communication) stream:
-					# that stream forked off the capturing stream at the bucket's ready events and rejoins it in join_comm_stream.  The asynchronous
-					# form -- torch's internal RCCL stream joined through work.wait() -- makes hipStreamEndCapture segfault on ROCm 7.2 / torch 2.10
-					# (profiles/r06_rccl_capture_probe.json: main-stream sync / async and side-stream sync capture and replay, side-stream async does not)
-					dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group)
+					# Under a HIP-graph capture the collective goes to RCCL directly (rccl.py), on the communication stream, which forked off the
+					# capturing stream at the bucket's ready events and rejoins it in join_comm_stream.  torch.distributed's wrapper does not survive a
+					# capture here: its asynchronous form (internal stream, work.wait()) makes hipStreamEndCapture segfault, its blocking form captures
+					# and replays but now and then leaves a Work with the watchdog thread, whose event query then aborts the process
+					# (profiles/r06_rccl_capture_probe.json, ROCm 7.2 / torch 2.10)
+					self._captured_all_reduce(view)
 					self._comm_dirty = True
 					return
 				work = dist.all_reduce(view, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
@@ -305,13 +329,18 @@ class DataParallelEngine(nn.Module):
 		comm = self._comm(t.device)
 		ev = torch.cuda.current_stream(t.device).record_event()
 
+		from . import functional as Fn
+
 		def job():
 			comm.wait_event(ev)
 			with torch.cuda.stream(comm):
-				dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
+				if Fn.capturing():
+					self._captured_all_reduce(t)
+				else:
+					dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)
 			t.record_stream(comm)
 			self._comm_dirty = True
-		if self._jobs is not None:
+		if self._jobs is not None and not Fn.capturing():
 			self._submit(job)
 		else:
 			job()

@@ -348,6 +348,8 @@ class GraphedTrainStep:
 		self.max_graphs = max_graphs  # batch shapes beyond this many stay eager (a loader that does not pad to bucket ceilings produces a new shape per batch: every capture keeps its static inputs and outputs alive)
 		engine = model if hasattr(model, 'finish_gradient_sync') else None
 		self.enabled = bool(enabled) and (engine is None or engine.capturable)  # (an engine whose collectives are RCCL's is captured with them: the communication stream forks off and rejoins inside the graph; gloo waits on the host and stays eager)
+		if self.enabled and engine is not None and engine.collectives:
+			engine.enable_capture()  # (a rendezvous of all ranks: the engine's own RCCL communicator, through which the captured collectives go -- parallel.DataParallelEngine.enable_capture)
 		self.graphs, self.seen = {}, {}
 		self.pool = None
 		self.epoch = Fn.structure_epoch()
@@ -362,8 +364,23 @@ class GraphedTrainStep:
 		g = self.graphs.get(key)
 		return None if g is None else g['static']
 
+	def _fence_transition(self, device, eager):
+		"""A host wait for the stream wherever an eagerly launched step meets a replayed one (either order).  Measured in round 6
+		(scratch/r6_interleave_debug3.py, profiles/r06_interleave_race.txt): with the order A A B A B B C A B C A on a small Wav2Letter (AdamW, bf16,
+		max_graphs = 2: C stays eager) the replay of A after the second eager C computed a different loss in 3 of 4 runs, bit-identical to the eager
+		run in 8 of 8 with a stream synchronisation on either side of the eager step (and in 3 of 3 with the stride-2 fold of the prologue off:
+		the one layer whose weight gradient goes through a temporary of the DEFAULT memory pool in eager steps).  Replay-after-replay sequences
+		have never differed (tests/test_full_size_and_step_graphs_gpu.py: 20 and 24 steps over 2 and 3 shapes).  Every stream hand-over the host
+		code makes is in place; what overlaps is decided inside the runtime's graph launch.  Eager steps are the exception once graphs exist -- the
+		warm-up of a new batch shape, shapes beyond max_graphs -- so the two kinds of step are simply fenced from each other: one host wait per
+		transition, nothing on the replay-to-replay path."""
+		if self.graphs and getattr(self, '_last_eager', None) is not None and self._last_eager != eager and device.type == 'cuda':
+			torch.cuda.current_stream(device).synchronize()
+		self._last_eager = eager
+
 	def _eager(self, x, xlen, y, ylen, iteration):
 		self.eager_steps += 1
+		self._fence_transition(x.device, eager = True)
 		return train_step(self.model, self.optimizer, x, xlen, y, ylen, max_norm = self.max_norm, iteration = iteration, world_size = self.world_size, sync_metrics = self.sync_metrics)
 
 	def _sync_lr(self):
@@ -391,6 +408,7 @@ class GraphedTrainStep:
 		# double-buffered device state (NovoGrad's EMAs, AdamW's applied-step counter, the loss scaler): the rows stop swapping for good --
 		# this graph, and every later eager step, hands the new state back to the row that is current now
 		opt._pinned = True
+		Fn.GRAPHS_CAPTURED[0] = True
 		if getattr(opt.flat, 'loss_scaler', None) is not None:
 			opt.flat.loss_scaler.pinned = True
 		# every version-keyed packed copy (padded-Cout forward operands, the folded prologue, the padded head, fp32 / split operands) is
@@ -439,6 +457,9 @@ class GraphedTrainStep:
 				_lib.call('convasr_copy', _lib.ptr(src if src.is_contiguous() else src.contiguous()), _lib.ptr(dst), dst.numel() * dst.element_size(), _lib.stream_ptr())
 		self._sync_lr()
 		opt = self.optimizer
+		Fn.join_prepack(x.device)  # (side streams an eager step may have left running are joined before the graph is launched)
+		self._fence_transition(x.device, eager = False)
+		Fn.join_side_streams()
 		opt.flat.mirror_carried_over(lambda p16: g['graph'].replay())  # (the same version bookkeeping an eager optimizer launch gets: the 16-bit mirror stays current, other packed copies go stale)
 		opt.steps += 1
 		self.replays += 1
