@@ -133,7 +133,7 @@ def throughput(model, device, B, secs, iters):
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--model', default = 'Wav2Letter')
-	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f16', 'f32'])
+	ap.add_argument('--dtype', default = 'bf16', choices = ['bf16', 'f16', 'f32', 'bf16x3', 'f16x3'], help = 'bf16x3 / f16x3: fp32 activations, the convs as split-operand products on the 16-bit matrix pipe (fp32-class logits)')
 	ap.add_argument('-B', type = int, default = 1)
 	ap.add_argument('-T', type = float, default = 6.0)
 	ap.add_argument('--rps', type = float, default = 60)
@@ -148,8 +148,10 @@ def main():
 	device = torch.device('cuda', 0)
 	torch.cuda.set_device(device)
 	torch.manual_seed(1)
-	dtype = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32)[args.dtype]
+	dtype = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32).get(args.dtype, torch.float32)
 	model = build_model(args.model, device, dtype)
+	if args.dtype in ('bf16x3', 'f16x3'):
+		model.set_compute_dtype(args.dtype, inference = True)
 	common = dict(model = args.model, dtype = args.dtype, sample_rate = SAMPLE_RATE, data = 'synthetic', weights = 'random init')
 	if not args.no_throughput:
 		print(json.dumps(dict(throughput(model, device, 64, 15, 10), **common)), flush = True)

@@ -79,6 +79,8 @@ _SIGNATURES = dict(
 	convasr_wgrad1x1_grouped_workspace_bytes = (c_i64, [c_int, c_p, c_p, c_int, c_int]),
 	convasr_wgrad1x1_grouped = (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
 	convasr_copy = (c_int, [c_p, c_p, c_i64, c_p]),
+	convasr_colsum_workspace_bytes = (c_i64, [c_i64, c_int]),
+	convasr_colsum = (c_int, [c_p, c_int, c_i64, c_int, c_p, c_p, c_int, c_p]),
 	convasr_cast_scale = (c_int, [c_p, c_int, c_p, c_int, c_i64, c_f32, c_p]),
 	convasr_bn_act_fwd_split3 = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_act_bwd_apply_split3 = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),

@@ -737,6 +737,23 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 	out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// out[c] (+)= sum over rows of a channels-last (rows, C) matrix, the bias gradient of a conv on its own (the weight-gradient entry point
+// forms it from the same dy it multiplies; a split-operand head multiplies dy's planes and needs the sum of dy itself)
+extern "C" int64_t convasr_colsum_workspace_bytes(int64_t rows, int C) { return ceil_div64(rows, 256) * (int64_t)C * 4; }
+extern "C" int convasr_colsum(const void* y, int dtype, int64_t rows, int C, float* out, void* workspace, int accumulate, void* stream) {
+	CONVASR_CHECK_ARG(y && out && workspace && rows > 0 && C > 0 && (dtype == CONVASR_F32 || convasr_is_half(dtype)), "colsum: bad arguments");
+	hipStream_t s = (hipStream_t)stream;
+	const int rows_per_block = 256;
+	dim3 grid((C + 63) / 64, (unsigned)ceil_div64(rows, rows_per_block));
+	float* part = (float*)workspace;
+	if (dtype == CONVASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)y, part, rows, C, rows_per_block);
+	else if (dtype == CONVASR_F16) hipLaunchKernelGGL((colsum_kernel<f16_t>), grid, dim3(256), 0, s, (const f16_t*)y, part, rows, C, rows_per_block);
+	else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)y, part, rows, C, rows_per_block);
+	hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, (const float*)part, (int)grid.y, C, out, accumulate);
+	CONVASR_CHECK_LAUNCH("colsum");
+	return 0;
+}
+
 extern "C" int64_t convasr_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int Tin, int Tout, int K, int stride, int dil) {
 	WgradParams p;
 	p.debug = 0;

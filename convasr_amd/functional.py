@@ -436,10 +436,11 @@ class Fold2:
 	enabled = os.environ.get('CONVASR_NO_FOLD2') != '1'  # tests / A-B runs flip this
 
 	@classmethod
-	def plan(cls, x, weight, spec, dt, x_needs_grad):
-		"""None, or (view of x, K', P', Tout) when the fold applies."""
+	def plan(cls, x, weight, spec, dt, x_needs_grad, split = None):
+		"""None, or (view of x, K', P', Tout) when the fold applies.  split (a 16-bit plane type) with dt = fp32: the folded conv of a
+		split-operand network (its view is split into planes by the caller)."""
 		B, Cin, Tin = x.shape
-		if not (cls.enabled and dt in ops.HALF_DTYPES and spec.stride == 2 and spec.dilation == 1 and Tin % 2 == 0 and (2 * Cin) % 128 == 0 and weight.shape[0] % 128 == 0 and not x_needs_grad and ops.is_cl(x) and x.stride(0) == Tin * Cin):
+		if not (cls.enabled and (dt in ops.HALF_DTYPES or (dt == torch.float32 and split is not None)) and spec.stride == 2 and spec.dilation == 1 and Tin % 2 == 0 and (2 * Cin) % 128 == 0 and weight.shape[0] % 128 == 0 and not x_needs_grad and ops.is_cl(x) and x.stride(0) == Tin * Cin):
 			return None
 		Kf, Pf = ops.fold2_geometry(spec.K, spec.padding)
 		Tout = ops.conv_out_len(Tin, spec.K, 2, 1, spec.padding)
@@ -471,6 +472,30 @@ class Fold2:
 			ent['wp'] = ops.fold2_pack_weight(weight, dt, pad, out = ent['wp'])
 			ent['ver'] = ver
 		return ent['wp']
+
+	@classmethod
+	def split_weight(cls, weight, split, pad):
+		"""Forward planes [K'][Cout][3 x 2 Cin] of the folded conv of a split-operand network: the fp32 folded weight (convasr_fold2_pack_weight
+		into a tap-major fp32 buffer) split like any other (functional.split_weight's kernel); refreshed per parameter version, in place."""
+		ver = param_version(weight)
+		ent = cls._cache.get((id(weight), 'split', split))
+		if ent is None:
+			ent = cls._cache[(id(weight), 'split', split)] = dict(w = weight, ver = None, wf = None, fwd = None)
+		if ent['ver'] != ver:
+			ent['wf'] = ops.fold2_pack_weight(weight, torch.float32, pad, out = ent['wf'])  # [K'][Cout][2 Cin] fp32 (Cout % 128 == 0: no padded rows)
+			ent['fwd'] = ops.pack_weight_split3(ent['wf'].permute(1, 2, 0), split, out = (ent['fwd'], None), want_dgrad = False)[0]
+			ent['ver'] = ver
+		return ent['fwd']
+
+	@staticmethod
+	def wgrad_split(x3, dy3, weight, spec, Kf, Pf, out, accumulate):
+		"""Weight gradient of the folded split conv: the plane tensors read as 3 T frames, dilation and padding tripled, then unfolded."""
+		Cout, Cin, K = weight.shape
+		xf, dyf = ops.split3_frames(x3), ops.split3_frames(dy3)
+		B, Tout = dy3.shape[0], dy3.shape[2]
+		dwf = torch.empty(Kf, Cout, 2 * Cin, dtype = torch.float32, device = dy3.device)
+		ops.conv1d_wgrad(xf, dyf, Cout, Kf, 1, 3, 3 * Pf, dwf.permute(1, 2, 0), work = 2.0 * B * Tout * Cout * Cin * K, family = SPLIT_WGRAD_FAMILY)
+		ops.fold2_unfold_wgrad(dwf, out, spec.padding, accumulate = accumulate)
 
 	@staticmethod
 	def wgrad(xv, dy, weight, spec, Kf, Pf, out, accumulate):
@@ -573,9 +598,16 @@ class ConvBnActFunction(torch.autograd.Function):
 		bn = cfg['bn']
 		stats = _stats_buffer(bn, Cout, dev, B, ops.conv_out_len(Tin, spec.K, spec.stride, spec.dilation, spec.padding))
 		x_needs_grad = x.requires_grad or ctx.needs_input_grad[1]
-		ctx.fold = Fold2.plan(x, weight, spec, dt, x_needs_grad)
+		ctx.fold = Fold2.plan(x, weight, spec, dt, x_needs_grad, split = cfg.get('split')) if planes is None else None
 		ctx.split = None
-		if ctx.fold is not None:
+		if ctx.fold is not None and dt == torch.float32:
+			# the strided prologue of a split-operand network: its stride-1 fold, with the folded view split into planes
+			xv, Kf, Pf, Tout = ctx.fold
+			ctx.split = cfg['split']
+			x = ops.split3(xv, ctx.split, ops.SPLIT_INPUT)
+			y = ops.conv1d(x, Fold2.split_weight(weight, ctx.split, spec.padding), Cout, Kf, 1, 1, Pf, out_dtype = torch.float32, stats = stats, Tout = Tout, work = 2.0 * B * Tout * Cout * Cin * spec.K, family = SPLIT_FAMILY)
+			ctx.fold = (Kf, Pf)
+		elif ctx.fold is not None:
 			xv, Kf, Pf, Tout = ctx.fold
 			y = ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, stats = stats, Tout = Tout, work = 2.0 * B * Tout * Cout * Cin * spec.K)
 			ctx.fold = (Kf, Pf)
@@ -755,11 +787,13 @@ class ConvBnActFunction(torch.autograd.Function):
 		if n_res == 0:
 			grouped_bn = None
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
-		if ctx.split is not None:
+		if ctx.split is not None and dy.dtype == torch.float32:  # (the residual forms of the BN backward deliver fp32; the residual-free one wrote the planes itself)
+			dy = ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
+		if ctx.split is not None and ctx.fold is not None:
+			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad_split(x, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
+		elif ctx.split is not None:
 			# split-operand conv: dy as its three planes (hi, hi, lo) once, for both gradients; the weight gradient pairs plane p of x with plane p of
 			# dy by reading both plane tensors as 3 T frames of C channels with the conv's dilation and padding tripled
-			if dy.dtype == torch.float32:  # (the residual forms of the BN backward deliver fp32; the residual-free one wrote the planes itself)
-				dy = ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
 			xf, dyf = ops.split3_frames(x), ops.split3_frames(dy)
 			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(xf, dyf, Cout, spec.K, 1, 3 * spec.dilation, 3 * spec.padding, outs[0], accumulate = acc, work = 2.0 * B * Tout * Cout * weight.shape[1] * spec.K, family = SPLIT_WGRAD_FAMILY))
 		elif ctx.fold is not None:
@@ -903,6 +937,22 @@ class _HeadPad:
 			ent['ver'] = ver
 		return ent['wd']
 
+	@classmethod
+	def split_weight(cls, weight, split):
+		"""(forward, dgrad) planes of a narrow one-tap head in a split-operand network, as 128-class operands: the fp32 weight is copied into the
+		live rows of a zero-padded (128, Cin, 1) fp32 buffer and split like any other weight; refreshed per parameter version, in place."""
+		Cout, Cin, K = weight.shape
+		ver = param_version(weight)
+		ent = cls._cache.get((id(weight), 'split', split))
+		if ent is None:
+			ent = cls._cache[(id(weight), 'split', split)] = dict(w = weight, ver = None, wp = torch.zeros(HEAD_PAD, Cin, 1, dtype = torch.float32, device = weight.device), fwd = None, dgr = None)
+		if ent['ver'] != ver:
+			src, wp = weight.detach(), ent['wp']
+			_lib.call('convasr_convert_layout', _lib.ptr(src), _lib.F32, 0, src.stride(0), src.stride(1), _lib.ptr(wp), _lib.F32, 0, wp.stride(0), wp.stride(1), 1, Cout, Cin, _lib.stream_ptr())
+			ent['fwd'], ent['dgr'] = ops.pack_weight_split3(wp, split, out = (ent['fwd'], ent['dgr']))
+			ent['ver'] = ver
+		return ent['fwd'], ent['dgr']
+
 	_pad_bufs = {}
 
 	@classmethod
@@ -931,7 +981,17 @@ class ConvBiasFunction(torch.autograd.Function):
 		spec, dt = cfg['spec'], cfg['compute_dtype']
 		ctx.producer_link = _take_link(x)
 		x = ops.as_cl(x, dt)
-		y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), weight.shape[0], spec.K, spec.stride, spec.dilation, spec.padding, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias)
+		Cout, Cin, K = weight.shape
+		ctx.split = None
+		if cfg.get('split') is not None and dt == torch.float32 and K == 1 and spec.stride == 1 and spec.padding == 0 and Cin % 128 == 0 and Cout <= HEAD_PAD and os.environ.get('CONVASR_NO_HEAD_PAD') != '1':
+			# the head of a split-operand network: the input's planes against the planes of the weight padded to 128 classes (rows >= Cout are zero
+			# and the kernel stores the Cout live columns only); backward runs dgrad / wgrad as 128-class split problems like _HeadPad's 16-bit form
+			ctx.split = cfg['split']
+			B, _, T = x.shape
+			x = ops.split3(x, ctx.split, ops.SPLIT_INPUT)
+			y = ops.conv1d(x, _HeadPad.split_weight(weight, ctx.split)[0], Cout, 1, 1, 1, 0, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias, work = 2.0 * B * T * Cout * Cin, family = SPLIT_FAMILY)
+		else:
+			y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), weight.shape[0], spec.K, spec.stride, spec.dilation, spec.padding, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias)
 		ctx.cfg = cfg
 		ctx.params = (weight, bias)
 		ctx.save_for_backward(x)
@@ -944,6 +1004,29 @@ class ConvBiasFunction(torch.autograd.Function):
 		weight, bias = ctx.params
 		x, = ctx.saved_tensors
 		Cout = weight.shape[0]
+		if ctx.split is not None:
+			Cin = weight.shape[1]
+			B, _, T = dy.shape
+			dy = ops.as_cl(dy, torch.float32)
+			dy3 = ops.split3(_HeadPad.pad_grad(dy, torch.float32), ctx.split, ops.SPLIT_GRAD)  # (B, 3 x 128, T): the padded classes are zero planes
+			dx = None
+			if ctx.needs_input_grad[1]:
+				dx = ops.conv1d(dy3, _HeadPad.split_weight(weight, ctx.split)[1], Cin, 1, 1, 1, 0, out_dtype = torch.float32, work = 2.0 * B * T * Cout * Cin, family = SPLIT_FAMILY)
+				_after_long_launch()
+
+			def wgrad3(outs, acc):
+				dwp = torch.empty(HEAD_PAD, Cin, 1, dtype = torch.float32, device = dy.device)
+				ops.conv1d_wgrad(ops.split3_frames(x), ops.split3_frames(dy3), HEAD_PAD, 1, 1, 3, 0, dwp, work = 2.0 * B * T * Cout * Cin, family = SPLIT_WGRAD_FAMILY)
+				if outs[0] is not None:
+					v = dwp[:Cout]
+					if acc:
+						outs[0].add_(v.view(outs[0].shape))
+					else:  # rows < Cout of the padded result into the gradient (arena) view, element (c, t) = (co, ci)
+						_lib.call('convasr_convert_layout', _lib.ptr(v), _lib.F32, 0, v.stride(0), v.stride(1), _lib.ptr(outs[0]), _lib.F32, 0, outs[0].stride(0), outs[0].stride(1), 1, Cout, Cin, _lib.stream_ptr())
+				if outs[1] is not None:
+					ops.colsum(dy, outs[1], accumulate = acc)  # the bias gradient: the sum of dy itself, not of its planes
+			dw, db = _deliver([weight, bias], wgrad3)
+			return None, dx, dw, db
 		if dt in ops.HALF_DTYPES and spec.K == 1 and spec.stride == 1 and spec.padding == 0 and Cout < HEAD_PAD and x.shape[1] % 128 == 0 and os.environ.get('CONVASR_NO_HEAD_PAD') != '1':
 			dyp = _HeadPad.pad_grad(dy, dt)
 			dx = _dgrad(x, dyp, weight, spec, dt, ctx.producer_link, wd = _HeadPad.dgrad_weight(weight, dt)) if ctx.needs_input_grad[1] else None
@@ -1009,9 +1092,15 @@ class ConvBnActEvalFunction:
 		xl = ops.xlen_f32(xlen, x.device) if (cfg['temporal_mask'] and xlen is not None) else None
 		scale, shift = (None, None) if scale_shift is None else (scale_shift[0], scale_shift[1])
 		fold = Fold2.plan(x, weight, spec, dt, False)
+		split = cfg.get('split_eval')  # (inference on the split-operand path: JasperNet.set_compute_dtype('bf16x3', inference = True))
 		if fold is not None:
 			xv, Kf, Pf, Tout = fold
 			conv = lambda **epilogue: ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, bias = bias, Tout = Tout, work = 2.0 * x.shape[0] * Tout * Cout * x.shape[1] * spec.K, **epilogue)
+		elif split_applies(split, dt, spec, x.shape[1], Cout):
+			# fp32 activations, the conv as hi*hi + hi*lo + lo*hi on the 16-bit matrix pipe (csrc/split3.hip): bias / folded BN / activation / mask in
+			# the conv's own epilogue as on every other path; the weights' planes are packed once per parameter version
+			x3, wp3 = ops.split3(x, split, ops.SPLIT_INPUT), split_weight(weight, split)[0]
+			conv = lambda **epilogue: ops.conv1d(x3, wp3, Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, bias = bias, work = 2.0 * x.shape[0] * ops.conv_out_len(x.shape[2], spec.K, 1, spec.dilation, spec.padding) * Cout * x.shape[1] * spec.K, family = SPLIT_FAMILY, **epilogue)
 		else:
 			wp = packed_weight(weight, dt, _lib.PACK_FWD)
 			conv = lambda **epilogue: ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, **epilogue)
@@ -1026,6 +1115,9 @@ class ConvBnActEvalFunction:
 			rx = ops.as_cl(rx, dt)
 			if rw is None:
 				res_y.append(rx); rscale.append(None); rshift.append(None)
+			elif split_applies(split, dt, ConvSpec(1), rx.shape[1], Cout):
+				res_y.append(ops.conv1d(ops.split3(rx, split, ops.SPLIT_INPUT), split_weight(rw, split)[0], Cout, 1, 1, 1, 0, out_dtype = torch.float32, bias = rb, work = 2.0 * rx.shape[0] * rx.shape[2] * Cout * rx.shape[1], family = SPLIT_FAMILY))
+				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])
 			else:
 				res_y.append(ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb))
 				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])

@@ -252,6 +252,7 @@ class ConvBn1d(nn.Module):
 		self.temporal_mask = temporal_mask
 		self.compute_dtype = torch.float32
 		self.split_dtype = None  # bf16 / fp16: the convs of an fp32 network run as split-operand MFMA convs (JasperNet.set_compute_dtype('bf16x3'))
+		self.split_inference = False  # the evaluation path too (set_compute_dtype('bf16x3', inference = True)); off by default: evaluation then runs the exact-fp32 kernels
 		self.tapped_output = False  # set by the network when later blocks take this block's output as a residual input: its gradient then has an accumulator the tapping blocks write into (functional.ConvBnActFunction, GRAD_ACC)
 		self.single_consumer_output = False  # set by the network when this block's output feeds exactly one conv (no residual taps): enables cross-layer backward fusion
 		self.feeds_block = None  # set by the network: weakref to the ConvBn1d whose first conv is the ONLY reader of this block's output (None: the decoder, several readers, or unknown)
@@ -276,7 +277,7 @@ class ConvBn1d(nn.Module):
 
 	def _cfg(self, i, last):
 		conv, bn = self.conv[i][-1], self.bn[i]
-		return dict(planes_out = self._planes_out(i, last), spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
+		return dict(planes_out = self._planes_out(i, last), spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, split_eval = self.split_dtype if self.split_inference else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
 
 	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
 		_lib.require_cuda(x)
@@ -357,10 +358,11 @@ class Decoder(nn.Sequential):
 			raise ValueError(type)
 		self.type = type
 		self.compute_dtype = torch.float32
+		self.split_dtype = None  # (JasperNet.set_compute_dtype('bf16x3'): the head as a split-operand conv too)
 
 	def _head(self, x):
 		conv = self[0]
-		cfg = dict(spec = _spec_of(conv), compute_dtype = self.compute_dtype, out_dtype = torch.float32)
+		cfg = dict(spec = _spec_of(conv), compute_dtype = self.compute_dtype, out_dtype = torch.float32, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None)
 		return Fn.ConvBiasFunction.apply(cfg, x, conv.weight, conv.bias)
 
 	def forward(self, x):
@@ -419,12 +421,13 @@ class JasperNet(nn.Module):
 
 	SPLIT_DTYPES = {'bf16x3': torch.bfloat16, 'f16x3': torch.float16}
 
-	def set_compute_dtype(self, dtype):
+	def set_compute_dtype(self, dtype, inference = False):
 		"""fp32 (exact-fp32 MFMA path: parity runs), or bf16 / fp16 (16-bit storage of activations and compute weights, MFMA with fp32
 		accumulation, fp32 master weights: throughput runs; fp16 is what the reference's apex O1-O3 levels compute in and trains under a
 		dynamic loss scaler, convasr_amd.train.LossScaler), or 'bf16x3' / 'f16x3': fp32 storage everywhere, the training convs as
 		split-operand products on the 16-bit matrix pipe (three MFMAs per product, fp32-class accuracy: csrc/split3.hip) -- the path that
-		meets the reference's fp32 results to 1e-4 in the CTC loss at MFMA rate; evaluation runs the exact-fp32 kernels."""
+		meets the reference's fp32 results to 1e-4 in the CTC loss at MFMA rate; evaluation runs the exact-fp32 kernels unless inference = True
+		(the folded / eval-mode convs then run as split convs as well: fp32-class logits at a third of the 16-bit rate instead of the fp32 MFMA rate)."""
 		split = None
 		if isinstance(dtype, str):
 			dtype, split = torch.float32, self.SPLIT_DTYPES[dtype]
@@ -433,8 +436,10 @@ class JasperNet(nn.Module):
 		for m in self.modules():
 			if isinstance(m, (ConvBn1d, Decoder)):
 				m.compute_dtype = dtype
-			if isinstance(m, ConvBn1d):
+			if isinstance(m, (ConvBn1d, Decoder)):
 				m.split_dtype = split
+			if isinstance(m, ConvBn1d):
+				m.split_inference = bool(inference) and split is not None
 		return self
 
 	def forward(self, x, xlen = None, y = None, ylen = None):
@@ -450,7 +455,7 @@ class JasperNet(nn.Module):
 			# which needs an even-length input: the conv's output is the same -- the frame lies in its zero padding -- exactly when the
 			# output length does not change (odd kernel sizes), which Fold2.wants_even_input checks together with the fold's own envelope
 			conv0 = self.backbone[0].conv[0][-1]
-			pad_even = self.compute_dtype in ops.HALF_DTYPES and x.shape[-1] % 2 == 1 and Fn.Fold2.wants_even_input(conv0.weight.shape, _spec_of(conv0), x.shape[-1])
+			pad_even = (self.compute_dtype in ops.HALF_DTYPES or (self.split_dtype is not None and self.training and torch.is_grad_enabled())) and x.shape[-1] % 2 == 1 and Fn.Fold2.wants_even_input(conv0.weight.shape, _spec_of(conv0), x.shape[-1])
 			x = self.normalize_features(x, xlen = xlen, out_dtype = self.compute_dtype, pad_time_to = 2 if pad_even else 1)
 		else:
 			x = ops.as_cl(x, self.compute_dtype)

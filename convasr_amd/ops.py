@@ -381,9 +381,9 @@ def split3_frames(x3):
 	return x3.as_strided((B, C3 // 3, 3 * T), (T * C3, 1, C3 // 3))
 
 
-def pack_weight_split3(w, dtype, out = None):
+def pack_weight_split3(w, dtype, out = None, want_dgrad = True):
 	"""(Cout, Cin, K) fp32 parameter -> (fwd [K][cout_pad][3 Cin], dgrad [K][cin_pad][3 Cout]) split operands, refreshed in place when
-	`out` = (fwd, dgrad) of an earlier call."""
+	`out` = (fwd, dgrad) of an earlier call.  want_dgrad = False: the forward planes only (dgrad is returned as None)."""
 	require_cuda(w)
 	w = w.detach()
 	layout = weight_layout(w) if w.dtype == torch.float32 else None
@@ -393,10 +393,19 @@ def pack_weight_split3(w, dtype, out = None):
 	fwd, dgr = out if out is not None else (None, None)
 	if fwd is None:
 		fwd = torch.zeros(K, cout_pad(Cout), 3 * Cin, dtype = dtype, device = w.device)
-	if dgr is None:
+	if dgr is None and want_dgrad:
 		dgr = torch.zeros(K, cout_pad(Cin), 3 * Cout, dtype = dtype, device = w.device)
-	call('convasr_pack_conv_weight_split3', ptr(w), layout, ptr(fwd), ptr(dgr), dtype_code(dtype), Cout, Cin, K, stream_ptr())
-	return fwd, dgr
+	call('convasr_pack_conv_weight_split3', ptr(w), layout, ptr(fwd), ptr(dgr) if want_dgrad else None, dtype_code(dtype), Cout, Cin, K, stream_ptr())
+	return fwd, (dgr if want_dgrad else None)
+
+
+def colsum(y, out, accumulate = False):
+	"""out (C,) fp32 (+)= sum over (b, t) of a channels-last (B, C, T) tensor: a conv's bias gradient on its own."""
+	B, C, T = y.shape
+	assert is_cl(y) and out.dtype == torch.float32 and out.numel() == C and out.is_contiguous()
+	ws = workspace(_lib.load().convasr_colsum_workspace_bytes(B * T, C), y.device, 'colsum')
+	call('convasr_colsum', ptr(y), dtype_code(y.dtype), B * T, C, ptr(out), ptr(ws), int(accumulate), stream_ptr())
+	return out
 
 
 _wgrad_ws_bytes = {}

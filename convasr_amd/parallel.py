@@ -224,7 +224,7 @@ class DataParallelEngine(nn.Module):
 			self._capture_comm = rccl.Communicator(self.flat.data.device, self.group)
 
 	def _captured_all_reduce(self, t):
-		"""SUM all-reduce on the CURRENT stream through the engine's own communicator (what a capture records)."""
+		"""SUM all-reduce on the CURRENT stream through the engine's own communicator (a plain kernel launch: what a capture records)."""
 		from . import _lib
 		if self._capture_comm is None:
 			raise _lib.ConvasrHipError('DataParallelEngine: a step with collectives is being captured but enable_capture() was not called (train.GraphedTrainStep does it on every rank)')
@@ -291,8 +291,8 @@ class DataParallelEngine(nn.Module):
 			with torch.cuda.stream(comm):
 				s = _lib.stream_ptr()
 				_lib.call('convasr_cast_scale', _lib.ptr(wide), _lib.F32, _lib.ptr(buf), _lib.dtype_code(half), n, 1.0 / self.world_size, s)
-				if Fn.capturing():
-					self._captured_all_reduce(buf)  # (under capture: RCCL directly, on THIS stream -- see below)
+				if self._capture_comm is not None:
+					self._captured_all_reduce(buf)  # (an engine whose steps are captured: RCCL directly, on THIS stream, eagerly too -- see below)
 				else:
 					work = dist.all_reduce(buf, op = dist.ReduceOp.SUM, group = self.group, async_op = True)
 					work.wait()  # RCCL: orders the communication stream behind the collective; gloo: a host wait
@@ -305,12 +305,14 @@ class DataParallelEngine(nn.Module):
 			for ev in events:
 				comm.wait_event(ev)
 			with torch.cuda.stream(comm):
-				if Fn.capturing():
-					# Under a HIP-graph capture the collective goes to RCCL directly (rccl.py), on the communication stream, which forked off the
-					# capturing stream at the bucket's ready events and rejoins it in join_comm_stream.  torch.distributed's wrapper does not survive a
-					# capture here: its asynchronous form (internal stream, work.wait()) makes hipStreamEndCapture segfault, its blocking form captures
-					# and replays but now and then leaves a Work with the watchdog thread, whose event query then aborts the process
-					# (profiles/r06_rccl_capture_probe.json, ROCm 7.2 / torch 2.10)
+				if self._capture_comm is not None:
+					# An engine whose steps are captured into HIP graphs (enable_capture) sends EVERY collective to RCCL directly (rccl.py), on the
+					# communication stream -- which, under a capture, forked off the capturing stream at the bucket's ready events and rejoins it in
+					# join_comm_stream.  torch.distributed's wrapper does not survive a capture here: its asynchronous form (internal stream,
+					# work.wait()) makes hipStreamEndCapture segfault; its blocking form captures and replays, but the process group's watchdog thread
+					# then now and then finds an event "last recorded in a capturing stream" among the Works it polls and terminates the process --
+					# also when only the EAGER steps between captures go through torch (the warm-up of new batch shapes; profiles/r06_rccl_capture_probe.json,
+					# profiles/r06_notes: ROCm 7.2 / torch 2.10).  Eager-only engines keep torch.distributed and its timeouts.
 					self._captured_all_reduce(view)
 					self._comm_dirty = True
 					return
@@ -334,7 +336,7 @@ class DataParallelEngine(nn.Module):
 		def job():
 			comm.wait_event(ev)
 			with torch.cuda.stream(comm):
-				if Fn.capturing():
+				if self._capture_comm is not None:
 					self._captured_all_reduce(t)
 				else:
 					dist.all_reduce(t, op = dist.ReduceOp.SUM, group = self.group)

@@ -383,6 +383,11 @@ int convasr_add16(const void* a, const void* b, void* out, int64_t n, int dtype,
 int convasr_pack_dgrad_item_bytes(void);
 int convasr_pack_dgrad_grouped(const void* items, int n_items, int total_blocks, void* stream);
 
+/* out[c] (+)= sum over the rows of a channels-last (rows, C) matrix of `dtype`: the bias gradient of nn.Conv1d (models.py:26, the decoder head) on
+ * its own -- two launches, per-block partial rows in `workspace` (convasr_colsum_workspace_bytes) added in a fixed order: no atomics. */
+int64_t convasr_colsum_workspace_bytes(int64_t rows, int C);
+int convasr_colsum(const void* y, int dtype, int64_t rows, int C, float* out, void* workspace, int accumulate, void* stream);
+
 /* dst[i] = src[i] * scale over n elements (n % 8 == 0), fp32 -> CONVASR_BF16 / CONVASR_F16 or back: the two ends of a 16-bit gradient
  * exchange (apex O2 keeps and all-reduces fp16 model gradients, models.py:744-762 / train.py:771): a bucket of the fp32 gradient arena is
  * packed into a 16-bit send buffer (scale = 1 / world size: the mean, formed before the sum so that fp16 cannot overflow in it),

@@ -59,7 +59,7 @@ for k in sq:
 		e['avg_duration_us_under_pmc'] = round(d / 1e3, 1); e['effective_clock_ghz'] = round(g / 8 / d, 3); e['mfma_busy_over_simd_cycles'] = round(mf / (1024 * g / 8), 4)
 	summary[k] = e
 json.dump(dict(note = 'rocprofv3 --kernel-trace --pmc (8 SQ counters in one pass; GRBM_GUI_ACTIVE + SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES in a second) over bench.py --steps 2 --warmup 1; means per dispatch.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles; effective clock = GRBM_GUI_ACTIVE / 8 / duration; mfma_busy_over_simd_cycles = MFMA busy cycles / (1024 SIMDs x kernel cycles)', kernels = summary), open(f'profiles/{tag}_pmc_sq.json', 'w'), indent = 1)
-for name in ('bench_line', 'bench_line_f16', 'launcher_n1', 'plain_n1', 'rccl_world1', 'config4_line', 'bench_infer'):
+for name in ('bench_line', 'bench_line_f16', 'bench_line_bf16x3', 'launcher_n1', 'plain_n1', 'rccl_world1', 'rccl_world1_graph', 'rccl_world1_config4', 'rccl_world1_config4_graph', 'config4_line', 'config4_line_eager', 'bench_infer'):
 	src = f'{G}/{tag}_{name}.json'
 	if os.path.exists(src) and os.path.getsize(src) > 0: shutil.copy(src, f'profiles/{tag}_{name}.json')
 tot = sum(float(r['TotalDurationNs']) for r in rows)
@@ -88,3 +88,29 @@ if c4:
 	print('--- configs[4]')
 	for r in rows4[:12]: print('%-80s %6s calls  avg %8.1f us  %5.1f%%' % (r['Name'][:80], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot4))
 if os.path.exists(f'{G}/{tag}_c4_layers.log'): shutil.copy(f'{G}/{tag}_c4_layers.log', f'profiles/{tag}_config4_layers.txt')
+
+
+# ---------------------------------------------------------------- the split-operand path (bench.py --dtype bf16x3), round 6 on
+x3 = glob.glob(f'{G}/{tag}_x3_stats/**/*kernel_stats.csv', recursive = True)
+if x3:
+	rows3 = list(csv.DictReader(open(x3[0])))
+	with open(f'profiles/{tag}_x3_kernel_stats.csv', 'w') as f:
+		f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --dtype bf16x3 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-jasper-leg   (Wav2Letter full, 64 x 15 s, fp32 storage, split-operand convs: the number of training steps = Calls of sgd_step_kernel)\n')
+		w = csv.writer(f); w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+		for r in rows3: w.writerow([r['Name'], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+	tr3 = {}
+	for c in ['FETCH_SIZE', 'WRITE_SIZE']:
+		ff = glob.glob(f'{G}/{tag}_x3_pmc_{c}/**/*counter_collection.csv', recursive = True)
+		if not ff: continue
+		agg = collections.defaultdict(list)
+		for r in csv.DictReader(open(ff[0])): agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+		for k, v in agg.items(): tr3.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+	out3 = {}
+	for k, v in tr3.items():
+		if not any(t in k for t in ('conv1d', 'wgrad', 'bn_act', 'split3')): continue
+		fs, n = v.get('FETCH_SIZE', (0, 0)); ws, _ = v.get('WRITE_SIZE', (0, 0))
+		out3[k] = dict(dispatches = n, fetch_kb = fs, write_kb = ws, hbm_bytes_per_launch = (2 * fs + ws) * 1024)
+	json.dump(dict(note = 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- bench.py --dtype bf16x3 --steps 2 --warmup 1; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (MI355X_MICROARCH.md, HBM), mean per dispatch', kernels = out3), open(f'profiles/{tag}_x3_traffic.json', 'w'), indent = 1)
+	print('--- bf16x3')
+	tot3 = sum(float(r['TotalDurationNs']) for r in rows3)
+	for r in rows3[:10]: print('%-80s %6s calls  avg %8.1f us  %5.1f%%' % (r['Name'][:80], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot3))

@@ -184,8 +184,10 @@ def test_split_operand_training_step_tracks_the_exact_fp32_path(name):
 		torch.cuda.synchronize()
 		res[dt] = (losses, flat.data.clone(), p0, [f for f, _ in timer.sequence])
 	fams = res[name][3]
-	assert fams.count('conv1d_igemm_v2s_kernel<x3>') == 2 * 2 * 17 and fams.count('conv1d_wgrad<x3>') == 2 * 17 and 'conv1d_igemm_v2s_kernel<x3>' not in res[torch.float32][3]
-	assert 'hbm:split3_kernel' not in fams  # every plane tensor is written by the pass that produces the values (bn_act forward / backward apply)
+	# per step: 17 stride-1 layers forward + dgrad, the folded prologue forward, the head forward + dgrad; a weight gradient for each of the 19
+	assert fams.count('conv1d_igemm_v2s_kernel<x3>') == 2 * (2 * 17 + 1 + 2) and fams.count('conv1d_wgrad<x3>') == 2 * 19 and 'conv1d_igemm_v2s_kernel<x3>' not in res[torch.float32][3]
+	assert not any(f in ('conv1d_igemm (other variants)', 'conv1d_wgrad') for f in fams)  # no exact-fp32 conv launch is left in the split step
+	assert fams.count('hbm:split3_kernel') == 2 * 3  # per step: the folded prologue's input, the head's input and the head's output gradient; every other plane tensor is written by the pass that produces the values (bn_act forward / backward apply)
 	# (first step: the same parameters in both runs; second step: after one update each -- two exact-fp32 implementations of this random-init
 	# network already differ by ~1e-2 in their deep gradients, summation-order noise amplified per layer: DESIGN section 2)
 	for (a, b), bar in zip(zip(res[name][0], res[torch.float32][0]), (1e-5, 5e-3)):  # (measured: 6e-8 / 1.0e-3 with bf16 planes -- the second loss sits behind an lr = 1e-2 step that took the loss from 482 to 353)
@@ -205,6 +207,35 @@ def test_split_operand_eval_and_no_grad_run_the_exact_fp32_kernels():
 	a.eval(); b.eval()
 	with torch.no_grad():
 		assert torch.equal(a(x, xlen)['logits'][0], b(x, xlen)['logits'][0])
+
+
+@pytest.mark.parametrize('name', ['bf16x3', 'f16x3'])
+def test_split_operand_inference_is_opt_in_and_tracks_the_exact_fp32_logits(name):
+	"""set_compute_dtype(name, inference = True): the fused evaluation path (fuse_conv_bn_eval: bias + activation + mask in the conv epilogue) and
+	a dense-residual network's eval-mode 1x1 branches as split convs -- logits within 2e-4 of their range of the exact-fp32 path's, greedy
+	paths equal wherever fp32 decides by a margin."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = _batch(d, 4, 4)
+	for build in (lambda: _small(ca, d, torch.float32), lambda: ca.models.JasperNet(64, [38], frontend = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window'), base_width = 64, kernel_sizes = [11, 13], out_width_factors = [2, 3], dropouts = [0.0, 0.0], out_width_factors_large = [4, 4], residual = 'dense', repeat = 2, check_time_dim_padded = False, temporal_mask = False).to(d).train()):
+		torch.manual_seed(11)
+		model = build()
+		with torch.no_grad():
+			model(x, xlen)  # one train-mode pass: running statistics that are not the initial ones
+		model.eval()
+		model.fuse_conv_bn_eval()
+		with torch.no_grad():
+			ref = model(x, xlen)['log_probs'][0].clone()
+			model.set_compute_dtype(name, inference = True)
+			assert model.backbone[1].split_inference
+			got = model(x, xlen)['log_probs'][0]
+			model.set_compute_dtype(name)
+			assert not model.backbone[1].split_inference and torch.equal(model(x, xlen)['log_probs'][0], ref)  # (default: evaluation stays exact fp32)
+		rng = float(ref.max() - ref.min())
+		assert float((got - ref).abs().max()) <= 2e-4 * rng, (float((got - ref).abs().max()), rng)
+		top2 = ref.topk(2, dim = 1).values
+		decided = (top2[:, 0] - top2[:, 1]) > 1e-3 * rng
+		assert bool((got.argmax(1) == ref.argmax(1))[decided].all())
 
 
 def test_split_operand_step_replays_bitwise_from_a_graph_with_dropout():
