@@ -15,8 +15,10 @@ for name, build in (('wav2letter', lambda: ca.models.Wav2Letter(64, [38])), ('ja
 	rows = {}
 	for world in (2, 4, 8):
 		for eff in (1.0, 0.7, 0.4):
-			p = eng.predict(world, ms[name], efficiency = eff)
+			p = eng.predict(world, ms[name], efficiency = eff, bytes_per_element = 4)
 			rows[f'N{world}_eff{eff}'] = {k: p[k] for k in ('exposed_comm_ms', 'comm_ms_total', 'backward_end_ms', 'predicted_scaling')}
+			h = eng.predict(world, ms[name], efficiency = eff, bytes_per_element = 2)  # the 16-bit exchange (round 6: DataParallelEngine(grad_comm_dtype); what apex O2 runs use by default)
+			rows[f'N{world}_eff{eff}_16bit_exchange'] = {k: h[k] for k in ('exposed_comm_ms', 'comm_ms_total', 'backward_end_ms', 'predicted_scaling')}
 		rows[f'N{world}_buckets'] = eng.predict(world, ms[name])['per_bucket']
 	out[name] = dict(step_ms = ms[name], gradient_mib = round(eng.flat.numel * 4 / 2 ** 20, 1), buckets_mib = [round((b['hi'] - b['lo']) * 4 / 2 ** 20, 1) for b in eng.buckets], predictions = rows)
 	eng.close()

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 G=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $G/r06_bench_line.json 2> $G/r06_bench_line.err
+SECONDS=0; python3 $R/bench.py > $G/r06_bench_line.json 2> $G/r06_bench_line.err; echo "default bench.py wall seconds: $SECONDS" > $G/r06_bench_wall.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $G/r06_stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-f16-leg --no-parity-legs --no-jasper-leg > $G/r06_stats_line.json 2> $G/r06_stats.log
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $G/r06_pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-traffic --no-f16-leg --no-parity-legs --no-jasper-leg > /dev/null 2> $G/r06_pmc_$c.log

@@ -152,6 +152,33 @@ def test_predicted_exposed_comm_model():
 		eng.close()
 
 
+def test_exchange_type_capturability_and_halved_prediction():
+	"""Round 6: what the gradient buckets travel as (DataParallelEngine(grad_comm_dtype)) and whether a step may be captured, decided without a
+	GPU: CPU arenas always exchange the fp32 arena in place and a gloo engine is never captured; 'auto' follows the model's compute type;
+	the prediction with 2 bytes per element moves half the bytes through every collective."""
+	import convasr_amd as ca
+	from convasr_amd.parallel import DataParallelEngine
+	model = ca.models.Wav2Letter(64, [38], base_width = 32).train()
+	eng = DataParallelEngine(model)
+	try:
+		assert eng.grad_comm_dtype == 'auto' and eng.comm_dtype() is None  # a CPU arena: no 16-bit send buffers
+		assert eng.capturable  # (no collectives: nothing stands in a capture's way)
+		full = eng.exchange_bytes()
+		assert full == sum((b['hi'] - b['lo']) * 4 for b in eng.buckets)
+		for spec, want in ((None, None), ('f32', None), ('f16', torch.float16), ('bf16', torch.bfloat16), (torch.float16, torch.float16)):
+			assert DataParallelEngine(model, flat = eng.flat, grad_comm_dtype = spec).grad_comm_dtype == want
+		a, b = eng.predict(8, 16.0, bytes_per_element = 4), eng.predict(8, 16.0, bytes_per_element = 2)
+		lat = 8 * 40e-3  # eight-ish collectives' fixed latency does not halve
+		assert b['bytes_per_element'] == 2 and 0.5 * a['comm_ms_total'] <= b['comm_ms_total'] <= 0.5 * a['comm_ms_total'] + len(eng.buckets) * 0.04 + 1e-6
+		assert b['exposed_comm_ms'] <= a['exposed_comm_ms']
+	finally:
+		eng.close()
+	from convasr_amd import rccl
+	assert rccl._NCCL_DTYPES[torch.float16] == 6 and rccl._NCCL_DTYPES[torch.float32] == 7 and rccl._NCCL_DTYPES[torch.bfloat16] == 9  # rccl.h: ncclDataType_t
+	import ctypes
+	assert ctypes.sizeof(rccl._UniqueId) == 128
+
+
 def test_flat_parameters_views_and_state_dict_roundtrip():
 	from convasr_amd.train import FlatParameters
 	model = Toy()
