@@ -402,12 +402,30 @@ def join_side_streams():
 	for dev, side in _side_streams.items():
 		if side is not None:
 			torch.cuda.current_stream(dev).wait_stream(side)
+	_wgrad_pending.clear()
+
+
+# WGRAD_AFTER_DGRAD (round 6, with the side stream on): a layer's weight gradient is enqueued on the side stream AFTER the same layer's dgrad and
+# ordered behind it, and the NEXT dgrad of the backward pass waits for it: the two MFMA-bound kernels of a layer never run side by side (that cost
+# the Wav2Letter step 1.5 % in round 3), but the memory-bound BN passes of the next layer (reduce / finalize / apply) run UNDER the weight gradient
+# instead of after it.  Off: the round-3 form -- wgrad enqueued before dgrad, both concurrently.
+WGRAD_AFTER_DGRAD = os.environ.get('CONVASR_WGRAD_AFTER_DGRAD', '0') == '1'
+_wgrad_pending = {}  # device -> a side-stream weight gradient the next dgrad must wait for
+
+
+def _join_pending_wgrad(dev):
+	if _wgrad_pending.pop(dev, False):
+		side = _side_streams.get(dev)
+		if side is not None:
+			torch.cuda.current_stream(dev).wait_stream(side)
 
 
 def _run_wgrad(dev, tensors, fn):
 	side = _side_streams.get(dev)
 	if side is None:
 		return fn()
+	if WGRAD_AFTER_DGRAD:
+		_wgrad_pending[dev] = True
 	side.wait_stream(torch.cuda.current_stream(dev))
 	with torch.cuda.stream(side):
 		out = fn()
@@ -551,6 +569,7 @@ def _dgrad(x, dy, weight, spec, dt, link = None, wd = None, split = None):
 	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad).
 	split: the 16-bit plane type of a split-operand conv -- dy is then its (B, 3 Cout, T) plane tensor (ops.split3, SPLIT_GRAD) and dx is fp32."""
 	pad = spec.dilation * (spec.K - 1) - spec.padding
+	_join_pending_wgrad(dy.device)
 	if split is not None:
 		Cout, Cin, K = weight.shape
 		B, _, Tdy = dy.shape
@@ -802,7 +821,8 @@ class ConvBnActFunction(torch.autograd.Function):
 			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad(xv, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
 		else:
 			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad(x, dy, Cout, spec.K, spec.stride, spec.dilation, spec.padding, outs[0], accumulate = acc))
-		if arena_mode:
+		after = WGRAD_AFTER_DGRAD and arena_mode and _side_streams.get(dev) is not None
+		if arena_mode and not after:
 			# enqueue before dgrad: both only read dy, and the side stream can start while dgrad is still being issued
 			dw, = _run_wgrad(dev, (x, dy), wg)
 		dx = None
@@ -810,6 +830,8 @@ class ConvBnActFunction(torch.autograd.Function):
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
 			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link, split = ctx.split)
+		if after:
+			dw, = _run_wgrad(dev, (x, dy), wg)  # behind this layer's dgrad on the side stream; the next dgrad waits for it (_join_pending_wgrad)
 		if not arena_mode:
 			dw, = wg()
 
