@@ -142,7 +142,8 @@ def _take_planes(x):
 def split_applies(split, dt, spec, Cin, Cout):
 	"""Does a conv of this geometry run as a split-operand conv?  fp32 storage with a 16-bit plane type set, stride 1 and channel counts
 	inside the LDS-DMA kernels' envelope (3 Cin % 64 == 0; the weight gradient's 128-channel tiles take Cin, Cout % 128 == 0 and fall back to the
-	general 16-bit kernel otherwise).  Everything else of an fp32 network -- the strided prologue, a ragged head -- stays on the exact-fp32 kernels."""
+	general 16-bit kernel otherwise).  The strided prologue joins through its stride-1 fold (Fold2.plan(split = ...)), a narrow one-tap head as a
+	128-class problem (_HeadPad.split_weight); what fits neither -- e.g. the one-tap residual branches of a dense block -- stays on the exact-fp32 kernels."""
 	return split is not None and dt == torch.float32 and spec.stride == 1 and Cin % 64 == 0 and Cout % 8 == 0
 
 
@@ -239,12 +240,11 @@ def prepack_dgrad_weights(weights, dtype):
 			stale.append(w)
 	if not stale:
 		return
-	# Once step graphs exist in this process, eager steps stay off the prepack stream too.  Measured in round 6 (scratch/r6_interleave_debug2.py,
-	# profiles/r06_interleave_race.txt): an eager step that packed on the side stream, followed by a replay of a graph whose pack nodes rewrite
-	# the same buffers, gave a different loss in the replayed step in roughly every other run (step 10 of the order A A B A B B C A B C A, small
-	# Wav2Letter, AdamW); with the copies on the main stream, or with a device synchronisation per step, never.  Every stream hand-over the
-	# host code makes is in place (side waits for main before the packs, main joins side before the first dgrad), so the overlap is between
-	# the replay and the side stream's tail inside the runtime; eager steps are the exception once graphs exist, so they simply do not fork.
+	# Once step graphs exist in this process, eager steps stay off the prepack stream too: one stream less at the boundary between an eagerly
+	# launched step and a replayed one, where round 6 found a race (profiles/r06_interleave_race.txt).  This alone did not close it -- what does
+	# is the host wait per transition in train.GraphedTrainStep._fence_transition -- but it removed the variant in which the replayed step's
+	# pack nodes rewrote buffers an eager step had just packed on the side stream (scratch/r6_interleave_debug2.py: differing losses in every other
+	# run before, none in 8 after).  Eager steps are the exception once graphs exist, so they simply do not fork.
 	if not PREPACK or GRAPHS_CAPTURED[0]:  # (A/B hook, and what a linear step-graph capture sets: the copies are made on the main stream, still in one launch)
 		_pack_dgrad_many(stale, dtype)
 		return
