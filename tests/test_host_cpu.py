@@ -152,3 +152,34 @@ def test_every_named_configuration_of_the_reference_builds_the_same_network():
 		got = json.loads(json.dumps(describe(cls(*args, **kw))))
 		for field in want:
 			assert got[field] == want[field], (key, field)
+
+
+def test_split_network_wiring_decides_which_outputs_exist_as_planes_only():
+	"""Round 6, host logic only: in a split-operand network (set_compute_dtype('bf16x3')) a layer output is handed on as its 16-bit planes ONLY when
+	its one reader is a split conv -- the next repeat of the block, or the first conv of the block the network wired behind it (feeds_block);
+	the last block (its reader is the decoder), tapped outputs of residual networks, evaluation mode and plain fp32 keep real fp32 outputs."""
+	import torch
+	import convasr_amd as ca
+	flags = lambda m: [[blk._planes_out(r, r == len(blk.conv) - 1) for r in range(len(blk.conv))] for blk in m.backbone]
+	m = ca.models.Wav2Letter(64, [38], compute_dtype = 'bf16x3').train()
+	assert m.compute_dtype == torch.float32 and m.split_dtype == torch.bfloat16 and m.decoder.split_dtype == torch.bfloat16
+	f = flags(m)
+	assert all(all(row) for row in f[:-1]) and f[-1] == [False], f  # 17 of the 18 layer outputs exist as planes only; the last feeds the head
+	assert [blk.feeds_block is not None for blk in m.backbone] == [True] * 7 + [False]
+	m.eval()
+	assert not any(any(row) for row in flags(m))
+	m.train()
+	m.set_compute_dtype(torch.float32)
+	assert m.split_dtype is None and not any(any(row) for row in flags(m))
+	m.set_compute_dtype('f16x3', inference = True)
+	assert m.split_dtype == torch.float16 and all(blk.split_inference for blk in m.backbone) and all(all(row) for row in flags(m)[:-1])
+	# a dense-residual network: block outputs that later blocks tap have several readers -> real tensors; repeats inside a block still hand planes on
+	j = ca.models.JasperNet(64, [38], base_width = 64, kernel_sizes = [11, 13], out_width_factors = [2, 3], dropouts = [0.0, 0.0], out_width_factors_large = [4, 4], residual = 'dense', repeat = 2, compute_dtype = 'bf16x3').train()
+	fj = flags(j)
+	tapped = [blk.tapped_output for blk in j.backbone]
+	for blk, row, tap in zip(j.backbone, fj, tapped):
+		assert row[:-1] == [True] * (len(row) - 1)  # inside a block: the next repeat is the one reader
+		assert row[-1] == (not tap and blk.feeds_block is not None), (row, tap)
+	assert any(tapped) and not fj[-1][-1]
+	# state-dict keys are untouched by the wiring (feeds_block is a weak reference, not a registered submodule)
+	assert not any('feeds_block' in k for k in j.state_dict())
