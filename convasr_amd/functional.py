@@ -116,6 +116,7 @@ def split_weight(w, dtype):
 
 
 _PLANES_ATTR = '_convasr_planes_only'
+_PLANES_CACHE_ATTR = '_convasr_planes_cache'  # on a REAL fp32 block output that several residual branches read: its planes, split once
 _nan_cells = {}
 
 
@@ -143,7 +144,8 @@ def split_applies(split, dt, spec, Cin, Cout):
 	"""Does a conv of this geometry run as a split-operand conv?  fp32 storage with a 16-bit plane type set, stride 1 and channel counts
 	inside the LDS-DMA kernels' envelope (3 Cin % 64 == 0; the weight gradient's 128-channel tiles take Cin, Cout % 128 == 0 and fall back to the
 	general 16-bit kernel otherwise).  The strided prologue joins through its stride-1 fold (Fold2.plan(split = ...)), a narrow one-tap head as a
-	128-class problem (_HeadPad.split_weight); what fits neither -- e.g. the one-tap residual branches of a dense block -- stays on the exact-fp32 kernels."""
+	128-class problem (_HeadPad.split_weight), the one-tap residual branches of a dense block with the tapped output's planes shared by its readers; what
+	fits none of these (channel counts outside the envelope) stays on the exact-fp32 kernels."""
 	return split is not None and dt == torch.float32 and spec.stride == 1 and Cin % 64 == 0 and Cout % 8 == 0
 
 
@@ -641,7 +643,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		Tout = y.shape[2]
 		bnp = ops.bn_finalize(stats, B * Tout, gamma, beta, bn.running_mean, bn.running_var, _momentum(bn), bn.eps, num_batches_tracked = bn.num_batches_tracked)
 
-		res_y, res_bnp = [], []
+		res_y, res_bnp, res_split = [], [], [False] * n_res
 		# where each batch-normed branch's input gradient goes in backward: the gradient accumulator its producer left on the tapped tensor
 		# (GRAD_ACC below), or None = hand it to autograd
 		ctx.res_gacc = [getattr(flat_res[5 * r], _GACC_ATTR, None) if (GROUP_RES and flat_res[5 * r + 1] is not None) else None for r in range(n_res)]
@@ -672,6 +674,17 @@ class ConvBnActFunction(torch.autograd.Function):
 				rbn = cfg['res_bn'][r]
 				if ys is not None:
 					ry, st = ys[r], sts[r]
+				elif split_applies(cfg.get('split'), dt, ConvSpec(1), rx.shape[1], Cout):
+					# a one-tap residual branch of a split-operand network: the tapped block output's planes (made once per step and kept on the
+					# tensor: up to ten later blocks read the same output) against the branch weight's planes
+					st = _stats_buffer(rbn, Cout, dev, B, Tout)
+					cache = flat_res[5 * r].__dict__
+					rx3 = cache.get(_PLANES_CACHE_ATTR)
+					if rx3 is None or rx3.dtype != cfg['split']:
+						rx3 = cache[_PLANES_CACHE_ATTR] = ops.split3(rx, cfg['split'], ops.SPLIT_INPUT)
+					ry = ops.conv1d(rx3, split_weight(rw, cfg['split'])[0], Cout, 1, 1, 1, 0, out_dtype = torch.float32, bias = rb, stats = st, work = 2.0 * B * Tout * Cout * rx.shape[1], family = SPLIT_FAMILY)
+					res_x[r] = rx3  # (what backward keeps of this branch's input: the weight gradient reads the planes as 3 T frames)
+					res_split[r] = True
 				else:
 					st = _stats_buffer(rbn, Cout, dev, B, Tout)
 					ry = ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, stats = st)
@@ -699,6 +712,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		ctx.x_needs_grad = x_needs_grad
 		ctx.save_for_backward(x, y, bnp, xl, *res_x, *[t for t in res_y], *[p for p in res_bnp if p is not None])
 		ctx.res_has_bn = [p is not None for p in res_bnp]
+		ctx.res_split = res_split
 		ctx.bwd_link = None
 		if FUSE_BWD and cfg.get('fuse_bwd') and n_res == 0 and dt in ops.HALF_DTYPES and Cout % 8 == 0:
 			ctx.bwd_link = dict(y = y, bnp = bnp, act = act, drop = (p_drop, seed, offset, skey), xl = xl, sums = _bwd_sums_buffer(bn, Cout, dev, B, Tout), dz = None, gate = gate)
@@ -848,6 +862,21 @@ class ConvBnActFunction(torch.autograd.Function):
 			p = res_bnp[r]
 			drg, drbeta, dry = grouped_bn[r] if grouped_bn else _bn_backward_from_g(g, res_y[r], rg, rbeta, p, rsum_of[r], B * Tout)
 			drx = None
+			if ctx.res_split[r]:
+				# split branch: dry as planes once; the input gradient as a split one-tap conv, the weight gradient over the planes read as frames
+				sp, cin_r = cfg['split'], rw.shape[1]
+				dry3 = ops.split3(dry, sp, ops.SPLIT_GRAD)
+				if need_rx:
+					drx = ops.conv1d(dry3, split_weight(rw, sp)[1], cin_r, 1, 1, 1, 0, out_dtype = torch.float32, work = 2.0 * B * Tout * Cout * cin_r, family = SPLIT_FAMILY)
+
+				def res_wgrad3(outs, acc, rx3 = rx, dry3 = dry3, rb = rb, cin_r = cin_r):
+					ops.conv1d_wgrad(ops.split3_frames(rx3), ops.split3_frames(dry3), Cout, 1, 1, 3, 0, outs[0], accumulate = acc, work = 2.0 * B * Tout * Cout * cin_r, family = SPLIT_WGRAD_FAMILY)
+					if outs[1] is not None and not acc and not (outs[1] is getattr(rb, '_convasr_grad', None) and getattr(rb, '_convasr_grad_is_zero', False)):
+						outs[1].zero_()  # (the bias of a conv that feeds a train-mode batch norm: an identically zero gradient, see below)
+						rb._convasr_grad_is_zero = outs[1] is getattr(rb, '_convasr_grad', None)
+				drw, drb = _deliver([rw, rb], res_wgrad3)
+				res_grads[5 * r:5 * r + 5] = [drx, drw, drb, drg, drbeta]
+				continue
 			if need_rx and ctx.res_gacc[r] is not None and rx.shape[1] % 128 == 0 and Cout % 64 == 0:
 				pending.append((r, dry))
 			elif need_rx:
