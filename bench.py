@@ -307,6 +307,9 @@ class Workload:
 					break
 			self.name = f'JasperNetLarge (Jasper 10x5, dense residuals, {sum(p.numel() for p in model.parameters()) / 1e6:.0f}M params), {self.batch} utterances of 5-20 s per GPU and step (BucketingBatchSampler -> collate_gpu, mixed lengths), logmel+convstack+CTC fwd+bwd+clip+NovoGrad, dropout {args.dropout:g}'
 		self.model._convasr_flat = self.flat
+		if dtype == 'f16x3':  # fp16 planes: the output gradients need the dynamic loss scaler like plain fp16's
+			ca.models.data_parallel_and_autocast(self.model, self.opt, compute_dtype = 'f16x3')
+			assert self.model.split_dtype == torch.float16 and self.flat.loss_scaler is not None
 		if dtype == 'f16':  # apex O2: fp16 compute, fp32 masters, dynamic loss scaling from 2^16 (the start-up overflows fall into the warm-up steps)
 			ca.models.data_parallel_and_autocast(self.model, self.opt, opt_level = 'O2')
 			assert self.model.compute_dtype == torch.float16 and self.flat.loss_scaler is not None

@@ -657,7 +657,8 @@ def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, op
 	keep_batchnorm_fp32 is accepted and has nothing left to decide) -- and, given an optimizer, attaches apex's loss scaling to it:
 	dynamic for O1 / O2 (train.LossScaler; overflowed steps are skipped and the scale halves), static 1.0 for O3, `loss_scale`
 	(a number or 'dynamic') overriding either, exactly apex's kwarg.  compute_dtype = torch.bfloat16 (an extension; env
-	CONVASR_AMP_DTYPE=bf16 makes it the default) runs the same kernels on bf16 storage, whose fp32 exponent range needs no loss scale."""
+	CONVASR_AMP_DTYPE=bf16 makes it the default) runs the same kernels on bf16 storage, whose fp32 exponent range needs no loss scale;
+	compute_dtype = 'bf16x3' / 'f16x3' selects the split-operand path (JasperNet.set_compute_dtype), 'f16x3' with the dynamic loss scaler."""
 	amp = opt_level not in (None, '', 'O0')
 	dtype = compute_dtype or (AMP_DTYPE if amp else torch.float32)
 	master_module(model).set_compute_dtype(dtype)
@@ -665,7 +666,7 @@ def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, op
 	if flat is not None:
 		from .train import LossScaler
 		if loss_scale is None:
-			loss_scale = 'dynamic' if (dtype == torch.float16 and opt_level in ('O1', 'O2')) else None
+			loss_scale = 'dynamic' if ((dtype == torch.float16 and opt_level in ('O1', 'O2')) or dtype == 'f16x3') else None  # ('f16x3': fp32 storage, but the output gradients travel as fp16 planes -- the same range problem, the same cure)
 		flat.loss_scaler = None if loss_scale in (None, 1, 1.0) else LossScaler(flat.data.device, loss_scale = loss_scale)
 	elif dtype == torch.float16 and master_module(model).training and opt_level in ('O1', 'O2'):
 		# apex would scale the loss here; without an arena optimizer (convasr_amd.train.SGD / optimizers.NovoGrad / AdamW) there is nothing

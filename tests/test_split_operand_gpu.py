@@ -228,6 +228,33 @@ def test_split_operand_dense_residual_network_tracks_the_exact_fp32_path():
 	assert worst[0] <= 2e-2, worst  # (measured 5.6e-3, in the prologue's batch-norm bias: the far end of a backward pass that amplifies any difference ~1.2x per layer)
 
 
+def test_f16x3_trains_under_the_dynamic_loss_scaler():
+	"""fp16 planes carry 22 significant bits but fp16's range: data_parallel_and_autocast(compute_dtype = 'f16x3') attaches the dynamic loss scaler
+	(the output gradients' planes are what over- / underflows).  From a deliberately high initial scale the start-up steps overflow and are skipped
+	(parameters untouched), the scale halves until the gradients fit, and the first applied step's loss equals the exact-fp32 path's to 1e-5."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	batch = _batch(d, 6, 4)
+	model = _small(ca, d, torch.float32)
+	flat = ca.train.FlatParameters(model)
+	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+	ca.models.data_parallel_and_autocast(model, opt, compute_dtype = 'f16x3')
+	assert model.split_dtype == torch.float16 and model.compute_dtype == torch.float32 and flat.loss_scaler is not None
+	flat.loss_scaler = ca.train.LossScaler(d, init_scale = 2.0 ** 24)
+	p0 = flat.data.clone()
+	ref = _small(ca, d, torch.float32)
+	ref_loss = float(ca.train.train_step(ref, ca.train.SGD(ca.train.FlatParameters(ref), lr = 1e-2, momentum = 0.9, weight_decay = 1e-3), *batch)['loss'])
+	hist = []
+	for it in range(12):
+		untouched = bool(torch.equal(flat.data, p0))
+		r = ca.train.train_step(model, opt, *batch, iteration = it)
+		hist.append((float(r['loss']), bool(torch.isfinite(r['grad_norm'])), flat.loss_scaler.loss_scale(), untouched))
+	skipped = [h for h in hist if not h[1]]
+	assert skipped and all(h[3] for h in hist[:len(skipped) + 1]) and any(h[1] for h in hist), hist  # overflowed steps first, parameters untouched until the first applied one
+	assert hist[-1][2] < 2.0 ** 24 and abs(hist[0][0] - ref_loss) / ref_loss <= 1e-5, (hist, ref_loss)
+	assert bool(torch.isfinite(flat.data).all()) and not torch.equal(flat.data, p0)
+
+
 def test_split_operand_eval_and_no_grad_run_the_exact_fp32_kernels():
 	import convasr_amd as ca
 	d = torch.device('cuda:0')
