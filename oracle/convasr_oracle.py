@@ -189,6 +189,25 @@ def conv_same_padding(x, weight, bias = None, stride = 1, dilation = 1):
 	return F.conv1d(x, weight, bias, stride = stride, padding = dilation * K // 2, dilation = dilation)
 
 
+def split_planes(x, dtype = torch.bfloat16):
+	"""The two 16-bit planes the MI355X split-operand path ('bf16x3' / 'f16x3', csrc/split3.hip) carries an fp32 value as:
+	hi = rn16(x), lo = rn16(x - hi); x - hi is exact in fp32.  Returned as fp32 tensors holding the rounded values."""
+	hi = x.to(dtype).to(torch.float32)
+	lo = (x - hi).to(dtype).to(torch.float32)
+	return hi, lo
+
+
+def conv1d_split3(x, weight, bias = None, stride = 1, padding = 0, dilation = 1, dtype = torch.bfloat16, accumulate = torch.float64):
+	"""nn.Conv1d (models.py:47-77) computed the way the split-operand path computes it: every product x w as x_hi w_hi + x_lo w_hi + x_hi w_lo
+	(x_lo w_lo dropped), each of the three an exact product of two 16-bit values; `accumulate` is the type the sums run in (float64 here
+	isolates what the split itself leaves out; the kernels accumulate in fp32).  The restatement of the ARITHMETIC, not of a kernel."""
+	xh, xl = (t.to(accumulate) for t in split_planes(x, dtype))
+	wh, wl = (t.to(accumulate) for t in split_planes(weight, dtype))
+	conv = lambda a, b: F.conv1d(a, b, None, stride = stride, padding = padding, dilation = dilation)
+	y = conv(xh, wh) + conv(xl, wh) + conv(xh, wl)
+	return y if bias is None else y + bias.to(accumulate).view(1, -1, 1)
+
+
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum = 0.1, eps = 1e-5):
 	"""nn.BatchNorm1d semantics; updates running stats in place when training."""
 	return F.batch_norm(x, running_mean, running_var, gamma, beta, training, momentum, eps)

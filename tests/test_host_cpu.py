@@ -183,3 +183,28 @@ def test_split_network_wiring_decides_which_outputs_exist_as_planes_only():
 	assert any(tapped) and not fj[-1][-1]
 	# state-dict keys are untouched by the wiring (feeds_block is a weak reference, not a registered submodule)
 	assert not any('feeds_block' in k for k in j.state_dict())
+
+
+def test_split_operand_arithmetic_restated_on_the_cpu():
+	"""What the MI355X split-operand path claims, checked on the CPU against float64 (oracle.conv1d_split3, the restatement of its arithmetic): two
+	bf16 planes hold 16 significant bits (fp16: 22, above its subnormal range), x - hi is exact, and a conv formed from the three kept
+	products sits 2^-17 .. 2^-16 from the float64 conv -- three orders of magnitude inside plain bf16's 2^-9 -- with the dropped lo x lo
+	term accounting for what is left."""
+	import torch
+	import torch.nn.functional as F
+	from oracle import convasr_oracle as O
+	torch.manual_seed(0)
+	x = torch.randn(3, 64, 200) * torch.logspace(-2, 1, 64).view(1, 64, 1)
+	w = torch.randn(96, 64, 11) / (64 * 11) ** 0.5
+	for dt, bits in ((torch.bfloat16, 8), (torch.float16, 11)):
+		hi, lo = O.split_planes(x, dt)
+		assert torch.equal((x - hi).to(dt).float(), lo) and bool(((hi + lo - x).abs() <= x.abs() * 2.0 ** (-2 * bits) + (2.0 ** -25 if dt == torch.float16 else 0)).all())
+	ref = F.conv1d(x.double(), w.double(), padding = 5)
+	rel = lambda a: float((a.double() - ref).norm() / ref.norm())
+	e3 = rel(O.conv1d_split3(x, w, padding = 5))
+	e1 = rel(F.conv1d(x.bfloat16().double(), w.bfloat16().double(), padding = 5))
+	assert 1e-6 < e3 < 8e-6 and e1 > 300 * e3, (e3, e1)  # measured on the MI355X kernels: 4.5e-6 and 2.3e-3
+	xh, xl = O.split_planes(x); wh, wl = O.split_planes(w)
+	full = O.conv1d_split3(x, w, padding = 5) + F.conv1d(xl.double(), wl.double(), padding = 5)  # + the dropped term: what is left is the planes' own residue
+	assert rel(full) < 0.8 * e3
+	assert rel(O.conv1d_split3(x, w, padding = 5, dtype = torch.float16)) < 5e-7
