@@ -168,33 +168,51 @@ class AdamW:
 
 
 def reset_options(optimizer):
+	"""optimizers.py:4-6: every parameter group back to the optimizer's constructor defaults."""
 	for group in optimizer.param_groups:
 		group.update(optimizer.defaults)
 
 
 class LRScheduler:
+	"""optimizers.py:9-16.  `step(n)` writes the schedule's rates for iteration n into the optimizer's parameter groups; the reference calls it
+	with the iteration number after every applied optimizer step (train.py:783).  Host arithmetic only: a captured step graph reads the rate from
+	device memory, which train.GraphedTrainStep refreshes whenever `param_groups[0]['lr']` moved."""
+
 	def __init__(self, optimizer):
 		self.optimizer = optimizer
 
+	def initial_rates(self):
+		return [float(group['lr']) for group in self.optimizer.param_groups]
+
+	def get_lr(self, step):
+		raise NotImplementedError
+
 	def step(self, step):
-		for group, lr in zip(self.optimizer.param_groups, self.get_lr(step)):
-			group['lr'] = lr
+		rates = self.get_lr(step)
+		for i, group in enumerate(self.optimizer.param_groups):
+			group['lr'] = rates[i]
 
 
 class NoopLR(LRScheduler):
+	"""optimizers.py:18-20: the rates stay what they are."""
+
 	def get_lr(self, step):
-		return [group['lr'] for group in self.optimizer.param_groups]
+		return self.initial_rates()
 
 
 class MultiStepLR(LRScheduler):
+	"""optimizers.py:23-32: rate x gamma^(index + 1 of the LAST milestone in list order that the step has reached) -- the reference's own reading of
+	its milestone list, kept as it is (for an ascending list: the number of milestones passed)."""
+
 	def __init__(self, optimizer, gamma, milestones):
-		self.init_lr = [group['lr'] for group in optimizer.param_groups]
-		self.gamma, self.milestones = gamma, milestones
 		super().__init__(optimizer)
+		self.init_lr, self.gamma, self.milestones = self.initial_rates(), gamma, milestones
 
 	def get_lr(self, step):
-		hit = [i + 1 for i, m in enumerate(self.milestones) if step >= m]  # the last milestone reached, in list order (optimizers.py:31)
-		power = hit[-1] if hit else 0
+		power = 0
+		for i, m in enumerate(self.milestones):
+			if step >= m:
+				power = i + 1
 		return [lr0 * self.gamma ** power for lr0 in self.init_lr]
 
 
@@ -203,13 +221,19 @@ class PolynomialDecayLR(LRScheduler):
 	reference's decay branch reads an undefined name and cannot run, this is the schedule its arguments describe)."""
 
 	def __init__(self, optimizer, decay_steps, power = 1.0, begin_decay_at = 0, end_lr = 0.0, warmup_steps = 0):
-		self.decay_steps, self.power, self.begin_decay_at, self.end_lr, self.warmup_steps = decay_steps, power, begin_decay_at, end_lr, warmup_steps
-		self.init_lr = [group['lr'] for group in optimizer.param_groups]
 		super().__init__(optimizer)
+		self.decay_steps, self.power, self.begin_decay_at, self.end_lr, self.warmup_steps = decay_steps, power, begin_decay_at, end_lr, warmup_steps
+		self.init_lr = self.initial_rates()
+
+	def _rate(self, lr0, step):
+		if step >= self.begin_decay_at:  # (the decay branch wins over the warm-up one where both apply, as in the reference's statement order)
+			k = min(step - self.begin_decay_at, self.decay_steps)
+			if k >= self.decay_steps:
+				return self.end_lr
+			return self.end_lr + (lr0 - self.end_lr) * ((self.decay_steps - k) / self.decay_steps) ** self.power
+		if self.warmup_steps > 0 and step < self.warmup_steps:
+			return lr0 * step / self.warmup_steps
+		return lr0
 
 	def get_lr(self, step):
-		lrs = [lr0 * step / self.warmup_steps if self.warmup_steps > 0 and step < self.warmup_steps else lr0 for lr0 in self.init_lr]
-		if step >= self.begin_decay_at:
-			k = min(step - self.begin_decay_at, self.decay_steps)
-			lrs = [self.end_lr + (lr0 - self.end_lr) * ((self.decay_steps - k) / self.decay_steps) ** self.power if k < self.decay_steps else self.end_lr for lr0 in self.init_lr]
-		return lrs
+		return [self._rate(lr0, step) for lr0 in self.init_lr]
