@@ -991,3 +991,46 @@ def test_fused_dgrad_epilogue_matrix_pipe_sums_at_the_bench_size(dtype):
 	close(got[:C], ref[:C], 1e-5, 2e-2, 'sum g')  # sums of ~48 K terms of magnitude ~1: fp32 chains in different orders
 	close(got[C:], ref[C:], 1e-5, 1e-1, 'sum g xhat')
 	assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+def test_colsum_is_the_bias_gradient_of_a_conv(dt):
+	"""convasr_colsum (the split-operand head's bias gradient, models.py:26): out[c] (+)= sum over (b, t) of a channels-last tensor, fp32 sums in a fixed
+	order -- against a float64 sum, bitwise repeatable, accumulate adds."""
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(0)
+	y = ops.as_cl((torch.randn(5, 38, 777) * 3).to(d), dt)
+	ref = y.double().sum(dim = (0, 2))
+	out = torch.empty(38, device = d)
+	ops.colsum(y, out)
+	again = torch.empty(38, device = d)
+	ops.colsum(y, again)
+	assert torch.equal(out, again)
+	assert float((out.double() - ref).abs().max()) <= 2e-6 * float(y.double().abs().sum(dim = (0, 2)).max())
+	ops.colsum(y, out, accumulate = True)
+	assert torch.allclose(out.double(), 2 * ref, rtol = 1e-5, atol = 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('half', [torch.float16, torch.bfloat16])
+def test_cast_scale_packs_and_unpacks_a_gradient_bucket(half):
+	"""convasr_cast_scale, the two ends of the 16-bit gradient exchange (models.py:744-765 under apex O2): fp32 -> 16-bit x scale with
+	round-to-nearest-even (inf beyond fp16's range: what the loss scaler's overflow check keys on), and back exactly."""
+	from convasr_amd import _lib
+	d = torch.device('cuda:0')
+	torch.manual_seed(1)
+	n = 8 * 1000
+	g = (torch.randn(n) * torch.logspace(-6, 3, n)).to(d)
+	g[5] = 1e6
+	buf = torch.empty(n, dtype = half, device = d)
+	back = torch.empty(n, device = d)
+	s = _lib.stream_ptr()
+	_lib.call('convasr_cast_scale', _lib.ptr(g), _lib.F32, _lib.ptr(buf), _lib.dtype_code(half), n, 0.125, s)
+	_lib.call('convasr_cast_scale', _lib.ptr(buf), _lib.dtype_code(half), _lib.ptr(back), _lib.F32, n, 1.0, s)
+	want = (g * 0.125).to(half)
+	assert torch.equal(buf, want) and torch.equal(back, want.float())
+	assert bool(torch.isinf(buf[5])) == (half == torch.float16)
+	with pytest.raises(_lib.ConvasrHipError):
+		_lib.call('convasr_cast_scale', _lib.ptr(g), _lib.F32, _lib.ptr(buf), _lib.dtype_code(half), n - 3, 1.0, s)  # n % 8 != 0
