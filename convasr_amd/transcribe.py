@@ -66,7 +66,11 @@ def setup(args):
 	model.eval()
 	model.fuse_conv_bn_eval()
 	if str(args.device) != 'cpu':
-		model, *_ = models.data_parallel_and_autocast(model, opt_level = getattr(args, 'fp16', None))
+		level = getattr(args, 'fp16', None)
+		if level in models.JasperNet.SPLIT_DTYPES:  # (this package's own: args.fp16 = 'bf16x3' / 'f16x3' -- fp32-class logits from split-operand convs on the 16-bit matrix pipe)
+			models.master_module(model).set_compute_dtype(level, inference = True)
+		else:
+			model, *_ = models.data_parallel_and_autocast(model, opt_level = level)
 	generator = GreedyCTCGenerator()
 	return text_pipeline, frontend, model, generator
 
