@@ -382,3 +382,30 @@ def test_capture_after_a_validation_pass_still_records_every_pack_launch():
 		assert graph[3].captures == 1 and graph[3].replays == 5
 		assert eager[0] == graph[0], (dt, list(zip(eager[0], graph[0])))
 		assert torch.equal(eager[1], graph[1])
+
+
+def test_transcribe_setup_with_split_operand_inference_reproduces_the_reference_strings():
+	"""convasr_amd.transcribe.setup(args.fp16 = 'bf16x3') against the vectors the reference's own transcribe body produced (tests/golden/transcribe.*):
+	log-probs within 5e-4 absolute (plain bf16 inference is at ~5e-2 on this net), greedy strings identical."""
+	import json
+	import os
+	import types
+	import numpy as np
+	import convasr_amd as ca
+	root = os.path.dirname(os.path.abspath(__file__))
+	g = np.load(os.path.join(root, 'golden', 'transcribe.npz'))
+	j = json.load(open(os.path.join(root, 'golden', 'transcribe.json')))
+	T_ = lambda a: torch.as_tensor(np.asarray(a))
+	sd = {k[3:]: T_(g[k]) for k in g.files if k.startswith('sd/')}
+	ckpt_args = dict(j['args'], alphabet = j['alphabet'], model_kwargs = dict(base_width = 32, kernel_sizes = [11], out_width_factors = [2], dropouts = [0.2], out_width_factors_large = [2, 2], residual = False, repeat = 1, nonlinearity = ('hardtanh', 0, 20), dilation = 2))
+	args = types.SimpleNamespace(checkpoint = dict(args = dict(ckpt_args), model_state_dict = sd), device = 'cuda:0', fp16 = 'bf16x3', frontend_in_model = True, model = None, align = False)
+	try:
+		text_pipeline, frontend, model, generator = ca.transcribe.setup(args)
+		assert model.split_dtype == torch.bfloat16 and model.backbone[1].split_inference and model.compute_dtype == torch.float32
+		res = ca.transcribe.transcribe_batch(args, text_pipeline, model, generator, T_(g['wav']).unsqueeze(1), T_(g['xlen']), T_(g['begin']), T_(g['end']))
+		assert torch.equal(res.olen.cpu(), T_(g['olen']))
+		err = float((res.log_probs.cpu() - T_(g['log_probs'])).abs().max())
+		assert err <= 5e-4, err  # measured 1.7e-4 on log-probs down to -11 (16 significant bits per operand); the exact fp32 path's bar in test_bf16_parity_gpu is 1e-4
+		assert res.hyp == j['hyp'], (res.hyp, j['hyp'])
+	finally:
+		torch.set_grad_enabled(True)  # (transcribe.setup switches autograd off for the process, like the reference)
