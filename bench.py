@@ -51,7 +51,7 @@ MAIN_KERNEL_SYMBOLS = dict(
 	bf16 = ('conv1d_igemm_v2s_kernel<unsigned short, unsigned short', 'conv1d_igemm_v2s_kernelIttLi'),
 	f16 = ('conv1d_igemm_v2s_kernel<_Float16, _Float16', 'conv1d_igemm_v2s_kernel<__half, __half', 'conv1d_igemm_v2s_kernelIDF16_DF16_Li'))
 MAIN_FAMILY = 'conv1d_igemm_v2s_kernel<bf16>'  # (family labels are shared by the two 16-bit types)
-SPLIT_FAMILY, SPLIT_WGRAD_FAMILY, SPLIT_DTYPES = 'conv1d_igemm_v2s_kernel<x3>', 'conv1d_wgrad<x3>', ('bf16x3', 'f16x3')  # convasr_amd.functional: the split-operand launches are booked apart, with their ALGORITHMIC FLOPs (each runs three MFMAs per product)
+SPLIT_FAMILY, SPLIT_WGRAD_FAMILY, SPLIT_DTYPES = 'conv1d_igemm_v2s_kernel<x3>', 'conv1d_wgrad<x3>', ('bf16x3', 'f16x3', 'bf16x3f', 'f16x3f')  # convasr_amd.functional: the split-operand launches are booked apart, with their ALGORITHMIC FLOPs (each runs three MFMAs per product)
 
 
 def graph_policy(opt, workload, gpus):
@@ -65,7 +65,7 @@ def parse_args(argv = None):
 	ap.add_argument('--steps', type = int, default = 10)
 	ap.add_argument('--warmup', type = int, default = 3)
 	ap.add_argument('--workload', default = 'wav2letter', choices = ['wav2letter', 'jasper_large'])
-	ap.add_argument('--dtype', default = None, choices = ['bf16', 'f16', 'f32', 'bf16x3', 'f16x3'], help = 'default: bf16 (wav2letter), f16 (jasper_large); bf16x3 / f16x3: fp32 storage with split-operand convs (three 16-bit MFMAs per product, fp32-class accuracy)')
+	ap.add_argument('--dtype', default = None, choices = ['bf16', 'f16', 'f32', 'bf16x3', 'f16x3', 'bf16x3f', 'f16x3f'], help = 'default: bf16 (wav2letter), f16 (jasper_large); bf16x3 / f16x3: fp32 storage with split-operand convs (three 16-bit MFMAs per product, fp32-class accuracy); bf16x3f / f16x3f: that forward (the same loss), one 16-bit product per gradient in the backward')
 	ap.add_argument('--dropout', type = float, default = 0.2, help = 'the reference default (train.py:1033) is 0.2; other values are for experiments only')
 	ap.add_argument('--batch', type = int, default = None, help = 'TEST ONLY: utterances per GPU (a line measured with it is not the headline)')
 	ap.add_argument('--secs', type = int, default = None, help = 'TEST ONLY: seconds per utterance (wav2letter)')
@@ -273,7 +273,7 @@ class Workload:
 		self.args, self.device = args, device
 		dtype = dtype or args.dtype
 		self.dtype = dtype
-		compute = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32, bf16x3 = 'bf16x3', f16x3 = 'f16x3')[dtype]
+		compute = dict(bf16 = torch.bfloat16, f16 = torch.float16, f32 = torch.float32, bf16x3 = 'bf16x3', f16x3 = 'f16x3', bf16x3f = 'bf16x3f', f16x3f = 'f16x3f')[dtype]
 		fe = ca.models.LogFilterBankFrontend(64, SAMPLE_RATE, 0.02, 0.01, 'hann_window')
 		n_batches = args.warmup + args.steps + min(args.steps, 5)
 		if args.workload == 'wav2letter':
@@ -307,8 +307,8 @@ class Workload:
 					break
 			self.name = f'JasperNetLarge (Jasper 10x5, dense residuals, {sum(p.numel() for p in model.parameters()) / 1e6:.0f}M params), {self.batch} utterances of 5-20 s per GPU and step (BucketingBatchSampler -> collate_gpu, mixed lengths), logmel+convstack+CTC fwd+bwd+clip+NovoGrad, dropout {args.dropout:g}'
 		self.model._convasr_flat = self.flat
-		if dtype == 'f16x3':  # fp16 planes: the output gradients need the dynamic loss scaler like plain fp16's
-			ca.models.data_parallel_and_autocast(self.model, self.opt, compute_dtype = 'f16x3')
+		if dtype in ('f16x3', 'f16x3f'):  # fp16 planes: the output gradients need the dynamic loss scaler like plain fp16's
+			ca.models.data_parallel_and_autocast(self.model, self.opt, compute_dtype = dtype)
 			assert self.model.split_dtype == torch.float16 and self.flat.loss_scaler is not None
 		if dtype == 'f16':  # apex O2: fp16 compute, fp32 masters, dynamic loss scaling from 2^16 (the start-up overflows fall into the warm-up steps)
 			ca.models.data_parallel_and_autocast(self.model, self.opt, opt_level = 'O2')
@@ -600,9 +600,10 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world, graphed = False):
 	tf = lambda k: k['work'] / (k['total_ms'] * 1e-3) / 1e12
 	k = kt[main_name]
 	n_plain = 0 if plain is None or plain is k else plain['launches']
+	hi_bwd = wl.dtype.endswith('x3f')
 	if split:
-		kernel = (f'conv1d_igemm_v2s_kernel<H, float, 0> as a split-operand conv ({k["launches"] // args.steps} forward + dgrad launches per step: 16-bit planes (hi, lo, hi) of the fp32 operands read as 3 C channels, fp32 output; '
-			'achieved / frac count ALGORITHMIC FLOPs, every product costs three MFMAs: executed_mfma_frac = 3 x frac; the strided prologue and the 38-class head run the exact-fp32 kernels)')
+		kernel = (f'conv1d_igemm_v2s_kernel<H, float, 0> as a split-operand conv ({k["launches"] // args.steps} ' + ('forward launches per step (the dgrads run as one 16-bit product: roofline.dgrad_one_product)' if hi_bwd else 'forward + dgrad launches per step') + ': 16-bit planes (hi, lo, hi) of the fp32 operands read as 3 C channels, fp32 output; '
+			'achieved / frac count ALGORITHMIC FLOPs, every product costs three MFMAs: executed_mfma_frac = 3 x frac; the strided prologue runs here as its stride-1 fold, the 38-class head as a 128-class problem)')
 	elif half:
 		kernel = (f'conv1d_igemm_v2s_kernel<O, BNF> ({(plain["launches"] if plain else 0) // args.steps} forward / plain + {(k["launches"] - n_plain) // args.steps} fused dgrad launches per step; '
 			'the fused dgrads also run pass 1 of the BN backward of the layer below in their epilogue; the prologue conv runs here as its stride-2 fold)')
@@ -620,10 +621,13 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world, graphed = False):
 			achieved = round(tf(plain), 2), frac = round(tf(plain) / peak, 4), launches_per_step = plain['launches'] // args.steps, avg_launch_us = round(plain['avg_us'], 2))
 	if split:
 		roof['executed_mfma_frac'] = round(3 * tf(k) / peak, 4)
-	wname = SPLIT_WGRAD_FAMILY if split else 'conv1d_wgrad'
+	wname = SPLIT_WGRAD_FAMILY if (split and not hi_bwd) else 'conv1d_wgrad'
+	if hi_bwd and MAIN_FAMILY in kt:
+		g = kt[MAIN_FAMILY]
+		roof['dgrad_one_product'] = dict(kernel = 'conv1d_igemm_v2s_kernel<H, float, 0>: dy rounded once to 16 bits x w_hi, fp32 dx', achieved = round(tf(g), 2), frac = round(tf(g) / peak, 4), launches_per_step = g['launches'] // args.steps, avg_launch_us = round(g['avg_us'], 2), ms_per_step = round(g['total_ms'] / args.steps, 3))
 	if wname in kt and kt[wname] is not k:
 		w = kt[wname]
-		roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel incl. its split-K combine' + (' over the planes read as 3 T frames (three MFMAs per product: executed = 3 x achieved)' if split else ' (+ general wgrad kernel on small layers)'), achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4),
+		roof['wgrad'] = dict(kernel = 'conv1d_wgrad_v2_kernel incl. its split-K combine' + (' over the hi plane of the saved planes, read in place (frames 3 Cin elements apart), x the 16-bit dy: one product' if hi_bwd else ' over the planes read as 3 T frames (three MFMAs per product: executed = 3 x achieved)' if split else ' (+ general wgrad kernel on small layers)'), achieved = round(tf(w), 2), frac = round(tf(w) / peak, 4),
 			launches_per_step = w['launches'] // args.steps, avg_launch_us = round(w['avg_us'], 2), ms_per_step = round(w['total_ms'] / args.steps, 3))
 	allc = list(kt.values())
 	stack = sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12
@@ -948,7 +952,7 @@ def main(argv = None):
 		if world == 1 and headline_run and not args.no_parity_legs:
 			# the same workload on the two paths that meet north_star's 1e-4, each its own model / arena / optimizer, right after the headline on the
 			# same device: bf16x3 (split-operand convs at MFMA rate) and exact fp32 (v_mfma_f32: ~0.2 s per step, three timed steps)
-			for name, steps, warmup, timer_off in (('bf16x3', min(args.steps, 10), 2, False), ('f32', min(args.steps, 3), 1, True)):
+			for name, steps, warmup, timer_off in (('bf16x3', min(args.steps, 10), 2, False), ('bf16x3f', min(args.steps, 10), 2, False), ('f32', min(args.steps, 3), 1, True)):
 				argsp = argparse.Namespace(**dict(vars(args), dtype = name, steps = steps, warmup = warmup, no_kernel_timer = timer_off, side_stream = False, graph = False))
 				try:
 					lp, _ = measure(argsp, device, rank, world, False, None, lambda: torch.cuda.synchronize(), None)
@@ -961,8 +965,12 @@ def main(argv = None):
 							conv_stack = rp.get('conv_stack'), hbm_kernels = rp.get('hbm_kernels')),
 							bf16x3_vs_f32_peak = round(lp['config']['whole_step_tflops'] * 1e12 / PEAK_F32_MFMA, 3),
 							bf16x3_note = 'second timed region, same device and workload: fp32 storage, every stride-1 conv as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (csrc/split3.hip); whole_step_frac prices the ALGORITHMIC FLOPs against the 2.5 PF bf16 peak (the MFMA work executed is ~3x that), bf16x3_vs_f32_peak against the 157.3 TF exact-fp32 MFMA peak')
+					elif name == 'bf16x3f':
+						rp = lp['roofline'] or {}
+						parity_legs.update(bf16x3f_roofline = dict(forward_frac = rp.get('frac'), forward_executed_mfma_frac = rp.get('executed_mfma_frac'), dgrad_one_product = rp.get('dgrad_one_product'), wgrad = rp.get('wgrad'), conv_stack = rp.get('conv_stack')),
+							bf16x3f_note = 'the bf16x3 forward -- the same launches, the same CTC loss bit for bit (tests/test_split_operand_gpu.py), i.e. parity.ctc_loss_rel_err["bf16x3"] -- with ONE 16-bit product per gradient in the backward (dy rounded once, x_hi read in place from the saved planes, w_hi): gradients of the bf16 headline\'s accuracy, as under the reference\'s apex O2 (models.py:744-762)')
 					else:
-						parity_legs.update(f32_note = 'third timed region, same device and workload: the exact-fp32 parity path (v_mfma_f32_32x32x2_f32 kernels of conv.hip), priced against the 157.3 TF fp32 MFMA peak')
+						parity_legs.update(f32_note = 'fourth timed region, same device and workload: the exact-fp32 parity path (v_mfma_f32_32x32x2_f32 kernels of conv.hip), priced against the 157.3 TF fp32 MFMA peak')
 				except Exception as e:  # (a leg must never cost the headline its line)
 					import traceback
 					traceback.print_exc(file = sys.stderr)

@@ -85,7 +85,9 @@ _SIGNATURES = dict(
 	convasr_bn_act_fwd_split3 = (c_int, [c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_bn_act_bwd_apply_split3 = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
 	convasr_split3 = (c_int, [c_p, c_p, c_int, c_i64, c_int, c_int, c_p]),
-	convasr_pack_conv_weight_split3 = (c_int, [c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_p]),
+	convasr_pack_conv_weight_split3 = (c_int, [c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_bn_act_bwd_apply_to_half = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
+	convasr_conv1d_wgrad_ld = (c_int, [c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),
 	convasr_collate_pad = (c_int, [c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_i64, c_p]),
 	convasr_ctc_alignment_workspace_bytes = (c_i64, [c_int, c_int, c_int]),
@@ -116,7 +118,7 @@ def load():
 		for name, (res, args) in _SIGNATURES.items():
 			fn = getattr(lib, name)
 			fn.restype, fn.argtypes = res, args
-		if lib.convasr_abi_version() != 9:
+		if lib.convasr_abi_version() != 10:
 			raise ConvasrHipError('ABI version mismatch')
 		_lib = lib
 	return _lib

@@ -317,6 +317,7 @@ __device__ __forceinline__ void fold_step_key(BnActParams& p) { if (p.drop_thr &
 // planes per frame, [row][3][C] (order 0: a conv input) -- the pass that would otherwise follow (read 4 + write 6 bytes per element) is gone.
 template <int SPLIT> struct PlaneType { typedef bf16_t H; };
 template <> struct PlaneType<2> { typedef f16_t H; };
+template <> struct PlaneType<4> { typedef f16_t H; };  // (3 / 4, the backward apply only: the hi plane alone, dense [row][C] bf16 / fp16 -- the one-product backward of a split-operand forward)
 template <typename T, int MODE, int SPLIT = 0> __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActParams p, ResArgs ra_) {
 	constexpr bool RES = MODE & 1, DROP = (MODE & 2) != 0, GATE = (MODE & 4) != 0, AFFINE = (MODE & 8) != 0, LEAKY = (MODE & 16) != 0;
 	ResArgs ra = ra_;
@@ -1032,6 +1033,7 @@ template <typename T, int SRC, int SPLIT = 0> __global__ __launch_bounds__(256) 
 #pragma unroll
 				for (int k = 0; k < 8; ++k) out[k] = fmaf(A[k], g[k], fmaf(Bc[k], yv[k], D[k]));
 				if constexpr (SPLIT == 0) store8<T>(dy + w.idx, out);
+				else if constexpr (SPLIT >= 3) store8<typename PlaneType<SPLIT>::H>(reinterpret_cast<typename PlaneType<SPLIT>::H*>(dy) + w.idx, out);
 				else split3_store8<typename PlaneType<SPLIT>::H>(reinterpret_cast<typename PlaneType<SPLIT>::H*>(dy) + 3 * w.idx - 2 * c, p.C, 1, out);
 			});
 	}
@@ -1039,7 +1041,7 @@ template <typename T, int SRC, int SPLIT = 0> __global__ __launch_bounds__(256) 
 
 static int bn_act_bwd_apply_impl(const void* dz_or_g, const void* y, void* dy, int dtype, const float* coef, int from_dz, const float* scale,
                                  const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
-                                 const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, int plane_dtype, void* stream) {
+                                 const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, int plane_dtype, void* stream, int hi_only = 0) {
 	CONVASR_CHECK_ARG(dz_or_g && y && dy && coef && B > 0 && T > 0 && C > 0 && (C & 7) == 0, "bn_act_bwd_apply: bad arguments (C must be a multiple of 8)");
 	CONVASR_CHECK_ARG(!gate || (from_dz && (act == CONVASR_ACT_RELU || act == CONVASR_ACT_HARDTANH || act == CONVASR_ACT_NONE)), "bn_act_bwd_apply: the one-bit gate needs from_dz and an activation whose derivative is 0 or 1");
 	CONVASR_CHECK_ARG((int64_t)B * T < (1ll << 31), "bn_act_bwd_apply: B * T must fit in 31 bits");
@@ -1056,7 +1058,8 @@ static int bn_act_bwd_apply_impl(const void* dz_or_g, const void* y, void* dy, i
 		if (from_dz && gate) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 2, S>), grid, block, 0, s, p, coef, (float*)dy); \
 		else if (from_dz) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 1, S>), grid, block, 0, s, p, coef, (float*)dy); \
 		else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float, 0, S>), grid, block, 0, s, p, coef, (float*)dy);
-		if (plane_dtype == CONVASR_BF16) { BN_APPLY_SPLIT(1) } else { BN_APPLY_SPLIT(2) }
+		if (hi_only) { if (plane_dtype == CONVASR_BF16) { BN_APPLY_SPLIT(3) } else { BN_APPLY_SPLIT(4) } }
+		else if (plane_dtype == CONVASR_BF16) { BN_APPLY_SPLIT(1) } else { BN_APPLY_SPLIT(2) }
 #undef BN_APPLY_SPLIT
 		CONVASR_CHECK_LAUNCH("bn_act_bwd_apply_split3");
 		return 0;
@@ -1079,6 +1082,14 @@ extern "C" int convasr_bn_act_bwd_apply_split3(const void* dz_or_g, const void* 
                                                const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
                                                const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
 	return bn_act_bwd_apply_impl(dz_or_g, y, dy3, CONVASR_F32, coef, from_dz, scale, shift, act, act_lo, act_hi, dropout_p, seed, offset, step_key, xlen, B, T, C, gate, plane_dtype, stream);
+}
+
+// ... and with dy rounded once to a dense 16-bit tensor [B * T][C] (fp32 dz / y in): the output gradient of a conv whose backward runs as ONE
+// 16-bit product per gradient while its forward ran split (compute types 'bf16x3f' / 'f16x3f').
+extern "C" int convasr_bn_act_bwd_apply_to_half(const void* dz_or_g, const void* y, void* dy16, int out_dtype, const float* coef, int from_dz, const float* scale,
+                                                const float* shift, int act, float act_lo, float act_hi, float dropout_p, uint64_t seed, uint64_t offset,
+                                                const uint64_t* step_key, const float* xlen, int B, int T, int C, const uint8_t* gate, void* stream) {
+	return bn_act_bwd_apply_impl(dz_or_g, y, dy16, CONVASR_F32, coef, from_dz, scale, shift, act, act_lo, act_hi, dropout_p, seed, offset, step_key, xlen, B, T, C, gate, out_dtype, stream, 1);
 }
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int accumulate) {

@@ -793,8 +793,8 @@ template <typename T> static int dispatch_wgrad(WgradParams& p, hipStream_t s) {
 	return 0;
 }
 
-extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
-                                    int Tout, int K, int stride, int dil, int pad, int accumulate, int dw_layout, void* stream) {
+static int wgrad_impl(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
+                      int Tout, int K, int stride, int dil, int pad, int accumulate, int dw_layout, void* stream) {
 	CONVASR_CHECK_ARG(x && dy && dw && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && stride > 0 && dil > 0 && (dw_layout == CONVASR_W_REFERENCE || dw_layout == CONVASR_W_KMAJOR), "conv1d_wgrad: bad arguments");
 	CONVASR_CHECK_ARG(dw_layout == CONVASR_W_REFERENCE || (((int64_t)Cout * Cin) & 3) == 0, "conv1d_wgrad: K-major dw needs Cout * Cin %% 4 == 0");
 	CONVASR_CHECK_ARG(K <= 64, "conv1d_wgrad: K %d > 64", K);
@@ -802,9 +802,11 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 	p.debug = g_conv_debug;
 	p.x = x; p.dy = dy; p.slab = (float*)workspace;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = stride; p.dil = dil; p.pad = pad;
+	p.x_ld = x_ld == Cin ? 0 : x_ld; p.dy_ld = dy_ld == Cout ? 0 : dy_ld;
 	hipStream_t s = (hipStream_t)stream;
 	int rc;
 	if (convasr_is_half(dtype) && g_conv_use_v2 && convasr_wgrad_v2_try(p, dtype, s)) rc = 0;
+	else if (p.x_ld || p.dy_ld) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_wgrad_ld: frames %d / %d elements apart need the LDS-DMA kernel's envelope (16-bit storage, stride 1, Cin %% 128 == 0, Cout %% 128 == 0)", x_ld, dy_ld);
 	else if (dtype == CONVASR_F32) rc = dispatch_wgrad<float>(p, s);
 	else if (dtype == CONVASR_BF16) rc = dispatch_wgrad<bf16_t>(p, s);
 	else if (dtype == CONVASR_F16) rc = dispatch_wgrad<f16_t>(p, s);
@@ -830,6 +832,19 @@ extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, fl
 		CONVASR_CHECK_LAUNCH("conv1d_dbias");
 	}
 	return 0;
+}
+
+extern "C" int convasr_conv1d_wgrad(const void* x, const void* dy, float* dw, float* dbias, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
+                                    int Tout, int K, int stride, int dil, int pad, int accumulate, int dw_layout, void* stream) {
+	return wgrad_impl(x, 0, dy, 0, dw, dbias, workspace, dtype, B, Cin, Cout, Tin, Tout, K, stride, dil, pad, accumulate, dw_layout, stream);
+}
+
+// The same gradient from operands whose frames are x_ld / dy_ld elements apart (>= Cin / Cout, multiples of 8): plane 0 of a split-operand
+// plane tensor [B][T][3][C] (csrc/split3.hip) read in place, ld = 3 C -- the one-product backward of a split-operand forward.
+extern "C" int convasr_conv1d_wgrad_ld(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, void* workspace, int dtype, int B, int Cin, int Cout, int Tin,
+                                       int Tout, int K, int dil, int pad, int accumulate, int dw_layout, void* stream) {
+	CONVASR_CHECK_ARG(x_ld >= Cin && dy_ld >= Cout && (x_ld & 7) == 0 && (dy_ld & 7) == 0 && convasr_is_half(dtype), "conv1d_wgrad_ld: x_ld >= Cin, dy_ld >= Cout, multiples of 8, 16-bit storage");
+	return wgrad_impl(x, x_ld, dy, dy_ld, dw, nullptr, workspace, dtype, B, Cin, Cout, Tin, Tout, K, 1, dil, pad, accumulate, dw_layout, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ stride-2 fold

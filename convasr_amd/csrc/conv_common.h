@@ -123,6 +123,7 @@ struct WgradParams {
 	int chunks_per_b, total_chunks, chunks_per_split;
 	int x_rows;
 	int debug;  // experiment flags (diagnostic builds only)
+	int x_ld, dy_ld;  // wgrad_v2 only: elements between consecutive frames of x / dy when they are not Cin / Cout (0 = dense) -- one plane of a split-operand plane tensor
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));

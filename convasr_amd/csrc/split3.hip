@@ -42,9 +42,11 @@ extern "C" int convasr_split3(const float* x, void* out, int dtype, int64_t rows
 // Packed operands of a split conv from the fp32 master, one launch for both:
 //   fwd  [K][co_pad][3 Cin]:  row (k, co)          = (w_hi[co][.][k], w_hi[co][.][k], w_lo[co][.][k])
 //   dgr  [K][ci_pad][3 Cout]: row (K - 1 - k, ci)  = (w_hi[.][ci][k], w_lo[.][ci][k], w_hi[.][ci][k])      (transposed, taps flipped)
+//     or, dgrad_planes = 1, [K][ci_pad][Cout]: w_hi alone -- the ordinary 16-bit dgrad operand, for a backward that runs one product per
+//     gradient behind a split forward ('bf16x3f' / 'f16x3f')
 // One block = one 64 (co) x 64 (ci) tile of one tap through LDS (the dgrad rows are the tile's columns).  Rows >= Cout / >= Cin of the
 // padded operands are never written (zero from their allocation).
-template <typename H> __global__ __launch_bounds__(256) void pack_split3_kernel(const float* __restrict__ w, int64_t s_co, int64_t s_ci, int64_t s_k, H* __restrict__ fwd, H* __restrict__ dgr, int Cout, int Cin, int K, int co_pad, int ci_pad) {
+template <typename H> __global__ __launch_bounds__(256) void pack_split3_kernel(const float* __restrict__ w, int64_t s_co, int64_t s_ci, int64_t s_k, H* __restrict__ fwd, H* __restrict__ dgr, int Cout, int Cin, int K, int co_pad, int ci_pad, int dgr_planes) {
 	__shared__ float tile[64][65];
 	const int k = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -71,7 +73,7 @@ template <typename H> __global__ __launch_bounds__(256) void pack_split3_kernel(
 		}
 	}
 	if (dgr) {
-		H* const dst = dgr + (int64_t)(K - 1 - k) * ci_pad * 3 * Cout;
+		H* const dst = dgr + (int64_t)(K - 1 - k) * ci_pad * dgr_planes * Cout;
 #pragma unroll 4
 		for (int i = 0; i < 16; ++i) {
 			const int ci = ci0 + ty + 4 * i, co = co0 + tx;
@@ -80,19 +82,20 @@ template <typename H> __global__ __launch_bounds__(256) void pack_split3_kernel(
 				H h, l;
 				Elem<H>::store(&h, v);
 				Elem<H>::store(&l, v - Elem<H>::load(&h));
-				H* const row = dst + (int64_t)ci * 3 * Cout + co;
-				row[0] = h; row[Cout] = l; row[2 * Cout] = h;
+				H* const row = dst + (int64_t)ci * dgr_planes * Cout + co;
+				row[0] = h;
+				if (dgr_planes == 3) { row[Cout] = l; row[2 * Cout] = h; }
 			}
 		}
 	}
 }
 
-extern "C" int convasr_pack_conv_weight_split3(const float* w, int w_layout, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream) {
-	CONVASR_CHECK_ARG(w && (packed_fwd || packed_dgrad) && Cout > 0 && Cin > 0 && K > 0 && K <= 64 && convasr_is_half(dtype) && (w_layout == CONVASR_W_REFERENCE || w_layout == CONVASR_W_KMAJOR), "pack_conv_weight_split3: bad arguments");
+extern "C" int convasr_pack_conv_weight_split3(const float* w, int w_layout, void* packed_fwd, void* packed_dgrad, int dgrad_planes, int dtype, int Cout, int Cin, int K, void* stream) {
+	CONVASR_CHECK_ARG(w && (packed_fwd || packed_dgrad) && (dgrad_planes == 3 || dgrad_planes == 1) && Cout > 0 && Cin > 0 && K > 0 && K <= 64 && convasr_is_half(dtype) && (w_layout == CONVASR_W_REFERENCE || w_layout == CONVASR_W_KMAJOR), "pack_conv_weight_split3: bad arguments");
 	const int co_pad = convasr_conv_cout_pad(Cout), ci_pad = convasr_conv_cout_pad(Cin);
 	const int64_t s_co = w_layout == CONVASR_W_KMAJOR ? Cin : (int64_t)Cin * K, s_ci = w_layout == CONVASR_W_KMAJOR ? 1 : K, s_k = w_layout == CONVASR_W_KMAJOR ? (int64_t)Cout * Cin : 1;
 	const dim3 grid((Cin + 63) / 64, (Cout + 63) / 64, K);
-	CONVASR_DISPATCH_HALF(dtype, H, hipLaunchKernelGGL((pack_split3_kernel<H>), grid, dim3(256), 0, (hipStream_t)stream, w, s_co, s_ci, s_k, (H*)packed_fwd, (H*)packed_dgrad, Cout, Cin, K, co_pad, ci_pad));
+	CONVASR_DISPATCH_HALF(dtype, H, hipLaunchKernelGGL((pack_split3_kernel<H>), grid, dim3(256), 0, (hipStream_t)stream, w, s_co, s_ci, s_k, (H*)packed_fwd, (H*)packed_dgrad, Cout, Cin, K, co_pad, ci_pad, dgrad_planes));
 	CONVASR_CHECK_LAUNCH("pack_conv_weight_split3");
 	return 0;
 }

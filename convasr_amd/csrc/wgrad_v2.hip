@@ -121,7 +121,7 @@ template <typename H> __device__ __forceinline__ void wgrad_v2_body(const WgradP
 	const int xbytes = p.x_rows * 256;  // x_rows is a multiple of 4: whole 1-KiB pieces
 	const int stage_bytes = W2_YBYTES + xbytes;
 	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-	const int y_row_bytes = p.Cout * 2, x_row_bytes = p.Cin * 2;
+	const int y_row_bytes = (p.dy_ld ? p.dy_ld : p.Cout) * 2, x_row_bytes = (p.x_ld ? p.x_ld : p.Cin) * 2;
 	const int y_pieces = W2_BKT / 4, x_pieces = p.x_rows >> 2, pieces = y_pieces + x_pieces;
 	const bool loader = wave >= 8;
 	const int lw = wave - 8;
@@ -337,7 +337,8 @@ template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1
 // Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
 int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
 	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0) return 0;
-	if ((int64_t)p.Tin * p.Cin * 2 >= (1ll << 31) || (int64_t)p.Tout * p.Cout * 2 >= (1ll << 31)) return 0;
+	if ((int64_t)p.Tin * (p.x_ld ? p.x_ld : p.Cin) * 2 >= (1ll << 31) || (int64_t)p.Tout * (p.dy_ld ? p.dy_ld : p.Cout) * 2 >= (1ll << 31)) return 0;
+	if ((p.x_ld & 7) || (p.dy_ld & 7)) return 0;  // (16-byte DMA pieces)
 	WgradParams q = p;
 	wgrad_plan(q, W2_BKT, 1.6);
 	q.x_rows = (q.x_rows + 3) & ~3;

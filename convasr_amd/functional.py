@@ -102,15 +102,16 @@ def force_repack():
 			ent['ver'] = None
 
 
-def split_weight(w, dtype):
+def split_weight(w, dtype, dgrad_planes = 3):
 	"""(forward, dgrad) split operands of a conv parameter for the split-operand path (csrc/split3.hip): hi / lo planes of the fp32 master
-	in the 16-bit type `dtype`, both refreshed by ONE launch when the parameter changed (in place: stable addresses)."""
+	in the 16-bit type `dtype`, both refreshed by ONE launch when the parameter changed (in place: stable addresses).  dgrad_planes = 1: the
+	dgrad operand is the ordinary 16-bit one (w_hi alone), for layers whose backward runs one product per gradient (cfg['split_hi_bwd'])."""
 	ver = param_version(w)
-	ent = _split_cache.get((id(w), dtype))
+	ent = _split_cache.get((id(w), dtype, dgrad_planes))
 	if ent is None:
-		ent = _split_cache[(id(w), dtype)] = dict(w = w, ver = None, fwd = None, dgr = None)  # holds `w`: id() stays unique
+		ent = _split_cache[(id(w), dtype, dgrad_planes)] = dict(w = w, ver = None, fwd = None, dgr = None)  # holds `w`: id() stays unique
 	if ent['ver'] != ver:
-		ent['fwd'], ent['dgr'] = ops.pack_weight_split3(w, dtype, out = (ent['fwd'], ent['dgr']))
+		ent['fwd'], ent['dgr'] = ops.pack_weight_split3(w, dtype, out = (ent['fwd'], ent['dgr']), dgrad_planes = dgrad_planes)
 		ent['ver'] = ver
 	return ent['fwd'], ent['dgr']
 
@@ -518,6 +519,15 @@ class Fold2:
 		ops.fold2_unfold_wgrad(dwf, out, spec.padding, accumulate = accumulate)
 
 	@staticmethod
+	def wgrad_hi(x3, dy, weight, spec, Kf, Pf, out, accumulate):
+		"""... with one product: plane 0 of the folded view's planes (read in place) against the dense 16-bit dy."""
+		Cout, Cin, K = weight.shape
+		B, _, Tout = dy.shape
+		dwf = torch.empty(Kf, Cout, 2 * Cin, dtype = torch.float32, device = dy.device)
+		ops.conv1d_wgrad_hi(x3, dy, Cout, Kf, 1, Pf, dwf.permute(1, 2, 0), work = 2.0 * B * Tout * Cout * Cin * K)
+		ops.fold2_unfold_wgrad(dwf, out, spec.padding, accumulate = accumulate)
+
+	@staticmethod
 	def wgrad(xv, dy, weight, spec, Kf, Pf, out, accumulate):
 		Cout, Cin, K = weight.shape
 		B, _, Tout = dy.shape
@@ -566,16 +576,20 @@ def _after_long_launch():
 		hook()
 
 
-def _dgrad(x, dy, weight, spec, dt, link = None, wd = None, split = None):
+def _dgrad(x, dy, weight, spec, dt, link = None, wd = None, split = None, hi = False):
 	"""dx of one conv; fused with the BN backward reduce of the layer that produced x when that layer left a link for it.
 	wd: packed dgrad weights to use instead of the cached copy of `weight` (the channel-padded head, see _HeadPad).
-	split: the 16-bit plane type of a split-operand conv -- dy is then its (B, 3 Cout, T) plane tensor (ops.split3, SPLIT_GRAD) and dx is fp32."""
+	split: the 16-bit plane type of a split-operand conv -- dy is then its (B, 3 Cout, T) plane tensor (ops.split3, SPLIT_GRAD) and dx is fp32;
+	hi: dy is the dense 16-bit (B, Cout, T) tensor instead and the product is dy x w_hi alone (cfg['split_hi_bwd']), dx still fp32."""
 	pad = spec.dilation * (spec.K - 1) - spec.padding
 	_join_pending_wgrad(dy.device)
 	if split is not None:
 		Cout, Cin, K = weight.shape
 		B, _, Tdy = dy.shape
-		dx = ops.conv1d(dy, split_weight(weight, split)[1], Cin, spec.K, 1, spec.dilation, pad, out_dtype = torch.float32, work = 2.0 * B * ops.conv_out_len(Tdy, K, 1, spec.dilation, pad) * Cout * Cin * K, family = SPLIT_FAMILY)
+		if hi:
+			dx = ops.conv1d(dy, split_weight(weight, split, 1)[1], Cin, spec.K, 1, spec.dilation, pad, out_dtype = torch.float32)
+		else:
+			dx = ops.conv1d(dy, split_weight(weight, split)[1], Cin, spec.K, 1, spec.dilation, pad, out_dtype = torch.float32, work = 2.0 * B * ops.conv_out_len(Tdy, K, 1, spec.dilation, pad) * Cout * Cin * K, family = SPLIT_FAMILY)
 		_after_long_launch()
 		return dx
 	Cin = x.shape[1]
@@ -637,7 +651,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			# the planes, not x, are what backward keeps (the weight gradient reads the same memory as 3 Tin frames of Cin channels)
 			ctx.split = cfg['split']
 			x = planes if planes is not None else ops.split3(x, ctx.split, ops.SPLIT_INPUT)
-			y = ops.conv1d(x, split_weight(weight, ctx.split)[0], Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, stats = stats, work = 2.0 * B * ops.conv_out_len(Tin, spec.K, 1, spec.dilation, spec.padding) * Cout * Cin * spec.K, family = SPLIT_FAMILY)
+			y = ops.conv1d(x, split_weight(weight, ctx.split, 1 if cfg.get('split_hi_bwd') else 3)[0], Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, stats = stats, work = 2.0 * B * ops.conv_out_len(Tin, spec.K, 1, spec.dilation, spec.padding) * Cout * Cin * spec.K, family = SPLIT_FAMILY)
 		else:
 			y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), Cout, spec.K, spec.stride, spec.dilation, spec.padding, stats = stats)
 		Tout = y.shape[2]
@@ -682,7 +696,7 @@ class ConvBnActFunction(torch.autograd.Function):
 					rx3 = cache.get(_PLANES_CACHE_ATTR)
 					if rx3 is None or rx3.dtype != cfg['split']:
 						rx3 = cache[_PLANES_CACHE_ATTR] = ops.split3(rx, cfg['split'], ops.SPLIT_INPUT)
-					ry = ops.conv1d(rx3, split_weight(rw, cfg['split'])[0], Cout, 1, 1, 1, 0, out_dtype = torch.float32, bias = rb, stats = st, work = 2.0 * B * Tout * Cout * rx.shape[1], family = SPLIT_FAMILY)
+					ry = ops.conv1d(rx3, split_weight(rw, cfg['split'], 1 if cfg.get('split_hi_bwd') else 3)[0], Cout, 1, 1, 1, 0, out_dtype = torch.float32, bias = rb, stats = st, work = 2.0 * B * Tout * Cout * rx.shape[1], family = SPLIT_FAMILY)
 					res_x[r] = rx3  # (what backward keeps of this branch's input: the weight gradient reads the planes as 3 T frames)
 					res_split[r] = True
 				else:
@@ -741,6 +755,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		B, Cout, Tout = y.shape
 		dev = y.device
 		dz = ops.as_cl(dz, dt)
+		hi = ctx.split is not None and bool(cfg.get('split_hi_bwd'))  # split forward, ONE 16-bit product per gradient (compute types 'bf16x3f' / 'f16x3f')
 		if ctx.gacc is not None and ctx.gacc['buf'] is not None:  # the input gradients of the residual branches that tapped this output
 			acc, ctx.gacc['buf'] = ctx.gacc['buf'], None
 			dz = ops.add16(dz, acc, out = acc)
@@ -759,7 +774,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				finalize([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey, planes = ctx.split)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey, planes = ctx.split, hi_only = hi)
 			g = rsum_of = None
 		elif n_res == 0:
 			# no residuals: pass 1 only reduces (g is not materialised), its finalize kernel emits dgamma / dbeta and the three
@@ -771,7 +786,7 @@ class ConvBnActFunction(torch.autograd.Function):
 			else:
 				reduce([None, None], False)
 				dgamma = dbeta = None
-			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey, planes = ctx.split)  # (a split-operand conv: dy straight into its planes)
+			dy = ops.bn_act_bwd_apply(dz, y, coef, True, bnp[2], bnp[3], act, xlen = xl, dropout_p = p_drop, seed = seed, offset = offset, gate = ctx.gate, step_key = skey, planes = ctx.split, hi_only = hi)  # (a split-operand conv: dy straight into its planes)
 			g = rsum_of = None
 		else:
 			bn_idx = [r for r in range(n_res) if res_bnp[r] is not None]
@@ -821,8 +836,13 @@ class ConvBnActFunction(torch.autograd.Function):
 			grouped_bn = None
 		arena_mode = getattr(weight, '_convasr_grad', None) is not None
 		if ctx.split is not None and dy.dtype == torch.float32:  # (the residual forms of the BN backward deliver fp32; the residual-free one wrote the planes itself)
-			dy = ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
-		if ctx.split is not None and ctx.fold is not None:
+			dy = ops.as_cl(dy, ctx.split) if hi else ops.split3(dy, ctx.split, ops.SPLIT_GRAD)
+		if hi and ctx.fold is not None:
+			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad_hi(x, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
+		elif hi:
+			# the hi plane of the forward's saved planes, read in place (frames 3 Cin elements apart), against the 16-bit dy: x_hi dy_hi alone
+			wg = lambda: _deliver([weight], lambda outs, acc: ops.conv1d_wgrad_hi(x, dy, Cout, spec.K, spec.dilation, spec.padding, outs[0], accumulate = acc))
+		elif ctx.split is not None and ctx.fold is not None:
 			wg = lambda: _deliver([weight], lambda outs, acc: Fold2.wgrad_split(x, dy, weight, spec, ctx.fold[0], ctx.fold[1], outs[0], acc))
 		elif ctx.split is not None:
 			# split-operand conv: dy as its three planes (hi, hi, lo) once, for both gradients; the weight gradient pairs plane p of x with plane p of
@@ -843,7 +863,7 @@ class ConvBnActFunction(torch.autograd.Function):
 		if ctx.x_needs_grad:
 			if spec.stride != 1:
 				raise _lib.ConvasrHipError('conv1d dgrad with stride > 1 is not implemented (only the prologue conv is strided and its input needs no gradient)')
-			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link, split = ctx.split)
+			dx = _dgrad(x, dy, weight, spec, dt, ctx.producer_link, split = ctx.split, hi = hi)
 		if after:
 			dw, = _run_wgrad(dev, (x, dy), wg)  # behind this layer's dgrad on the side stream; the next dgrad waits for it (_join_pending_wgrad)
 		if not arena_mode:
@@ -865,12 +885,18 @@ class ConvBnActFunction(torch.autograd.Function):
 			if ctx.res_split[r]:
 				# split branch: dry as planes once; the input gradient as a split one-tap conv, the weight gradient over the planes read as frames
 				sp, cin_r = cfg['split'], rw.shape[1]
-				dry3 = ops.split3(dry, sp, ops.SPLIT_GRAD)
-				if need_rx:
+				hi_r = bool(cfg.get('split_hi_bwd'))
+				dry3 = ops.as_cl(dry, sp) if hi_r else ops.split3(dry, sp, ops.SPLIT_GRAD)
+				if need_rx and hi_r:
+					drx = ops.conv1d(dry3, split_weight(rw, sp, 1)[1], cin_r, 1, 1, 1, 0, out_dtype = torch.float32)
+				elif need_rx:
 					drx = ops.conv1d(dry3, split_weight(rw, sp)[1], cin_r, 1, 1, 1, 0, out_dtype = torch.float32, work = 2.0 * B * Tout * Cout * cin_r, family = SPLIT_FAMILY)
 
-				def res_wgrad3(outs, acc, rx3 = rx, dry3 = dry3, rb = rb, cin_r = cin_r):
-					ops.conv1d_wgrad(ops.split3_frames(rx3), ops.split3_frames(dry3), Cout, 1, 1, 3, 0, outs[0], accumulate = acc, work = 2.0 * B * Tout * Cout * cin_r, family = SPLIT_WGRAD_FAMILY)
+				def res_wgrad3(outs, acc, rx3 = rx, dry3 = dry3, rb = rb, cin_r = cin_r, hi_r = hi_r):
+					if hi_r:
+						ops.conv1d_wgrad_hi(rx3, dry3, Cout, 1, 1, 0, outs[0], accumulate = acc)
+					else:
+						ops.conv1d_wgrad(ops.split3_frames(rx3), ops.split3_frames(dry3), Cout, 1, 1, 3, 0, outs[0], accumulate = acc, work = 2.0 * B * Tout * Cout * cin_r, family = SPLIT_WGRAD_FAMILY)
 					if outs[1] is not None and not acc and not (outs[1] is getattr(rb, '_convasr_grad', None) and getattr(rb, '_convasr_grad_is_zero', False)):
 						outs[1].zero_()  # (the bias of a conv that feeds a train-mode batch norm: an identically zero gradient, see below)
 						rb._convasr_grad_is_zero = outs[1] is getattr(rb, '_convasr_grad', None)

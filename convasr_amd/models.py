@@ -252,6 +252,7 @@ class ConvBn1d(nn.Module):
 		self.temporal_mask = temporal_mask
 		self.compute_dtype = torch.float32
 		self.split_dtype = None  # bf16 / fp16: the convs of an fp32 network run as split-operand MFMA convs (JasperNet.set_compute_dtype('bf16x3'))
+		self.split_hi_bwd = False  # 'bf16x3f' / 'f16x3f': the backward of a split conv as ONE 16-bit product per gradient (hi planes only)
 		self.split_inference = False  # the evaluation path too (set_compute_dtype('bf16x3', inference = True)); off by default: evaluation then runs the exact-fp32 kernels
 		self.tapped_output = False  # set by the network when later blocks take this block's output as a residual input: its gradient then has an accumulator the tapping blocks write into (functional.ConvBnActFunction, GRAD_ACC)
 		self.single_consumer_output = False  # set by the network when this block's output feeds exactly one conv (no residual taps): enables cross-layer backward fusion
@@ -277,7 +278,7 @@ class ConvBn1d(nn.Module):
 
 	def _cfg(self, i, last):
 		conv, bn = self.conv[i][-1], self.bn[i]
-		return dict(planes_out = self._planes_out(i, last), spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, split_eval = self.split_dtype if self.split_inference else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
+		return dict(planes_out = self._planes_out(i, last), spec = _spec_of(conv), bn = bn, res_bn = list(self.bn_residual) if last else [], act = ops.act_args(self.activation.nonlinearity), dropout_p = float(self.activation.dropout) if self.training else 0.0, temporal_mask = self.temporal_mask, compute_dtype = self.compute_dtype, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, split_hi_bwd = self.split_hi_bwd, split_eval = self.split_dtype if self.split_inference else None, fuse_bwd = self.training and torch.is_grad_enabled() and (not last or self.single_consumer_output), tappable = last and self.tapped_output and torch.is_grad_enabled())
 
 	def forward(self, x, lengths_fraction = None, residual: typing.List = []):
 		_lib.require_cuda(x)
@@ -419,18 +420,20 @@ class JasperNet(nn.Module):
 			blk.feeds_block = weakref.ref(self.backbone[i + 1]) if (not tapped and i < len(self.backbone) - 1) else None  # (a weak reference: a plain attribute would register the block twice)
 		self.set_compute_dtype(compute_dtype)
 
-	SPLIT_DTYPES = {'bf16x3': torch.bfloat16, 'f16x3': torch.float16}
+	SPLIT_DTYPES = {'bf16x3': torch.bfloat16, 'f16x3': torch.float16, 'bf16x3f': torch.bfloat16, 'f16x3f': torch.float16}  # (...f: split forward, one-product backward)
 
 	def set_compute_dtype(self, dtype, inference = False):
 		"""fp32 (exact-fp32 MFMA path: parity runs), or bf16 / fp16 (16-bit storage of activations and compute weights, MFMA with fp32
 		accumulation, fp32 master weights: throughput runs; fp16 is what the reference's apex O1-O3 levels compute in and trains under a
 		dynamic loss scaler, convasr_amd.train.LossScaler), or 'bf16x3' / 'f16x3': fp32 storage everywhere, the training convs as
 		split-operand products on the 16-bit matrix pipe (three MFMAs per product, fp32-class accuracy: csrc/split3.hip) -- the path that
-		meets the reference's fp32 results to 1e-4 in the CTC loss at MFMA rate; evaluation runs the exact-fp32 kernels unless inference = True
+		meets the reference's fp32 results to 1e-4 in the CTC loss at MFMA rate; 'bf16x3f' / 'f16x3f': that forward (the same loss, bit for bit)
+		with the backward of every split conv as ONE 16-bit product per gradient (dy rounded once, x_hi, w_hi: gradients of the plain 16-bit
+		path's accuracy, as under the reference's apex O2; two thirds of the backward's matrix work gone); evaluation runs the exact-fp32 kernels unless inference = True
 		(the folded / eval-mode convs then run as split convs as well: fp32-class logits at a third of the 16-bit rate instead of the fp32 MFMA rate)."""
-		split = None
+		split, hi_bwd = None, False
 		if isinstance(dtype, str):
-			dtype, split = torch.float32, self.SPLIT_DTYPES[dtype]
+			dtype, split, hi_bwd = torch.float32, self.SPLIT_DTYPES[dtype], dtype.endswith('x3f')
 		assert dtype in (torch.float32, ) + ops.HALF_DTYPES
 		self.compute_dtype, self.split_dtype = dtype, split
 		for m in self.modules():
@@ -440,6 +443,7 @@ class JasperNet(nn.Module):
 				m.split_dtype = split
 			if isinstance(m, ConvBn1d):
 				m.split_inference = bool(inference) and split is not None
+				m.split_hi_bwd = hi_bwd
 		return self
 
 	def forward(self, x, xlen = None, y = None, ylen = None):
@@ -658,7 +662,8 @@ def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, op
 	dynamic for O1 / O2 (train.LossScaler; overflowed steps are skipped and the scale halves), static 1.0 for O3, `loss_scale`
 	(a number or 'dynamic') overriding either, exactly apex's kwarg.  compute_dtype = torch.bfloat16 (an extension; env
 	CONVASR_AMP_DTYPE=bf16 makes it the default) runs the same kernels on bf16 storage, whose fp32 exponent range needs no loss scale;
-	compute_dtype = 'bf16x3' / 'f16x3' selects the split-operand path (JasperNet.set_compute_dtype), 'f16x3' with the dynamic loss scaler."""
+	compute_dtype = 'bf16x3' / 'f16x3' (/ 'bf16x3f' / 'f16x3f') selects the split-operand path (JasperNet.set_compute_dtype), the fp16 forms with the
+	dynamic loss scaler."""
 	amp = opt_level not in (None, '', 'O0')
 	dtype = compute_dtype or (AMP_DTYPE if amp else torch.float32)
 	master_module(model).set_compute_dtype(dtype)
@@ -666,7 +671,7 @@ def data_parallel_and_autocast(model, optimizer = None, data_parallel = True, op
 	if flat is not None:
 		from .train import LossScaler
 		if loss_scale is None:
-			loss_scale = 'dynamic' if ((dtype == torch.float16 and opt_level in ('O1', 'O2')) or dtype == 'f16x3') else None  # ('f16x3': fp32 storage, but the output gradients travel as fp16 planes -- the same range problem, the same cure)
+			loss_scale = 'dynamic' if ((dtype == torch.float16 and opt_level in ('O1', 'O2')) or dtype in ('f16x3', 'f16x3f')) else None  # ('f16x3': fp32 storage, but the output gradients travel as fp16 planes -- the same range problem, the same cure)
 		flat.loss_scaler = None if loss_scale in (None, 1, 1.0) else LossScaler(flat.data.device, loss_scale = loss_scale)
 	elif dtype == torch.float16 and master_module(model).training and opt_level in ('O1', 'O2'):
 		# apex would scale the loss here; without an arena optimizer (convasr_amd.train.SGD / optimizers.NovoGrad / AdamW) there is nothing

@@ -381,9 +381,45 @@ def split3_frames(x3):
 	return x3.as_strided((B, C3 // 3, 3 * T), (T * C3, 1, C3 // 3))
 
 
-def pack_weight_split3(w, dtype, out = None, want_dgrad = True):
+def split3_plane(x3, plane = 0):
+	"""One plane of a (B, 3 C, T) plane tensor as a dense channels-last (B, C, T) tensor (a strided copy)."""
+	B, C3, T = x3.shape
+	C = C3 // 3
+	assert is_cl(x3) and C3 % 3 == 0
+	out = empty_cl(B, C, T, x3.dtype, x3.device)
+	out.permute(0, 2, 1).copy_(x3.as_strided((B, T, C), (T * C3, C3, 1), x3.storage_offset() + plane * C))
+	return out
+
+
+def conv1d_wgrad_hi(x3, dy, Cout, K, dil, pad, dw, accumulate = False, work = None, family = None):
+	"""conv1d_wgrad (stride 1) of plane 0 (hi) of the split-operand plane tensor x3 (B, 3 Cin, Tin) against a dense 16-bit dy: the plane is read in
+	place (frames 3 Cin elements apart, convasr_conv1d_wgrad_ld) inside the LDS-DMA kernel's envelope, copied out first outside it."""
+	B, C3, Tin = x3.shape
+	Cin, Tout = C3 // 3, dy.shape[2]
+	layout = weight_layout(dw)
+	assert is_cl(x3) and is_cl(dy) and x3.dtype == dy.dtype and x3.dtype in HALF_DTYPES and layout is not None and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, K), (dw.shape, dw.stride())
+	if Cin % 128 != 0 or Cout % 128 != 0 or Tin * C3 * 2 >= 2 ** 31:
+		return conv1d_wgrad(split3_plane(x3), dy, Cout, K, 1, dil, pad, dw, accumulate = accumulate, work = work, family = family)
+	if K == 1 and (Cout * Cin) % 4 == 0:
+		layout = _lib.W_KMAJOR
+	wkey = (B, Cin, Cout, Tin, Tout, K, 1, dil)
+	nbytes = _wgrad_ws_bytes.get(wkey)
+	if nbytes is None:
+		nbytes = _wgrad_ws_bytes[wkey] = _lib.load().convasr_conv1d_wgrad_workspace_bytes(*wkey)
+	ws = workspace(nbytes, x3.device, 'wgrad')
+	try:
+		_lib.timed(family or 'conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad_ld', ptr(x3), C3, ptr(dy), Cout, ptr(dw), ptr(ws), dtype_code(dy.dtype), B, Cin, Cout, Tin, Tout, K, dil, pad, int(accumulate), layout, stream_ptr()))
+	except _lib.ConvasrHipError as e:
+		if 'envelope' not in str(e):
+			raise
+		return conv1d_wgrad(split3_plane(x3), dy, Cout, K, 1, dil, pad, dw, accumulate = accumulate, work = work, family = family)  # (a tap window too wide for the kernel's LDS ring)
+	return dw
+
+
+def pack_weight_split3(w, dtype, out = None, want_dgrad = True, dgrad_planes = 3):
 	"""(Cout, Cin, K) fp32 parameter -> (fwd [K][cout_pad][3 Cin], dgrad [K][cin_pad][3 Cout]) split operands, refreshed in place when
-	`out` = (fwd, dgrad) of an earlier call.  want_dgrad = False: the forward planes only (dgrad is returned as None)."""
+	`out` = (fwd, dgrad) of an earlier call.  want_dgrad = False: the forward planes only (dgrad is returned as None).  dgrad_planes = 1: the
+	dgrad operand as the ordinary 16-bit one, [K][cin_pad][Cout] (w_hi alone: a one-product backward)."""
 	require_cuda(w)
 	w = w.detach()
 	layout = weight_layout(w) if w.dtype == torch.float32 else None
@@ -394,8 +430,9 @@ def pack_weight_split3(w, dtype, out = None, want_dgrad = True):
 	if fwd is None:
 		fwd = torch.zeros(K, cout_pad(Cout), 3 * Cin, dtype = dtype, device = w.device)
 	if dgr is None and want_dgrad:
-		dgr = torch.zeros(K, cout_pad(Cin), 3 * Cout, dtype = dtype, device = w.device)
-	call('convasr_pack_conv_weight_split3', ptr(w), layout, ptr(fwd), ptr(dgr) if want_dgrad else None, dtype_code(dtype), Cout, Cin, K, stream_ptr())
+		dgr = torch.zeros(K, cout_pad(Cin), dgrad_planes * Cout, dtype = dtype, device = w.device)
+	assert dgr is None or dgr.shape[2] == dgrad_planes * Cout
+	call('convasr_pack_conv_weight_split3', ptr(w), layout, ptr(fwd), ptr(dgr) if want_dgrad else None, dgrad_planes, dtype_code(dtype), Cout, Cin, K, stream_ptr())
 	return fwd, (dgr if want_dgrad else None)
 
 
@@ -566,10 +603,16 @@ def bn_act_bwd_reduce(dz, y, scale, shift, mean, invstd, act, xlen = None, res =
 	return g
 
 
-def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None, planes = None):
+def bn_act_bwd_apply(dz_or_g, y, coef, from_dz, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, dropout_p = 0.0, seed = 0, offset = 0, out = None, gate = None, step_key = None, planes = None, hi_only = False):
 	"""planes (a 16-bit dtype, fp32 inputs only): dy is returned as its split-operand planes, the (B, 3 C, T) tensor split3(dy, planes, SPLIT_GRAD)
-	would produce -- written by this pass itself."""
+	would produce -- written by this pass itself; hi_only: as the dense (B, C, T) tensor of that type instead (dy rounded once: the operand of a
+	one-product backward)."""
 	B, C, T = y.shape
+	if planes is not None and hi_only:
+		assert y.dtype == torch.float32 and planes in HALF_DTYPES and out is None
+		dy16 = empty_cl(B, C, T, planes, y.device)
+		_lib.timed('hbm:bn_act_bwd_apply_kernel', 0.0, lambda: call('convasr_bn_act_bwd_apply_to_half', ptr(dz_or_g), ptr(y), ptr(dy16), dtype_code(planes), ptr(coef), int(from_dz), ptr(scale), ptr(shift), act[0], act[1], act[2], float(dropout_p), int(seed), int(offset), step_key, ptr(xlen), B, T, C, ptr(gate), stream_ptr()), nbytes = float(B * T * C * 10))
+		return dy16
 	if planes is not None:
 		assert y.dtype == torch.float32 and planes in HALF_DTYPES and out is None
 		dy3 = empty_cl(B, 3 * C, T, planes, y.device)

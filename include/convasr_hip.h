@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CONVASR_ABI_VERSION 9
+#define CONVASR_ABI_VERSION 10
 
 enum { CONVASR_F32 = 0, CONVASR_BF16 = 1, CONVASR_I16 = 2, CONVASR_F16 = 3 };
 enum { CONVASR_ACT_NONE = 0, CONVASR_ACT_RELU = 1, CONVASR_ACT_HARDTANH = 2, CONVASR_ACT_LEAKY_RELU = 3 };
@@ -407,8 +407,17 @@ int convasr_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype,
  *             plane p of frame t, so the reduction over frames pairs plane p of x with plane p of dy.
  * convasr_pack_conv_weight_split3: (Cout, Cin, K) fp32 parameter in layout w_layout ->
  *   packed_fwd   [K][cout_pad(Cout)][3 Cin] : row (k, co)         = (w_hi[co][.][k], w_hi[co][.][k], w_lo[co][.][k])
- *   packed_dgrad [K][cout_pad(Cin)][3 Cout] : row (K - 1 - k, ci) = (w_hi[.][ci][k], w_lo[.][ci][k], w_hi[.][ci][k])
- * either may be NULL; rows beyond Cout / Cin are not written (zero-fill once). */
+ *   packed_dgrad [K][cout_pad(Cin)][3 Cout] : row (K - 1 - k, ci) = (w_hi[.][ci][k], w_lo[.][ci][k], w_hi[.][ci][k])      (dgrad_planes = 3)
+ *             or [K][cout_pad(Cin)][Cout]   : row (K - 1 - k, ci) =  w_hi[.][ci][k], the ordinary 16-bit dgrad operand    (dgrad_planes = 1)
+ * either may be NULL; rows beyond Cout / Cin are not written (zero-fill once).
+ *
+ * Split forward, ONE-product backward (compute types 'bf16x3f' / 'f16x3f': the loss carries the split forward's fp32-class accuracy, the
+ * gradients the 16-bit path's, as under the reference's apex O2, models.py:744-762; two thirds of the backward's MFMA work are gone):
+ *   dy:    convasr_bn_act_bwd_apply_to_half -- the fp32 BN backward with dy rounded once to a dense 16-bit tensor [B * T][C];
+ *   dgrad: convasr_conv1d_fwd(dy16, packed_dgrad with dgrad_planes = 1, dx fp32);
+ *   wgrad: convasr_conv1d_wgrad_ld -- convasr_conv1d_wgrad (stride 1) over operands whose frames are x_ld / dy_ld elements apart: plane 0 (hi)
+ *          of the forward's saved planes x3 read IN PLACE (x_ld = 3 Cin) against dy16.  16-bit storage, Cin % 128 == 0, Cout % 128 == 0,
+ *          ld % 8 == 0; CONVASR_EUNSUPPORTED outside (the host then copies the plane out and calls convasr_conv1d_wgrad). */
 int convasr_split3(const float* x, void* out, int dtype, int64_t rows, int C, int order, void* stream);
 /* The two fp32 streaming passes whose result is consumed by split convs only, with the split folded in (the separate convasr_split3 pass --
  * 4 bytes read + 6 written per element -- disappears):
@@ -425,7 +434,13 @@ int convasr_bn_act_bwd_apply_split3(const void* dz_or_g, const void* y, void* dy
                                     const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
                                     uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C,
                                     const uint8_t* gate, void* stream);
-int convasr_pack_conv_weight_split3(const float* w, int w_layout, void* packed_fwd, void* packed_dgrad, int dtype, int Cout, int Cin, int K, void* stream);
+int convasr_pack_conv_weight_split3(const float* w, int w_layout, void* packed_fwd, void* packed_dgrad, int dgrad_planes, int dtype, int Cout, int Cin, int K, void* stream);
+int convasr_bn_act_bwd_apply_to_half(const void* dz_or_g, const void* y, void* dy16, int out_dtype, const float* coef, int from_dz,
+                                     const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
+                                     uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C,
+                                     const uint8_t* gate, void* stream);
+int convasr_conv1d_wgrad_ld(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, void* workspace, int dtype,
+                            int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int accumulate, int dw_layout, void* stream);
 
 /* ---- per-step device state: what lets train.py:745-783 replay from a HIP graph ------------------------------------- */
 

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
 	lib = _lib.load()
 	for name in declared:
 		assert hasattr(lib, name), name
-	assert lib.convasr_abi_version() == 9
+	assert lib.convasr_abi_version() == 10
 	assert lib.convasr_conv_cout_pad(38) == 128 and lib.convasr_conv_cout_pad(256) == 256
 	# every ctypes signature has as many arguments as the header's prototype
 	protos = re.sub(r'/\*.*?\*/', '', header, flags = re.S)

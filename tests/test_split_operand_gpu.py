@@ -409,3 +409,133 @@ def test_transcribe_setup_with_split_operand_inference_reproduces_the_reference_
 		assert res.hyp == j['hyp'], (res.hyp, j['hyp'])
 	finally:
 		torch.set_grad_enabled(True)  # (transcribe.setup switches autograd off for the process, like the reference)
+
+
+# ---- split forward, one-product backward ('bf16x3f' / 'f16x3f') -------------------------------------------------------------------
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(3, 256, 384, 300, 11, 1, 5), (2, 768, 896, 200, 29, 2, 29), (3, 896, 128, 257, 1, 1, 0), (2, 192, 136, 77, 3, 1, 1)])
+def test_wgrad_reads_the_hi_plane_of_a_plane_tensor_in_place(dt, shape):
+	"""convasr_conv1d_wgrad_ld (frames 3 Cin elements apart) = convasr_conv1d_wgrad on the plane copied out, bit for bit (the same kernel, the same
+	order of summation); outside the LDS-DMA kernel's envelope (the last shape) ops.conv1d_wgrad_hi copies the plane out itself.  The hi plane is
+	the value rounded once."""
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	B, Cin, Cout, T, K, dil, pad = shape
+	torch.manual_seed(2)
+	x = ops.as_cl(torch.randn(B, Cin, T).to(d), torch.float32)
+	Tout = ops.conv_out_len(T, K, 1, dil, pad)
+	dy = ops.as_cl((torch.randn(B, Cout, Tout) * 1e-2).to(d), dt)
+	x3 = ops.split3(x, dt, ops.SPLIT_INPUT)
+	x16 = ops.split3_plane(x3)
+	assert torch.equal(x16, ops.as_cl(x, dt)) and torch.equal(ops.split3_plane(x3, 2), x16)
+	a, b = torch.empty(Cout, Cin, K, device = d), torch.empty(Cout, Cin, K, device = d)
+	ops.conv1d_wgrad_hi(x3, dy, Cout, K, dil, pad, a)
+	ops.conv1d_wgrad(x16, dy, Cout, K, 1, dil, pad, b)
+	assert torch.equal(a, b)
+	ref = torch.nn.grad.conv1d_weight(x16.double().cpu(), (Cout, Cin, K), dy.double().cpu(), padding = pad, dilation = dil)
+	assert _rel(a, ref) <= 2e-6
+	ops.conv1d_wgrad_hi(x3, dy, Cout, K, dil, pad, a, accumulate = True)  # (+)=
+	assert _rel(a, 2 * ref) <= 2e-6
+	# tap-major gradient memory (the training arena's) behind the same view
+	c = torch.empty(K, Cout, Cin, device = d).permute(1, 2, 0)
+	ops.conv1d_wgrad_hi(x3, dy, Cout, K, dil, pad, c)
+	assert torch.equal(c, b)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_bn_backward_apply_rounds_dy_once_and_the_dgrad_operand_is_the_plain_16_bit_one(dt):
+	from convasr_amd import ops, _lib
+	d = torch.device('cuda:0')
+	torch.manual_seed(7)
+	B, C, T = 3, 136, 53
+	y = ops.as_cl(torch.randn(B, C, T).to(d) * 3, torch.float32)
+	scale, shift = (torch.rand(C) + 0.5).to(d), torch.randn(C).to(d)
+	xl = torch.tensor([1.0, 0.7, 0.4], device = d)
+	act = (_lib.ACT_HARDTANH, 0.0, 20.0)
+	gate = torch.zeros(B * T * C // 8, dtype = torch.uint8, device = d)
+	ops.bn_act(y, scale, shift, act, gate = gate, xlen = xl, dropout_p = 0.2, seed = 5, offset = 11)
+	coef = torch.randn(3 * C, device = d)
+	dz = ops.as_cl(torch.randn(B, C, T).to(d) * 1e-2, torch.float32)
+	for g, from_dz in ((None, True), (gate, True), (None, False)):
+		kw = dict(xlen = xl, dropout_p = 0.2, seed = 5, offset = 11, gate = g)
+		dy = ops.bn_act_bwd_apply(dz, y, coef, from_dz, scale, shift, act, **kw)
+		dy16 = ops.bn_act_bwd_apply(dz, y, coef, from_dz, scale, shift, act, planes = dt, hi_only = True, **kw)
+		assert dy16.dtype == dt and dy16.shape == dy.shape and ops.is_cl(dy16) and torch.equal(dy16, ops.as_cl(dy, dt))
+	# the packed operands: forward planes as ever, the dgrad operand = the ordinary 16-bit pack of the same weight
+	w = (torch.randn(136, 192, 5) / 30).to(d)
+	f3, d3 = ops.pack_weight_split3(w, dt)
+	f1, d1 = ops.pack_weight_split3(w, dt, dgrad_planes = 1)
+	assert torch.equal(f1, f3) and torch.equal(d1, ops.pack_weight(w, dt, _lib.PACK_DGRAD)) and torch.equal(d1[:, :192], d3[:, :192, :136])
+
+
+@pytest.mark.parametrize('name', ['bf16x3f', 'f16x3f'])
+def test_split_forward_with_one_product_backward(name):
+	"""compute_dtype = 'bf16x3f' / 'f16x3f' on a small Wav2Letter: the loss is the split path's bit for bit (the forward is the same launches), every
+	conv's backward is one 16-bit product per gradient (no split dgrad / wgrad launch is left besides the 38-class head's), and the gradients sit
+	where the plain 16-bit path's do against the full split path's."""
+	import convasr_amd as ca
+	from convasr_amd import _lib
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = _batch(d, 6, 4)
+	out = {}
+	for dt in (name[:-1], name, {'bf16x3f': torch.bfloat16, 'f16x3f': torch.float16}[name]):
+		model = _small(ca, d, dt)
+		flat = ca.train.FlatParameters(model)
+		timer = _lib.KernelTimer(only = ())
+		_lib.timer = timer
+		try:
+			res = model(x, xlen, y = y, ylen = ylen)
+			(res['loss'] * ylen[:, 0]).mean().mul(256.0).backward()  # (a fixed loss scale: fp16's output gradients underflow without one)
+		finally:
+			_lib.timer = None
+		ca.functional.join_side_streams()
+		flat.finalize_grads()
+		torch.cuda.synchronize()
+		out[dt] = (res['loss'].detach().clone(), {n: p._convasr_grad.clone() / 256.0 for n, p in model.named_parameters() if hasattr(p, '_convasr_grad')}, [f for f, _ in timer.sequence])
+	full, mixed, half = out.values()
+	assert torch.equal(full[0], mixed[0])
+	assert model.compute_dtype in (torch.bfloat16, torch.float16)
+	fams = mixed[2]
+	assert fams.count('conv1d_igemm_v2s_kernel<x3>') == 17 + 1 + 2 and fams.count('conv1d_wgrad<x3>') == 1, (fams.count('conv1d_igemm_v2s_kernel<x3>'), fams.count('conv1d_wgrad<x3>'))  # the forwards + the head's dgrad; the head's wgrad
+	assert sum('conv1d_igemm_v2s_kernel' in f and '<x3>' not in f for f in fams) == 17 and fams.count('conv1d_wgrad') == 18 and 'conv1d_igemm (other variants)' not in fams, [f for f in fams if 'conv' in f]  # (a small one-tap launch is booked as memory-bound)
+	assert fams.count('hbm:split3_kernel') == 3
+	worst = max((_rel(mixed[1][n], full[1][n]), n) for n in full[1] if float(full[1][n].abs().max()) > 0)
+	worst16 = max((_rel(half[1][n], full[1][n]), n) for n in full[1] if float(full[1][n].abs().max()) > 0)
+	assert worst[0] <= 3e-2 and worst[0] <= 1.5 * worst16[0], (worst, worst16)
+
+
+def test_one_product_backward_in_a_dense_residual_network_and_under_graph_replay():
+	"""'bf16x3f' through the residual forms (1x1 branches, fp32 dy of the grouped BN backward rounded once) -- gradients within the 16-bit bar of the
+	full split path's -- and its training step replayed from a graph, bit for bit against the eager steps (dropout on)."""
+	import convasr_amd as ca
+	d = torch.device('cuda:0')
+	x, xlen, y, ylen = _batch(d, 4, 4)
+	out = {}
+	for dt in ('bf16x3', 'bf16x3f'):
+		torch.manual_seed(4)
+		fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
+		model = ca.models.JasperNet(64, [38], frontend = fe, base_width = 64, kernel_sizes = [11, 13, 17], out_width_factors = [2, 3, 4], dropouts = [0.0] * 3, out_width_factors_large = [4, 4], residual = 'dense', repeat = 2, num_subblocks = 2, dropout = 0, check_time_dim_padded = False, temporal_mask = False, compute_dtype = dt).to(d).train()
+		flat = ca.train.FlatParameters(model)
+		res = model(x, xlen, y = y, ylen = ylen)
+		(res['loss'] * ylen[:, 0]).mean().backward()
+		ca.functional.join_side_streams()
+		flat.finalize_grads()
+		torch.cuda.synchronize()
+		out[dt] = (res['loss'].detach().clone(), {n: p._convasr_grad.clone() for n, p in model.named_parameters() if hasattr(p, '_convasr_grad')})
+	a, b = out['bf16x3'], out['bf16x3f']
+	assert torch.equal(a[0], b[0])
+	worst = max((_rel(b[1][n], a[1][n]), n) for n in a[1] if float(a[1][n].abs().max()) > 0)
+	assert worst[0] <= 3e-2, worst
+	traces = []
+	for graphed in (False, True):
+		ca.functional.manual_seed(17)
+		model = _small(ca, d, 'bf16x3f', dropout = 0.2)
+		flat = ca.train.FlatParameters(model)
+		opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
+		stepper = ca.train.GraphedTrainStep(model, opt, warmup = 1, enabled = graphed)
+		batch = _batch(d, 6, 4)
+		tr = [float(stepper(*batch, iteration = it)['loss']) for it in range(5)]
+		torch.cuda.synchronize()
+		traces.append((tr, flat.data.clone(), stepper.replays))
+	assert traces[0][0] == traces[1][0] and torch.equal(traces[0][1], traces[1][1]) and traces[1][2] >= 3
