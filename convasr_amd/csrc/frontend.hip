@@ -47,10 +47,15 @@ template <typename S> __global__ __launch_bounds__(256) void absmax_kernel(const
 	if (threadIdx.x == 0) atomicMax(out + b, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));  // non-negative floats order like their bit patterns
 }
 
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) p[i] = 0u;
+}
+
 extern "C" int convasr_signal_absmax(const void* signal, int signal_dtype, int B, int T, float* absmax, void* stream) {
 	CONVASR_CHECK_ARG(signal && absmax && B > 0 && T > 0, "signal_absmax: bad arguments");
 	hipStream_t s = (hipStream_t)stream;
-	if (hipMemsetAsync(absmax, 0, sizeof(float) * B, s) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "signal_absmax: memset failed");
+	hipLaunchKernelGGL(zero_words_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (unsigned*)absmax, B);  // (a kernel, not hipMemsetAsync: no memset node in a captured step, see convasr_copy)
 	int gx = (T + 256 * 32 - 1) / (256 * 32);
 	if (gx > 32) gx = 32;
 	if (signal_dtype == CONVASR_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(gx, B), dim3(256), 0, s, (const float*)signal, T, (unsigned*)absmax);

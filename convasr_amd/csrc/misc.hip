@@ -410,10 +410,27 @@ extern "C" int convasr_cast_scale(const void* src, int src_dtype, void* dst, int
 	return 0;
 }
 
+// A device-to-device copy as a KERNEL, never hipMemcpyAsync: a stream-ordered launch like every other in the step, and a kernel node (not a
+// memcpy node, which the runtime may hand to a DMA engine) when the step is captured into a HIP graph -- see convasr_copy below.
+__global__ __launch_bounds__(256) void copy_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int64_t n16, int64_t nbytes, int aligned) {
+	const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+	if (aligned) {
+		for (int64_t i = i0; i < n16; i += step) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+		for (int64_t i = n16 * 16 + i0; i < nbytes; i += step) dst[i] = src[i];
+	} else {
+		for (int64_t i = i0; i < nbytes; i += step) dst[i] = src[i];
+	}
+}
+
 extern "C" int convasr_copy(const void* src, void* dst, int64_t nbytes, void* stream) {
 	CONVASR_CHECK_ARG(src && dst && nbytes >= 0, "copy: bad arguments");
 	if (nbytes == 0) return 0;
-	if (hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return convasr_fail(CONVASR_ELAUNCH, "copy: hipMemcpyAsync failed");
+	const int aligned = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+	const int64_t n16 = aligned ? nbytes >> 4 : 0;
+	int64_t blocks = ceil_div64(aligned ? (n16 > 0 ? n16 : 1) : nbytes, 256);
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src, (unsigned char*)dst, n16, nbytes, aligned);
+	CONVASR_CHECK_LAUNCH("copy");
 	return 0;
 }
 

@@ -317,6 +317,39 @@ def train_step(model, optimizer, x, xlen, y, ylen, max_norm = 100.0, accumulate_
 	return res
 
 
+_HIP_NODE_TYPES = {0: 'kernel', 1: 'memcpy', 2: 'memset', 3: 'host', 4: 'graph', 5: 'empty', 6: 'wait_event', 7: 'event_record', 8: 'ext_sem_signal', 9: 'ext_sem_wait', 10: 'mem_alloc', 11: 'mem_free', 12: 'memcpy_from_symbol', 13: 'memcpy_to_symbol'}  # hipGraphNodeType
+_hip_runtime = []
+
+
+def capture_node_kinds(device):
+	"""{node type: count} of the graph being captured on the current stream of `device` (hipStreamGetCaptureInfo_v2 -> hipGraphGetNodes ->
+	hipGraphNodeGetType, over the HIP runtime torch has loaded), or None when the stream is not capturing / the runtime cannot be asked."""
+	import ctypes
+	try:
+		if not _hip_runtime:
+			_hip_runtime.append(ctypes.CDLL('libamdhip64.so'))
+		hip = _hip_runtime[0]
+		status, gid, graph, deps, ndeps = ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t(0)
+		stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+		if hip.hipStreamGetCaptureInfo_v2(stream, ctypes.byref(status), ctypes.byref(gid), ctypes.byref(graph), ctypes.byref(deps), ctypes.byref(ndeps)) != 0 or status.value != 1 or not graph:
+			return None
+		n = ctypes.c_size_t(0)
+		if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
+			return None
+		nodes = (ctypes.c_void_p * max(n.value, 1))()
+		if hip.hipGraphGetNodes(graph, nodes, ctypes.byref(n)) != 0:
+			return None
+		kinds = {}
+		for i in range(n.value):
+			t = ctypes.c_int(-1)
+			hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+			name = _HIP_NODE_TYPES.get(t.value, str(t.value))
+			kinds[name] = kinds.get(name, 0) + 1
+		return kinds
+	except (OSError, AttributeError):
+		return None
+
+
 class GraphedTrainStep:
 	"""train_step(model, optimizer, x, xlen, y, ylen) with accumulate_iterations = 1, replayed from a HIP graph: one graph per batch shape
 	(x.shape, y.shape -- a bucketed loader that pads every batch of a bucket to the bucket's ceiling, datasets.bucket_ceiling, produces
@@ -354,6 +387,7 @@ class GraphedTrainStep:
 		self.pool = None
 		self.epoch = Fn.structure_epoch()
 		self.replays = self.captures = self.eager_steps = 0
+		self.non_kernel_nodes = os.environ.get('CONVASR_GRAPH_FENCE') == '1'  # does any captured step hold a memset / memcpy / ... node (see _fence_transition)?
 		self._lr = None
 
 	@staticmethod
@@ -365,16 +399,17 @@ class GraphedTrainStep:
 		return None if g is None else g['static']
 
 	def _fence_transition(self, device, eager):
-		"""A host wait for the stream wherever an eagerly launched step meets a replayed one (either order).  Measured in round 6
-		(scratch/r6_interleave_debug3.py, profiles/r06_interleave_race.txt): with the order A A B A B B C A B C A on a small Wav2Letter (AdamW, bf16,
-		max_graphs = 2: C stays eager) the replay of A after the second eager C computed a different loss in 3 of 4 runs, bit-identical to the eager
-		run in 8 of 8 with a stream synchronisation on either side of the eager step (and in 3 of 3 with the stride-2 fold of the prologue off:
-		the one layer whose weight gradient goes through a temporary of the DEFAULT memory pool in eager steps).  Replay-after-replay sequences
-		have never differed (tests/test_full_size_and_step_graphs_gpu.py: 20 and 24 steps over 2 and 3 shapes).  Every stream hand-over the host
-		code makes is in place; what overlaps is decided inside the runtime's graph launch.  Eager steps are the exception once graphs exist -- the
-		warm-up of a new batch shape, shapes beyond max_graphs -- so the two kinds of step are simply fenced from each other: one host wait per
-		transition, nothing on the replay-to-replay path."""
-		if self.graphs and getattr(self, '_last_eager', None) is not None and self._last_eager != eager and device.type == 'cuda':
+		"""A host wait for the stream wherever an eagerly launched step meets a replayed one (either order) -- armed only when a captured step
+		contains a node that is not a kernel.  Round 6 (profiles/r06_interleave_race.txt): with the order A A B A B B C A B C A on a small Wav2Letter
+		(AdamW, bf16, max_graphs = 2: C stays eager) the replay of A after the second eager C computed a different loss in most runs.  Root cause:
+		the MEMSET node the capture recorded for convasr_signal_absmax's hipMemsetAsync (the first node of the step).  On ROCm 7.2 it is not
+		reliably ordered against the graph's own next kernel (the atomicMax reduction into the words it clears) when the replay follows eagerly
+		launched work; the utterances' maxima then come out cleared and normalize_signal scales by 1 / eps.  With that clear (and convasr_copy,
+		a hipMemcpyAsync before) turned into kernels every captured step consists of kernel nodes only (tests/test_full_size_and_step_graphs_gpu.py
+		counts them) and the sequence is bit-identical to the eager run with no fence (6 of 6; 2 of 6 with the memset node back in).  The fence stays
+		as the guard for graphs that do contain memset / memcpy nodes (a user module's torch ops may record them): one host wait per transition,
+		nothing on the replay-to-replay path."""
+		if self.graphs and self.non_kernel_nodes and getattr(self, '_last_eager', None) is not None and self._last_eager != eager and device.type == 'cuda':
 			torch.cuda.current_stream(device).synchronize()
 		self._last_eager = eager
 
@@ -430,12 +465,15 @@ class GraphedTrainStep:
 		try:
 			with torch.cuda.graph(graph, pool = self.pool):
 				res = train_step(self.model, opt, *static, max_norm = self.max_norm, iteration = iteration, world_size = self.world_size, sync_metrics = self.sync_metrics)
+				kinds = capture_node_kinds(dev)
 		finally:
 			Fn.CAPTURING[0] = False
 			Fn._side_streams.update(side)
 			Fn.PREPACK = prepack
 		opt.steps = steps0  # (nothing ran: the replay below is this step)
-		self.graphs[key] = dict(graph = graph, static = static, res = res)
+		self.graphs[key] = dict(graph = graph, static = static, res = res, node_kinds = kinds)
+		if kinds is not None and any(k != 'kernel' for k in kinds):
+			self.non_kernel_nodes = True  # (arms _fence_transition)
 		self.captures += 1
 
 	def __call__(self, x, xlen, y, ylen, iteration = 0):
