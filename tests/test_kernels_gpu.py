@@ -54,6 +54,20 @@ def test_library_exports_every_declared_symbol():
 		assert len(_lib._SIGNATURES[name][1]) == n, (name, n, len(_lib._SIGNATURES[name][1]))
 
 
+def test_argument_envelope_of_the_one_product_backward_entry_points_is_checked_before_any_launch():
+	"""convasr_conv1d_wgrad_ld / convasr_pack_conv_weight_split3 refuse bad pitches / plane counts with an error code and a message (no GPU is
+	touched: the checks run first, so this runs on the CPU box too)."""
+	import ctypes
+	from convasr_amd import _lib
+	lib = _lib.load()
+	p = ctypes.c_void_p(4096)  # any non-NULL value: never dereferenced
+	bf16 = _lib.dtype_code(torch.bfloat16)
+	args = lambda x_ld, dy_ld, dt = bf16: (p, x_ld, p, dy_ld, p, p, dt, 2, 128, 128, 64, 64, 3, 1, 1, 0, _lib.W_REFERENCE, None)
+	for bad in (args(64, 128), args(3 * 128 + 4, 128), args(3 * 128, 100), args(3 * 128, 128, _lib.F32)):
+		assert lib.convasr_conv1d_wgrad_ld(*bad) < 0 and b'conv1d_wgrad_ld' in lib.convasr_last_error()
+	assert lib.convasr_pack_conv_weight_split3(p, _lib.W_REFERENCE, p, p, 2, bf16, 128, 128, 3, None) < 0 and b'pack_conv_weight_split3' in lib.convasr_last_error()
+
+
 def test_product_path_refuses_cpu_tensors():
 	from convasr_amd import ops, _lib
 	with pytest.raises(_lib.ConvasrHipError):
