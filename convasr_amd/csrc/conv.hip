@@ -424,6 +424,7 @@ template <typename T, typename O> static int dispatch_conv(const ConvParams& p, 
 int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* m_tiles_out);  // conv_v2s.hip
 int convasr_conv1x1_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s, int* rows_out);        // conv1x1.hip
 int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s);      // wgrad_v2.hip
+int convasr_wgrad_v2_supports(const WgradParams& p);
 static int g_conv_use_v2 = 1;
 static int g_conv_debug = 0;
 // test / A-B hook: bit 0 clear forces the register-staged kernels for every dtype; bits 8.. are experiment flags (ConvParams::debug)
@@ -845,6 +846,15 @@ extern "C" int convasr_conv1d_wgrad_ld(const void* x, int x_ld, const void* dy, 
                                        int Tout, int K, int dil, int pad, int accumulate, int dw_layout, void* stream) {
 	CONVASR_CHECK_ARG(x_ld >= Cin && dy_ld >= Cout && (x_ld & 7) == 0 && (dy_ld & 7) == 0 && convasr_is_half(dtype), "conv1d_wgrad_ld: x_ld >= Cin, dy_ld >= Cout, multiples of 8, 16-bit storage");
 	return wgrad_impl(x, x_ld, dy, dy_ld, dw, nullptr, workspace, dtype, B, Cin, Cout, Tin, Tout, K, 1, dil, pad, accumulate, dw_layout, stream);
+}
+
+// Is this geometry inside convasr_conv1d_wgrad_ld's envelope (1) or must the caller make the operands dense first (0)?  No launch, no GPU.
+extern "C" int convasr_conv1d_wgrad_ld_supported(int dtype, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int x_ld, int dy_ld) {
+	if (!convasr_is_half(dtype) || B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0 || K <= 0 || K > 64 || dil <= 0 || x_ld < Cin || dy_ld < Cout) return 0;
+	WgradParams p = WgradParams();
+	p.B = B; p.Cin = Cin; p.Cout = Cout; p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = 1; p.dil = dil;
+	p.x_ld = x_ld == Cin ? 0 : x_ld; p.dy_ld = dy_ld == Cout ? 0 : dy_ld;
+	return g_conv_use_v2 && convasr_wgrad_v2_supports(p);
 }
 
 // ------------------------------------------------------------------------------------------------ stride-2 fold

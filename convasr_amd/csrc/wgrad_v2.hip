@@ -334,18 +334,30 @@ template <typename H> __global__ __launch_bounds__(W2_ALL_THREADS, 3) void conv1
 	wgrad_v2_body<H>(g.prob[q], v - g.first[q], smem);
 }
 
-// Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
-int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
+// The kernel's envelope: fills the plan in `q` (a copy of `p`) and returns the dynamic LDS bytes, or 0 if the shape is outside it.
+static size_t wgrad_v2_plan(const WgradParams& p, WgradParams& q) {
 	if (p.stride != 1 || (p.Cin & 127) != 0 || (p.Cout & 127) != 0) return 0;
 	if ((int64_t)p.Tin * (p.x_ld ? p.x_ld : p.Cin) * 2 >= (1ll << 31) || (int64_t)p.Tout * (p.dy_ld ? p.dy_ld : p.Cout) * 2 >= (1ll << 31)) return 0;
 	if ((p.x_ld & 7) || (p.dy_ld & 7)) return 0;  // (16-byte DMA pieces)
-	WgradParams q = p;
+	q = p;
 	wgrad_plan(q, W2_BKT, 1.6);
 	q.x_rows = (q.x_rows + 3) & ~3;
 	const int pieces = W2_BKT / 4 + q.x_rows / 4;
 	if (pieces > 40) return 0;  // at most 10 pieces per loader wave: the counted waits above
 	const size_t smem = 4 * (size_t)(W2_YBYTES + q.x_rows * 256);
-	if (smem > 160 * 1024) return 0;
+	return smem > 160 * 1024 ? 0 : smem;
+}
+
+int convasr_wgrad_v2_supports(const WgradParams& p) {
+	WgradParams q;
+	return wgrad_v2_plan(p, q) != 0;
+}
+
+// Fills the plan in `p` and launches; returns 0 (plan untouched) if the shape is outside this kernel's envelope.
+int convasr_wgrad_v2_try(WgradParams& p, int dtype, hipStream_t s) {
+	WgradParams q;
+	const size_t smem = wgrad_v2_plan(p, q);
+	if (!smem) return 0;
 	const bool f16 = dtype == CONVASR_F16;
 	const void* kern = f16 ? (const void*)conv1d_wgrad_v2_kernel<f16_t> : (const void*)conv1d_wgrad_v2_kernel<bf16_t>;
 	static unsigned long long set[2] = {0, 0};

@@ -398,7 +398,11 @@ def conv1d_wgrad_hi(x3, dy, Cout, K, dil, pad, dw, accumulate = False, work = No
 	Cin, Tout = C3 // 3, dy.shape[2]
 	layout = weight_layout(dw)
 	assert is_cl(x3) and is_cl(dy) and x3.dtype == dy.dtype and x3.dtype in HALF_DTYPES and layout is not None and dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, K), (dw.shape, dw.stride())
-	if Cin % 128 != 0 or Cout % 128 != 0 or Tin * C3 * 2 >= 2 ** 31:
+	skey = (x3.dtype, B, Cin, Cout, Tin, Tout, K, dil)
+	ok = _wgrad_ld_ok.get(skey)
+	if ok is None:
+		ok = _wgrad_ld_ok[skey] = bool(_lib.load().convasr_conv1d_wgrad_ld_supported(dtype_code(x3.dtype), B, Cin, Cout, Tin, Tout, K, dil, C3, Cout))
+	if not ok:  # outside the LDS-DMA kernel's envelope (channel counts not multiples of 128, a tap window too wide for its LDS ring): a dense copy of the plane
 		return conv1d_wgrad(split3_plane(x3), dy, Cout, K, 1, dil, pad, dw, accumulate = accumulate, work = work, family = family)
 	if K == 1 and (Cout * Cin) % 4 == 0:
 		layout = _lib.W_KMAJOR
@@ -407,13 +411,11 @@ def conv1d_wgrad_hi(x3, dy, Cout, K, dil, pad, dw, accumulate = False, work = No
 	if nbytes is None:
 		nbytes = _wgrad_ws_bytes[wkey] = _lib.load().convasr_conv1d_wgrad_workspace_bytes(*wkey)
 	ws = workspace(nbytes, x3.device, 'wgrad')
-	try:
-		_lib.timed(family or 'conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad_ld', ptr(x3), C3, ptr(dy), Cout, ptr(dw), ptr(ws), dtype_code(dy.dtype), B, Cin, Cout, Tin, Tout, K, dil, pad, int(accumulate), layout, stream_ptr()))
-	except _lib.ConvasrHipError as e:
-		if 'envelope' not in str(e):
-			raise
-		return conv1d_wgrad(split3_plane(x3), dy, Cout, K, 1, dil, pad, dw, accumulate = accumulate, work = work, family = family)  # (a tap window too wide for the kernel's LDS ring)
+	_lib.timed(family or 'conv1d_wgrad', 2.0 * B * Tout * Cout * Cin * K if work is None else work, lambda: call('convasr_conv1d_wgrad_ld', ptr(x3), C3, ptr(dy), Cout, ptr(dw), ptr(ws), dtype_code(dy.dtype), B, Cin, Cout, Tin, Tout, K, dil, pad, int(accumulate), layout, stream_ptr()))
 	return dw
+
+
+_wgrad_ld_ok = {}
 
 
 def pack_weight_split3(w, dtype, out = None, want_dgrad = True, dgrad_planes = 3):

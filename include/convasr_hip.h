@@ -417,7 +417,8 @@ int convasr_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype,
  *   dgrad: convasr_conv1d_fwd(dy16, packed_dgrad with dgrad_planes = 1, dx fp32);
  *   wgrad: convasr_conv1d_wgrad_ld -- convasr_conv1d_wgrad (stride 1) over operands whose frames are x_ld / dy_ld elements apart: plane 0 (hi)
  *          of the forward's saved planes x3 read IN PLACE (x_ld = 3 Cin) against dy16.  16-bit storage, Cin % 128 == 0, Cout % 128 == 0,
- *          ld % 8 == 0; CONVASR_EUNSUPPORTED outside (the host then copies the plane out and calls convasr_conv1d_wgrad). */
+ *          ld % 8 == 0; CONVASR_EUNSUPPORTED outside -- convasr_conv1d_wgrad_ld_supported answers beforehand (the host then copies the plane out and calls
+ *          convasr_conv1d_wgrad). */
 int convasr_split3(const float* x, void* out, int dtype, int64_t rows, int C, int order, void* stream);
 /* The two fp32 streaming passes whose result is consumed by split convs only, with the split folded in (the separate convasr_split3 pass --
  * 4 bytes read + 6 written per element -- disappears):
@@ -439,6 +440,8 @@ int convasr_bn_act_bwd_apply_to_half(const void* dz_or_g, const void* y, void* d
                                      const float* scale, const float* shift, int act, float act_lo, float act_hi, float dropout_p,
                                      uint64_t seed, uint64_t offset, const uint64_t* step_key, const float* xlen, int B, int T, int C,
                                      const uint8_t* gate, void* stream);
+/* 1 when convasr_conv1d_wgrad_ld takes this geometry, 0 when the caller must make the operands dense and call convasr_conv1d_wgrad (no launch). */
+int convasr_conv1d_wgrad_ld_supported(int dtype, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int x_ld, int dy_ld);
 int convasr_conv1d_wgrad_ld(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, void* workspace, int dtype,
                             int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad, int accumulate, int dw_layout, void* stream);
 

@@ -66,6 +66,10 @@ def test_argument_envelope_of_the_one_product_backward_entry_points_is_checked_b
 	for bad in (args(64, 128), args(3 * 128 + 4, 128), args(3 * 128, 100), args(3 * 128, 128, _lib.F32)):
 		assert lib.convasr_conv1d_wgrad_ld(*bad) < 0 and b'conv1d_wgrad_ld' in lib.convasr_last_error()
 	assert lib.convasr_pack_conv_weight_split3(p, _lib.W_REFERENCE, p, p, 2, bf16, 128, 128, 3, None) < 0 and b'pack_conv_weight_split3' in lib.convasr_last_error()
+	# the envelope query the host asks before choosing between the in-place read and a dense copy of the plane
+	q = lambda Cin, Cout, K, dil, x_ld, dt = bf16: lib.convasr_conv1d_wgrad_ld_supported(dt, 64, Cin, Cout, 753, 753, K, dil, x_ld, Cout)
+	assert q(768, 768, 11, 1, 3 * 768) == 1 and q(768, 768, 29, 2, 3 * 768) == 1 and q(128, 256, 6, 1, 3 * 128) == 1
+	assert q(64, 768, 11, 1, 3 * 64) == 0 and q(768, 136, 11, 1, 3 * 768) == 0 and q(768, 768, 11, 1, 3 * 768 + 4) == 0 and q(768, 768, 11, 1, 3 * 768, _lib.F32) == 0 and q(768, 768, 11, 1, 512) == 0
 
 
 def test_product_path_refuses_cpu_tensors():
