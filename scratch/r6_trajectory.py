@@ -13,17 +13,17 @@ xlen = torch.linspace(0.5, 1, B).to(d)
 y = torch.randint(0, 37, (B, 1, 10 * secs), generator = g).to(d)
 ylen = (torch.linspace(0.5, 1, B) * 8 * secs).long().clamp(min = 1).view(B, 1).to(d)
 out = {}
-for name, dt in (('f32', torch.float32), ('bf16x3', 'bf16x3'), ('f16x3', 'f16x3'), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+for name, dt in (('f32', torch.float32), ('bf16x3', 'bf16x3'), ('bf16x3f', 'bf16x3f'), ('f16x3', 'f16x3'), ('f16x3f', 'f16x3f'), ('f16', torch.float16), ('bf16', torch.bfloat16)):
 	torch.manual_seed(1)
 	fe = ca.models.LogFilterBankFrontend(64, 16000, 0.02, 0.01, 'hann_window')
-	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0.0, check_time_dim_padded = False, compute_dtype = dt if name not in ('f16', 'f16x3') else torch.float32).to(d).train()
+	model = ca.models.Wav2Letter(64, [38], frontend = fe, dropout = 0.0, check_time_dim_padded = False, compute_dtype = dt if name not in ('f16', 'f16x3', 'f16x3f') else torch.float32).to(d).train()
 	flat = ca.train.FlatParameters(model)
 	opt = ca.train.SGD(flat, lr = 1e-2, momentum = 0.9, weight_decay = 1e-3)
 	if name == 'f16':
 		ca.models.data_parallel_and_autocast(model, opt, opt_level = 'O2')
 		flat.loss_scaler = ca.train.LossScaler(d, init_scale = 2.0 ** 13)  # (a scale that fits from the first step: no skipped start-up steps in the comparison)
-	elif name == 'f16x3':
-		ca.models.data_parallel_and_autocast(model, opt, compute_dtype = 'f16x3')
+	elif name in ('f16x3', 'f16x3f'):
+		ca.models.data_parallel_and_autocast(model, opt, compute_dtype = name)
 		flat.loss_scaler = ca.train.LossScaler(d, init_scale = 2.0 ** 13)
 	losses = []
 	for it in range(steps):
