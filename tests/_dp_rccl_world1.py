@@ -52,7 +52,7 @@ def run(graphed, comm, dt = torch.bfloat16, opt_level = None, n = 10):
 		if after1 is None and bool(torch.isfinite(r['grad_norm'])):
 			after1 = (it, flat.data.clone())  # the parameters right after the first update that was applied
 	torch.cuda.synchronize()
-	out = dict(trace = trace, params = flat.data.clone(), captures = stepper.captures, replays = stepper.replays, comm_dtype = str(engine.comm_dtype()), exchange = engine.exchange_bytes(), after1 = after1, p0 = p0)
+	out = dict(trace = trace, params = flat.data.clone(), captures = stepper.captures, replays = stepper.replays, node_kinds = [g['node_kinds'] for g in stepper.graphs.values()], fence_armed = stepper.non_kernel_nodes, comm_dtype = str(engine.comm_dtype()), exchange = engine.exchange_bytes(), after1 = after1, p0 = p0)
 	engine.close()
 	return out
 
@@ -60,10 +60,10 @@ def run(graphed, comm, dt = torch.bfloat16, opt_level = None, n = 10):
 res = {}
 try:
 	e32, g32 = run(False, None), run(True, None)
-	res['fp32_exchange'] = dict(captures = g32['captures'], replays = g32['replays'], trace_equal = e32['trace'] == g32['trace'], params_equal = bool(torch.equal(e32['params'], g32['params'])), exchange_bytes = e32['exchange'])
+	res['fp32_exchange'] = dict(captures = g32['captures'], replays = g32['replays'], node_kinds = g32['node_kinds'], fence_armed = g32['fence_armed'], trace_equal = e32['trace'] == g32['trace'], params_equal = bool(torch.equal(e32['params'], g32['params'])), exchange_bytes = e32['exchange'])
 	e16, g16 = run(False, 'auto', torch.float16, 'O2'), run(True, 'auto', torch.float16, 'O2')
 	ref16 = run(False, None, torch.float16, 'O2')
-	res['fp16_exchange'] = dict(comm_dtype = e16['comm_dtype'], captures = g16['captures'], replays = g16['replays'], trace_equal = e16['trace'] == g16['trace'], params_equal = bool(torch.equal(e16['params'], g16['params'])),
+	res['fp16_exchange'] = dict(comm_dtype = e16['comm_dtype'], captures = g16['captures'], replays = g16['replays'], node_kinds = g16['node_kinds'], fence_armed = g16['fence_armed'], trace_equal = e16['trace'] == g16['trace'], params_equal = bool(torch.equal(e16['params'], g16['params'])),
 		exchange_bytes = e16['exchange'], exchange_bytes_fp32 = ref16['exchange'],
 		first_loss_equal_to_fp32_exchange = e16['trace'][0][0] == ref16['trace'][0][0],
 		first_update_at = (e16['after1'][0], ref16['after1'][0]),

@@ -192,6 +192,10 @@ def test_rccl_world1_data_parallel_step_replays_bitwise_from_graphs_with_fp32_an
 	assert a['captures'] == 2 and a['replays'] >= 7 and a['trace_equal'] and a['params_equal'], a
 	assert b['comm_dtype'] == 'torch.float16' and b['captures'] == 2 and b['trace_equal'] and b['params_equal'], b
 	assert b['exchange_bytes'] * 2 == b['exchange_bytes_fp32'] and b['first_loss_equal_to_fp32_exchange'], b
+	# what the captures hold: RCCL's all-reduces are kernel nodes like everything else of the step (a memset / memcpy node would arm the eager / replay fence)
+	for leg in (a, b):
+		assert leg['node_kinds'] and all(k is not None and k.get('kernel', 0) >= 100 for k in leg['node_kinds']), leg['node_kinds']
+		assert leg['fence_armed'] == any(set(k) != {'kernel'} for k in leg['node_kinds']), leg
 	# the first applied update with the gradients exchanged as fp16 against the same update with the fp32 exchange: apart by fp16's rounding of
 	# the gradient (2^-11 per element), relative to the update itself.  (A gradient of the scaled loss that fits fp32 but not fp16 overflows in the
 	# 16-bit send buffer -- as it would in apex O2's fp16 gradients -- and costs one more skipped start-up step: compared when both runs applied the same step.)
