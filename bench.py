@@ -632,6 +632,9 @@ def roofline_of(args, wl, kt, kt2, steps2, value, world, graphed = False):
 	allc = list(kt.values())
 	stack = sum(v['work'] for v in allc) / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12
 	roof['conv_stack'] = dict(achieved = round(stack, 2), ms_per_step = round(sum(v['total_ms'] for v in allc) / args.steps, 3), frac = round(stack / peak, 4))
+	if split:  # the MFMA work the stack EXECUTES: three products per algorithmic FLOP in the split-operand launches, one in the others ('...x3f': the backward)
+		executed = sum(v['work'] * (3.0 if name in (SPLIT_FAMILY, SPLIT_WGRAD_FAMILY) else 1.0) for name, v in kt.items())
+		roof['conv_stack']['executed_mfma_frac'] = round(executed / (sum(v['total_ms'] for v in allc) * 1e-3) / 1e12 / peak, 4)
 	roof['whole_step_frac'] = round(value / world / (peak * 1e12), 4)  # (value here: algorithmic conv FLOP/s of the whole job)
 	# the HBM-bound kernels of the path (frontend, BN + activation passes): algorithmic bytes / HIP-event time against 8 TB/s
 	gbs = lambda v: v['bytes'] / (v['total_ms'] * 1e-3) / 1e9

@@ -1015,18 +1015,19 @@ class _HeadPad:
 		return ent['wd']
 
 	@classmethod
-	def split_weight(cls, weight, split):
+	def split_weight(cls, weight, split, dgrad_planes = 3):
 		"""(forward, dgrad) planes of a narrow one-tap head in a split-operand network, as 128-class operands: the fp32 weight is copied into the
-		live rows of a zero-padded (128, Cin, 1) fp32 buffer and split like any other weight; refreshed per parameter version, in place."""
+		live rows of a zero-padded (128, Cin, 1) fp32 buffer and split like any other weight; refreshed per parameter version, in place.
+		dgrad_planes = 1: the dgrad operand as the ordinary 16-bit one (a one-product backward, functional.split_weight)."""
 		Cout, Cin, K = weight.shape
 		ver = param_version(weight)
-		ent = cls._cache.get((id(weight), 'split', split))
+		ent = cls._cache.get((id(weight), 'split', split, dgrad_planes))
 		if ent is None:
-			ent = cls._cache[(id(weight), 'split', split)] = dict(w = weight, ver = None, wp = torch.zeros(HEAD_PAD, Cin, 1, dtype = torch.float32, device = weight.device), fwd = None, dgr = None)
+			ent = cls._cache[(id(weight), 'split', split, dgrad_planes)] = dict(w = weight, ver = None, wp = torch.zeros(HEAD_PAD, Cin, 1, dtype = torch.float32, device = weight.device), fwd = None, dgr = None)
 		if ent['ver'] != ver:
 			src, wp = weight.detach(), ent['wp']
 			_lib.call('convasr_convert_layout', _lib.ptr(src), _lib.F32, 0, src.stride(0), src.stride(1), _lib.ptr(wp), _lib.F32, 0, wp.stride(0), wp.stride(1), 1, Cout, Cin, _lib.stream_ptr())
-			ent['fwd'], ent['dgr'] = ops.pack_weight_split3(wp, split, out = (ent['fwd'], ent['dgr']))
+			ent['fwd'], ent['dgr'] = ops.pack_weight_split3(wp, split, out = (ent['fwd'], ent['dgr']), dgrad_planes = dgrad_planes)
 			ent['ver'] = ver
 		return ent['fwd'], ent['dgr']
 
@@ -1041,7 +1042,7 @@ class _HeadPad:
 		key = (B, T, Cout, dt, dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
 		out = None if CAPTURING[0] else cls._pad_bufs.get(key)
 		if CAPTURING[0]:
-			out = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)  # (inside a capture: the graph's own buffer, zero-filled by a memset node at every replay)
+			out = ops.zeros_cl(B, HEAD_PAD, T, dt, dy.device)  # (inside a capture: the graph's own buffer, zero-filled at every replay -- by a fill KERNEL node: torch.zeros records no memset node, train.capture_node_kinds)
 		elif out is None:
 			if len(cls._pad_bufs) >= 64:
 				cls._pad_bufs.clear()  # mixed-length training: one entry per padded length; bounded
@@ -1066,7 +1067,7 @@ class ConvBiasFunction(torch.autograd.Function):
 			ctx.split = cfg['split']
 			B, _, T = x.shape
 			x = ops.split3(x, ctx.split, ops.SPLIT_INPUT)
-			y = ops.conv1d(x, _HeadPad.split_weight(weight, ctx.split)[0], Cout, 1, 1, 1, 0, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias, work = 2.0 * B * T * Cout * Cin, family = SPLIT_FAMILY)
+			y = ops.conv1d(x, _HeadPad.split_weight(weight, ctx.split, 1 if cfg.get('split_hi_bwd') else 3)[0], Cout, 1, 1, 1, 0, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias, work = 2.0 * B * T * Cout * Cin, family = SPLIT_FAMILY)
 		else:
 			y = ops.conv1d(x, packed_weight(weight, dt, _lib.PACK_FWD), weight.shape[0], spec.K, spec.stride, spec.dilation, spec.padding, out_dtype = cfg.get('out_dtype', torch.float32), bias = bias)
 		ctx.cfg = cfg
@@ -1085,15 +1086,22 @@ class ConvBiasFunction(torch.autograd.Function):
 			Cin = weight.shape[1]
 			B, _, T = dy.shape
 			dy = ops.as_cl(dy, torch.float32)
-			dy3 = ops.split3(_HeadPad.pad_grad(dy, torch.float32), ctx.split, ops.SPLIT_GRAD)  # (B, 3 x 128, T): the padded classes are zero planes
+			hi = bool(cfg.get('split_hi_bwd'))  # one 16-bit product per gradient: dy rounded once into the padded 128-class buffer, x_hi read in place, w_hi
+			dy3 = _HeadPad.pad_grad(dy, ctx.split) if hi else ops.split3(_HeadPad.pad_grad(dy, torch.float32), ctx.split, ops.SPLIT_GRAD)  # (B, 3 x 128, T): the padded classes are zero planes
 			dx = None
-			if ctx.needs_input_grad[1]:
+			if ctx.needs_input_grad[1] and hi:
+				dx = ops.conv1d(dy3, _HeadPad.split_weight(weight, ctx.split, 1)[1], Cin, 1, 1, 1, 0, out_dtype = torch.float32, work = 2.0 * B * T * Cout * Cin)
+				_after_long_launch()
+			elif ctx.needs_input_grad[1]:
 				dx = ops.conv1d(dy3, _HeadPad.split_weight(weight, ctx.split)[1], Cin, 1, 1, 1, 0, out_dtype = torch.float32, work = 2.0 * B * T * Cout * Cin, family = SPLIT_FAMILY)
 				_after_long_launch()
 
 			def wgrad3(outs, acc):
 				dwp = torch.empty(HEAD_PAD, Cin, 1, dtype = torch.float32, device = dy.device)
-				ops.conv1d_wgrad(ops.split3_frames(x), ops.split3_frames(dy3), HEAD_PAD, 1, 1, 3, 0, dwp, work = 2.0 * B * T * Cout * Cin, family = SPLIT_WGRAD_FAMILY)
+				if hi:
+					ops.conv1d_wgrad_hi(x, dy3, HEAD_PAD, 1, 1, 0, dwp, work = 2.0 * B * T * Cout * Cin)
+				else:
+					ops.conv1d_wgrad(ops.split3_frames(x), ops.split3_frames(dy3), HEAD_PAD, 1, 1, 3, 0, dwp, work = 2.0 * B * T * Cout * Cin, family = SPLIT_WGRAD_FAMILY)
 				if outs[0] is not None:
 					v = dwp[:Cout]
 					if acc:

@@ -360,10 +360,11 @@ class Decoder(nn.Sequential):
 		self.type = type
 		self.compute_dtype = torch.float32
 		self.split_dtype = None  # (JasperNet.set_compute_dtype('bf16x3'): the head as a split-operand conv too)
+		self.split_hi_bwd = False  # ('bf16x3f': ... with a one-product backward)
 
 	def _head(self, x):
 		conv = self[0]
-		cfg = dict(spec = _spec_of(conv), compute_dtype = self.compute_dtype, out_dtype = torch.float32, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None)
+		cfg = dict(spec = _spec_of(conv), compute_dtype = self.compute_dtype, out_dtype = torch.float32, split = self.split_dtype if (self.training and torch.is_grad_enabled()) else None, split_hi_bwd = self.split_hi_bwd)
 		return Fn.ConvBiasFunction.apply(cfg, x, conv.weight, conv.bias)
 
 	def forward(self, x):
@@ -440,10 +441,9 @@ class JasperNet(nn.Module):
 			if isinstance(m, (ConvBn1d, Decoder)):
 				m.compute_dtype = dtype
 			if isinstance(m, (ConvBn1d, Decoder)):
-				m.split_dtype = split
+				m.split_dtype, m.split_hi_bwd = split, hi_bwd
 			if isinstance(m, ConvBn1d):
 				m.split_inference = bool(inference) and split is not None
-				m.split_hi_bwd = hi_bwd
 		return self
 
 	def forward(self, x, xlen = None, y = None, ylen = None):
