@@ -87,6 +87,8 @@ _SIGNATURES = dict(
 	convasr_split3 = (c_int, [c_p, c_p, c_int, c_i64, c_int, c_int, c_p]),
 	convasr_pack_conv_weight_split3 = (c_int, [c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_bn_act_bwd_apply_to_half = (c_int, [c_p, c_p, c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_f32, c_f32, c_f32, c_u64, c_u64, c_p, c_p, c_int, c_int, c_int, c_p, c_p]),
+	convasr_conv1d_fwd_splitk_plan = (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
+	convasr_conv1d_fwd_splitk = (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_int, c_f32, c_f32, c_p, c_int, c_p, c_p]),
 	convasr_conv1d_wgrad_ld_supported = (c_int, [c_int] * 10),
 	convasr_conv1d_wgrad_ld = (c_int, [c_p, c_int, c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p]),
 	convasr_novograd_item_elems = (c_i64, []),

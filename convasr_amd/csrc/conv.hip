@@ -498,6 +498,88 @@ extern "C" int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_
 
 extern "C" int convasr_conv_stats_max_rows(int B, int Tout) { return B * ((Tout + BM - 1) / BM); }
 
+// ------------------------------------------------------------------------------------------------ split-K forward (launches of a few tiles)
+// One request of online inference (transcribe.py:140, benchmark_online.py:125: B = 1 x 6 s) is 2 m tiles x (Cout / 128) n tiles per layer: 4-16
+// workgroups on 256 CUs, each reducing ALL of Cin x K on its own -- the launch takes a whole tile's K loop (~60-110 us) whatever the chip could do.
+// Split-K over the 64-channel input blocks: workgroup (tile, split) reduces its blocks and stores an fp32 partial tile; a second, streaming
+// kernel adds the partials IN SPLIT ORDER (deterministic) and runs the epilogue the unsplit kernel runs in its own tail (bias, folded scale /
+// shift, activation, length mask, rounding to the storage type) -- same formulas, the sum associated by input block instead of running through.
+static int splitk_plan(int B, int Cin, int Cout, int Tout, int* cib_per_split) {
+	const int n_cu = convasr_cu_count();
+	const int n_cib = Cin >> 6;
+	const int tiles = B * ((Tout + 255) / 256) * (convasr_conv_cout_pad(Cout) / BN);
+	if ((Cin & 63) || n_cib < 2 || tiles * 4 > n_cu) return 1;  // (from a quarter of the CUs up the unsplit launch is the better one: every split pays a tile's prologue and epilogue)
+	int want = n_cu / tiles;  // about one workgroup per CU
+	if (want > n_cib) want = n_cib;
+	if (want > 32) want = 32;
+	const int cps = (n_cib + want - 1) / want;
+	*cib_per_split = cps;
+	return (n_cib + cps - 1) / cps;
+}
+
+template <typename O> __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int splits, int64_t split_stride, O* __restrict__ y, const float* __restrict__ bias,
+                                                                                     const float* __restrict__ scale, const float* __restrict__ shift, int act, float lo, float hi, const float* __restrict__ xlen, int B, int T, int C) {
+	const ActConst ac = act_const(act, lo, hi);
+	const int c8 = C >> 3;
+	const int64_t n = (int64_t)B * T * c8;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+		const int64_t row = i / c8;
+		const int c = (int)(i - row * c8) << 3, b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+		float v[8], a[8];
+		load8<float>(part + row * C + c, v);
+		for (int s = 1; s < splits; ++s) {
+			load8<float>(part + s * split_stride + row * C + c, a);
+#pragma unroll
+			for (int k = 0; k < 8; ++k) v[k] += a[k];
+		}
+		const bool live = t < valid_len(xlen, b, T);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			float val = v[k] + (bias ? bias[c + k] : 0.f);
+			val = apply_act(scale ? val * scale[c + k] + shift[c + k] : val, ac);
+			v[k] = live ? val : 0.f;
+		}
+		store8<O>(y + row * C + c, v);
+	}
+}
+
+// Splits this launch would be cut into (1: not worth it / outside the kernel's envelope -- call convasr_conv1d_fwd) and the fp32 workspace it needs.
+extern "C" int convasr_conv1d_fwd_splitk_plan(int x_dtype, int B, int Cin, int Cout, int Tout, int K, int64_t* workspace_bytes) {
+	int cps = 0;
+	if (!convasr_is_half(x_dtype) || B <= 0 || Cin <= 0 || Cout <= 0 || Tout <= 0 || K <= 0 || (Cout & 7) || !g_conv_use_v2) return 1;
+	const int splits = splitk_plan(B, Cin, Cout, Tout, &cps);
+	if (workspace_bytes) *workspace_bytes = splits > 1 ? (int64_t)splits * B * Tout * Cout * 4 : 0;
+	return splits;
+}
+
+// convasr_conv1d_fwd (stride 1, no statistics) as a split-K launch + the epilogue pass; `splits` = convasr_conv1d_fwd_splitk_plan's answer (>= 2).
+extern "C" int convasr_conv1d_fwd_splitk(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad,
+                                         const float* bias, const float* scale, const float* shift, int act, float act_lo, float act_hi, const float* xlen, int splits, void* workspace, void* stream) {
+	CONVASR_CHECK_ARG(x && wp && y && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && dil > 0 && (Cout & 7) == 0 && convasr_is_half(x_dtype) && (y_dtype == x_dtype || y_dtype == CONVASR_F32), "conv1d_fwd_splitk: bad arguments (16-bit input, Cout %% 8 == 0)");
+	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd_splitk: scale and shift go together");
+	CONVASR_CHECK_ARG(Tout <= (int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1), "conv1d_fwd_splitk: Tout %d inconsistent with Tin %d K %d dil %d pad %d", Tout, Tin, K, dil, pad);
+	int cps = 0;
+	if (splitk_plan(B, Cin, Cout, Tout, &cps) != splits || splits < 2) return convasr_fail(CONVASR_EINVAL, "conv1d_fwd_splitk: splits %d is not this geometry's plan", splits);
+	ConvParams p = {};
+	p.x = x; p.w = wp; p.y = workspace;
+	p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = convasr_conv_cout_pad(Cout); p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = 1; p.dil = dil; p.pad = pad;
+	p.act = CONVASR_ACT_NONE; p.debug = g_conv_debug | 2048;  // (2048: no 128-row tiles for the whole launch -- the splits fill the chip, and a 128-row tile costs 1.2-1.4x per FLOP)
+	p.n_tiles = p.CoutPad / BN;
+	p.cib_per_split = cps; p.split_stride = (long long)B * Tout * Cout;
+	hipStream_t s = (hipStream_t)stream;
+	if (!convasr_conv1d_v2_try(p, x_dtype, CONVASR_F32, s, nullptr)) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd_splitk: the geometry is outside the LDS-DMA kernel's envelope");
+	CONVASR_CHECK_LAUNCH("conv1d_fwd_splitk");
+	int64_t blocks = ceil_div64((int64_t)B * Tout * (Cout >> 3), 256);
+	if (blocks > 4096) blocks = 4096;
+	const dim3 g((unsigned)blocks), t(256);
+	const float* part = (const float*)workspace;
+	if (y_dtype == CONVASR_F32) hipLaunchKernelGGL((splitk_epilogue_kernel<float>), g, t, 0, s, part, splits, p.split_stride, (float*)y, bias, scale, shift, act, act_lo, act_hi, xlen, B, Tout, Cout);
+	else if (y_dtype == CONVASR_F16) hipLaunchKernelGGL((splitk_epilogue_kernel<f16_t>), g, t, 0, s, part, splits, p.split_stride, (f16_t*)y, bias, scale, shift, act, act_lo, act_hi, xlen, B, Tout, Cout);
+	else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t>), g, t, 0, s, part, splits, p.split_stride, (bf16_t*)y, bias, scale, shift, act, act_lo, act_hi, xlen, B, Tout, Cout);
+	CONVASR_CHECK_LAUNCH("conv1d_fwd_splitk (epilogue)");
+	return 0;
+}
+
 extern "C" int convasr_conv1d_dgrad_bn_reduce(const void* dy, const void* packed_dgrad, void* dx, int dtype, int B, int Cout, int Cin, int T_dy, int T_dx, int K, int dil, int pad,
                                               const void* bn_y, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                                               int bn_act, float bn_act_lo, float bn_act_hi, float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* step_key,

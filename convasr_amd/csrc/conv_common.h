@@ -34,6 +34,11 @@ struct ConvParams {
 	int bn_act; float bn_lo, bn_hi; unsigned bn_drop_thr; float bn_keep_scale; uint64_t bn_seed, bn_offset; const uint64_t* bn_step_key;  // (bn_step_key, optional: device word XORed into bn_seed, see convasr_step_begin)
 	const uint8_t* bn_gate;  // optional: the one-bit gradient gates convasr_bn_act_fwd stored (instead of re-deriving act' / dropout / mask from bn_y)
 	int debug;   // experiment flags (scratch/ only): 1 = skip DMA issue in the main loop, 2 = skip MFMAs, 4 = skip epilogue stores
+	// conv_v2s only, optional (cib_per_split > 0): split-K over 64-channel input blocks for launches of a few tiles (small-batch inference).
+	// Workgroup (x, y = split) reduces input blocks [split * cib_per_split, ...) and stores its fp32 partial tile at y + split * split_stride
+	// (elements); convasr_conv1d_fwd_splitk's second kernel adds the partials in split order and runs the epilogue.
+	int cib_per_split;
+	long long split_stride;
 };
 
 // Two 128-B rows share one 256-B bank row; 16-B slot = (row parity, chunk ^ row-pair index): 16 consecutive rows at the same

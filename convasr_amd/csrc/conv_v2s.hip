@@ -43,7 +43,7 @@ template <> struct HalfOnes<bf16_t> { static constexpr unsigned pair = 0x3F803F8
 template <> struct HalfOnes<f16_t> { static constexpr unsigned pair = 0x3C003C00u; };
 template <> struct HalfOnes<float> { static constexpr unsigned pair = 0u; };  // (never used: the fused epilogues exist for 16-bit outputs only)
 
-template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int mtile, const int ntile, const int half, const int bm_full) {
+template <typename I, typename O, int NB, int BNF, int BM_, bool SK = false> __device__ __forceinline__ void v2s_tile(const ConvParams& p, char* smem, const int mtile, const int ntile, const int half, const int bm_full, const int split) {
 	constexpr int BN_ = 32 * NB, MI = BM_ / 64, WROWS = 16 * MI;  // MI 16-row blocks = WROWS rows per wave
 	// LDS map of the epilogue (everything the main loop used is dead by then): output tile, BN-statistics scratch, and for BNF == 2 the
 	// consumer layer's y tile (row-major, BN_ * 2 bytes per row, brought in by the loader waves) and the 256-entry gate -> mask table
@@ -66,10 +66,14 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 	auto xoff = [&](int c) { return (unsigned)((k1 ? c % 3 : (c & 1)) * xbytes); };
 	const unsigned wbase = (k1 ? 3 : 2) * xbytes;
 	const int row_bytes = p.Cin * 2;
-	const v4i32 xsrc = make_srd(reinterpret_cast<const I*>(p.x) + (int64_t)b * p.Tin * p.Cin, (unsigned)(p.Tin * row_bytes));
-	const v4i32 wsrc = make_srd(p.w, (unsigned)(p.K * p.CoutPad * row_bytes));
+	// split-K launches (ConvParams::cib_per_split): this workgroup's 64-channel input blocks start cib0 blocks into every row of x and w -- the
+	// descriptors' bases move by that many bytes and their ranges shrink by as much, so the range check still ends where the tensors end
+	// (SK is a template parameter: the training launches' instantiations carry none of this -- two more kernel parameters read at run time cost them 0.5 %, measured)
+	const int cib0 = SK ? split * p.cib_per_split : 0;
+	const int n_cib = SK ? min(p.cib_per_split, (p.Cin >> 6) - cib0) : (p.Cin >> 6);
+	const v4i32 xsrc = make_srd(reinterpret_cast<const char*>(reinterpret_cast<const I*>(p.x) + (int64_t)b * p.Tin * p.Cin) + cib0 * 128, (unsigned)(p.Tin * row_bytes - cib0 * 128));
+	const v4i32 wsrc = make_srd(reinterpret_cast<const char*>(p.w) + cib0 * 128, (unsigned)(p.K * p.CoutPad * row_bytes - cib0 * 128));
 	const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-	const int n_cib = p.Cin >> 6;
 	const int x_units = x_rows >> 3;
 
 	// Waves 0-7 compute; waves 8-11 (one per SIMD) only issue the LDS-DMA pieces.  A piece costs its issuing wave ~100 cycles
@@ -371,7 +375,7 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 		prow[p.Cout + co0 + tid] = q2;
 	}
 	STAMPI(t_e3)
-	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
+	O* const yb = reinterpret_cast<O*>(p.y) + (SK ? (int64_t)split * p.split_stride : 0) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN_ / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
 	// Fused pass 1 of the consumer layer's batch-norm backward (bf16 only): this tile IS dz of that layer; with its conv output y
@@ -499,7 +503,7 @@ template <typename I, typename O, int NB, int BNF, int BM_> __device__ __forcein
 #endif
 }
 
-template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
+template <typename I, typename O, int BNF, int BM_, bool SK = false> __global__ __launch_bounds__(V2S_THREADS, 3) void conv1d_igemm_v2s_kernel(ConvParams p) {
 
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int bid = blockIdx.x;
@@ -529,12 +533,13 @@ template <typename I, typename O, int BNF, int BM_> __global__ __launch_bounds__
 	const bool all_short = p.tail128 == 2;
 	const bool tail = all_short || (p.tail128 && (mtile % p.m_tiles_per_b) == p.m_tiles_per_b - 1);
 	const int bm_full = all_short ? 128 : BM_;
+	const int split = SK ? blockIdx.y : 0;  // (a split-K launch: grid.y = number of splits)
 	if (!tail) {
-		if (!narrow) v2s_tile<I, O, 4, BNF, BM_>(p, smem, mtile, ntile, 0, BM_);
-		else v2s_tile<I, O, 2, BNF, BM_>(p, smem, mtile, ntile, half, BM_);
+		if (!narrow) v2s_tile<I, O, 4, BNF, BM_, SK>(p, smem, mtile, ntile, 0, BM_, split);
+		else v2s_tile<I, O, 2, BNF, BM_, SK>(p, smem, mtile, ntile, half, BM_, split);
 	} else {
-		if (!narrow) v2s_tile<I, O, 4, BNF, 128>(p, smem, mtile, ntile, 0, bm_full);
-		else v2s_tile<I, O, 2, BNF, 128>(p, smem, mtile, ntile, half, bm_full);
+		if (!narrow) v2s_tile<I, O, 4, BNF, 128, SK>(p, smem, mtile, ntile, 0, bm_full, split);
+		else v2s_tile<I, O, 2, BNF, 128, SK>(p, smem, mtile, ntile, half, bm_full, split);
 	}
 }
 
@@ -544,6 +549,7 @@ template <typename I, int BM_> static const void* v2s_kernel(int ki) {
 	if (ki == 0) return (const void*)conv1d_igemm_v2s_kernel<I, I, 0, BM_>;
 	if (ki == 1) return (const void*)conv1d_igemm_v2s_kernel<I, I, 1, BM_>;
 	if (ki == 3) return (const void*)conv1d_igemm_v2s_kernel<I, I, 2, BM_>;
+	if (ki == 4) return (const void*)conv1d_igemm_v2s_kernel<I, float, 0, BM_, true>;  // the split-K launches of small-batch inference (fp32 partial tiles)
 	return (const void*)conv1d_igemm_v2s_kernel<I, float, 0, BM_>;
 }
 
@@ -591,13 +597,14 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 	p.tail128 = all_short ? 2 : ((bm == V2_BM && tail_rows <= 128 && !(p.debug & 128)) ? 1 : 0);  // (debug bit 128: short tails off, A/B runs)
 	const bool f16 = x_dtype == CONVASR_F16, wide = y_dtype == CONVASR_F32, fused = p.bn_y != nullptr;
 	if (fused && wide) return 0;  // the fused BN-backward epilogue reads dz back in the storage type
-	const int ki = wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0), bi = bm == 192 ? 1 : 0;  // (bm == 128 runs the 256-row kernel's 128-row instantiation)
+	if (p.cib_per_split && !wide) return 0;  // (split-K partial tiles are fp32)
+	const int ki = p.cib_per_split ? 4 : (wide ? 2 : (fused ? (mfma_sums ? 3 : 1) : 0)), bi = bm == 192 ? 1 : 0;  // (bm == 128 runs the 256-row kernel's 128-row instantiation)
 #ifdef CONVASR_AB_TILE192
 	const void* kern = f16 ? (bi ? v2s_kernel<f16_t, 192>(ki) : v2s_kernel<f16_t, V2_BM>(ki)) : (bi ? v2s_kernel<bf16_t, 192>(ki) : v2s_kernel<bf16_t, V2_BM>(ki));
 #else
 	const void* kern = f16 ? v2s_kernel<f16_t, V2_BM>(ki) : v2s_kernel<bf16_t, V2_BM>(ki);
 #endif
-	static unsigned long long attr_set[2][2][4] = {};
+	static unsigned long long attr_set[2][2][5] = {};
 	convasr_allow_160k_lds(kern, attr_set[f16][bi][ki]);
 	// a last partial round that would occupy at most half of the CUs is cut into half-width tiles (debug bit 32: off)
 	p.full_tiles = p.total_tiles;
@@ -606,8 +613,9 @@ int convasr_conv1d_v2_try(ConvParams p, int x_dtype, int y_dtype, hipStream_t s,
 		if (rest > 0 && 2 * rest <= n_cu && ((p.total_tiles - rest) & 7) == 0) p.full_tiles = p.total_tiles - rest;
 	}
 	const int grid = p.full_tiles + 2 * (p.total_tiles - p.full_tiles);
+	const int splits = p.cib_per_split ? ((p.Cin >> 6) + p.cib_per_split - 1) / p.cib_per_split : 1;
 	void* args[] = {&p};
-	if (hipLaunchKernel(kern, dim3(grid), dim3(V2S_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
+	if (hipLaunchKernel(kern, dim3(grid, splits), dim3(V2S_THREADS), args, smem, s) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (the caller's fallback starts from a clean error state)
 	if (m_tiles_out) *m_tiles_out = p.B * p.m_tiles_per_b;
 	return 1;
 }

@@ -5,6 +5,7 @@ channels-last: strides (T*C, 1, C).  `empty_cl` allocates one, `as_cl` converts 
 PyTorch is used for allocation, streams and dtype bookkeeping only; every arithmetic op is a kernel of libconvasr_hip.so.
 """
 import math
+import os
 
 import ctypes
 
@@ -212,8 +213,10 @@ class ConvStats:
 		return out
 
 
-def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, Tout = None, work = None, family = None):
+def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias = None, stats = None, scale = None, shift = None, act = (_lib.ACT_NONE, 0.0, 0.0), xlen = None, Tout = None, work = None, family = None, splitk = False):
 	"""x: channels-last (B, Cin, Tin); wp: packed weights.  Returns channels-last (B, Cout, Tout).
+	splitk (the inference path's launches): a launch of a few tiles -- one online request is 4-16 workgroups per layer on 256 CUs -- is cut over the
+	input channels (convasr_conv1d_fwd_splitk: fp32 partial tiles, added in split order by a second kernel that also runs the epilogue).
 	Tout (optional): compute only the first Tout frames of the output; work: FLOPs to book for the bench's timer (the stride-2 fold).
 	stats: None, a ConvStats (the production path: partial rows, consumed by bn_finalize), or a (2 Cout,) fp64 tensor that
 	receives the totals (sum, sum of squares) -- a convenience for tests and tools, one extra tiny launch."""
@@ -225,6 +228,15 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	part = stats if isinstance(stats, ConvStats) or stats is None else ConvStats(Cout, B, Tout, x.device)
 	rows = ctypes.c_int(0)
 	launch = lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr())
+	if splitk and SPLITK and stats is None and stride == 1 and x.dtype in HALF_DTYPES and Cout % 8 == 0:
+		skey = (x.dtype, B, Cin, Cout, Tout, K)
+		plan = _splitk_plans.get(skey)
+		if plan is None:
+			nb = ctypes.c_int64(0)
+			plan = _splitk_plans[skey] = (_lib.load().convasr_conv1d_fwd_splitk_plan(dtype_code(x.dtype), B, Cin, Cout, Tout, K, ctypes.byref(nb)), nb.value)
+		if plan[0] >= 2:
+			ws = workspace(plan[1], x.device, 'splitk')
+			launch = lambda: call('convasr_conv1d_fwd_splitk', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, dil, pad, ptr(bias), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), plan[0], ptr(ws), stream_ptr())
 	if _lib.timer is None:  # (the labels below are for the bench's per-kernel timer only: not on the path of an ordinary step)
 		launch()
 		if part is not None:
@@ -247,6 +259,10 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 		if part is not stats:
 			stats.copy_(part.totals())
 	return y
+
+
+SPLITK = os.environ.get('CONVASR_NO_SPLITK') != '1'  # A/B hook: small-batch inference launches cut over the input channels
+_splitk_plans = {}
 
 
 def _int_array(vals):
@@ -318,7 +334,7 @@ def workspace(nbytes, device, tag = 'default'):
 	"""Grow-only scratch buffer per (device, tag, current stream): kernels that share one are ordered by that stream, and a
 	buffer replaced by a bigger one is released by the caching allocator in the order of the stream it was allocated on (the
 	side-stream wgrad and a main-stream wgrad of the same backward never share or free each other's slabs)."""
-	if _capturing[0]:
+	if _capturing[0] or (tag == 'splitk' and device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):  # (the inference path is captured by its callers -- bench_infer.py, a server -- not by train.GraphedTrainStep: ask the runtime)
 		return torch.empty(max(int(nbytes), 256), dtype = torch.uint8, device = device)  # inside a graph capture: from the graph's own pool, never a cached buffer a later eager step could replace
 	key = (device, tag, _lib.stream_ptr() if device.type == 'cuda' else 0)  # (the current device's current stream: kernels are launched there)
 	buf = _workspaces.get(key)

@@ -116,6 +116,19 @@ int convasr_conv1d_fwd(const void* x, const void* wp, void* y, int x_dtype, int 
                        int act, float act_lo, float act_hi, const float* xlen, int* stats_rows, void* stream);
 int convasr_conv_stats_max_rows(int B, int Tout);
 
+/* Split-K form of convasr_conv1d_fwd for launches of a few tiles -- online inference, transcribe.py:140 / benchmark_online.py:125 (B = 1 x 6 s is
+ * 4-16 workgroups per layer on 256 CUs, each reducing all of Cin x K alone): the reduction is cut over the 64-channel input blocks, workgroup
+ * (tile, split) stores an fp32 partial tile into `workspace`, a second streaming kernel adds the partials in split order (deterministic) and
+ * runs the same epilogue (bias, scale / shift, activation, length mask, rounding to y_dtype).  stride 1, 16-bit input, no statistics.
+ *   convasr_conv1d_fwd_splitk_plan: the number of splits for this geometry (1: not worth it -- from a quarter of the CUs' worth of tiles up -- or
+ *     outside the envelope: call convasr_conv1d_fwd) and the workspace bytes (splits x B x Tout x Cout fp32);
+ *   convasr_conv1d_fwd_splitk: `splits` must be the plan's answer (>= 2). */
+int convasr_conv1d_fwd_splitk_plan(int x_dtype, int B, int Cin, int Cout, int Tout, int K, int64_t* workspace_bytes);
+int convasr_conv1d_fwd_splitk(const void* x, const void* wp, void* y, int x_dtype, int y_dtype,
+                              int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad,
+                              const float* bias, const float* scale, const float* shift, int act, float act_lo, float act_hi,
+                              const float* xlen, int splits, void* workspace, void* stream);
+
 /* Stride-2 fold (the prologue conv of every model, models.py:312: ConvBn1d(kernel_size_prologue = 11, stride = 2) on the 64 mel
  * channels).  A stride-2, dilation-1 conv over an EVEN number of frames Tin equals the stride-1 conv with K' taps and padding P'
  * over the same memory read as (Tin / 2) frames of 2 Cin channels (frames 2r, 2r+1 side by side -- a view, no copy):

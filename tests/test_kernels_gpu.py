@@ -187,6 +187,51 @@ def test_conv1d_forward(case, dtype):
 
 
 @gpu
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', [(1, 256, 256, 300, 11, 1), (1, 1024, 1024, 300, 1, 1), (2, 768, 896, 150, 29, 2), (1, 512, 136, 77, 3, 1), (1, 3 * 384, 512, 300, 13, 1), (1, 128, 256, 300, 6, 1)])
+def test_conv1d_split_k_forward_for_launches_of_a_few_tiles(case, dtype):
+	"""convasr_conv1d_fwd_splitk (one online request is 4-16 workgroups per layer: the reduction is cut over the 64-channel input blocks, fp32 partial
+	tiles, a second kernel adds them in split order and runs the epilogue) against the unsplit launch -- fp32 output: the same products, another
+	association of the sum; 16-bit output: at most the last bit of a few elements -- and against float64; bias, folded scale / shift, hardtanh and
+	the length mask in the epilogue; bit-identical from run to run; a batch that fills the chip is not split."""
+	import ctypes
+	from convasr_amd import ops, _lib
+	B, Cin, Cout, T, K, dil = case
+	dt = HALF[dtype][0]
+	d = dev()
+	torch.manual_seed(sum(case))
+	x = torch.randn(B, Cin, T).to(dt).float()
+	w = (torch.randn(Cout, Cin, K) / (Cin * K) ** 0.5).to(dt).float()
+	bias, scale, shift = torch.randn(Cout), torch.rand(Cout) + 0.5, torch.randn(Cout)
+	xlen = torch.tensor([0.7, 1.0][:B])
+	pad = dil * (K // 2)
+	Tout = ops.conv_out_len(T, K, 1, dil, pad)
+	lib = _lib.load()
+	nb = ctypes.c_int64(0)
+	splits = lib.convasr_conv1d_fwd_splitk_plan(_lib.dtype_code(dt), B, Cin, Cout, Tout, K, ctypes.byref(nb))
+	assert 2 <= splits <= Cin // 64 and nb.value == splits * B * Tout * Cout * 4
+	assert lib.convasr_conv1d_fwd_splitk_plan(_lib.dtype_code(dt), 64, Cin, Cout, Tout, K, ctypes.byref(nb)) == 1 and nb.value == 0  # 64 utterances fill the chip
+	xg, wp = ops.as_cl(x.to(d), dt), ops.pack_weight(w.to(d), dt, _lib.PACK_FWD)
+	ref = torch.nn.functional.conv1d(x.double(), w.double(), bias.double(), padding = pad, dilation = dil)
+	ref_epi = torch.nn.functional.hardtanh(ref * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1), 0.0, 20.0)
+	ref_epi = ref_epi * (torch.arange(Tout).view(1, 1, -1) < torch.ceil(xlen.double() * Tout).view(-1, 1, 1))
+	for out_dt in (torch.float32, dt):
+		plain = dict(bias = bias.to(d))
+		full = dict(bias = bias.to(d), scale = scale.to(d), shift = shift.to(d), act = (_lib.ACT_HARDTANH, 0.0, 20.0), xlen = xlen.to(d))
+		for kw, want in ((plain, ref), (full, ref_epi)):
+			a = ops.conv1d(xg, wp, Cout, K, 1, dil, pad, out_dtype = out_dt, splitk = True, **kw)
+			b = ops.conv1d(xg, wp, Cout, K, 1, dil, pad, out_dtype = out_dt, **kw)
+			a2 = ops.conv1d(xg, wp, Cout, K, 1, dil, pad, out_dtype = out_dt, splitk = True, **kw)
+			assert a.dtype == out_dt and a.shape == b.shape and torch.equal(a, a2)
+			if out_dt == torch.float32:
+				assert float((a - b).norm() / b.norm()) <= 2e-6 and float((a.double().cpu() - want).norm() / want.norm()) <= 2e-6
+			else:
+				ulp = 2.0 ** (-7 if dt == torch.bfloat16 else -10)
+				assert float(((a.float() - b.float()).abs() / b.float().abs().clamp(min = 1e-2)).max()) <= ulp and float((a != b).float().mean()) <= 2e-2, (float((a != b).float().mean()))
+				assert float((a.double().cpu() - want).norm() / want.norm()) <= HALF[dtype][1]
+
+
+@gpu
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[5] == 1 and c[1] % 64 == 0])
 def test_conv1d_lds_dma_kernel_is_bit_identical_to_register_staged_kernel(case):
 	from convasr_amd import ops, _lib
