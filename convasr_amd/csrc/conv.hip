@@ -31,7 +31,7 @@ template <typename T, bool ALIGNED> __device__ __forceinline__ uint4 load_chunk(
 	return v;
 }
 
-template <typename T, typename O, int XI, bool ALIGNED_X>
+template <typename T, typename O, int XI, bool ALIGNED_X, bool SK = false>  // (SK: a split-K launch of small-batch inference -- blockIdx.y's range of input slabs, an fp32 partial tile: convasr_conv1d_fwd_splitk)
 __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 1 : 2) void conv1d_igemm_kernel(ConvParams p) {  // (fp32: one workgroup per CU, its fp64 totals below take 128 registers)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int EPC = Mma<T>::EPC;
@@ -50,14 +50,15 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 1 : 2) void conv1d_igemm
 	char* const wbuf = smem + 2 * xbytes;
 	const T* const xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.Tin * p.Cin;
 	const T* const wp = reinterpret_cast<const T*>(p.w);
-	const int n_cib = (p.Cin + BK - 1) / BK;
+	const int cib0 = SK ? (int)blockIdx.y * p.cib_per_split : 0;  // this workgroup's first input slab (BK channels each)
+	const int n_cib = SK ? min(p.cib_per_split, (p.Cin + BK - 1) / BK - cib0) : (p.Cin + BK - 1) / BK;
 	const int total_x_chunks = p.x_rows * 8;
 
 	uint4 xreg[XI];
 	uint4 wreg[4];
 
 	auto load_x = [&](int cib) {
-		const int ci0 = cib * BK;
+		const int ci0 = (cib0 + cib) * BK;
 #pragma unroll
 		for (int i = 0; i < XI; ++i) {
 			const int e = tid + NTHREADS * i;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 1 : 2) void conv1d_igemm
 		}
 	};
 	auto load_w = [&](int cib, int tap) {
-		const int ci0 = cib * BK;
+		const int ci0 = (cib0 + cib) * BK;
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			const int e = tid + NTHREADS * i;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NTHREADS, sizeof(T) == 4 ? 1 : 2) void conv1d_igemm
 		prow[co0 + tid] = (double)red[(0 * 2 + 0) * BN + tid] + (double)red[(0 * 2 + 1) * BN + tid];
 		prow[p.Cout + co0 + tid] = (double)red[(1 * 2 + 0) * BN + tid] + (double)red[(1 * 2 + 1) * BN + tid];
 	}
-	O* const yb = reinterpret_cast<O*>(p.y) + (int64_t)b * p.Tout * p.Cout;
+	O* const yb = reinterpret_cast<O*>(p.y) + (SK ? (int64_t)blockIdx.y * p.split_stride : 0) + (int64_t)b * p.Tout * p.Cout;
 	constexpr int OEPC = 16 / sizeof(O), OCHUNKS = BN / OEPC;
 	const bool vec_ok = ((p.Cout * sizeof(O)) & 15) == 0;
 	for (int e = tid; e < BM * OCHUNKS; e += NTHREADS) {
@@ -400,24 +401,26 @@ extern "C" int convasr_pack_conv_weight(const float* w, void* packed_fwd, void* 
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad launcher
-template <typename T, typename O, int XI, bool AL> static int launch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
-	auto kern = conv1d_igemm_kernel<T, O, XI, AL>;
+template <typename T, typename O, int XI, bool AL, bool SK = false> static int launch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
+	auto kern = conv1d_igemm_kernel<T, O, XI, AL, SK>;
 	static unsigned long long attr_set = 0;
 	convasr_allow_160k_lds(reinterpret_cast<const void*>(kern), attr_set);
-	hipLaunchKernelGGL(kern, dim3(p.total_tiles), dim3(NTHREADS), smem, s, p);
+	constexpr int BK = ROW_BYTES / sizeof(T);
+	const int splits = SK ? ((p.Cin + BK - 1) / BK + p.cib_per_split - 1) / p.cib_per_split : 1;
+	hipLaunchKernelGGL(kern, dim3(p.total_tiles, splits), dim3(NTHREADS), smem, s, p);
 	return 0;
 }
 
-template <typename T, typename O> static int dispatch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
+template <typename T, typename O, bool SK = false> static int dispatch_conv(const ConvParams& p, size_t smem, hipStream_t s) {
 	const int xi = (p.x_rows * 8 + NTHREADS - 1) / NTHREADS;
 	const bool al = ((p.Cin * sizeof(T)) & 15) == 0;
 	if (!al) {
-		if (xi <= 9) return launch_conv<T, O, 9, false>(p, smem, s);
+		if (xi <= 9) return launch_conv<T, O, 9, false, SK>(p, smem, s);
 		return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
 	}
-	if (xi <= 5) return launch_conv<T, O, 5, true>(p, smem, s);
-	if (xi <= 9) return launch_conv<T, O, 9, true>(p, smem, s);
-	if (xi <= 16) return launch_conv<T, O, 16, true>(p, smem, s);
+	if (xi <= 5) return launch_conv<T, O, 5, true, SK>(p, smem, s);
+	if (xi <= 9) return launch_conv<T, O, 9, true, SK>(p, smem, s);
+	if (xi <= 16) return launch_conv<T, O, 16, true, SK>(p, smem, s);
 	return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d: halo too large (x_rows %d)", p.x_rows);
 }
 
@@ -504,11 +507,14 @@ extern "C" int convasr_conv_stats_max_rows(int B, int Tout) { return B * ((Tout 
 // Split-K over the 64-channel input blocks: workgroup (tile, split) reduces its blocks and stores an fp32 partial tile; a second, streaming
 // kernel adds the partials IN SPLIT ORDER (deterministic) and runs the epilogue the unsplit kernel runs in its own tail (bias, folded scale /
 // shift, activation, length mask, rounding to the storage type) -- same formulas, the sum associated by input block instead of running through.
-static int splitk_plan(int B, int Cin, int Cout, int Tout, int* cib_per_split) {
+static int splitk_plan(int x_dtype, int B, int Cin, int Cout, int Tout, int* cib_per_split) {
+	// 16-bit storage: the LDS-DMA kernel, 256-row tiles, 64-channel input blocks; fp32 (the exact-fp32 parity path): the register-staged kernel,
+	// 128-row tiles, 32-channel slabs
+	const bool half = convasr_is_half(x_dtype);
 	const int n_cu = convasr_cu_count();
-	const int n_cib = Cin >> 6;
-	const int tiles = B * ((Tout + 255) / 256) * (convasr_conv_cout_pad(Cout) / BN);
-	if ((Cin & 63) || n_cib < 2 || tiles * 4 > n_cu) return 1;  // (from a quarter of the CUs up the unsplit launch is the better one: every split pays a tile's prologue and epilogue)
+	const int n_cib = half ? Cin >> 6 : (Cin + 31) / 32;
+	const int tiles = B * ((Tout + (half ? 255 : BM - 1)) / (half ? 256 : BM)) * (convasr_conv_cout_pad(Cout) / BN);
+	if ((half && (Cin & 63)) || n_cib < 2 || tiles * 4 > n_cu) return 1;  // (from a quarter of the CUs up the unsplit launch is the better one: every split pays a tile's prologue and epilogue)
 	int want = n_cu / tiles;  // about one workgroup per CU
 	if (want > n_cib) want = n_cib;
 	if (want > 32) want = 32;
@@ -526,12 +532,17 @@ template <typename O> __global__ __launch_bounds__(256) void splitk_epilogue_ker
 		const int64_t row = i / c8;
 		const int c = (int)(i - row * c8) << 3, b = (int)(row / T), t = (int)(row - (int64_t)b * T);
 		float v[8], a[8];
-		load8<float>(part + row * C + c, v);
+		double acc[8];  // (the partials are added in fp64: the exact-fp32 path's two-level sum keeps its last bits, and the pass is bound by its loads)
+		load8<float>(part + row * C + c, a);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) acc[k] = (double)a[k];
 		for (int s = 1; s < splits; ++s) {
 			load8<float>(part + s * split_stride + row * C + c, a);
 #pragma unroll
-			for (int k = 0; k < 8; ++k) v[k] += a[k];
+			for (int k = 0; k < 8; ++k) acc[k] += (double)a[k];
 		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = (float)acc[k];
 		const bool live = t < valid_len(xlen, b, T);
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
@@ -546,8 +557,8 @@ template <typename O> __global__ __launch_bounds__(256) void splitk_epilogue_ker
 // Splits this launch would be cut into (1: not worth it / outside the kernel's envelope -- call convasr_conv1d_fwd) and the fp32 workspace it needs.
 extern "C" int convasr_conv1d_fwd_splitk_plan(int x_dtype, int B, int Cin, int Cout, int Tout, int K, int64_t* workspace_bytes) {
 	int cps = 0;
-	if (!convasr_is_half(x_dtype) || B <= 0 || Cin <= 0 || Cout <= 0 || Tout <= 0 || K <= 0 || (Cout & 7) || !g_conv_use_v2) return 1;
-	const int splits = splitk_plan(B, Cin, Cout, Tout, &cps);
+	if (!(convasr_is_half(x_dtype) || x_dtype == CONVASR_F32) || B <= 0 || Cin <= 0 || Cout <= 0 || Tout <= 0 || K <= 0 || (Cout & 7) || (convasr_is_half(x_dtype) && !g_conv_use_v2)) return 1;
+	const int splits = splitk_plan(x_dtype, B, Cin, Cout, Tout, &cps);
 	if (workspace_bytes) *workspace_bytes = splits > 1 ? (int64_t)splits * B * Tout * Cout * 4 : 0;
 	return splits;
 }
@@ -555,11 +566,12 @@ extern "C" int convasr_conv1d_fwd_splitk_plan(int x_dtype, int B, int Cin, int C
 // convasr_conv1d_fwd (stride 1, no statistics) as a split-K launch + the epilogue pass; `splits` = convasr_conv1d_fwd_splitk_plan's answer (>= 2).
 extern "C" int convasr_conv1d_fwd_splitk(const void* x, const void* wp, void* y, int x_dtype, int y_dtype, int B, int Cin, int Cout, int Tin, int Tout, int K, int dil, int pad,
                                          const float* bias, const float* scale, const float* shift, int act, float act_lo, float act_hi, const float* xlen, int splits, void* workspace, void* stream) {
-	CONVASR_CHECK_ARG(x && wp && y && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && dil > 0 && (Cout & 7) == 0 && convasr_is_half(x_dtype) && (y_dtype == x_dtype || y_dtype == CONVASR_F32), "conv1d_fwd_splitk: bad arguments (16-bit input, Cout %% 8 == 0)");
+	const bool half = convasr_is_half(x_dtype);
+	CONVASR_CHECK_ARG(x && wp && y && workspace && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && K > 0 && dil > 0 && (Cout & 7) == 0 && (half ? (y_dtype == x_dtype || y_dtype == CONVASR_F32) : (x_dtype == CONVASR_F32 && y_dtype == CONVASR_F32)), "conv1d_fwd_splitk: bad arguments (16-bit or fp32 input, Cout %% 8 == 0)");
 	CONVASR_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv1d_fwd_splitk: scale and shift go together");
 	CONVASR_CHECK_ARG(Tout <= (int64_t)Tin + 2 * (int64_t)pad - (int64_t)dil * (K - 1), "conv1d_fwd_splitk: Tout %d inconsistent with Tin %d K %d dil %d pad %d", Tout, Tin, K, dil, pad);
 	int cps = 0;
-	if (splitk_plan(B, Cin, Cout, Tout, &cps) != splits || splits < 2) return convasr_fail(CONVASR_EINVAL, "conv1d_fwd_splitk: splits %d is not this geometry's plan", splits);
+	if (splitk_plan(x_dtype, B, Cin, Cout, Tout, &cps) != splits || splits < 2) return convasr_fail(CONVASR_EINVAL, "conv1d_fwd_splitk: splits %d is not this geometry's plan", splits);
 	ConvParams p = {};
 	p.x = x; p.w = wp; p.y = workspace;
 	p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutPad = convasr_conv_cout_pad(Cout); p.Tin = Tin; p.Tout = Tout; p.K = K; p.stride = 1; p.dil = dil; p.pad = pad;
@@ -567,7 +579,19 @@ extern "C" int convasr_conv1d_fwd_splitk(const void* x, const void* wp, void* y,
 	p.n_tiles = p.CoutPad / BN;
 	p.cib_per_split = cps; p.split_stride = (long long)B * Tout * Cout;
 	hipStream_t s = (hipStream_t)stream;
-	if (!convasr_conv1d_v2_try(p, x_dtype, CONVASR_F32, s, nullptr)) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd_splitk: the geometry is outside the LDS-DMA kernel's envelope");
+	if (half) {
+		if (!convasr_conv1d_v2_try(p, x_dtype, CONVASR_F32, s, nullptr)) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd_splitk: the geometry is outside the LDS-DMA kernel's envelope");
+	} else {  // the exact-fp32 kernel (two-level sums: fp64 totals per workgroup, rounded once into its fp32 partial tile)
+		p.m_tiles_per_b = (Tout + BM - 1) / BM;
+		p.total_tiles = B * p.m_tiles_per_b * p.n_tiles;
+		p.x_rows = ((BM - 1) + (K - 1) * dil + 1 + 1) & ~1;
+		size_t smem = 2 * (size_t)p.x_rows * ROW_BYTES + 2 * BN * ROW_BYTES;
+		const size_t epi = (size_t)BM * (BN * 4 + 16) + 4 * BN * sizeof(float);
+		if (epi > smem) smem = epi;
+		if (smem > 160 * 1024) return convasr_fail(CONVASR_EUNSUPPORTED, "conv1d_fwd_splitk: tile needs %zu B of LDS", smem);
+		const int rc = dispatch_conv<float, float, true>(p, smem, s);
+		if (rc) return rc;
+	}
 	CONVASR_CHECK_LAUNCH("conv1d_fwd_splitk");
 	int64_t blocks = ceil_div64((int64_t)B * Tout * (Cout >> 3), 256);
 	if (blocks > 4096) blocks = 4096;

@@ -1177,18 +1177,21 @@ class ConvBnActEvalFunction:
 		xl = ops.xlen_f32(xlen, x.device) if (cfg['temporal_mask'] and xlen is not None) else None
 		scale, shift = (None, None) if scale_shift is None else (scale_shift[0], scale_shift[1])
 		fold = Fold2.plan(x, weight, spec, dt, False)
+		# split-K for launches of a few tiles (ops.conv1d): inference only, i.e. no gradient is being recorded -- a frozen block inside a training step keeps
+		# the unsplit kernel's association of the sum (its output feeds a chaotic two-step golden comparison, tests/test_training_features_gpu.py, and nothing is latency-bound there)
+		sk = not torch.is_grad_enabled()
 		split = cfg.get('split_eval')  # (inference on the split-operand path: JasperNet.set_compute_dtype('bf16x3', inference = True))
 		if fold is not None:
 			xv, Kf, Pf, Tout = fold
-			conv = lambda **epilogue: ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, bias = bias, Tout = Tout, work = 2.0 * x.shape[0] * Tout * Cout * x.shape[1] * spec.K, splitk = True, **epilogue)
+			conv = lambda **epilogue: ops.conv1d(xv, Fold2.packed_weight(weight, dt, spec.padding), Cout, Kf, 1, 1, Pf, bias = bias, Tout = Tout, work = 2.0 * x.shape[0] * Tout * Cout * x.shape[1] * spec.K, splitk = sk, **epilogue)
 		elif split_applies(split, dt, spec, x.shape[1], Cout):
 			# fp32 activations, the conv as hi*hi + hi*lo + lo*hi on the 16-bit matrix pipe (csrc/split3.hip): bias / folded BN / activation / mask in
 			# the conv's own epilogue as on every other path; the weights' planes are packed once per parameter version
 			x3, wp3 = ops.split3(x, split, ops.SPLIT_INPUT), split_weight(weight, split)[0]
-			conv = lambda **epilogue: ops.conv1d(x3, wp3, Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, bias = bias, work = 2.0 * x.shape[0] * ops.conv_out_len(x.shape[2], spec.K, 1, spec.dilation, spec.padding) * Cout * x.shape[1] * spec.K, family = SPLIT_FAMILY, splitk = True, **epilogue)
+			conv = lambda **epilogue: ops.conv1d(x3, wp3, Cout, spec.K, 1, spec.dilation, spec.padding, out_dtype = torch.float32, bias = bias, work = 2.0 * x.shape[0] * ops.conv_out_len(x.shape[2], spec.K, 1, spec.dilation, spec.padding) * Cout * x.shape[1] * spec.K, family = SPLIT_FAMILY, splitk = sk, **epilogue)
 		else:
 			wp = packed_weight(weight, dt, _lib.PACK_FWD)
-			conv = lambda **epilogue: ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, splitk = True, **epilogue)  # (splitk: a launch of a few tiles -- one online request -- is cut over the input channels, ops.conv1d)
+			conv = lambda **epilogue: ops.conv1d(x, wp, Cout, spec.K, spec.stride, spec.dilation, spec.padding, bias = bias, splitk = sk, **epilogue)  # (splitk: a launch of a few tiles -- one online request -- is cut over the input channels, ops.conv1d)
 		# dropout > 0 here means a FROZEN block (JasperNet.freeze, models.py:328-339): its batch norms run on their running statistics
 		# but the block is still in training mode, and the reference's ResidualActivation applies dropout by self.training (models.py:365-369)
 		p_drop = float(cfg.get('dropout_p', 0.0))
@@ -1201,10 +1204,10 @@ class ConvBnActEvalFunction:
 			if rw is None:
 				res_y.append(rx); rscale.append(None); rshift.append(None)
 			elif split_applies(split, dt, ConvSpec(1), rx.shape[1], Cout):
-				res_y.append(ops.conv1d(ops.split3(rx, split, ops.SPLIT_INPUT), split_weight(rw, split)[0], Cout, 1, 1, 1, 0, out_dtype = torch.float32, bias = rb, work = 2.0 * rx.shape[0] * rx.shape[2] * Cout * rx.shape[1], family = SPLIT_FAMILY, splitk = True))
+				res_y.append(ops.conv1d(ops.split3(rx, split, ops.SPLIT_INPUT), split_weight(rw, split)[0], Cout, 1, 1, 1, 0, out_dtype = torch.float32, bias = rb, work = 2.0 * rx.shape[0] * rx.shape[2] * Cout * rx.shape[1], family = SPLIT_FAMILY, splitk = sk))
 				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])
 			else:
-				res_y.append(ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, splitk = True))
+				res_y.append(ops.conv1d(rx, packed_weight(rw, dt, _lib.PACK_FWD), Cout, 1, 1, 1, 0, bias = rb, splitk = sk))
 				rscale.append(None if rss is None else rss[0]); rshift.append(None if rss is None else rss[1])
 		# rscale None (identity residual, or a residual conv already fused with its BN) means "add as is"
 		seed, offset = _DropoutState.next(y.numel()) if p_drop > 0 else (0, 0)

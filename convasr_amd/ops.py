@@ -228,7 +228,7 @@ def conv1d(x, wp, Cout, K, stride = 1, dil = 1, pad = 0, out_dtype = None, bias 
 	part = stats if isinstance(stats, ConvStats) or stats is None else ConvStats(Cout, B, Tout, x.device)
 	rows = ctypes.c_int(0)
 	launch = lambda: call('convasr_conv1d_fwd', ptr(x), ptr(wp), ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, Cin, Cout, Tin, Tout, K, stride, dil, pad, ptr(bias), None if part is None else ptr(part.buf), ptr(scale), ptr(shift), act[0], act[1], act[2], ptr(xlen), ctypes.byref(rows) if part is not None else None, stream_ptr())
-	if splitk and SPLITK and stats is None and stride == 1 and x.dtype in HALF_DTYPES and Cout % 8 == 0:
+	if splitk and SPLITK and stats is None and stride == 1 and (x.dtype in HALF_DTYPES or (x.dtype == torch.float32 and out_dtype == torch.float32)) and Cout % 8 == 0:
 		skey = (x.dtype, B, Cin, Cout, Tout, K)
 		plan = _splitk_plans.get(skey)
 		if plan is None:

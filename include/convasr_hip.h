@@ -119,7 +119,8 @@ int convasr_conv_stats_max_rows(int B, int Tout);
 /* Split-K form of convasr_conv1d_fwd for launches of a few tiles -- online inference, transcribe.py:140 / benchmark_online.py:125 (B = 1 x 6 s is
  * 4-16 workgroups per layer on 256 CUs, each reducing all of Cin x K alone): the reduction is cut over the 64-channel input blocks, workgroup
  * (tile, split) stores an fp32 partial tile into `workspace`, a second streaming kernel adds the partials in split order (deterministic) and
- * runs the same epilogue (bias, scale / shift, activation, length mask, rounding to y_dtype).  stride 1, 16-bit input, no statistics.
+ * runs the same epilogue (bias, scale / shift, activation, length mask, rounding to y_dtype).  stride 1, no statistics; 16-bit input (the LDS-DMA
+ * kernel, 64-channel blocks) or fp32 in and out (the exact-fp32 kernel, 32-channel slabs; the partials are added in fp64).
  *   convasr_conv1d_fwd_splitk_plan: the number of splits for this geometry (1: not worth it -- from a quarter of the CUs' worth of tiles up -- or
  *     outside the envelope: call convasr_conv1d_fwd) and the workspace bytes (splits x B x Tout x Cout fp32);
  *   convasr_conv1d_fwd_splitk: `splits` must be the plan's answer (>= 2). */

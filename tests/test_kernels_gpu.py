@@ -232,6 +232,36 @@ def test_conv1d_split_k_forward_for_launches_of_a_few_tiles(case, dtype):
 
 
 @gpu
+@pytest.mark.parametrize('case', [(1, 256, 256, 300, 11, 1), (2, 768, 896, 150, 29, 2), (1, 512, 136, 77, 3, 1), (1, 72, 256, 300, 5, 1)])
+def test_conv1d_split_k_forward_exact_fp32(case):
+	"""The same for the exact-fp32 kernel (32-channel slabs, fp64 totals per workgroup rounded once into the fp32 partial, partials added in fp64): as close to
+	float64 as the unsplit launch (both ~1e-7), the epilogue included; a channel count that is no multiple of the slab."""
+	import ctypes
+	from convasr_amd import ops, _lib
+	B, Cin, Cout, T, K, dil = case
+	d = dev()
+	torch.manual_seed(sum(case))
+	x, w = torch.randn(B, Cin, T), torch.randn(Cout, Cin, K) / (Cin * K) ** 0.5
+	bias, scale, shift = torch.randn(Cout), torch.rand(Cout) + 0.5, torch.randn(Cout)
+	xlen = torch.tensor([0.7, 1.0][:B])
+	pad = dil * (K // 2)
+	Tout = ops.conv_out_len(T, K, 1, dil, pad)
+	nb = ctypes.c_int64(0)
+	splits = _lib.load().convasr_conv1d_fwd_splitk_plan(_lib.F32, B, Cin, Cout, Tout, K, ctypes.byref(nb))
+	assert 2 <= splits <= (Cin + 31) // 32 and nb.value == splits * B * Tout * Cout * 4
+	xg, wp = ops.as_cl(x.to(d), torch.float32), ops.pack_weight(w.to(d), torch.float32, _lib.PACK_FWD)
+	ref = torch.nn.functional.conv1d(x.double(), w.double(), bias.double(), padding = pad, dilation = dil)
+	ref_epi = torch.nn.functional.hardtanh(ref * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1), 0.0, 20.0)
+	ref_epi = ref_epi * (torch.arange(Tout).view(1, 1, -1) < torch.ceil(xlen.double() * Tout).view(-1, 1, 1))
+	full = dict(bias = bias.to(d), scale = scale.to(d), shift = shift.to(d), act = (_lib.ACT_HARDTANH, 0.0, 20.0), xlen = xlen.to(d))
+	for kw, want in ((dict(bias = bias.to(d)), ref), (full, ref_epi)):
+		a = ops.conv1d(xg, wp, Cout, K, 1, dil, pad, splitk = True, **kw)
+		b = ops.conv1d(xg, wp, Cout, K, 1, dil, pad, **kw)
+		ea, eb = float((a.double().cpu() - want).norm() / want.norm()), float((b.double().cpu() - want).norm() / want.norm())
+		assert torch.equal(a, ops.conv1d(xg, wp, Cout, K, 1, dil, pad, splitk = True, **kw)) and ea <= max(1.5 * eb, 3e-7) and float((a - b).norm() / b.norm()) <= 5e-7, (ea, eb)
+
+
+@gpu
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[5] == 1 and c[1] % 64 == 0])
 def test_conv1d_lds_dma_kernel_is_bit_identical_to_register_staged_kernel(case):
 	from convasr_amd import ops, _lib
