@@ -774,6 +774,7 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 	graph_info = None
 	if graphed:
 		graph_info = dict(enabled = True, linear_capture = wl.stepper.linear, graphs = wl.stepper.captures, replays = wl.stepper.replays, eager_warmup_steps = wl.stepper.eager_steps, extra_untimed_warmup_steps = run_timed.extra_warmup,
+			node_kinds = [g.get('node_kinds') for g in list(wl.stepper.graphs.values())[:4]], transition_fence_armed = bool(wl.stepper.non_kernel_nodes),  # (hipGraphNodeGetType over every captured step: kernel nodes only -- train.capture_node_kinds)
 			note = 'every timed step is one hipGraphLaunch of the whole iteration (forward, CTC, backward, clip, optimizer), one graph per batch shape; the per-step inputs are copied into the graph\'s static buffers inside the timed region')
 	# host time of a step with the GPU drained first (the enqueue never waits for queue space): how far ahead of the GPU the Python side
 	# can run.  Eagerly the Wav2Letter step needs ~4 ms of it for 16 ms of GPU work and a JasperNetLarge step ~20 ms for ~44 (1,200 launches:

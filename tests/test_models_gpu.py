@@ -421,3 +421,36 @@ def test_training_is_bitwise_reproducible():
 		losses.append(ls)
 	assert losses[0] == losses[1], losses
 	assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize('name', ['f32', 'bf16'])
+def test_one_request_alone_equals_its_row_of_a_full_batch(name):
+	"""Online inference cuts a launch of a few tiles over the input channels (convasr_conv1d_fwd_splitk: every conv of a 1 x 3 s request), a batch
+	that fills the chip runs the unsplit kernels: the same utterance gives the same log-probs either way -- exact fp32: 1e-5 absolute and the same
+	greedy path; bf16 storage: within its rounding -- and with the split switched off the request reproduces itself to the same bars."""
+	import bench_infer
+	from convasr_amd import ops
+	d = torch.device('cuda:0')
+	torch.manual_seed(3)
+	dt = dict(f32 = torch.float32, bf16 = torch.bfloat16)[name]
+	model = bench_infer.build_model('Wav2Letter', d, dt)
+	x = (torch.rand(48, 48000, generator = torch.Generator().manual_seed(4)) * 2 - 1).to(d)
+	calls = []
+	call = ops.call
+	ops.call = lambda fn, *a: (calls.append(fn), call(fn, *a))[1]
+	try:
+		with torch.no_grad():
+			full = model(x, torch.ones(48, device = d))
+			n_full = calls.count('convasr_conv1d_fwd_splitk')
+			solo = model(x[:1], torch.ones(1, device = d))
+			n_solo = calls.count('convasr_conv1d_fwd_splitk') - n_full
+			ops.SPLITK = False
+			unsplit = model(x[:1], torch.ones(1, device = d))
+	finally:
+		ops.call, ops.SPLITK = call, True
+	assert n_full == 0 and n_solo >= 17, (n_full, n_solo)  # every conv of the request but the 64-channel prologue and what is too small to cut
+	bar = 1e-5 if name == 'f32' else 6e-2
+	for other in (full[:1], unsplit):
+		assert float((solo.float() - other.float()).abs().max()) <= bar, float((solo.float() - other.float()).abs().max())
+	if name == 'f32':
+		assert torch.equal(solo.argmax(1), full[:1].argmax(1))
