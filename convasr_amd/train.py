@@ -472,8 +472,8 @@ class GraphedTrainStep:
 			Fn.PREPACK = prepack
 		opt.steps = steps0  # (nothing ran: the replay below is this step)
 		self.graphs[key] = dict(graph = graph, static = static, res = res, node_kinds = kinds)
-		if kinds is not None and any(k != 'kernel' for k in kinds):
-			self.non_kernel_nodes = True  # (arms _fence_transition)
+		if kinds is None or any(k != 'kernel' for k in kinds):
+			self.non_kernel_nodes = True  # (arms _fence_transition; a capture that cannot be inspected is treated like one that holds other nodes)
 		self.captures += 1
 
 	def __call__(self, x, xlen, y, ylen, iteration = 0):
