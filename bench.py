@@ -847,6 +847,9 @@ def measure(args, device, rank, world, use_dist, dist_info, fence, probe = None)
 		headline = args.workload == 'wav2letter' and args.batch is None and args.secs is None
 		conv_flops_per_s = world * (flops[0] + flops[1]) / elapsed
 		roof = roofline_of(args, wl, kt, kt2, steps2, conv_flops_per_s, world, graphed = graphed) if (kt or kt2) else None
+		if roof is not None:
+			kind = 'hipEventDisableSystemFence' if (os.environ.get('CONVASR_TIMER_EVENTS', 'raw') != 'torch' and _lib._TimingEvent.runtime() is not None) else 'torch.cuda.Event'
+			roof['events'] = kind + (' (timing-only HIP events: their record carries no system-scope cache writeback / invalidate; default events cost the timed region 1.5 % around the 34 launches per step, these 0.4 %: profiles/r06_event_kinds.txt)' if kind.startswith('hip') else '')
 		metric = 'audio-seconds/sec/node (fwd+bwd+CTC) at bs64x15s' if headline else f'audio-seconds/sec/node (fwd+bwd+CTC), {args.workload}' + ('' if args.batch is None and args.secs is None else ' (TEST-ONLY size)')
 		line = dict(metric = metric, value = round(value, 1), unit = 'audio-seconds/sec', n_gpus = world, steps = args.steps, warmup = args.warmup,
 			ms_per_step = round(1e3 * elapsed / args.steps, 3), higher_is_better = True, scaling = 'weak', vs_baseline = None, dtype = args.dtype, data = 'synthetic',

@@ -151,20 +151,66 @@ def call_rc(name, *args):
 	return rc
 
 
+class _TimingEvent:
+	"""A HIP event made for TIMING only: hipEventDisableSystemFence -- recording it does not write back and invalidate the caches the way a
+	default event's system-scope fence does ("can improve the accuracy of timing measurements by avoiding the cost of cache writeback and
+	invalidation, and the performance impact of those actions on the execution of following work", hip_runtime_api.h).  The default events
+	torch.cuda.Event makes cost the benchmark's timed region 1.6 % around 34 launches per step (profiles/r06_event_cost.txt)."""
+	_hip = None
+	FLAGS = int(os.environ.get('CONVASR_TIMER_EVENT_FLAGS', '0x20000000'), 0)  # hipEventDisableSystemFence
+
+	@classmethod
+	def runtime(cls):
+		if cls._hip is None:
+			try:
+				hip = ctypes.CDLL('libamdhip64.so')
+				hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+				hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+				hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+				hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+				cls._hip = hip
+			except (OSError, AttributeError):
+				cls._hip = False
+		return cls._hip or None
+
+	def __init__(self):
+		self.handle = ctypes.c_void_p()
+		if self.runtime().hipEventCreateWithFlags(ctypes.byref(self.handle), self.FLAGS) != 0:
+			raise ConvasrHipError('hipEventCreateWithFlags failed')
+
+	def record(self):
+		if self._hip.hipEventRecord(self.handle, stream_ptr()) != 0:
+			raise ConvasrHipError('hipEventRecord failed')
+
+	def elapsed_time(self, end):
+		ms = ctypes.c_float(0.0)
+		if self._hip.hipEventElapsedTime(ctypes.byref(ms), self.handle, end.handle) != 0:
+			raise ConvasrHipError('hipEventElapsedTime failed (were the events recorded and the stream synchronised?)')
+		return ms.value
+
+	def __del__(self):
+		if self.handle and self._hip:
+			self._hip.hipEventDestroy(self.handle)
+			self.handle = None
+
+
 class KernelTimer:
 	"""HIP-event timing of selected launches on the stream they are launched on (bench.py's roofline leg).  Events are
-	recorded around the C-ABI call; elapsed times are read after the caller synchronises."""
+	recorded around the C-ABI call; elapsed times are read after the caller synchronises.  The events are timing-only ones
+	(_TimingEvent: no system-scope fence at the record) unless CONVASR_TIMER_EVENTS=torch or the HIP runtime cannot be reached."""
 
 	def __init__(self, only = None):
 		self.records = {}
-		self.only = None if only is None else set(only)  # families to time; launches of other families run untouched (an event pair costs ~5 us of stream time)
+		self.only = None if only is None else set(only)  # families to time; launches of other families run untouched (an event pair costs stream time)
 		self.sequence = []  # (family, symbol class) of EVERY launch that came through, in launch order (bench.py maps a profiler's dispatch list onto it)
+		self.raw = os.environ.get('CONVASR_TIMER_EVENTS', 'raw') != 'torch' and _TimingEvent.runtime() is not None
+		self.event_kind = 'hipEventDisableSystemFence' if self.raw else 'torch.cuda.Event'
 
 	def timed(self, family, work, fn, nbytes = 0.0, symbol = None):
 		self.sequence.append((family, symbol))
 		if self.only is not None and family not in self.only:
 			return fn()
-		start, end = torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True)
+		start, end = (_TimingEvent(), _TimingEvent()) if self.raw else (torch.cuda.Event(enable_timing = True), torch.cuda.Event(enable_timing = True))
 		start.record()
 		fn()
 		end.record()
