@@ -224,6 +224,46 @@ class KernelTimer:
 		return out
 
 
+class _OrderEvents:
+	"""stream_wait(dst, src): dst waits for what is enqueued on src so far -- torch's dst.wait_stream(src) with an event that carries neither a
+	time stamp nor a system-scope fence (hipEventDisableTiming | hipEventDisableSystemFence): the hand-overs between the step's streams (weight
+	gradients on a side stream, the dgrad-copy stream) order DEVICE work only, nothing the host inspects."""
+	FLAGS = 0x2 | 0x20000000
+	ring, pos = {}, {}
+
+	@classmethod
+	def wait(cls, dst, src):
+		hip = _TimingEvent.runtime()
+		if hip is None:
+			return dst.wait_stream(src)
+		dev = src.device_index
+		ring = cls.ring.get(dev)
+		if ring is None:
+			hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+			ring = cls.ring[dev] = []
+			with torch.cuda.device(dev):
+				for _ in range(256):
+					h = ctypes.c_void_p()
+					if hip.hipEventCreateWithFlags(ctypes.byref(h), cls.FLAGS) != 0:
+						raise ConvasrHipError('hipEventCreateWithFlags failed')
+					ring.append(h)
+			cls.pos[dev] = 0
+		ev = ring[cls.pos[dev]]
+		cls.pos[dev] = (cls.pos[dev] + 1) % len(ring)
+		if hip.hipEventRecord(ev, ctypes.c_void_p(src.cuda_stream)) != 0 or hip.hipStreamWaitEvent(ctypes.c_void_p(dst.cuda_stream), ev, 0) != 0:
+			raise ConvasrHipError('stream_wait: hipEventRecord / hipStreamWaitEvent failed')
+
+
+RAW_STREAM_EVENTS = os.environ.get('CONVASR_RAW_STREAM_EVENTS') == '1'  # A/B hook (round 6): the side-stream hand-overs through fence-free events
+
+
+def stream_wait(dst, src):
+	if RAW_STREAM_EVENTS and not torch.cuda.is_current_stream_capturing():
+		_OrderEvents.wait(dst, src)
+	else:
+		dst.wait_stream(src)
+
+
 timer = None  # set to a KernelTimer by bench.py for the timed region
 
 

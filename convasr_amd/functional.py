@@ -255,7 +255,7 @@ def prepack_dgrad_weights(weights, dtype):
 	if st is None:
 		st = _prepack_streams[dev] = [torch.cuda.Stream(device = dev), False]
 	side, main = st[0], torch.cuda.current_stream(dev)
-	side.wait_stream(main)  # the parameters, their 16-bit mirror and every earlier reader of the buffers are ordered before the packs
+	_lib.stream_wait(side, main)  # the parameters, their 16-bit mirror and every earlier reader of the buffers are ordered before the packs
 	with torch.cuda.stream(side):
 		_pack_dgrad_many(stale, dtype)
 	st[1] = True
@@ -264,7 +264,7 @@ def prepack_dgrad_weights(weights, dtype):
 def join_prepack(device):
 	st = _prepack_streams.get(device)
 	if st is not None and st[1]:
-		torch.cuda.current_stream(device).wait_stream(st[0])
+		_lib.stream_wait(torch.cuda.current_stream(device), st[0])
 		st[1] = False
 
 
@@ -404,7 +404,7 @@ def side_stream(device):
 def join_side_streams():
 	for dev, side in _side_streams.items():
 		if side is not None:
-			torch.cuda.current_stream(dev).wait_stream(side)
+			_lib.stream_wait(torch.cuda.current_stream(dev), side)
 	_wgrad_pending.clear()
 
 
@@ -429,7 +429,7 @@ def _run_wgrad(dev, tensors, fn):
 		return fn()
 	if WGRAD_AFTER_DGRAD:
 		_wgrad_pending[dev] = True
-	side.wait_stream(torch.cuda.current_stream(dev))
+	_lib.stream_wait(side, torch.cuda.current_stream(dev))
 	with torch.cuda.stream(side):
 		out = fn()
 	for t in tensors:
