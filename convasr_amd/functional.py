@@ -401,11 +401,17 @@ def side_stream(device):
 	return _side_streams.get(torch.device(device))
 
 
+SIDE_KEEPALIVE = os.environ.get('CONVASR_NO_SIDE_KEEPALIVE') != '1'  # the side stream's operands are kept alive until the join instead of record_stream() (round 6: -0.6 .. -0.8 % on the JasperNetLarge step, +0.4 GiB; profiles/r06_ab_side_keepalive.txt)
+_side_keepalive = {}
+
+
 def join_side_streams():
 	for dev, side in _side_streams.items():
 		if side is not None:
 			_lib.stream_wait(torch.cuda.current_stream(dev), side)
 	_wgrad_pending.clear()
+	for held in _side_keepalive.values():
+		del held[:]  # (released on the main stream, which has just been ordered behind the side stream's last reader)
 
 
 # WGRAD_AFTER_DGRAD (round 6, with the side stream on): a layer's weight gradient is enqueued on the side stream AFTER the same layer's dgrad and
@@ -432,8 +438,12 @@ def _run_wgrad(dev, tensors, fn):
 	_lib.stream_wait(side, torch.cuda.current_stream(dev))
 	with torch.cuda.stream(side):
 		out = fn()
-	for t in tensors:
-		t.record_stream(side)
+	held = _side_keepalive.setdefault(dev, [])
+	if SIDE_KEEPALIVE and len(held) < 16384:  # (a caller that never joins must not pile tensors up: past this many the allocator's own bookkeeping takes over)
+		held.extend(tensors)  # held until join_side_streams(): no record_stream bookkeeping (an allocator event per tensor at its release)
+	else:
+		for t in tensors:
+			t.record_stream(side)
 	return out
 
 
